@@ -1,0 +1,71 @@
+"""Builds libbasedet_hip.so (gfx950) in-tree with hipcc.  `python -m basedet_amd.build [--force]`."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT_DIR, "libbasedet_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+# per-file extra flags: the box ops must not contract a*b+c into FMA (bit-exact parity with the numpy oracle)
+SOURCES = {
+    "image_ops.hip": [],
+    "conv_igemm.hip": [],
+    "conv_wgrad.hip": [],
+    "stem.hip": [],
+    "boxops.hip": ["-ffp-contract=off"],
+    "losses.hip": [],
+}
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)) + ["../../include/basedet_hip.h"]:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode())
+            h.update(f.read())
+    h.update(repr(sorted(SOURCES.items())).encode() + repr(COMMON).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    stamp = os.path.join(OUT_DIR, "build.stamp")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    objs = []
+    procs = []
+    for src, extra in SOURCES.items():
+        obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *COMMON, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- {src} failed ---\n{out}\n")
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

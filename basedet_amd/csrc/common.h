@@ -1,0 +1,56 @@
+// Shared device/host helpers for libbasedet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/basedet_hip.h"
+
+typedef unsigned short bf16_raw;  // storage type of a bf16 element
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+__device__ __forceinline__ float bf2f(bf16_raw h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_raw f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
+    return __builtin_bit_cast(bf16_raw, b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// wave64 sum reduction (result valid in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+void bd_set_error(const char* fmt, ...);
+
+#define BD_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            bd_set_error(__VA_ARGS__);   \
+            return BD_EINVAL;            \
+        }                                \
+    } while (0)
+
+#define BD_CHECK_LAUNCH(name)                                                     \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            bd_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return BD_ELAUNCH;                                                    \
+        }                                                                         \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,408 @@
+// Implicit-GEMM convolution forward and data-gradient on CDNA4 MFMA (gfx950).
+//
+//   D[co][pix] = sum_{tap, ck}  W[co][tap][ck] * SRC[srcpix(pix, tap)][ck]
+//
+// MFMA A operand = packed weights (rows = output channels), B operand = NHWC activations
+// (columns = pixels), both K-contiguous in memory, so fragments are plain 16-byte LDS reads.
+// With the output channel on the MFMA row, every lane ends up holding 4 consecutive channels of one
+// pixel -> 8-byte NHWC stores, and the per-channel bias is a per-register constant.
+//
+// Workgroup = 256 threads = 4 waves (2 channel halves x 2 pixel halves); tile = 128 channels x 128 pixels,
+// K step = BK channels of one filter tap.  Global->register->LDS staging (loads of step t+1 are issued
+// before the MFMAs of step t, written after them), two LDS buffers, one barrier per K step.
+// LDS rows are padded (BK*2 + 32 bytes) so that ds_read_b128 fragment reads are bank-conflict free.
+//
+// mode 0 (forward):  pix = output pixel, src = conv input,  sy = oy*stride - pad + r
+// mode 1 (dgrad):    pix = input pixel,  src = dY,          sy = (iy + pad - r)/stride when divisible.
+//   For stride 2 the pixels are enumerated parity-class-major so that a tile only visits the taps
+//   that can contribute to its class (no multiply-by-zero work).
+#include "common.h"
+
+namespace {
+
+constexpr int TILE_C = 128;   // output channels per workgroup
+constexpr int TILE_P = 128;   // pixels per workgroup
+constexpr int MAX_SUB = 8;
+
+struct SubSeg {
+    int m_start;             // first GEMM column of this sub-segment
+    int Hs, Ws;              // enumeration extent per image
+    int y0, x0, step;        // dst pixel = (y0 + step*yy, x0 + step*xx)
+    int Wd, dst_off;         // dst row pitch (pixels) and pixel offset inside one image
+    int Hsrc, Wsrc, src_off; // src geometry
+};
+
+struct IgemmParams {
+    const bf16_raw* src;
+    const bf16_raw* w;
+    const float* bias;
+    const bf16_raw* add;
+    const bf16_raw* mask;
+    bf16_raw* dst;
+    int CK, CO, R, S, stride, pad, mode, flags;
+    int M, nsub;
+    int src_pix_per_img, dst_pix_per_img;
+    int m_tiles, n_tiles;
+    SubSeg sub[MAX_SUB];
+};
+
+template <int BK>
+struct Cfg {
+    static constexpr int CHUNKS = BK / 8;             // 16-byte chunks per row
+    static constexpr int ROWS_PER_PASS = 256 / CHUNKS;
+    static constexpr int PASSES = 128 / ROWS_PER_PASS;
+    static constexpr int LDS_STRIDE = BK * 2 + 32;    // bytes per row (conflict-free for b128 reads)
+    static constexpr int TILE_BYTES = 128 * LDS_STRIDE;
+};
+
+template <int BK>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
+    using C = Cfg<BK>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: [buf][A tile | B tile]; the stride-2 dgrad tap mask borrows the first word before staging starts
+    unsigned char* tiles = smem;
+    unsigned int* s_tapmask = reinterpret_cast<unsigned int*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave >> 1;   // channel half
+    const int wp = wave & 1;    // pixel half
+
+    // XCD-aware bijective remap: consecutive tile ids stay on one XCD (shared weights / halo rows in its L2)
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.n_tiles;
+    const int tile_n = bid - tile_m * p.n_tiles;
+    const int m0 = tile_m * TILE_P;
+    const int co0 = tile_n * TILE_C;
+
+    const int chunk = tid % C::CHUNKS;
+    const int row0 = tid / C::CHUNKS;
+
+    // ---- per-row pixel decode (B operand rows handled by this thread) ----
+    int b_py[C::PASSES], b_px[C::PASSES], b_hs[C::PASSES], b_ws[C::PASSES];
+    long long b_base[C::PASSES];   // src pixel base of the image (+ level offset), -1 if row is out of range
+    unsigned int my_tapmask = 0;
+    const int RS = p.R * p.S;
+    if (tid == 0) *s_tapmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::PASSES; ++i) {
+        const int row = row0 + i * C::ROWS_PER_PASS;
+        const int m = m0 + row;
+        b_base[i] = -1; b_py[i] = 0; b_px[i] = 0; b_hs[i] = 0; b_ws[i] = 0;
+        if (m < p.M) {
+            int s = 0;
+#pragma unroll
+            for (int k = 1; k < MAX_SUB; ++k)
+                if (k < p.nsub && m >= p.sub[k].m_start) s = k;
+            const SubSeg ss = p.sub[s];
+            const int local = m - ss.m_start;
+            const int per_img = ss.Hs * ss.Ws;
+            const int n = local / per_img;
+            const int rem = local - n * per_img;
+            const int yy = rem / ss.Ws;
+            const int xx = rem - yy * ss.Ws;
+            const int py = ss.y0 + ss.step * yy;
+            const int px = ss.x0 + ss.step * xx;
+            b_base[i] = (long long)n * p.src_pix_per_img + ss.src_off;
+            b_hs[i] = ss.Hsrc; b_ws[i] = ss.Wsrc;
+            if (p.mode == 0) { b_py[i] = py * p.stride - p.pad; b_px[i] = px * p.stride - p.pad; }
+            else             { b_py[i] = py + p.pad;            b_px[i] = px + p.pad; }
+            if (p.mode == 1 && p.stride > 1) {
+                for (int t = 0; t < RS; ++t) {
+                    const int r = t / p.S, sx = t - r * p.S;
+                    const int ty = b_py[i] - r, tx = b_px[i] - sx;
+                    const bool ok = ty >= 0 && tx >= 0 && ((ty | tx) & (p.stride - 1)) == 0 &&
+                                    (ty >> 1) < ss.Hsrc && (tx >> 1) < ss.Wsrc;
+                    if (ok) my_tapmask |= 1u << t;
+                }
+            }
+        }
+    }
+    unsigned int tapmask;
+    if (p.mode == 1 && p.stride > 1) {
+        __syncthreads();
+        if (my_tapmask) atomicOr(s_tapmask, my_tapmask);
+        __syncthreads();
+        tapmask = *s_tapmask;
+        __syncthreads();
+    } else {
+        tapmask = (RS >= 32) ? 0xffffffffu : ((1u << RS) - 1u);
+    }
+    const int kblocks = (p.CK + BK - 1) / BK;
+    const int nsteps = __popc(tapmask) * kblocks;
+
+    // ---- staging state ----
+    u32x4_t ra[C::PASSES], rb[C::PASSES];
+    unsigned int rem_mask = tapmask;
+    int cur_tap = -1, cur_kb = kblocks;   // forces a tap advance on first call
+    int tap_r = 0, tap_s = 0;
+
+    auto stage_load = [&]() {
+        if (cur_kb == kblocks) {
+            cur_kb = 0;
+            cur_tap = __ffs(rem_mask) - 1;
+            rem_mask &= rem_mask - 1;
+            tap_r = cur_tap / p.S;
+            tap_s = cur_tap - tap_r * p.S;
+        }
+        const int c0 = cur_kb * BK + chunk * 8;
+        const bool cvalid = c0 + 8 <= p.CK;   // zero-fill the channel tail (CK % 8 == 0)
+        // A: weights [co][tap][ck]
+#pragma unroll
+        for (int i = 0; i < C::PASSES; ++i) {
+            const int co = co0 + row0 + i * C::ROWS_PER_PASS;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (cvalid && co < p.CO) {
+                const bf16_raw* g = p.w + ((long long)co * RS + cur_tap) * p.CK + c0;
+                v = *reinterpret_cast<const u32x4_t*>(g);
+            }
+            ra[i] = v;
+        }
+        // B: activations
+#pragma unroll
+        for (int i = 0; i < C::PASSES; ++i) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            int sy, sx;
+            bool ok = cvalid && b_base[i] >= 0;
+            if (p.mode == 0) {
+                sy = b_py[i] + tap_r; sx = b_px[i] + tap_s;
+                ok = ok && sy >= 0 && sx >= 0 && sy < b_hs[i] && sx < b_ws[i];
+            } else {
+                const int ty = b_py[i] - tap_r, tx = b_px[i] - tap_s;
+                ok = ok && ty >= 0 && tx >= 0;
+                if (p.stride == 2) { ok = ok && (((ty | tx) & 1) == 0); sy = ty >> 1; sx = tx >> 1; }
+                else { sy = ty; sx = tx; }
+                ok = ok && sy < b_hs[i] && sx < b_ws[i];
+            }
+            if (ok) {
+                const bf16_raw* g = p.src + (b_base[i] + (long long)sy * b_ws[i] + sx) * p.CK + c0;
+                v = *reinterpret_cast<const u32x4_t*>(g);
+            }
+            rb[i] = v;
+        }
+        ++cur_kb;
+    };
+    auto stage_write = [&](int buf) {
+        unsigned char* At = tiles + buf * 2 * C::TILE_BYTES;
+        unsigned char* Bt = At + C::TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::PASSES; ++i) {
+            const int row = row0 + i * C::ROWS_PER_PASS;
+            *reinterpret_cast<u32x4_t*>(At + row * C::LDS_STRIDE + chunk * 16) = ra[i];
+            *reinterpret_cast<u32x4_t*>(Bt + row * C::LDS_STRIDE + chunk * 16) = rb[i];
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int frag_row = lane & 15;
+    const int frag_chunk = lane >> 4;
+
+    auto compute = [&](int buf) {
+        const unsigned char* At = tiles + buf * 2 * C::TILE_BYTES + (wc * 64 + frag_row) * C::LDS_STRIDE;
+        const unsigned char* Bt = tiles + buf * 2 * C::TILE_BYTES + C::TILE_BYTES + (wp * 64 + frag_row) * C::LDS_STRIDE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8_t a[4], b[4];
+            const int off = (kk * 4 + frag_chunk) * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(At + i * 16 * C::LDS_STRIDE + off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bt + j * 16 * C::LDS_STRIDE + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nsteps > 0) {
+        stage_load();
+        stage_write(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        const bool more = (t + 1 < nsteps);
+        if (more) stage_load();
+        compute(cur);
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds channels (cg*4 .. cg*4+3) of pixel (lane & 15) for each (i, j) ----
+    const int cg = lane >> 4;
+    const bool do_relu = p.flags & BD_EPI_RELU;
+    const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
+    const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
+    const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        int dstpix;
+        {
+            int s = 0;
+#pragma unroll
+            for (int k = 1; k < MAX_SUB; ++k)
+                if (k < p.nsub && m >= p.sub[k].m_start) s = k;
+            const SubSeg ss = p.sub[s];
+            const int local = m - ss.m_start;
+            const int per_img = ss.Hs * ss.Ws;
+            const int n = local / per_img;
+            const int rem = local - n * per_img;
+            const int yy = rem / ss.Ws;
+            const int xx = rem - yy * ss.Ws;
+            dstpix = n * p.dst_pix_per_img + ss.dst_off + (ss.y0 + ss.step * yy) * ss.Wd + ss.x0 + ss.step * xx;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + wc * 64 + i * 16 + cg * 4;
+            if (co >= p.CO) continue;
+            const long long idx = (long long)dstpix * p.CO + co;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + co);
+                v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+            }
+            if (add_before) {
+                const u32x2_t av = *reinterpret_cast<const u32x2_t*>(p.add + idx);
+                v[0] += bf_lo(av[0]); v[1] += bf_hi(av[0]); v[2] += bf_lo(av[1]); v[3] += bf_hi(av[1]);
+            }
+            if (do_relu) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (do_mask) {
+                const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(p.mask + idx);
+                if (!(bf_lo(mv[0]) > 0.f)) v[0] = 0.f;
+                if (!(bf_hi(mv[0]) > 0.f)) v[1] = 0.f;
+                if (!(bf_lo(mv[1]) > 0.f)) v[2] = 0.f;
+                if (!(bf_hi(mv[1]) > 0.f)) v[3] = 0.f;
+            }
+            if (add_after) {
+                const u32x2_t av = *reinterpret_cast<const u32x2_t*>(p.add + idx);
+                v[0] += bf_lo(av[0]); v[1] += bf_hi(av[0]); v[2] += bf_lo(av[1]); v[3] += bf_hi(av[1]);
+            }
+            u32x2_t o;
+            o[0] = pack_bf2(v[0], v[1]);
+            o[1] = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<u32x2_t*>(p.dst + idx) = o;
+        }
+    }
+}
+
+template <int BK>
+int launch_igemm(const IgemmParams& p, hipStream_t stream) {
+    using C = Cfg<BK>;
+    const size_t lds = 4 * C::TILE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = p.m_tiles * p.n_tiles;
+    hipLaunchKernelGGL(conv_igemm_kernel<BK>, dim3(grid), dim3(256), lds, stream, p);
+    return 0;
+}
+
+int check_desc(const bd_conv_desc* d) {
+    BD_REQUIRE(d != nullptr, "conv: null descriptor");
+    BD_REQUIRE(d->nseg >= 1 && d->nseg <= BD_MAX_SEGS, "conv: nseg=%d out of range", d->nseg);
+    BD_REQUIRE(d->N >= 1 && d->Cin >= 1 && d->Cout >= 1, "conv: bad N/Cin/Cout");
+    BD_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d unsupported (1 or 2)", d->stride);
+    BD_REQUIRE(d->R * d->S <= 32, "conv: %dx%d kernel unsupported by the generic path", d->R, d->S);
+    for (int s = 0; s < d->nseg; ++s) {
+        BD_REQUIRE((d->Hi[s] + 2 * d->pad - d->R) / d->stride + 1 == d->Ho[s] &&
+                   (d->Wi[s] + 2 * d->pad - d->S) / d->stride + 1 == d->Wo[s],
+                   "conv: level %d output size inconsistent with input/stride/pad", s);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                             const void* add, void* y, int flags, bd_stream_t stream) {
+    if (int e = check_desc(d)) return e;
+    BD_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
+    BD_REQUIRE(d->Cin % 8 == 0, "conv2d_fwd: Cin=%d must be a multiple of 8", d->Cin);
+    BD_REQUIRE(d->Cout % 4 == 0, "conv2d_fwd: Cout=%d must be a multiple of 4", d->Cout);
+    BD_REQUIRE(!(flags & BD_EPI_MASK), "conv2d_fwd: BD_EPI_MASK is a dgrad-only flag");
+    IgemmParams p{};
+    p.src = (const bf16_raw*)x; p.w = (const bf16_raw*)w_packed; p.bias = bias;
+    p.add = (const bf16_raw*)add; p.mask = nullptr; p.dst = (bf16_raw*)y;
+    p.CK = d->Cin; p.CO = d->Cout; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
+    p.mode = 0; p.flags = flags;
+    p.nsub = d->nseg;
+    long long m = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        SubSeg& ss = p.sub[s];
+        ss.m_start = (int)m;
+        ss.Hs = d->Ho[s]; ss.Ws = d->Wo[s]; ss.y0 = 0; ss.x0 = 0; ss.step = 1;
+        ss.Wd = d->Wo[s]; ss.dst_off = d->out_off[s];
+        ss.Hsrc = d->Hi[s]; ss.Wsrc = d->Wi[s]; ss.src_off = d->in_off[s];
+        m += (long long)d->N * d->Ho[s] * d->Wo[s];
+    }
+    BD_REQUIRE(m < (1ll << 31) / 4, "conv2d_fwd: too many pixels");
+    p.M = (int)m;
+    p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
+    p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
+    if (p.CK > 32) launch_igemm<64>(p, (hipStream_t)stream);
+    else launch_igemm<32>(p, (hipStream_t)stream);
+    BD_CHECK_LAUNCH("bd_conv2d_fwd");
+    return BD_OK;
+}
+
+extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add,
+                               const void* mask, void* dx, int flags, bd_stream_t stream) {
+    if (int e = check_desc(d)) return e;
+    BD_REQUIRE(g && w_packed_t && dx, "conv2d_dgrad: null pointer");
+    BD_REQUIRE(d->Cout % 8 == 0, "conv2d_dgrad: Cout=%d must be a multiple of 8 (pad the gradient)", d->Cout);
+    BD_REQUIRE(d->Cin % 4 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 4", d->Cin);
+    BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad: BD_EPI_RELU is a forward-only flag");
+    IgemmParams p{};
+    p.src = (const bf16_raw*)g; p.w = (const bf16_raw*)w_packed_t; p.bias = nullptr;
+    p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)dx;
+    p.CK = d->Cout; p.CO = d->Cin; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
+    p.mode = 1; p.flags = flags;
+    long long m = 0;
+    int ns = 0;
+    const int st = d->stride;
+    for (int s = 0; s < d->nseg; ++s) {
+        for (int qy = 0; qy < st; ++qy)
+            for (int qx = 0; qx < st; ++qx) {
+                const int Hs = (d->Hi[s] - qy + st - 1) / st, Ws = (d->Wi[s] - qx + st - 1) / st;
+                if (Hs <= 0 || Ws <= 0) continue;
+                BD_REQUIRE(ns < MAX_SUB, "conv2d_dgrad: too many sub-segments (levels x stride^2 > %d)", MAX_SUB);
+                SubSeg& ss = p.sub[ns++];
+                ss.m_start = (int)m;
+                ss.Hs = Hs; ss.Ws = Ws; ss.y0 = qy; ss.x0 = qx; ss.step = st;
+                ss.Wd = d->Wi[s]; ss.dst_off = d->in_off[s];
+                ss.Hsrc = d->Ho[s]; ss.Wsrc = d->Wo[s]; ss.src_off = d->out_off[s];
+                m += (long long)d->N * Hs * Ws;
+            }
+    }
+    p.nsub = ns;
+    BD_REQUIRE(m < (1ll << 31) / 4, "conv2d_dgrad: too many pixels");
+    p.M = (int)m;
+    p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
+    p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
+    if (p.CK > 32) launch_igemm<64>(p, (hipStream_t)stream);
+    else launch_igemm<32>(p, (hipStream_t)stream);
+    BD_CHECK_LAUNCH("bd_conv2d_dgrad");
+    return BD_OK;
+}

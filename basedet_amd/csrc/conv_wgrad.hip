@@ -1,0 +1,311 @@
+// Convolution weight gradient on CDNA4 MFMA (gfx950).
+//
+//   dW[co][tap][ci] = sum_pix  G[pix][co] * X[srcpix(pix, tap)][ci]
+//
+// The reduction index (pixel) is the slow index of both NHWC operands, so both MFMA operands need a
+// transpose.  Tiles are staged [pixel][channel] exactly as they lie in HBM (coalesced 16-byte loads,
+// conflict-free ds_write_b128) and fragments are fetched with gfx950's transposing LDS read
+// ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered pixel-contiguous per channel).
+// The MFMA k index -> pixel mapping is permuted (same permutation for both operands) so that the two
+// 16-lane groups of a half-wave read 8 distinct LDS rows = all 64 banks: conflict-free with the 288-byte
+// row pitch.
+//
+// D'[ci][co]: A operand = X^T (rows = ci), B operand = G (cols = co)  => each lane owns 4 consecutive ci of one
+// co, i.e. one 16-byte fp32 store into the [co][tap][ci] slab.
+//
+// Split over pixels: grid = splits x taps x ci-tiles x co-tiles; every workgroup writes its own fp32 slab,
+// a second kernel sums the slabs in a fixed order (bitwise reproducible), applies the FrozenBN row scale and
+// stores / accumulates into the fp32 gradient.
+#include "common.h"
+
+namespace {
+
+constexpr int TILE = 128;       // channels per tile side
+constexpr int ROW_PITCH = 288;  // bytes per staged pixel row (256 data + 32 pad)
+constexpr int MAX_SEG = BD_MAX_SEGS;
+
+struct WSeg {
+    int m_start;
+    int Ho, Wo, per_img;
+    float inv_per_img, inv_wo;
+    int Hi, Wi, in_off, out_off;
+};
+
+struct WgradParams {
+    const bf16_raw* x;
+    const bf16_raw* g;
+    float* slab;     // [splits][Cout][RS][Cin]
+    int Cin, Cout, R, S, stride, pad;
+    int M, nseg;
+    int in_pix_per_img, out_pix_per_img;
+    int ci_tiles, co_tiles, splits, steps_per_split, total_steps;
+    WSeg seg[MAX_SEG];
+};
+
+__device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+
+template <int BKP, bool USE_TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int PASSES = BKP / 16;
+    constexpr int TILE_BYTES = BKP * ROW_PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wci = wave >> 1;  // ci half (MFMA rows)
+    const int wco = wave & 1;   // co half (MFMA cols)
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int RS = p.R * p.S;
+    const int tiles_per_split = RS * p.ci_tiles * p.co_tiles;
+    const int split = bid / tiles_per_split;
+    int t = bid - split * tiles_per_split;
+    const int tap = t / (p.ci_tiles * p.co_tiles);
+    t -= tap * (p.ci_tiles * p.co_tiles);
+    const int ci_tile = t / p.co_tiles;
+    const int co_tile = t - ci_tile * p.co_tiles;
+    const int ci0 = ci_tile * TILE, co0 = co_tile * TILE;
+    const int tap_r = tap / p.S, tap_s = tap - tap_r * p.S;
+
+    const int step_begin = split * p.steps_per_split;
+    int step_end = step_begin + p.steps_per_split;
+    if (step_end > p.total_steps) step_end = p.total_steps;
+
+    const int chunk = tid & 15;
+    const int row0 = tid >> 4;
+    const bool ci_ok = ci0 + chunk * 8 < p.Cin;   // Cin % 8 == 0
+    const bool co_ok = co0 + chunk * 8 < p.Cout;  // Cout % 8 == 0
+
+    u32x4_t rx[PASSES], rg[PASSES];
+
+    auto stage_load = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int m = step * BKP + row0 + i * 16;
+            u32x4_t vx = {0u, 0u, 0u, 0u}, vg = {0u, 0u, 0u, 0u};
+            if (m < p.M) {
+                int s = 0;
+#pragma unroll
+                for (int k = 1; k < MAX_SEG; ++k)
+                    if (k < p.nseg && m >= p.seg[k].m_start) s = k;
+                const WSeg sg = p.seg[s];
+                int n, rem, oy, ox;
+                fast_divmod(m - sg.m_start, sg.per_img, sg.inv_per_img, n, rem);
+                fast_divmod(rem, sg.Wo, sg.inv_wo, oy, ox);
+                if (co_ok) {
+                    const long long gp = (long long)n * p.out_pix_per_img + sg.out_off + oy * sg.Wo + ox;
+                    vg = *reinterpret_cast<const u32x4_t*>(p.g + gp * p.Cout + co0 + chunk * 8);
+                }
+                const int sy = oy * p.stride - p.pad + tap_r, sx = ox * p.stride - p.pad + tap_s;
+                if (ci_ok && sy >= 0 && sx >= 0 && sy < sg.Hi && sx < sg.Wi) {
+                    const long long xp = (long long)n * p.in_pix_per_img + sg.in_off + sy * sg.Wi + sx;
+                    vx = *reinterpret_cast<const u32x4_t*>(p.x + xp * p.Cin + ci0 + chunk * 8);
+                }
+            }
+            rx[i] = vx; rg[i] = vg;
+        }
+    };
+    auto stage_write = [&](int buf) {
+        unsigned char* Xt = smem + buf * 2 * TILE_BYTES;
+        unsigned char* Gt = Xt + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int row = row0 + i * 16;
+            *reinterpret_cast<u32x4_t*>(Xt + row * ROW_PITCH + chunk * 16) = rx[i];
+            *reinterpret_cast<u32x4_t*>(Gt + row * ROW_PITCH + chunk * 16) = rg[i];
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // k -> pixel permutation (identical for A and B): k = 8*g4 + j  <->  pixel 16*(g4>>1) + 4*(g4&1) + (j&3) + 8*(j>>2)
+    const int g4 = lane >> 4, idx = lane & 15;
+    const int prow_base = 16 * (g4 >> 1) + 4 * (g4 & 1);
+    // transposing read: lane 4q+p of the group supplies &tile[row + q][col0 + 4p]
+    const int tr_q = idx >> 2, tr_p = idx & 3;
+
+    auto load_frag = [&](const unsigned char* tile, int kk, int cbase) -> bf16x8_t {
+        bf16x8_t f;
+        if constexpr (USE_TR) {
+            const unsigned char* a0 = tile + (kk * 32 + prow_base + tr_q) * ROW_PITCH + (cbase + 4 * tr_p) * 2;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 8 * ROW_PITCH));
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            f = __builtin_bit_cast(bf16x8_t, v);
+        } else {
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            s16x8_t v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int prow = kk * 32 + prow_base + (j & 3) + 8 * (j >> 2);
+                v[j] = *reinterpret_cast<const short*>(tile + prow * ROW_PITCH + (cbase + idx) * 2);
+            }
+            f = __builtin_bit_cast(bf16x8_t, v);
+        }
+        return f;
+    };
+
+    auto compute = [&](int buf) {
+        const unsigned char* Xt = smem + buf * 2 * TILE_BYTES;
+        const unsigned char* Gt = Xt + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BKP / 32; ++kk) {
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = load_frag(Xt, kk, wci * 64 + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = load_frag(Gt, kk, wco * 64 + j * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (step_begin < step_end) {
+        stage_load(step_begin);
+        stage_write(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int st = step_begin; st < step_end; ++st) {
+        const bool more = st + 1 < step_end;
+        if (more) stage_load(st + 1);
+        compute(cur);
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // D'[row = ci][col = co]: lane holds ci = (lane>>4)*4 + r (4 consecutive), co = lane & 15
+    float* slab = p.slab + (long long)split * p.Cout * RS * p.Cin;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + wco * 64 + j * 16 + idx;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = ci0 + wci * 64 + i * 16 + g4 * 4;
+            if (ci >= p.Cin) continue;   // Cin % 4 == 0
+            *reinterpret_cast<f32x4_t*>(slab + ((long long)co * RS + tap) * p.Cin + ci) = acc[i][j];
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long long n, int row_len,
+                                    const float* __restrict__ row_scale, float* __restrict__ dw, int accumulate) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; ++k) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(slab + (long long)k * n + i);
+        s += v;
+    }
+    if (row_scale) {
+        const float sc = row_scale[i / row_len];
+        s *= sc;
+    }
+    if (accumulate) s += *reinterpret_cast<const f32x4_t*>(dw + i);
+    *reinterpret_cast<f32x4_t*>(dw + i) = s;
+}
+
+struct Plan { int ci_tiles, co_tiles, splits, steps_per_split, total_steps; long long M; };
+
+constexpr int BKP_DEFAULT = 64;
+int g_wgrad_use_tr = 1;
+
+Plan make_plan(const bd_conv_desc* d) {
+    Plan pl;
+    long long M = 0;
+    for (int s = 0; s < d->nseg; ++s) M += (long long)d->N * d->Ho[s] * d->Wo[s];
+    pl.M = M;
+    pl.ci_tiles = cdiv(d->Cin, TILE);
+    pl.co_tiles = cdiv(d->Cout, TILE);
+    pl.total_steps = (int)cdiv64(M, BKP_DEFAULT);
+    const int tiles = d->R * d->S * pl.ci_tiles * pl.co_tiles;
+    int splits = 1024 / tiles;
+    if (splits < 1) splits = 1;
+    const int max_splits = pl.total_steps / 4 > 0 ? pl.total_steps / 4 : 1;
+    if (splits > max_splits) splits = max_splits;
+    pl.steps_per_split = cdiv(pl.total_steps, splits);
+    pl.splits = cdiv(pl.total_steps, pl.steps_per_split);
+    return pl;
+}
+
+}  // namespace
+
+extern "C" int bd_wgrad_set_transpose_read(int use_tr) { g_wgrad_use_tr = use_tr; return BD_OK; }
+
+extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
+    if (!d || d->nseg < 1 || d->nseg > BD_MAX_SEGS) return 0;
+    const Plan pl = make_plan(d);
+    return (size_t)pl.splits * d->Cout * d->R * d->S * d->Cin * sizeof(float);
+}
+
+extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale,
+                               float* dw, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(d && x && g && dw && ws, "conv2d_wgrad: null pointer");
+    BD_REQUIRE(d->nseg >= 1 && d->nseg <= BD_MAX_SEGS, "conv2d_wgrad: nseg out of range");
+    BD_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, "conv2d_wgrad: Cin=%d / Cout=%d must be multiples of 8", d->Cin, d->Cout);
+    const Plan pl = make_plan(d);
+    BD_REQUIRE(pl.M < (1ll << 24), "conv2d_wgrad: %lld pixels exceed the 2^24 fast-division range", pl.M);
+    const size_t need = bd_conv2d_wgrad_workspace_bytes(d);
+    if (ws_bytes < need) {
+        bd_set_error("conv2d_wgrad: workspace %zu < required %zu bytes", ws_bytes, need);
+        return BD_EWORKSPACE;
+    }
+    WgradParams p{};
+    p.x = (const bf16_raw*)x; p.g = (const bf16_raw*)g; p.slab = (float*)ws;
+    p.Cin = d->Cin; p.Cout = d->Cout; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
+    p.M = (int)pl.M; p.nseg = d->nseg;
+    p.in_pix_per_img = d->in_pix_per_img; p.out_pix_per_img = d->out_pix_per_img;
+    p.ci_tiles = pl.ci_tiles; p.co_tiles = pl.co_tiles; p.splits = pl.splits;
+    p.steps_per_split = pl.steps_per_split; p.total_steps = pl.total_steps;
+    long long m = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        WSeg& sg = p.seg[s];
+        sg.m_start = (int)m;
+        sg.Ho = d->Ho[s]; sg.Wo = d->Wo[s]; sg.per_img = d->Ho[s] * d->Wo[s];
+        sg.inv_per_img = 1.0f / (float)sg.per_img; sg.inv_wo = 1.0f / (float)sg.Wo;
+        sg.Hi = d->Hi[s]; sg.Wi = d->Wi[s]; sg.in_off = d->in_off[s]; sg.out_off = d->out_off[s];
+        m += (long long)d->N * sg.per_img;
+    }
+    const int grid = pl.splits * d->R * d->S * pl.ci_tiles * pl.co_tiles;
+    const size_t lds = 4 * BKP_DEFAULT * ROW_PITCH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BKP_DEFAULT, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BKP_DEFAULT, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (g_wgrad_use_tr)
+        hipLaunchKernelGGL((conv_wgrad_kernel<BKP_DEFAULT, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<BKP_DEFAULT, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    BD_CHECK_LAUNCH("bd_conv2d_wgrad");
+    const long long n = (long long)d->Cout * d->R * d->S * d->Cin;
+    const int rblocks = (int)cdiv64(n / 4, 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
+                       pl.splits, n, d->R * d->S * d->Cin, row_scale, dw, accumulate);
+    BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
+    return BD_OK;
+}

@@ -1,0 +1,253 @@
+// Fused loss forward + gradient kernels (bf16 predictions in, bf16 gradients out, fp32 math).
+// They replace the dense one-hot target + boolean-mask gathers of the reference
+// (models/det/retinanet.py:144-162, models/det/fcos.py:146-170) by reading the int32 anchor labels directly.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float load_norm(const void* norm, int is_float) {
+    float v = is_float ? *reinterpret_cast<const float*>(norm) : (float)*reinterpret_cast<const int*>(norm);
+    return fmaxf(v, 1.f);   // F.maximum(1, num_fg)
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// sigmoid_focal_loss (layers/losses/sigmoid_focal_loss.py:30-35) + binary_cross_entropy (cross_entropy.py:26)
+__device__ __forceinline__ void focal_elem(float x, bool t, float alpha, float gamma, float& loss, float& grad) {
+    const float e = __expf(-fabsf(x));
+    const float l1p = log1pf(e);
+    const float ls_pos = fminf(x, 0.f) - l1p;     // logsigmoid(x)
+    const float ls_neg = fminf(-x, 0.f) - l1p;    // logsigmoid(-x)
+    const float inv = 1.f / (1.f + e);
+    const float p = x >= 0.f ? inv : e * inv;     // sigmoid(x)
+    const float ce = t ? -ls_pos : -ls_neg;
+    const float pt = t ? 1.f - p : p;             // t*(1-p) + (1-t)*p
+    const float a = alpha >= 0.f ? (t ? alpha : 1.f - alpha) : 1.f;
+    const float dce = p - (t ? 1.f : 0.f);
+    const float dpt = (t ? -1.f : 1.f) * p * (1.f - p);
+    float mod, dmod;
+    if (gamma == 2.f) { mod = pt * pt; dmod = 2.f * pt; }
+    else if (gamma == 0.f) { mod = 1.f; dmod = 0.f; }
+    else { mod = powf(pt, gamma); dmod = gamma * powf(pt, gamma - 1.f); }
+    loss = a * ce * mod;
+    grad = a * (dce * mod + ce * dmod * dpt);
+}
+
+__global__ __launch_bounds__(256) void focal_kernel(const bf16_raw* __restrict__ logits, const int* __restrict__ labels,
+                                                    long long rows, int K, float alpha, float gamma, const void* norm,
+                                                    int norm_is_float, float grad_scale, float* __restrict__ loss_sum,
+                                                    bf16_raw* __restrict__ dlogits) {
+    __shared__ float red[4];
+    const float inv_norm = 1.f / load_norm(norm, norm_is_float);
+    const float gs = grad_scale * inv_norm;
+    const int kv = K / 8;
+    const long long nvec = rows * kv;
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const long long row = i / kv;
+        const int c0 = (int)(i - row * kv) * 8;
+        const int lab = labels[row];
+        u32x4_t o = {0u, 0u, 0u, 0u};
+        if (lab >= 0) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(logits + i * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float l0, g0, l1, g1;
+                focal_elem(bf_lo(v[k]), lab - 1 == c0 + 2 * k, alpha, gamma, l0, g0);
+                focal_elem(bf_hi(v[k]), lab - 1 == c0 + 2 * k + 1, alpha, gamma, l1, g1);
+                acc += l0 + l1;
+                o[k] = pack_bf2(g0 * gs, g1 * gs);
+            }
+        }
+        *reinterpret_cast<u32x4_t*>(dlogits + i * 8) = o;
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s * inv_norm);
+}
+
+// smooth_l1_loss (layers/losses/smooth_l1_loss.py:26-33) on fg rows; prediction addressed as
+// pred[(row / A) * ld + (row % A) * 4 + k]; pad slots (ld/4 - A per pixel) get zero gradient.
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const bf16_raw* __restrict__ pred, const float* __restrict__ target,
+                                                        const int* __restrict__ labels, long long pixels, int A, int ld,
+                                                        float beta, const void* norm, int norm_is_float, float weight,
+                                                        float* __restrict__ loss_sum, bf16_raw* __restrict__ dpred) {
+    __shared__ float red[4];
+    const float inv_norm = 1.f / load_norm(norm, norm_is_float);
+    const float gs = weight * inv_norm;
+    const int slots = ld / 4;
+    const long long total = pixels * slots;
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / slots;
+        const int a = (int)(i - pix * slots);
+        u32x2_t o = {0u, 0u};
+        if (a < A) {
+            const long long row = pix * A + a;
+            if (labels[row] > 0) {
+                const u32x2_t pv = *reinterpret_cast<const u32x2_t*>(pred + pix * ld + a * 4);
+                const f32x4_t tv = *reinterpret_cast<const f32x4_t*>(target + row * 4);
+                const float x[4] = {bf_lo(pv[0]) - tv[0], bf_hi(pv[0]) - tv[1], bf_lo(pv[1]) - tv[2], bf_hi(pv[1]) - tv[3]};
+                float g[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ax = fabsf(x[k]);
+                    if (beta < 1e-5f) { acc += ax; g[k] = x[k] > 0.f ? 1.f : (x[k] < 0.f ? -1.f : 0.f); }
+                    else if (ax < beta) { acc += 0.5f * x[k] * x[k] / beta; g[k] = x[k] / beta; }
+                    else { acc += ax - 0.5f * beta; g[k] = x[k] > 0.f ? 1.f : -1.f; }
+                }
+                o[0] = pack_bf2(g[0] * gs, g[1] * gs);
+                o[1] = pack_bf2(g[2] * gs, g[3] * gs);
+            }
+        }
+        *reinterpret_cast<u32x2_t*>(dpred + pix * ld + a * 4) = o;
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s * gs);
+}
+
+// iou_loss(box_mode="ltrb", loss_type="giou") (layers/losses/iou_loss.py:9-56, 59-105), weighted by centerness
+__global__ __launch_bounds__(256) void giou_ltrb_kernel(const bf16_raw* __restrict__ pred, const float* __restrict__ target,
+                                                        const float* __restrict__ wgt, const int* __restrict__ labels,
+                                                        long long rows, const float* __restrict__ norm, float loss_weight,
+                                                        float* __restrict__ loss_sum, bf16_raw* __restrict__ dpred) {
+    __shared__ float red[4];
+    const float eps = 1e-8f;
+    const float gs = loss_weight / fmaxf(*norm, 1.f);
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows; i += (long long)gridDim.x * 256) {
+        u32x2_t o = {0u, 0u};
+        if (labels[i] > 0) {
+            const u32x2_t pv = *reinterpret_cast<const u32x2_t*>(pred + i * 4);
+            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(target + i * 4);
+            const float p[4] = {bf_lo(pv[0]), bf_hi(pv[0]), bf_lo(pv[1]), bf_hi(pv[1])};   // l, t, r, b
+            // areas
+            const float pw = p[0] + p[2], ph = p[1] + p[3];
+            const float pwc = fmaxf(pw, 0.f), phc = fmaxf(ph, 0.f);
+            const float a1 = pwc * phc;
+            const float a2 = fmaxf(t[0] + t[2], 0.f) * fmaxf(t[1] + t[3], 0.f);
+            // intersection
+            const float wi_raw = fminf(p[2], t[2]) + fminf(p[0], t[0]);
+            const float hi_raw = fminf(p[3], t[3]) + fminf(p[1], t[1]);
+            const float wi = fmaxf(wi_raw, 0.f), hi = fmaxf(hi_raw, 0.f);
+            const float ai = wi * hi;
+            const float au = a1 + a2 - ai;
+            const float auc = fmaxf(au, eps);
+            const float iou = ai / auc;
+            // hull
+            const float gw = fmaxf(p[2], t[2]) + fmaxf(p[0], t[0]);
+            const float gh = fmaxf(p[3], t[3]) + fmaxf(p[1], t[1]);
+            const float ac = gw * gh;
+            const float acc_ = fmaxf(ac, eps);
+            const float giou = iou - (ac - au) / acc_;
+            const float w = wgt ? wgt[i] : 1.f;
+            acc += (1.f - giou) * w;
+            // gradients w.r.t. p[k]; index k: 0 l, 1 t, 2 r, 3 b   (l,r are "x" sides, t,b are "y" sides)
+            float g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool isx = (k & 1) == 0;
+                const float da1 = isx ? (pw > 0.f ? phc : 0.f) : (ph > 0.f ? pwc : 0.f);
+                const float dmin = p[k] < t[k] ? 1.f : 0.f;                 // d min(p,t)/dp
+                const float dai = isx ? (wi_raw > 0.f ? dmin * hi : 0.f) : (hi_raw > 0.f ? dmin * wi : 0.f);
+                const float dau = da1 - dai;
+                const float dauc = au > eps ? dau : 0.f;
+                const float diou = (dai * auc - ai * dauc) / (auc * auc);
+                const float dmax = p[k] > t[k] ? 1.f : 0.f;                 // d max(p,t)/dp
+                const float dac = isx ? dmax * gh : dmax * gw;
+                const float dacc = ac > eps ? dac : 0.f;
+                const float dterm = ((dac - dau) * acc_ - (ac - au) * dacc) / (acc_ * acc_);
+                g[k] = -(diou - dterm) * w * gs;
+            }
+            o[0] = pack_bf2(g[0], g[1]);
+            o[1] = pack_bf2(g[2], g[3]);
+        }
+        *reinterpret_cast<u32x2_t*>(dpred + i * 4) = o;
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s * gs);
+}
+
+// binary_cross_entropy with logits on fg rows (layers/losses/cross_entropy.py:26)
+__global__ __launch_bounds__(256) void bce_kernel(const bf16_raw* __restrict__ pred, const float* __restrict__ target,
+                                                  const int* __restrict__ labels, long long rows, const float* __restrict__ norm,
+                                                  float* __restrict__ loss_sum, bf16_raw* __restrict__ dpred) {
+    __shared__ float red[4];
+    const float gs = 1.f / fmaxf(*norm, 1.f);
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows; i += (long long)gridDim.x * 256) {
+        float g = 0.f;
+        if (labels[i] > 0) {
+            const float x = bf2f(pred[i]), t = target[i];
+            const float e = __expf(-fabsf(x));
+            const float l1p = log1pf(e);
+            const float ls_pos = fminf(x, 0.f) - l1p, ls_neg = fminf(-x, 0.f) - l1p;
+            acc += -(t * ls_pos + (1.f - t) * ls_neg);
+            const float inv = 1.f / (1.f + e);
+            const float p = x >= 0.f ? inv : e * inv;
+            g = (p - t) * gs;
+        }
+        dpred[i] = f2bf(g);
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s * gs);
+}
+
+inline int loss_grid(long long n) {
+    long long g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    return (int)(g < 4096 ? g : 4096);
+}
+
+}  // namespace
+
+extern "C" int bd_focal_loss_fwd_bwd(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha, float gamma,
+                                     const void* norm, int norm_is_float, float grad_scale, float* loss_sum, void* dlogits,
+                                     bd_stream_t stream) {
+    BD_REQUIRE(logits && labels && norm && loss_sum && dlogits, "focal_loss: null pointer");
+    BD_REQUIRE(K > 0 && K % 8 == 0, "focal_loss: K=%d must be a multiple of 8", K);
+    if (rows == 0) return BD_OK;
+    hipLaunchKernelGGL(focal_kernel, dim3(loss_grid(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_raw*)logits, labels, (long long)rows, K, alpha, gamma, norm, norm_is_float, grad_scale,
+                       loss_sum, (bf16_raw*)dlogits);
+    BD_CHECK_LAUNCH("bd_focal_loss_fwd_bwd");
+    return BD_OK;
+}
+
+extern "C" int bd_smooth_l1_fwd_bwd(const void* pred, const float* target, const int32_t* labels, int64_t pixels, int A,
+                                    int ld, float beta, const void* norm, int norm_is_float, float weight, float* loss_sum,
+                                    void* dpred, bd_stream_t stream) {
+    BD_REQUIRE(pred && target && labels && norm && loss_sum && dpred, "smooth_l1: null pointer");
+    BD_REQUIRE(A > 0 && ld >= 4 * A && ld % 4 == 0, "smooth_l1: ld=%d must be a multiple of 4 and >= 4*A", ld);
+    if (pixels == 0) return BD_OK;
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(loss_grid(pixels * (ld / 4))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_raw*)pred, target, labels, (long long)pixels, A, ld, beta, norm, norm_is_float, weight,
+                       loss_sum, (bf16_raw*)dpred);
+    BD_CHECK_LAUNCH("bd_smooth_l1_fwd_bwd");
+    return BD_OK;
+}
+
+extern "C" int bd_giou_ltrb_fwd_bwd(const void* pred, const float* target, const float* weight, const int32_t* labels,
+                                    int64_t rows, const float* norm, float loss_weight, float* loss_sum, void* dpred,
+                                    bd_stream_t stream) {
+    BD_REQUIRE(pred && target && labels && norm && loss_sum && dpred, "giou_ltrb: null pointer");
+    if (rows == 0) return BD_OK;
+    hipLaunchKernelGGL(giou_ltrb_kernel, dim3(loss_grid(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)pred,
+                       target, weight, labels, (long long)rows, norm, loss_weight, loss_sum, (bf16_raw*)dpred);
+    BD_CHECK_LAUNCH("bd_giou_ltrb_fwd_bwd");
+    return BD_OK;
+}
+
+extern "C" int bd_bce_logits_fwd_bwd(const void* pred, const float* target, const int32_t* labels, int64_t rows,
+                                     const float* norm, float* loss_sum, void* dpred, bd_stream_t stream) {
+    BD_REQUIRE(pred && target && labels && norm && loss_sum && dpred, "bce_logits: null pointer");
+    if (rows == 0) return BD_OK;
+    hipLaunchKernelGGL(bce_kernel, dim3(loss_grid(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)pred, target,
+                       labels, (long long)rows, norm, loss_sum, (bf16_raw*)dpred);
+    BD_CHECK_LAUNCH("bd_bce_logits_fwd_bwd");
+    return BD_OK;
+}

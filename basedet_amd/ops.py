@@ -1,0 +1,247 @@
+"""Thin torch-tensor wrappers over the C ABI (include/basedet_hip.h).  torch only carries memory and the stream.
+
+Activations are "pixel-major" bf16 tensors of shape (N * pix_per_img, C) described by a `Geom`.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, EPI_ADD_AFTER, EPI_ADD_BEFORE, EPI_MASK, EPI_RELU, check, f32arr, i32arr, ptr, stream_ptr
+
+
+@dataclass
+class Geom:
+    """Pixel layout of an NHWC activation that may hold several pyramid levels per image."""
+    N: int
+    H: List[int]
+    W: List[int]
+    off: List[int] = field(default_factory=list)   # pixel offset of each level inside one image
+    pix_per_img: int = 0
+
+    def __post_init__(self):
+        if not self.off:
+            o = 0
+            self.off = []
+            for h, w in zip(self.H, self.W):
+                self.off.append(o)
+                o += h * w
+            if not self.pix_per_img:
+                self.pix_per_img = o
+        if not self.pix_per_img:
+            self.pix_per_img = sum(h * w for h, w in zip(self.H, self.W))
+
+    @property
+    def nlev(self):
+        return len(self.H)
+
+    @property
+    def pixels(self):
+        return self.N * self.pix_per_img
+
+    def level(self, i):
+        """Single-level view that keeps the parent's strides."""
+        return Geom(self.N, [self.H[i]], [self.W[i]], [self.off[i]], self.pix_per_img)
+
+    def conv_out(self, R, stride, pad):
+        H = [(h + 2 * pad - R) // stride + 1 for h in self.H]
+        W = [(w + 2 * pad - R) // stride + 1 for w in self.W]
+        return Geom(self.N, H, W)
+
+
+def single(N, H, W):
+    return Geom(N, [H], [W])
+
+
+def conv_desc(gin: Geom, gout: Geom, Cin, Cout, R, S, stride, pad) -> ConvDesc:
+    d = ConvDesc()
+    d.N, d.Cin, d.Cout, d.R, d.S, d.stride, d.pad, d.nseg = gin.N, Cin, Cout, R, S, stride, pad, gin.nlev
+    assert gin.nlev == gout.nlev <= _lib.BD_MAX_SEGS
+    for i in range(gin.nlev):
+        d.Hi[i], d.Wi[i], d.Ho[i], d.Wo[i] = gin.H[i], gin.W[i], gout.H[i], gout.W[i]
+        d.in_off[i], d.out_off[i] = gin.off[i], gout.off[i]
+    d.in_pix_per_img, d.out_pix_per_img = gin.pix_per_img, gout.pix_per_img
+    return d
+
+
+def L():
+    return _lib.load()
+
+
+# ---- dense path -------------------------------------------------------------------------------------------
+def conv2d_fwd(d, x, w_packed, bias, y, add=None, flags=0):
+    check(L().bd_conv2d_fwd(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), flags, stream_ptr()), "bd_conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(d, g, w_packed_t, dx, add=None, mask=None, flags=0):
+    check(L().bd_conv2d_dgrad(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(dx), flags, stream_ptr()), "bd_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad_workspace_bytes(d):
+    return int(L().bd_conv2d_wgrad_workspace_bytes(C.byref(d)))
+
+
+def conv2d_wgrad(d, x, g, dw, ws, row_scale=None, accumulate=False):
+    check(L().bd_conv2d_wgrad(C.byref(d), ptr(x), ptr(g), ptr(row_scale), ptr(dw), int(accumulate), ptr(ws),
+                              ws.numel() * ws.element_size(), stream_ptr()), "bd_conv2d_wgrad")
+    return dw
+
+
+def stem_conv7x7_fwd(N, H, W, x_halo, w_stem, bias, y):
+    check(L().bd_stem_conv7x7_fwd(N, H, W, ptr(x_halo), ptr(w_stem), ptr(bias), ptr(y), stream_ptr()), "bd_stem_conv7x7_fwd")
+    return y
+
+
+def stem_weight_pack(w, row_scale, w_stem):
+    check(L().bd_stem_weight_pack(ptr(w), ptr(row_scale), ptr(w_stem), stream_ptr()), "bd_stem_weight_pack")
+
+
+def weight_pack(w, row_scale, w_fwd, w_dgrad, Cout, RS, Cin):
+    check(L().bd_weight_pack(ptr(w), ptr(row_scale), ptr(w_fwd), ptr(w_dgrad), Cout, RS, Cin, stream_ptr()), "bd_weight_pack")
+
+
+def colsum_workspace_bytes(Cn):
+    return int(L().bd_colsum_workspace_bytes(Cn))
+
+
+def colsum_bf16(g, rows, Cn, out, ws, accumulate=False):
+    check(L().bd_colsum_bf16(ptr(g), rows, Cn, ptr(out), int(accumulate), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_colsum_bf16")
+    return out
+
+
+# ---- image ops --------------------------------------------------------------------------------------------
+def pad_normalize(x, Hp, Wp, mean, std, out):
+    N, _, H, W = x.shape
+    check(L().bd_pad_normalize(ptr(x), N, H, W, Hp, Wp, f32arr(mean), f32arr(std), ptr(out), stream_ptr()), "bd_pad_normalize")
+    return out
+
+
+def pad_normalize_nchw(x, Hp, Wp, mean, std, out):
+    N, _, H, W = x.shape
+    check(L().bd_pad_normalize_nchw(ptr(x), N, H, W, Hp, Wp, f32arr(mean), f32arr(std), ptr(out), stream_ptr()), "bd_pad_normalize_nchw")
+    return out
+
+
+def maxpool3x3s2_fwd(x, N, H, W, Cn, y):
+    check(L().bd_maxpool3x3s2_fwd(ptr(x), N, H, W, Cn, ptr(y), stream_ptr()), "bd_maxpool3x3s2_fwd")
+    return y
+
+
+def upsample2x_add_fwd(top, gtop: Geom, lat, glat: Geom, Cn):
+    check(L().bd_upsample2x_add_fwd(ptr(top), gtop.pix_per_img, gtop.off[0], ptr(lat), glat.pix_per_img, glat.off[0],
+                                    gtop.N, gtop.H[0], gtop.W[0], Cn, stream_ptr()), "bd_upsample2x_add_fwd")
+
+
+def upsample2x_add_bwd(dlat, glat: Geom, dtop, gtop: Geom, Cn, accumulate):
+    check(L().bd_upsample2x_add_bwd(ptr(dlat), glat.pix_per_img, glat.off[0], ptr(dtop), gtop.pix_per_img, gtop.off[0],
+                                    gtop.N, gtop.H[0], gtop.W[0], Cn, int(accumulate), stream_ptr()), "bd_upsample2x_add_bwd")
+
+
+def relu_bf16(x, y):
+    check(L().bd_relu_bf16(ptr(x), ptr(y), x.numel(), stream_ptr()), "bd_relu_bf16")
+    return y
+
+
+def relu_bwd_bf16(g, mask, y, add=None):
+    check(L().bd_relu_bwd_bf16(ptr(g), ptr(mask), ptr(add), ptr(y), g.numel(), stream_ptr()), "bd_relu_bwd_bf16")
+    return y
+
+
+def add_bf16(a, b, y):
+    check(L().bd_add_bf16(ptr(a), ptr(b), ptr(y), a.numel(), stream_ptr()), "bd_add_bf16")
+    return y
+
+
+# ---- box ops ----------------------------------------------------------------------------------------------
+def anchors_generate(H, W, stride, offset, base, out):
+    check(L().bd_anchors_generate(H, W, stride, float(offset), ptr(base), base.shape[0], ptr(out), stream_ptr()), "bd_anchors_generate")
+    return out
+
+
+def points_generate(H, W, stride, offset, A, out):
+    check(L().bd_points_generate(H, W, stride, float(offset), A, ptr(out), stream_ptr()), "bd_points_generate")
+    return out
+
+
+def box_pairwise(b1, b2, mode):
+    m, n = b1.shape[0], b2.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=b1.device)
+    check(L().bd_box_pairwise(ptr(b1), m, ptr(b2), n, mode, ptr(out), stream_ptr()), "bd_box_pairwise")
+    return out
+
+
+def box_encode(anchors, gt, mean, std):
+    out = torch.empty_like(anchors)
+    check(L().bd_box_encode(ptr(anchors), ptr(gt), anchors.shape[0], f32arr(mean), f32arr(std), ptr(out), stream_ptr()), "bd_box_encode")
+    return out
+
+
+def box_decode(anchors, deltas, mean, std):
+    out = torch.empty_like(anchors)
+    check(L().bd_box_decode(ptr(anchors), ptr(deltas), anchors.shape[0], f32arr(mean), f32arr(std), ptr(out), stream_ptr()), "bd_box_decode")
+    return out
+
+
+def retina_assign_encode(anchors, gt_boxes, num_gt, thr_lo, thr_hi, allow_lq, mean, std, labels, match_idx, offsets, num_fg, ws):
+    A = anchors.shape[0]
+    N, Gmax = gt_boxes.shape[0], gt_boxes.shape[1]
+    check(L().bd_retina_assign_encode(ptr(anchors), A, ptr(gt_boxes), ptr(num_gt), N, Gmax, float(thr_lo), float(thr_hi),
+                                      int(allow_lq), f32arr(mean), f32arr(std), ptr(labels), ptr(match_idx), ptr(offsets),
+                                      ptr(num_fg), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_retina_assign_encode")
+
+
+def fcos_assign(points, lvl_start, soi, strides, radius, gt_boxes, num_gt, labels, offsets, ctrness, stats):
+    P = points.shape[0]
+    N, Gmax = gt_boxes.shape[0], gt_boxes.shape[1]
+    Ln = len(strides)
+    soi_flat = [min(max(float(v), -3.0e38), 3.0e38) if v not in (float("inf"), float("-inf")) else v for s in soi for v in s]
+    check(L().bd_fcos_assign(ptr(points), P, i32arr(lvl_start), f32arr(soi_flat), i32arr(strides), Ln, float(radius),
+                             ptr(gt_boxes), ptr(num_gt), N, Gmax, ptr(labels), ptr(offsets), ptr(ctrness), ptr(stats),
+                             stream_ptr()), "bd_fcos_assign")
+
+
+def nms_workspace_bytes(n):
+    return int(L().bd_nms_workspace_bytes(n))
+
+
+def batched_nms(boxes, scores, idxs, iou_thresh, max_output=None):
+    n = boxes.shape[0]
+    dev = boxes.device
+    keep = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    num = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty((nms_workspace_bytes(n),), dtype=torch.uint8, device=dev)
+    check(L().bd_batched_nms(ptr(boxes), ptr(scores), ptr(idxs), n, float(iou_thresh), int(max_output or 0), ptr(keep),
+                             ptr(num), ptr(ws), ws.numel(), stream_ptr()), "bd_batched_nms")
+    return keep[: int(num.item())]
+
+
+# ---- losses -----------------------------------------------------------------------------------------------
+def focal_loss_fwd_bwd(logits, labels, rows, K, alpha, gamma, norm, grad_scale, loss_sum, dlogits):
+    check(L().bd_focal_loss_fwd_bwd(ptr(logits), ptr(labels), rows, K, float(alpha), float(gamma), ptr(norm),
+                                    int(norm.dtype == torch.float32), float(grad_scale), ptr(loss_sum), ptr(dlogits),
+                                    stream_ptr()), "bd_focal_loss_fwd_bwd")
+
+
+def smooth_l1_fwd_bwd(pred, target, labels, pixels, A, ld, beta, norm, weight, loss_sum, dpred):
+    check(L().bd_smooth_l1_fwd_bwd(ptr(pred), ptr(target), ptr(labels), pixels, A, ld, float(beta), ptr(norm),
+                                   int(norm.dtype == torch.float32), float(weight), ptr(loss_sum), ptr(dpred), stream_ptr()),
+          "bd_smooth_l1_fwd_bwd")
+
+
+def giou_ltrb_fwd_bwd(pred, target, weight, labels, rows, norm, loss_weight, loss_sum, dpred):
+    check(L().bd_giou_ltrb_fwd_bwd(ptr(pred), ptr(target), ptr(weight), ptr(labels), rows, ptr(norm), float(loss_weight),
+                                   ptr(loss_sum), ptr(dpred), stream_ptr()), "bd_giou_ltrb_fwd_bwd")
+
+
+def bce_logits_fwd_bwd(pred, target, labels, rows, norm, loss_sum, dpred):
+    check(L().bd_bce_logits_fwd_bwd(ptr(pred), ptr(target), ptr(labels), rows, ptr(norm), ptr(loss_sum), ptr(dpred),
+                                    stream_ptr()), "bd_bce_logits_fwd_bwd")
+
+
+def sgd_momentum_step(w, v, g, lr, momentum, wd, grad_scale=1.0):
+    check(L().bd_sgd_momentum_step(ptr(w), ptr(v), ptr(g), w.numel(), float(lr), float(momentum), float(wd),
+                                   float(grad_scale), stream_ptr()), "bd_sgd_momentum_step")

@@ -1,0 +1,230 @@
+/*
+ * basedet_hip.h -- flat C ABI of libbasedet_hip.so (MI355X / gfx950).
+ *
+ * The reference (megvii-research/basedet) has no FFI/plugin ABI of its own: its hot path sits behind two
+ * Python surfaces (basedet.layers / basedet.structures operator signatures, and the BaseNet/Solver protocol)
+ * and all arithmetic is delegated to MegEngine.  Each entry point below therefore cites the reference
+ * *Python call site* (file:line under basedet/) whose MegEngine kernels it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 (BD_OK) or a negative BD_E* code; bd_last_error_string() gives a thread-local message;
+ *     no C++ exception crosses the ABI.
+ *   - all pointers are caller-owned DEVICE memory unless the name ends in _host; the library never allocates or
+ *     frees user tensors.  Scratch comes from a caller-provided workspace (query with *_workspace_bytes).
+ *   - every call is asynchronous and ordered on `stream` (a hipStream_t passed as void*); no host sync inside.
+ *   - activations are NHWC bf16 ("pixel-major": element (n, y, x, c) at ((n*pix_per_img + off + y*W + x)*C + c)),
+ *     master weights/gradients are fp32 [Cout][R][S][Cin]; packed bf16 weight copies are made by bd_weight_pack.
+ *   - integer/index results (labels, match indices, NMS keep lists, anchors) are bit-exact w.r.t. oracle/box_ops.py;
+ *     these kernels are compiled with -ffp-contract=off and IEEE division.
+ */
+#ifndef BASEDET_HIP_H
+#define BASEDET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BD_OK 0
+#define BD_EINVAL (-1)     /* bad argument / unsupported shape */
+#define BD_ELAUNCH (-2)    /* HIP launch failure */
+#define BD_EWORKSPACE (-3) /* workspace too small */
+
+#define BD_MAX_SEGS 8
+
+/* epilogue flags for bd_conv2d_fwd / bd_conv2d_dgrad */
+#define BD_EPI_RELU 1            /* y = max(y, 0)                                         */
+#define BD_EPI_ADD_BEFORE 2      /* y = acc + bias + add[idx]   (residual add, then relu/mask) */
+#define BD_EPI_ADD_AFTER 4       /* y = mask(acc + bias) + add[idx]                        */
+#define BD_EPI_MASK 8            /* y = mask[idx] > 0 ? y : 0   (ReLU backward from the stored forward output) */
+
+typedef void* bd_stream_t; /* hipStream_t */
+
+/* Geometry of one convolution over up to BD_MAX_SEGS pyramid levels that share weights
+ * (RetinaNetHead applies the same convs to P3..P7: layers/head/retina_head.py:103-112).
+ * A single-level conv uses nseg = 1, in_off = out_off = 0, *_pix_per_img = H*W. */
+typedef struct bd_conv_desc {
+    int32_t N;                 /* images */
+    int32_t Cin, Cout;
+    int32_t R, S;              /* kernel height / width */
+    int32_t stride, pad;
+    int32_t nseg;
+    int32_t Hi[BD_MAX_SEGS], Wi[BD_MAX_SEGS];   /* input  size per level */
+    int32_t Ho[BD_MAX_SEGS], Wo[BD_MAX_SEGS];   /* output size per level */
+    int32_t in_off[BD_MAX_SEGS], out_off[BD_MAX_SEGS]; /* pixel offset of the level inside one image */
+    int32_t in_pix_per_img, out_pix_per_img;    /* pixel stride between images */
+} bd_conv_desc;
+
+const char* bd_last_error_string(void);
+int bd_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Dense path: convolution forward / data-gradient / weight-gradient (MFMA implicit GEMM).
+ * Replaces M.Conv2d + norm + F.relu + residual add at models/cls/resnet.py:28-52,70-113,142-146,
+ * layers/backbone/fpn_backbone.py:61-76,123-160,198-204, layers/head/retina_head.py:49-70,103-112 and
+ * their MegEngine autodiff backward (GradManager.backward, solver/default_solver.py:118-124).
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* y = epi(conv(x, w) + bias [+ add]); w_packed = [Cout][R][S][Cin] bf16 (bd_weight_pack fwd layout).
+ * Requires Cin % 8 == 0 and Cout % 4 == 0. bias may be NULL. add/mask per flags (same shape as y). */
+int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                  const void* add, void* y, int flags, bd_stream_t stream);
+
+/* dx = epi(conv_transpose(g, w) [+ add]) ; w_packed_t = [Cin][R][S][Cout] bf16 (bd_weight_pack dgrad layout).
+ * g has the conv's OUTPUT geometry, dx/add/mask the INPUT geometry. Requires Cout % 8 == 0, Cin % 4 == 0. */
+int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add,
+                    const void* mask, void* dx, int flags, bd_stream_t stream);
+
+/* dw[Cout][R][S][Cin] (fp32) = sum over pixels g^T x, times row_scale[Cout] (NULL = 1); split over pixels with
+ * fp32 partial slabs in ws, reduced in a fixed order (bitwise reproducible).  accumulate != 0 adds to dw. */
+size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d);
+int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
+                    int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
+
+/* debug/measurement knob: 1 (default) = operand transposes through ds_read_b64_tr_b16, 0 = scalar 16-bit LDS reads
+ * (slow reference path used by the parity tests to validate the transposing read). */
+int bd_wgrad_set_transpose_read(int use_tr);
+
+/* ResNet stem: 7x7/2 pad 3 conv (3->64) + folded FrozenBN + ReLU (models/cls/resnet.py:142-146,238-240).
+ * x_halo: bf16 [N][H+6][W+8][4] as written by bd_pad_normalize (zero halo, channel 3 = 0);
+ * w_stem: bf16 [64][7][8][4] as written by bd_stem_weight_pack; y: bf16 NHWC [N][H/2][W/2][64]. */
+int bd_stem_conv7x7_fwd(int N, int H, int W, const void* x_halo, const void* w_stem, const float* bias,
+                        void* y, bd_stream_t stream);
+int bd_stem_weight_pack(const float* w /*[64][7][7][3] fp32*/, const float* row_scale, void* w_stem,
+                        bd_stream_t stream);
+
+/* fp32 master [Cout][R*S][Cin] (* row_scale[Cout] if non-NULL) -> bf16 fwd layout [Cout][RS][Cin] and
+ * bf16 dgrad layout [Cin][RS][Cout] (either output may be NULL). */
+int bd_weight_pack(const float* w, const float* row_scale, void* w_fwd, void* w_dgrad, int Cout, int RS,
+                   int Cin, bd_stream_t stream);
+
+/* column sums of a bf16 [rows][C] matrix into fp32 out[C] (bias gradients); accumulate != 0 adds.
+ * C % 8 == 0, C <= 2048; two-stage fixed-order reduction through ws (bitwise reproducible). */
+size_t bd_colsum_workspace_bytes(int C);
+int bd_colsum_bf16(const void* g, int64_t rows, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
+                   bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Memory-bound image ops.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* layers/common/pre_processing.py:11-49 (data_to_input/get_padded_tensor): zero-pad (top-left aligned) to
+ * (Hp, Wp), THEN (x-mean)/std, so the pad region holds -mean/std.  in: fp32 NCHW [N][3][H][W].
+ * out: bf16 [N][Hp+6][Wp+8][4] with a zero halo of 3 rows / 4 columns and channel 3 = 0 (stem layout). */
+int bd_pad_normalize(const float* in, int N, int H, int W, int Hp, int Wp, const float* mean3,
+                     const float* std3, void* out, bd_stream_t stream);
+/* same arithmetic, fp32 NCHW output [N][3][Hp][Wp] (parity checks of the reference semantics). */
+int bd_pad_normalize_nchw(const float* in, int N, int H, int W, int Hp, int Wp, const float* mean3,
+                          const float* std3, float* out, bd_stream_t stream);
+
+/* M.MaxPool2d(3, 2, 1) (models/cls/resnet.py:146) on NHWC bf16. */
+int bd_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, void* y, bd_stream_t stream);
+
+/* FPN top-down merge (fpn_backbone.py:143-148): lateral[n,y,x,c] += bilinear_up2x(top)[n,y,x,c]
+ * (align_corners=False, border-clamped). top: [N][H][W][C]; lateral: [N][2H][2W][C] with pixel addressing
+ * (n*lat_pix_per_img + lat_off + y*2W + x). */
+int bd_upsample2x_add_fwd(const void* top, int64_t top_pix_per_img, int64_t top_off, void* lateral,
+                          int64_t lat_pix_per_img, int64_t lat_off, int N, int H, int W, int C,
+                          bd_stream_t stream);
+/* gradient of the above w.r.t. top: dtop[n,y,x,c] (+)= sum_w dlat * w. accumulate != 0 adds into dtop. */
+int bd_upsample2x_add_bwd(const void* dlat, int64_t lat_pix_per_img, int64_t lat_off, void* dtop,
+                          int64_t top_pix_per_img, int64_t top_off, int N, int H, int W, int C,
+                          int accumulate, bd_stream_t stream);
+
+/* elementwise helpers on bf16 buffers of n elements (n % 8 == 0) */
+int bd_relu_bf16(const void* x, void* y, int64_t n, bd_stream_t stream);
+/* y = (mask > 0 ? g : 0) [+ add] */
+int bd_relu_bwd_bf16(const void* g, const void* mask, const void* add, void* y, int64_t n, bd_stream_t stream);
+int bd_add_bf16(const void* a, const void* b, void* y, int64_t n, bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Box operators (basedet.layers / basedet.structures).
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* DefaultAnchorGenerator (layers/common/anchor_generator.py:111-122): out[(i*W+j)*A+a] =
+ * (x,y,x,y)+base[a], x = offset*stride + j*stride.  base: fp32 [A][4] (host-computed in float64, :99-109). */
+int bd_anchors_generate(int H, int W, int stride, float offset, const float* base, int A, float* out,
+                        bd_stream_t stream);
+/* AnchorPointGenerator (anchor_generator.py:152-165): out[(i*W+j)*A+a] = (x, y). */
+int bd_points_generate(int H, int W, int stride, float offset, int A, float* out, bd_stream_t stream);
+
+/* structures/op_patch.py:33-97 (IOU), :170-227 (IOA), structures/boxes.py:74-95 (giou), :114-130
+ * (intersection).  mode: 0 iou, 1 ioa, 2 intersection, 3 giou.  b1 [m][4], b2 [n][4], out [m][n], fp32. */
+int bd_box_pairwise(const float* b1, int m, const float* b2, int n, int mode, float* out, bd_stream_t stream);
+
+/* BoxCoder.encode/decode (structures/boxcoder.py:61-98) with mean/std[4]; rows independent. */
+int bd_box_encode(const float* anchors, const float* gt, int64_t n, const float* mean4_host,
+                  const float* std4_host, float* out, bd_stream_t stream);
+int bd_box_decode(const float* anchors, const float* deltas, int64_t n, const float* mean4_host,
+                  const float* std4_host, float* out, bd_stream_t stream);
+
+/* RetinaNet.get_ground_truth (models/det/retinanet.py:211-232) for a whole batch in two launches:
+ * IoU (op_patch.py:33-97) -> Matcher (layers/common/matcher.py:31-51, thresholds lo/hi, low-quality rule)
+ * -> labels[fg] = class -> BoxCoder.encode of the matched gt for every anchor.
+ * gt_boxes [N][Gmax][5] (x1,y1,x2,y2,class 1-based), num_gt [N] int32, anchors [A][4].
+ * labels/match_idx [N][A] int32, offsets [N][A][4] fp32, num_fg: int32[1] (sum over the batch, zeroed inside).
+ * ws: N*Gmax floats (per-gt max IoU). argmax tie-break: lowest gt index. */
+int bd_retina_assign_encode(const float* anchors, int A, const float* gt_boxes, const int32_t* num_gt, int N,
+                            int Gmax, float thr_lo, float thr_hi, int allow_low_quality,
+                            const float* mean4_host, const float* std4_host, int32_t* labels,
+                            int32_t* match_idx, float* offsets, int32_t* num_fg, void* ws, size_t ws_bytes,
+                            bd_stream_t stream);
+
+/* FCOS.get_ground_truth (models/det/fcos.py:222-293). points [P][2]; level_of_point via lvl_start[L+1];
+ * soi [L][2]; strides [L] (host arrays). labels [N][P] int32, offsets [N][P][4], ctrness [N][P];
+ * stats[0] = num_fg, stats[1] = sum of centerness over fg (fp32, zeroed inside). */
+int bd_fcos_assign(const float* points, int P, const int32_t* lvl_start_host, const float* soi_host,
+                   const int32_t* strides_host, int L, float radius, const float* gt_boxes,
+                   const int32_t* num_gt, int N, int Gmax, int32_t* labels, float* offsets, float* ctrness,
+                   float* stats, bd_stream_t stream);
+
+/* layers/common/post_processing.py:17-47 batched_nms (class-offset trick + greedy NMS, suppress iff IoU > thr).
+ * boxes [n][4], scores [n], idxs [n] (may be NULL = plain NMS).  keep: int32[n] (descending score order),
+ * num_keep: int32[1].  max_output <= 0 means unlimited.  ws from bd_nms_workspace_bytes(n). */
+size_t bd_nms_workspace_bytes(int n);
+int bd_batched_nms(const float* boxes, const float* scores, const int32_t* idxs, int n, float iou_thresh,
+                   int max_output, int32_t* keep, int32_t* num_keep, void* ws, size_t ws_bytes,
+                   bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Losses: fused forward value + gradient w.r.t. the prediction (bf16 in / bf16 grad out).
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* sigmoid_focal_loss (layers/losses/sigmoid_focal_loss.py:9-36) as used at models/det/retinanet.py:148-156:
+ * rows with label < 0 ignored, one-hot column = label-1 for label > 0; loss_sum[0] += sum(loss) / max(1,num_fg),
+ * dlogits = dloss/dlogit * grad_scale / max(1,num_fg).  norm: device float/int scalar holding num_fg
+ * (norm_is_float selects the type).  logits/dlogits bf16 [rows][K]. */
+int bd_focal_loss_fwd_bwd(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha,
+                          float gamma, const void* norm, int norm_is_float, float grad_scale,
+                          float* loss_sum, void* dlogits, bd_stream_t stream);
+
+/* smooth_l1_loss (layers/losses/smooth_l1_loss.py:7-34) over rows with label > 0 (retinanet.py:158-162).
+ * Row r = pixel*A + a; pred/dpred are bf16 with `ld` channels per pixel (ld >= 4*A, ld % 4 == 0), element
+ * (r, k) at pixel*ld + a*4 + k; pad channels of dpred are written as zero.  target fp32 [rows][4]. */
+int bd_smooth_l1_fwd_bwd(const void* pred, const float* target, const int32_t* labels, int64_t pixels, int A,
+                         int ld, float beta, const void* norm, int norm_is_float, float weight, float* loss_sum,
+                         void* dpred, bd_stream_t stream);
+
+/* iou_loss(box_mode="ltrb", loss_type="giou") * ctrness weight (layers/losses/iou_loss.py:9-105,
+ * models/det/fcos.py:157-164); norm = max(1, sum_ctr). */
+int bd_giou_ltrb_fwd_bwd(const void* pred, const float* target, const float* weight, const int32_t* labels,
+                         int64_t rows, const float* norm, float loss_weight, float* loss_sum, void* dpred,
+                         bd_stream_t stream);
+
+/* binary_cross_entropy with logits over fg rows (layers/losses/cross_entropy.py:7-29, fcos.py:166-170). */
+int bd_bce_logits_fwd_bwd(const void* pred, const float* target, const int32_t* labels, int64_t rows,
+                          const float* norm, float* loss_sum, void* dpred, bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Optimizer (megengine.optimizer.SGD as configured at solver/default_solver.py:96-114).
+ * g' = g*grad_scale + wd*w ; v = momentum*v + g' ; w -= lr*v   (all fp32, n elements)
+ * ------------------------------------------------------------------------------------------------------- */
+int bd_sgd_momentum_step(float* w, float* v, const float* g, int64_t n, float lr, float momentum, float wd,
+                         float grad_scale, bd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASEDET_HIP_H */

@@ -1,0 +1,199 @@
+"""CPU ORACLE (test infrastructure only) -- torch-CPU fp32 restatement of the reference's
+RetinaNet / FCOS training step (backbone + FPN + head + target assignment + losses + SGD).
+
+NOT part of the product path: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this.  PARITY UNPINNED: the reference's model tests assert no values
+(tests/models/test_retinanet.py:18-31) and megengine/basecore cannot be imported here, so this
+restatement (with the documented choices below) is the only oracle for conv/loss values.
+
+Documented choices where the reference delegates to un-vendored code:
+  * FrozenBN (basecore ``get_norm("FrozenBN")``, layers/backbone/build.py:23): y = x*scale + shift with
+    scale = weight / sqrt(running_var + 1e-5), shift = bias - running_mean*scale; no gradients.
+  * ``F.nn.interpolate(scale_factor=2, mode="BILINEAR")`` (fpn_backbone.py:143): align_corners=False,
+    source index clamped at the border (PyTorch semantics).
+  * SGD (megengine.optimizer.SGD): g' = g + wd*w; v = momentum*v + g'; w -= lr*v.
+Parameters are passed in as a dict name -> numpy array, names follow the reference's state_dict
+(``backbone.bottom_up.layer2.0.conv1.weight`` ...), conv weights OIHW, 1-D bias/BN vectors.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+from . import box_ops
+
+BN_EPS = 1e-5
+
+RESNET_SPECS = {
+    "resnet18": ("basic", [2, 2, 2, 2]),
+    "resnet34": ("basic", [3, 4, 6, 3]),
+    "resnet50": ("bottleneck", [3, 4, 6, 3]),
+    "resnet101": ("bottleneck", [3, 4, 23, 3]),
+}
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).float()
+
+
+class Oracle:
+    """Functional model over a parameter dict.  ``trainable`` names get requires_grad."""
+
+    def __init__(self, params, arch, trainable=()):
+        self.arch = dict(arch)
+        self.p = {}
+        tset = set(trainable)
+        for k, v in params.items():
+            t = _t(v).clone()
+            if k in tset:
+                t.requires_grad_(True)
+            self.p[k] = t
+        self.trainable = [k for k in params if k in tset]
+
+    # ---- primitives -------------------------------------------------------------------------
+    def _bn(self, x, prefix):
+        p = self.p
+        scale = p[prefix + ".weight"] / torch.sqrt(p[prefix + ".running_var"] + BN_EPS)
+        shift = p[prefix + ".bias"] - p[prefix + ".running_mean"] * scale
+        return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+
+    def _conv(self, x, name, stride=1, pad=0):
+        b = self.p.get(name + ".bias")
+        return TF.conv2d(x, self.p[name + ".weight"], b, stride=stride, padding=pad)
+
+    # ---- backbone (models/cls/resnet.py) -----------------------------------------------------
+    def _bottleneck(self, x, pre, stride, has_ds):
+        idt = x
+        y = TF.relu(self._bn(self._conv(x, pre + ".conv1"), pre + ".bn1"))
+        y = TF.relu(self._bn(self._conv(y, pre + ".conv2", stride, 1), pre + ".bn2"))   # stride on the 3x3 (:72-81)
+        y = self._bn(self._conv(y, pre + ".conv3"), pre + ".bn3")
+        if has_ds:
+            idt = self._bn(self._conv(x, pre + ".downsample.0", stride), pre + ".downsample.1")
+        return TF.relu(y + idt)
+
+    def _basic(self, x, pre, stride, has_ds):
+        idt = x
+        y = TF.relu(self._bn(self._conv(x, pre + ".conv1", stride, 1), pre + ".bn1"))
+        y = self._bn(self._conv(y, pre + ".conv2", 1, 1), pre + ".bn2")
+        if has_ds:
+            idt = self._bn(self._conv(x, pre + ".downsample.0", stride), pre + ".downsample.1")
+        return TF.relu(y + idt)
+
+    def backbone(self, x):
+        """ResNet.extract_features (resnet.py:236-252)."""
+        bu = "backbone.bottom_up"
+        kind, layers = RESNET_SPECS[self.arch["backbone"]]
+        x = TF.relu(self._bn(self._conv(x, bu + ".conv1", 2, 3), bu + ".bn1"))
+        x = TF.max_pool2d(x, 3, 2, 1)
+        outs = {"stem": x}
+        block = self._bottleneck if kind == "bottleneck" else self._basic
+        for li, nblk in enumerate(layers):
+            for b in range(nblk):
+                stride = 2 if (b == 0 and li > 0) else 1
+                has_ds = (bu + f".layer{li + 1}.{b}.downsample.0.weight") in self.p
+                x = block(x, bu + f".layer{li + 1}.{b}", stride, has_ds)
+            outs[f"res{li + 2}"] = x
+        return outs
+
+    def fpn(self, feats):
+        """FPN.forward + LastLevelP6P7 (fpn_backbone.py:123-160, 198-204)."""
+        names = self.arch.get("fpn_in", ["res3", "res4", "res5"])
+        stages = [int(n[-1]) for n in names]
+        x = [feats[n] for n in names[::-1]]
+        st = stages[::-1]
+        prev = self._conv(x[0], f"backbone.fpn_lateral{st[0]}")
+        results = [self._conv(prev, f"backbone.fpn_output{st[0]}", 1, 1)]
+        for f, s in zip(x[1:], st[1:]):
+            td = TF.interpolate(prev, scale_factor=2, mode="bilinear", align_corners=False)
+            prev = self._conv(f, f"backbone.fpn_lateral{s}") + td
+            results.insert(0, self._conv(prev, f"backbone.fpn_output{s}", 1, 1))
+        p6 = self._conv(feats["res5"], "backbone.top_block.p6", 2, 1)
+        p7 = self._conv(TF.relu(p6), "backbone.top_block.p7", 2, 1)
+        return results + [p6, p7]
+
+    # ---- heads --------------------------------------------------------------------------------
+    def retina_head(self, feats):
+        """RetinaNetHead.forward (retina_head.py:103-112); Sequential indices 0,2,4,6 are the convs."""
+        logits, offsets = [], []
+        nconv = self.arch.get("num_convs", 4)
+        for f in feats:
+            c = f
+            b = f
+            for i in range(nconv):
+                c = TF.relu(self._conv(c, f"head.cls_subnet.{2 * i}", 1, 1))
+                b = TF.relu(self._conv(b, f"head.bbox_subnet.{2 * i}", 1, 1))
+            logits.append(self._conv(c, "head.cls_score", 1, 1))
+            offsets.append(self._conv(b, "head.bbox_pred", 1, 1))
+        return logits, offsets
+
+    @staticmethod
+    def _permute(t, K):
+        """permute_to_N_Any_K (layers/common/function.py:26-32)."""
+        n = t.shape[0]
+        return t.permute(0, 2, 3, 1).reshape(n, -1, K)
+
+    # ---- RetinaNet.get_losses (models/det/retinanet.py:120-170) --------------------------------
+    def retinanet_forward(self, image):
+        feats = self.fpn(self.backbone(image))
+        logits, offsets = self.retina_head(feats)
+        K = self.arch["num_classes"]
+        logits = torch.cat([self._permute(x, K) for x in logits], dim=1)
+        offsets = torch.cat([self._permute(x, 4) for x in offsets], dim=1)
+        sizes = [tuple(f.shape[-2:]) for f in feats]
+        return logits, offsets, sizes, feats
+
+    def retinanet_losses(self, batch):
+        a = self.arch
+        image = _t(box_ops.data_to_input(batch["data"], a["img_mean"], a["img_std"]))
+        logits, offsets, sizes, _ = self.retinanet_forward(image)
+        anchors = np.concatenate(box_ops.default_anchors(sizes, a["strides"], a["anchor_scales"], a["anchor_ratios"], a["anchor_offset"]), 0)
+        num_valid = np.asarray(batch["im_info"])[:, 4].astype(np.int32)
+        labels, gt_off, _ = box_ops.retinanet_ground_truth(anchors, batch["gt_boxes"], num_valid)
+        K = a["num_classes"]
+        logits = logits.reshape(-1, K)
+        offsets = offsets.reshape(-1, 4)
+        labels_t = torch.from_numpy(labels.reshape(-1)).long()
+        gt_off_t = _t(gt_off.reshape(-1, 4))
+        valid = labels_t >= 0
+        fg = labels_t > 0
+        num_fg = int(fg.sum())
+        tgt = torch.zeros_like(logits)
+        tgt[fg, labels_t[fg] - 1] = 1
+        x = logits[valid]
+        t = tgt[valid]
+        p = torch.sigmoid(x)
+        ce = -(t * TF.logsigmoid(x) + (1 - t) * TF.logsigmoid(-x))
+        fl = ce * (t * (1 - p) + (1 - t) * p) ** a.get("focal_gamma", 2.0)
+        al = a.get("focal_alpha", 0.25)
+        fl = fl * (t * al + (1 - t) * (1 - al))
+        cls_loss = fl.sum() / max(1, num_fg)
+        d = offsets[fg] - gt_off_t[fg]
+        beta = a.get("smooth_l1_beta", 0.0)
+        if beta < 1e-5:
+            l1 = d.abs()
+        else:
+            l1 = torch.where(d.abs() < beta, 0.5 * d ** 2 / beta, d.abs() - 0.5 * beta)
+        reg_loss = l1.sum() / max(1, num_fg) * a.get("reg_loss_weight", 1.0)
+        total = cls_loss + reg_loss
+        return {"total_loss": total, "cls_loss": cls_loss, "reg_loss": reg_loss}, {
+            "labels": labels, "gt_offsets": gt_off, "anchors": anchors, "logits": logits, "offsets": offsets, "num_fg": num_fg}
+
+    # ---- one training step: backward + SGD (solver/default_solver.py:96-124) --------------------
+    def grads(self, loss):
+        ps = [self.p[k] for k in self.trainable]
+        gs = torch.autograd.grad(loss, ps, allow_unused=True)
+        return {k: (g if g is not None else torch.zeros_like(p)) for k, g, p in zip(self.trainable, gs, ps)}
+
+    def sgd_step(self, grads, state, lr, momentum=0.9, weight_decay=1e-4):
+        with torch.no_grad():
+            for k in self.trainable:
+                w = self.p[k]
+                g = grads[k] + weight_decay * w
+                v = state.get(k)
+                v = g.clone() if v is None else momentum * v + g
+                state[k] = v
+                w -= lr * v
+        return state
+
+
+def bilinear_up2(x):
+    return TF.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)

@@ -1,0 +1,225 @@
+"""GPU parity: MFMA implicit-GEMM conv forward / dgrad / wgrad + stem vs a torch-CPU fp32 reference evaluated
+on the same bf16-rounded operands.  Tolerance: rel-L2 <= 1e-2 (bf16 output rounding ~4e-3), stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from tests.util import bf16_round, nchw_to_pm, pm_to_nchw, oihw_to_ohwi, rel_l2, pack_weights
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-2
+
+
+def _ops():
+    from basedet_amd import ops
+    return ops
+
+
+CASES = [
+    # N, Cin, Cout, H, W, R, stride, pad
+    (2, 64, 64, 20, 28, 1, 1, 0),
+    (2, 64, 256, 17, 23, 1, 1, 0),
+    (1, 256, 128, 24, 20, 3, 1, 1),
+    (2, 128, 128, 26, 30, 3, 2, 1),
+    (2, 256, 512, 16, 18, 1, 2, 0),
+    (1, 256, 720, 13, 21, 3, 1, 1),     # ragged Cout tile (cls_score)
+    (1, 256, 40, 13, 21, 3, 1, 1),      # padded bbox_pred
+    (3, 32, 64, 9, 11, 3, 1, 1),        # BK=32 path
+    (1, 2048, 256, 25, 42, 3, 2, 1),    # P6 conv
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    ops = _ops()
+    N, Cin, Cout, H, W, R, stride, pad = case
+    g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
+    x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
+    w = bf16_round(torch.randn(Cout, Cin, R, R, generator=g) / np.sqrt(Cin * R * R))
+    bias = torch.randn(Cout, generator=g)
+    gin = ops.single(N, H, W)
+    gout = gin.conv_out(R, stride, pad)
+    Ho, Wo = gout.H[0], gout.W[0]
+    d = ops.conv_desc(gin, gout, Cin, Cout, R, R, stride, pad)
+    wf, wd = pack_weights(ops, w)
+    xp = nchw_to_pm(x)
+    # ---- forward: bias + residual add + relu
+    res = bf16_round(torch.randn(N, Cout, Ho, Wo, generator=g))
+    y = torch.empty((gout.pixels, Cout), dtype=torch.bfloat16, device="cuda")
+    ops.conv2d_fwd(d, xp, wf, bias.cuda(), y, add=nchw_to_pm(res), flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE)
+    ref = TF.relu(TF.conv2d(x, w, bias, stride=stride, padding=pad) + res)
+    got = pm_to_nchw(y, N, Ho, Wo)
+    assert rel_l2(got, ref) < TOL
+    # plain
+    ops.conv2d_fwd(d, xp, wf, None, y)
+    ref = TF.conv2d(x, w, None, stride=stride, padding=pad)
+    assert rel_l2(pm_to_nchw(y, N, Ho, Wo), ref) < TOL
+    # ---- dgrad with add_before + mask
+    gy = bf16_round(torch.randn(N, Cout, Ho, Wo, generator=g))
+    addt = bf16_round(torch.randn(N, Cin, H, W, generator=g))
+    maskt = bf16_round(torch.randn(N, Cin, H, W, generator=g))
+    dx = torch.empty((gin.pixels, Cin), dtype=torch.bfloat16, device="cuda")
+    ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, dx, add=nchw_to_pm(addt), mask=nchw_to_pm(maskt), flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
+    xr = x.clone().requires_grad_(True)
+    TF.conv2d(xr, w, None, stride=stride, padding=pad).backward(gy)
+    ref = (xr.grad + addt) * (maskt > 0)
+    assert rel_l2(pm_to_nchw(dx, N, H, W), ref) < TOL
+    # add_after variant
+    ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, dx, add=nchw_to_pm(addt), mask=nchw_to_pm(maskt), flags=ops.EPI_ADD_AFTER | ops.EPI_MASK)
+    ref = xr.grad * (maskt > 0) + addt
+    assert rel_l2(pm_to_nchw(dx, N, H, W), ref) < TOL
+    # ---- wgrad (transposing LDS read and the scalar-read fallback must agree with the reference)
+    wr = w.clone().requires_grad_(True)
+    TF.conv2d(x, wr, None, stride=stride, padding=pad).backward(gy)
+    ref_dw = oihw_to_ohwi(wr.grad)
+    ws = torch.empty((ops.conv2d_wgrad_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
+    scale = torch.rand(Cout, generator=g) + 0.5
+    for use_tr in (0, 1):
+        ops.L().bd_wgrad_set_transpose_read(use_tr)
+        dw = torch.full((Cout, R, R, Cin), 7.0, dtype=torch.float32, device="cuda")
+        ops.conv2d_wgrad(d, xp, nchw_to_pm(gy), dw, ws)
+        assert rel_l2(dw.cpu(), ref_dw) < 2e-3, f"use_tr={use_tr}"
+        ops.conv2d_wgrad(d, xp, nchw_to_pm(gy), dw, ws, row_scale=scale.cuda(), accumulate=True)
+        assert rel_l2(dw.cpu(), ref_dw * (1 + scale.view(-1, 1, 1, 1))) < 2e-3
+    ops.L().bd_wgrad_set_transpose_read(1)
+
+
+def test_conv_multilevel_head_layout():
+    """Five pyramid levels through one launch (RetinaNetHead weight sharing, retina_head.py:103-112)."""
+    ops = _ops()
+    N, C, Cout = 2, 64, 72
+    Hs, Ws = [12, 6, 3, 2, 1], [20, 10, 5, 3, 2]
+    g = torch.Generator().manual_seed(7)
+    geo = ops.Geom(N, Hs, Ws)
+    w = bf16_round(torch.randn(Cout, C, 3, 3, generator=g) / 24)
+    bias = torch.randn(Cout, generator=g)
+    wf, wd = pack_weights(ops, w)
+    xs = [bf16_round(torch.randn(N, C, h, ww, generator=g)) for h, ww in zip(Hs, Ws)]
+    xp = torch.empty((geo.pixels, C), dtype=torch.bfloat16, device="cuda")
+    xv = xp.view(N, geo.pix_per_img, C)
+    for i, x in enumerate(xs):
+        xv[:, geo.off[i]: geo.off[i] + Hs[i] * Ws[i]] = x.permute(0, 2, 3, 1).reshape(N, -1, C).to(torch.bfloat16).cuda()
+    d = ops.conv_desc(geo, geo, C, Cout, 3, 3, 1, 1)
+    y = torch.empty((geo.pixels, Cout), dtype=torch.bfloat16, device="cuda")
+    ops.conv2d_fwd(d, xp, wf, bias.cuda(), y, flags=ops.EPI_RELU)
+    yv = y.view(N, geo.pix_per_img, Cout).float().cpu()
+    gys = []
+    for i, x in enumerate(xs):
+        ref = TF.relu(TF.conv2d(x, w, bias, padding=1))
+        got = yv[:, geo.off[i]: geo.off[i] + Hs[i] * Ws[i]].reshape(N, Hs[i], Ws[i], Cout).permute(0, 3, 1, 2)
+        assert rel_l2(got, ref) < TOL, f"level {i}"
+    # wgrad + dgrad over all levels at once
+    gy = bf16_round(torch.randn(N, geo.pix_per_img, Cout, generator=g))
+    gyp = gy.reshape(-1, Cout).to(torch.bfloat16).cuda()
+    ws = torch.empty((ops.conv2d_wgrad_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
+    dw = torch.empty((Cout, 3, 3, C), dtype=torch.float32, device="cuda")
+    ops.conv2d_wgrad(d, xp, gyp, dw, ws)
+    dx = torch.empty((geo.pixels, C), dtype=torch.bfloat16, device="cuda")
+    ops.conv2d_dgrad(d, gyp, wd, dx)
+    ref_dw = torch.zeros(Cout, C, 3, 3)
+    dxv = dx.view(N, geo.pix_per_img, C).float().cpu()
+    for i, x in enumerate(xs):
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        gl = gy[:, geo.off[i]: geo.off[i] + Hs[i] * Ws[i]].reshape(N, Hs[i], Ws[i], Cout).permute(0, 3, 1, 2)
+        TF.conv2d(xr, wr, None, padding=1).backward(gl)
+        ref_dw += wr.grad
+        got = dxv[:, geo.off[i]: geo.off[i] + Hs[i] * Ws[i]].reshape(N, Hs[i], Ws[i], C).permute(0, 3, 1, 2)
+        assert rel_l2(got, xr.grad) < TOL, f"dgrad level {i}"
+    assert rel_l2(dw.cpu(), oihw_to_ohwi(ref_dw)) < 2e-3
+
+
+def test_stem_conv_and_pad_normalize():
+    """bd_pad_normalize + bd_stem_conv7x7_fwd + bd_maxpool3x3s2_fwd vs conv1/bn1/relu/maxpool (resnet.py:236-241)."""
+    ops = _ops()
+    N, H, W = 2, 50, 70   # pads to 64 x 96
+    Hp, Wp = 64, 96
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(N, 3, H, W, generator=g) * 255
+    mean, std = [103.530, 116.280, 123.675], [57.375, 57.12, 58.395]
+    xh = torch.empty((N, Hp + 6, Wp + 8, 4), dtype=torch.bfloat16, device="cuda")
+    ops.pad_normalize(img.cuda(), Hp, Wp, mean, std, xh)
+    from oracle import box_ops
+    xo = torch.from_numpy(box_ops.data_to_input(img.numpy(), mean, std))
+    # exact fp32 semantics through the NCHW variant (bit-exact: same (x-mean)/std in fp32)
+    xn = torch.empty((N, 3, Hp, Wp), dtype=torch.float32, device="cuda")
+    ops.pad_normalize_nchw(img.cuda(), Hp, Wp, mean, std, xn)
+    assert torch.equal(xn.cpu(), xo)
+    inner = xh[:, 3:3 + Hp, 4:4 + Wp, :3].float().cpu().permute(0, 3, 1, 2)
+    assert torch.equal(inner, bf16_round(xo))
+    assert float(xh[:, :3].float().abs().max()) == 0 and float(xh[:, :, :4].float().abs().max()) == 0
+    assert float(xh[..., 3].float().abs().max()) == 0
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.1
+    wst = torch.empty((64, 7, 8, 4), dtype=torch.bfloat16, device="cuda")
+    ops.stem_weight_pack(oihw_to_ohwi(w).cuda(), scale.cuda(), wst)
+    y = torch.empty((N * (Hp // 2) * (Wp // 2), 64), dtype=torch.bfloat16, device="cuda")
+    ops.stem_conv7x7_fwd(N, Hp, Wp, xh, wst, shift.cuda(), y)
+    weff = bf16_round(w * scale.view(-1, 1, 1, 1))
+    ref = TF.relu(TF.conv2d(bf16_round(xo), weff, shift, stride=2, padding=3))
+    got = pm_to_nchw(y, N, Hp // 2, Wp // 2)
+    assert rel_l2(got, ref) < TOL
+    p = torch.empty((N * (Hp // 4) * (Wp // 4), 64), dtype=torch.bfloat16, device="cuda")
+    ops.maxpool3x3s2_fwd(y, N, Hp // 2, Wp // 2, 64, p)
+    refp = TF.max_pool2d(got, 3, 2, 1)
+    assert torch.equal(pm_to_nchw(p, N, Hp // 4, Wp // 4), refp)
+
+
+def test_upsample_add_fwd_bwd():
+    """FPN top-down merge (fpn_backbone.py:143-148) and its gradient."""
+    ops = _ops()
+    N, C, H, W = 2, 16, 5, 7
+    g = torch.Generator().manual_seed(5)
+    top = bf16_round(torch.randn(N, C, H, W, generator=g))
+    lat = bf16_round(torch.randn(N, C, 2 * H, 2 * W, generator=g))
+    gt_, gl_ = ops.single(N, H, W), ops.single(N, 2 * H, 2 * W)
+    latp = nchw_to_pm(lat)
+    ops.upsample2x_add_fwd(nchw_to_pm(top), gt_, latp, gl_, C)
+    ref = lat + TF.interpolate(top, scale_factor=2, mode="bilinear", align_corners=False)
+    assert rel_l2(pm_to_nchw(latp, N, 2 * H, 2 * W), ref) < 5e-3
+    dl = bf16_round(torch.randn(N, C, 2 * H, 2 * W, generator=g))
+    tr = top.clone().requires_grad_(True)
+    TF.interpolate(tr, scale_factor=2, mode="bilinear", align_corners=False).backward(dl)
+    prev = bf16_round(torch.randn(N, C, H, W, generator=g))
+    dt = nchw_to_pm(prev)
+    ops.upsample2x_add_bwd(nchw_to_pm(dl), gl_, dt, gt_, C, accumulate=True)
+    assert rel_l2(pm_to_nchw(dt, N, H, W), prev + tr.grad) < 5e-3
+    ops.upsample2x_add_bwd(nchw_to_pm(dl), gl_, dt, gt_, C, accumulate=False)
+    assert rel_l2(pm_to_nchw(dt, N, H, W), tr.grad) < 5e-3
+
+
+def test_elementwise_pack_colsum_sgd():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    a = bf16_round(torch.randn(4096, generator=g)); b = bf16_round(torch.randn(4096, generator=g)); c = bf16_round(torch.randn(4096, generator=g))
+    ad, bd_, cd = (t.to(torch.bfloat16).cuda() for t in (a, b, c))
+    y = torch.empty_like(ad)
+    assert torch.equal(ops.relu_bf16(ad, y).float().cpu(), a.clamp(min=0))
+    assert torch.equal(ops.add_bf16(ad, bd_, y).float().cpu(), bf16_round(a + b))
+    assert torch.equal(ops.relu_bwd_bf16(ad, bd_, y, add=cd).float().cpu(), bf16_round(a * (b > 0) + c))
+    # colsum
+    for rows, Cn in ((1000, 256), (777, 720), (513, 40)):
+        m = bf16_round(torch.randn(rows, Cn, generator=g))
+        out = torch.zeros(Cn, device="cuda")
+        ws = torch.empty((ops.colsum_workspace_bytes(Cn) // 4,), dtype=torch.float32, device="cuda")
+        ops.colsum_bf16(m.to(torch.bfloat16).cuda(), rows, Cn, out, ws)
+        assert torch.allclose(out.cpu(), m.sum(0), rtol=1e-4, atol=1e-3)
+    # weight pack
+    w = torch.randn(24, 40, 3, 3, generator=g)
+    sc = torch.rand(24, generator=g) + 0.5
+    wf, wd = pack_weights(ops, w, sc)
+    ref = bf16_round(oihw_to_ohwi(w) * sc.view(-1, 1, 1, 1)).reshape(24, 9, 40)
+    assert torch.equal(wf.float().cpu(), ref)
+    assert torch.equal(wd.float().cpu(), ref.permute(2, 1, 0).contiguous())
+    # sgd (megengine.optimizer.SGD form, oracle/model.py sgd_step)
+    n = 10007
+    wv = torch.randn(n, generator=g); vv = torch.randn(n, generator=g); gv = torch.randn(n, generator=g)
+    wd_, vd, gd = wv.cuda(), vv.cuda(), gv.cuda()
+    ops.sgd_momentum_step(wd_, vd, gd, lr=0.01, momentum=0.9, wd=1e-4, grad_scale=0.5)
+    gg = gv * 0.5 + 1e-4 * wv
+    vref = 0.9 * vv + gg
+    assert torch.allclose(vd.cpu(), vref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(wd_.cpu(), wv - 0.01 * vref, rtol=1e-6, atol=1e-7)
