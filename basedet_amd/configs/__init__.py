@@ -1,0 +1,96 @@
+"""Minimal config tree that keeps the reference's names and default values for the hot path.
+
+Mirrors basedet/configs/extra_cfg.py (ModelConfig/SolverConfig/TrainerConfig/TestConfig defaults),
+basedet/configs/det_model/retinanet_cfg.py:5-49 and fcos_cfg.py:7-56.  The reference's ConfigDict comes from
+the un-vendored `basecore`; this one supports attribute access, nested `merge`, `get`, and key-value `opts`.
+"""
+import copy
+
+
+class ConfigDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, ConfigDict):
+            v = ConfigDict(v)
+        super().__setitem__(k, v)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def merge(self, other):
+        """basecore ConfigDict.merge: recursive update; also accepts a flat [KEY, VALUE, ...] opts list
+        (basedet/tools/det_train.py:58-63,71)."""
+        if isinstance(other, (list, tuple)):
+            assert len(other) % 2 == 0
+            for k, v in zip(other[0::2], other[1::2]):
+                node = self
+                parts = k.split(".")
+                for p in parts[:-1]:
+                    node = node[p]
+                old = node.get(parts[-1])
+                if isinstance(v, str) and old is not None and not isinstance(old, str):
+                    import ast
+                    v = ast.literal_eval(v)
+                node[parts[-1]] = v
+            return self
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(self.get(k), dict):
+                self[k].merge(v)
+            else:
+                self[k] = copy.deepcopy(v)
+        return self
+
+
+def _base():
+    cfg = ConfigDict()
+    cfg.MODEL = dict(
+        NAME="", BATCHSIZE=2, WEIGHTS=None,
+        BACKBONE=dict(NAME="resnet50", IMG_MEAN=[103.530, 116.280, 123.675], IMG_STD=[57.375, 57.12, 58.395],
+                      NORM="FrozenBN", FREEZE_AT=2),                                   # extra_cfg.py:46-57
+    )
+    cfg.DATA = dict(NUM_CLASSES=80)
+    cfg.SOLVER = dict(BUILDER_NAME="DetSolver", OPTIMIZER_NAME="SGD", LR_SCHEDULER_NAME="MultiStepLR",
+                      BASIC_LR=0.01 / 16.0, WEIGHT_DECAY=1e-4, EXTRA_OPT_ARGS=dict(momentum=0.9),
+                      REDUCE_MODE="MEAN", EPOCHWISE_STEP=False, WARM_ITERS=500, NUM_IMAGE_PER_EPOCH=80000,
+                      MAX_EPOCH=18, LR_DECAY_STAGES=[12, 16], LR_DECAY_RATE=0.1)       # extra_cfg.py:60-78
+    cfg.TRAINER = dict(NAME="DetTrainer", RESUME=False, AMP=dict(ENABLE=False, DYNAMIC_SCALE=False),
+                       GRAD_CLIP=dict(ENABLE=False))
+    cfg.TEST = dict(IOU_THRESHOLD=0.5, CLS_THRESHOLD=0.05, MAX_BOXES_PER_IMAGE=100)
+    return cfg
+
+
+class RetinaNetConfig(ConfigDict):
+    """basedet/configs/det_model/retinanet_cfg.py:5-56."""
+
+    def __init__(self):
+        super().__init__(_base())
+        self.merge(dict(MODEL=dict(
+            NAME="RetinaNet",
+            BACKBONE=dict(OUT_FEATURES=["res3", "res4", "res5"], OUT_FEATURE_CHANNELS=[512, 1024, 2048]),
+            FPN=dict(OUT_FEATURES=["p3", "p4", "p5", "p6", "p7"], NORM=None, STRIDES=[8, 16, 32, 64, 128],
+                     TOP_BLOCK_IN_CHANNELS=2048, TOP_BLOCK_IN_FEATURE="res5", OUT_CHANNELS=256),
+            ANCHOR=dict(SCALES=[[x, x * 2 ** (1.0 / 3), x * 2 ** (2.0 / 3)] for x in [32, 64, 128, 256, 512]],
+                        RATIOS=[[0.5, 1, 2]], OFFSET=0.5),
+            LOSSES=dict(FOCAL_LOSS_ALPHA=0.25, FOCAL_LOSS_GAMMA=2, SMOOTH_L1_BETA=0.0, REG_LOSS_WEIGHT=1.0),
+            BOX_REG=dict(MEAN=[0.0, 0.0, 0.0, 0.0], STD=[1.0, 1.0, 1.0, 1.0]),
+            MATCHER=dict(THRESHOLDS=[0.4, 0.5], LABELS=[0, -1, 1], ALLOW_LOW_QUALITY=True),
+            HEAD=dict(NUM_CONVS=4, CLS_PRIOR_PROB=0.01),
+        )))
+
+
+def retinanet_r18_config():
+    """BASELINE.json configs[0]: RetinaNet-R18-FPN."""
+    cfg = RetinaNetConfig()
+    cfg.merge(dict(MODEL=dict(BACKBONE=dict(NAME="resnet18", OUT_FEATURE_CHANNELS=[128, 256, 512]),
+                              FPN=dict(TOP_BLOCK_IN_CHANNELS=512))))
+    return cfg

@@ -1,0 +1,138 @@
+"""Host-side runtime for the HIP training path: parameter arenas, packed-weight maintenance and the
+conv layer object whose forward / dgrad / wgrad map 1:1 onto the C ABI (include/basedet_hip.h).
+
+torch tensors are used as the memory carrier only -- no torch operator computes anything on this path
+(allocation, zero-fill and views aside).
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..ops import Geom
+
+BN_EPS = 1e-5  # basecore FrozenBatchNorm eps (un-vendored; documented choice, same as oracle/model.py)
+
+
+class ParamArena:
+    """Flat fp32 arenas (weights / gradients / momentum) for all trainable parameters: one SGD launch,
+    contiguous buckets for the RCCL all-reduce (solver/default_solver.py:118-124)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = []   # (name, shape, offset, numel)
+        self.total = 0
+        self.w = self.g = self.v = None
+
+    def reserve(self, name, shape):
+        n = int(np.prod(shape))
+        off = self.total
+        self.entries.append((name, tuple(shape), off, n))
+        self.total += (n + 63) // 64 * 64     # 256-byte aligned slices
+        return len(self.entries) - 1
+
+    def allocate(self):
+        self.w = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.g = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.v = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+
+    def view(self, which, idx):
+        _, shape, off, n = self.entries[idx]
+        return getattr(self, which)[off:off + n].view(shape)
+
+
+class ConvLayer:
+    """One convolution (+ folded FrozenBN or bias).  Master weight fp32 [Cout][R][S][Cin] (OHWI);
+    bf16 packed copies for the forward ([Cout][RS][Cin], BN scale folded in) and dgrad ([Cin][RS][Cout]) kernels."""
+
+    def __init__(self, name, cin, cout, k, stride, pad, device, bn_prefix=None, has_bias=False, trainable=True,
+                 cout_pad=None):
+        self.name, self.cin, self.cout_real, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+        self.cout = cout_pad or cout          # padded channel count seen by the kernels (bbox_pred: 36 -> 40)
+        self.bn_prefix, self.has_bias, self.trainable = bn_prefix, has_bias, trainable
+        self.device = device
+        self.w = self.b = self.gw = self.gb = None
+        self.row_scale = None
+        self.w_fwd = torch.empty((self.cout, k * k, cin), dtype=torch.bfloat16, device=device)
+        self.w_dgrad = torch.empty((cin, k * k, self.cout), dtype=torch.bfloat16, device=device) if trainable else None
+        self._desc_cache = {}
+
+    # -- parameters -------------------------------------------------------------------------------
+    def bind(self, arena, params):
+        """Load numpy parameters (reference layout) into arena views / standalone tensors."""
+        w = torch.from_numpy(params[self.name + ".weight"]).permute(0, 2, 3, 1).contiguous()   # OIHW -> OHWI
+        if self.cout != self.cout_real:
+            pad = torch.zeros((self.cout - self.cout_real,) + tuple(w.shape[1:]))
+            w = torch.cat([w, pad], 0)
+        if self.trainable:
+            self.w = arena.view("w", self._wi); self.gw = arena.view("g", self._wi)
+            self.w.copy_(w)
+        else:
+            self.w = w.to(self.device)
+        if self.bn_prefix:
+            g, b = params[self.bn_prefix + ".weight"], params[self.bn_prefix + ".bias"]
+            m, v = params[self.bn_prefix + ".running_mean"], params[self.bn_prefix + ".running_var"]
+            scale = g / np.sqrt(v + BN_EPS)
+            self.row_scale = torch.from_numpy(scale.astype(np.float32)).to(self.device)
+            self.b = torch.from_numpy((b - m * scale).astype(np.float32)).to(self.device)
+        elif self.has_bias:
+            b = torch.from_numpy(params[self.name + ".bias"])
+            if self.cout != self.cout_real:
+                b = torch.cat([b, torch.zeros(self.cout - self.cout_real)])
+            if self.trainable:
+                self.b = arena.view("w", self._bi); self.gb = arena.view("g", self._bi)
+                self.b.copy_(b)
+            else:
+                self.b = b.to(self.device)
+
+    def reserve(self, arena):
+        if not self.trainable:
+            return
+        self._wi = arena.reserve(self.name + ".weight", (self.cout, self.k, self.k, self.cin))
+        if self.has_bias:
+            self._bi = arena.reserve(self.name + ".bias", (self.cout,))
+
+    def export(self, out):
+        """Back to the reference layout (OIHW numpy)."""
+        out[self.name + ".weight"] = self.w[: self.cout_real].permute(0, 3, 1, 2).contiguous().cpu().numpy()
+        if self.has_bias and not self.bn_prefix:
+            out[self.name + ".bias"] = self.b[: self.cout_real].cpu().numpy().copy()
+
+    def pack(self):
+        ops.weight_pack(self.w, self.row_scale, self.w_fwd, self.w_dgrad, self.cout, self.k * self.k, self.cin)
+
+    # -- kernels ----------------------------------------------------------------------------------
+    def desc(self, gin: Geom, gout: Geom):
+        key = (gin.N, tuple(gin.H), tuple(gin.W), tuple(gin.off), gin.pix_per_img,
+               tuple(gout.H), tuple(gout.W), tuple(gout.off), gout.pix_per_img)
+        d = self._desc_cache.get(key)
+        if d is None:
+            d = ops.conv_desc(gin, gout, self.cin, self.cout, self.k, self.k, self.stride, self.pad)
+            self._desc_cache[key] = d
+        return d
+
+    def forward(self, x, gin, gout, y, add=None, relu=False):
+        flags = (ops.EPI_RELU if relu else 0) | (ops.EPI_ADD_BEFORE if add is not None else 0)
+        return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags)
+
+    def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None):
+        """dx (+)= conv^T(g).  first=False accumulates onto dx (pre-mask); mask = forward activation whose
+        ReLU gates dx; add_after = tensor added after masking (P6: gradient that bypasses the ReLU)."""
+        flags, add = 0, None
+        if add_after is not None:
+            flags |= ops.EPI_ADD_AFTER
+            add = add_after
+        elif not first:
+            flags |= ops.EPI_ADD_BEFORE
+            add = dx
+        if mask is not None:
+            flags |= ops.EPI_MASK
+        return ops.conv2d_dgrad(self.desc(gin, gout), g, self.w_dgrad, dx, add=add, mask=mask, flags=flags)
+
+    def wgrad(self, x, g, gin, gout, ws, colsum_ws=None):
+        d = self.desc(gin, gout)
+        ops.conv2d_wgrad(d, x, g, self.gw, ws, row_scale=self.row_scale)
+        if self.gb is not None:
+            ops.colsum_bf16(g, gout.pixels, self.cout, self.gb, colsum_ws)
+
+    def wgrad_ws_bytes(self, gin, gout):
+        return ops.conv2d_wgrad_workspace_bytes(self.desc(gin, gout))

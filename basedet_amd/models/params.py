@@ -1,0 +1,127 @@
+"""Parameter tables (names, shapes, initialisers) of the detectors, as plain numpy dicts.
+
+Names follow the reference's state_dict (``backbone.bottom_up.layer2.0.conv1.weight`` ...), conv weights are
+OIHW float32, biases / BN vectors are 1-D.  Initialisers restate:
+  * ResNet: msra_normal fan_out for convs, BN gamma=1 beta=0 mean=0 var=1 (models/cls/resnet.py:174-189)
+  * FPN lateral/output: msra_normal fan_in, zero bias (layers/backbone/fpn_backbone.py:78-83)
+  * P6/P7: MegEngine ``M.Conv2d`` default init N(0, sqrt(1/fan_in)), zero bias (fpn_backbone.py:196-197)
+  * RetinaNetHead: N(0, 0.01), zero bias, cls_score bias = -log((1-pi)/pi) (layers/head/retina_head.py:114-126)
+"""
+import math
+
+import numpy as np
+
+RESNET_SPECS = {
+    "resnet18": ("basic", [2, 2, 2, 2]),
+    "resnet34": ("basic", [3, 4, 6, 3]),
+    "resnet50": ("bottleneck", [3, 4, 6, 3]),
+    "resnet101": ("bottleneck", [3, 4, 23, 3]),
+    "resnet152": ("bottleneck", [3, 8, 36, 3]),
+}
+
+
+def resnet_conv_table(name):
+    """[(prefix, cin, cout, k, stride, pad, bn_prefix)] in forward order + per-block structure."""
+    kind, layers = RESNET_SPECS[name]
+    exp = 4 if kind == "bottleneck" else 1
+    blocks = []
+    cin = 64
+    for li, nblk in enumerate(layers):
+        ch = 64 * 2 ** li
+        for b in range(nblk):
+            stride = 2 if (b == 0 and li > 0) else 1
+            pre = f"backbone.bottom_up.layer{li + 1}.{b}"
+            has_ds = (cin != ch * exp) or stride != 1
+            blocks.append(dict(prefix=pre, kind=kind, cin=cin, ch=ch, cout=ch * exp, stride=stride, has_ds=has_ds, layer=li + 1))
+            cin = ch * exp
+    return blocks
+
+
+def _msra_normal(rng, shape, mode):
+    co, ci, kh, kw = shape
+    fan = co * kh * kw if mode == "fan_out" else ci * kh * kw
+    return (rng.standard_normal(shape) * math.sqrt(2.0 / fan)).astype(np.float32)
+
+
+def _bn(p, prefix, c):
+    p[prefix + ".weight"] = np.ones(c, np.float32)
+    p[prefix + ".bias"] = np.zeros(c, np.float32)
+    p[prefix + ".running_mean"] = np.zeros(c, np.float32)
+    p[prefix + ".running_var"] = np.ones(c, np.float32)
+
+
+def init_resnet(p, rng, name):
+    bu = "backbone.bottom_up"
+    p[bu + ".conv1.weight"] = _msra_normal(rng, (64, 3, 7, 7), "fan_out")
+    _bn(p, bu + ".bn1", 64)
+    for blk in resnet_conv_table(name):
+        pre = blk["prefix"]
+        if blk["kind"] == "bottleneck":
+            specs = [("conv1", blk["cin"], blk["ch"], 1), ("conv2", blk["ch"], blk["ch"], 3), ("conv3", blk["ch"], blk["cout"], 1)]
+        else:
+            specs = [("conv1", blk["cin"], blk["ch"], 3), ("conv2", blk["ch"], blk["cout"], 3)]
+        for i, (cn, ci, co, k) in enumerate(specs):
+            p[f"{pre}.{cn}.weight"] = _msra_normal(rng, (co, ci, k, k), "fan_out")
+            _bn(p, f"{pre}.bn{i + 1}", co)
+        if blk["has_ds"]:
+            p[f"{pre}.downsample.0.weight"] = _msra_normal(rng, (blk["cout"], blk["cin"], 1, 1), "fan_out")
+            _bn(p, f"{pre}.downsample.1", blk["cout"])
+
+
+def init_fpn(p, rng, in_channels, stages, out_ch, top_in):
+    for s, ci in zip(stages, in_channels):
+        p[f"backbone.fpn_lateral{s}.weight"] = _msra_normal(rng, (out_ch, ci, 1, 1), "fan_in")
+        p[f"backbone.fpn_lateral{s}.bias"] = np.zeros(out_ch, np.float32)
+        p[f"backbone.fpn_output{s}.weight"] = _msra_normal(rng, (out_ch, out_ch, 3, 3), "fan_in")
+        p[f"backbone.fpn_output{s}.bias"] = np.zeros(out_ch, np.float32)
+    for nm, ci in (("p6", top_in), ("p7", out_ch)):
+        p[f"backbone.top_block.{nm}.weight"] = (rng.standard_normal((out_ch, ci, 3, 3)) * math.sqrt(1.0 / (ci * 9))).astype(np.float32)
+        p[f"backbone.top_block.{nm}.bias"] = np.zeros(out_ch, np.float32)
+
+
+def init_retina_head(p, rng, ch, num_anchors, num_classes, num_convs, prior_prob):
+    for tower in ("cls_subnet", "bbox_subnet"):
+        for i in range(num_convs):
+            p[f"head.{tower}.{2 * i}.weight"] = (rng.standard_normal((ch, ch, 3, 3)) * 0.01).astype(np.float32)
+            p[f"head.{tower}.{2 * i}.bias"] = np.zeros(ch, np.float32)
+    p["head.cls_score.weight"] = (rng.standard_normal((num_anchors * num_classes, ch, 3, 3)) * 0.01).astype(np.float32)
+    p["head.cls_score.bias"] = np.full(num_anchors * num_classes, -math.log((1 - prior_prob) / prior_prob), np.float32)
+    p["head.bbox_pred.weight"] = (rng.standard_normal((num_anchors * 4, ch, 3, 3)) * 0.01).astype(np.float32)
+    p["head.bbox_pred.bias"] = np.zeros(num_anchors * 4, np.float32)
+
+
+def init_retinanet_params(cfg, seed=0):
+    rng = np.random.default_rng(seed)
+    m = cfg.MODEL
+    p = {}
+    init_resnet(p, rng, m.BACKBONE.NAME)
+    stages = [int(f[-1]) for f in m.BACKBONE.OUT_FEATURES]
+    init_fpn(p, rng, m.BACKBONE.OUT_FEATURE_CHANNELS, stages, m.FPN.OUT_CHANNELS, m.FPN.TOP_BLOCK_IN_CHANNELS)
+    na = len(m.ANCHOR.SCALES[0]) * len(m.ANCHOR.RATIOS[0])
+    init_retina_head(p, rng, m.FPN.OUT_CHANNELS, na, cfg.DATA.NUM_CLASSES, m.HEAD.NUM_CONVS, m.HEAD.CLS_PRIOR_PROB)
+    return p
+
+
+def trainable_names(params, freeze_at=2):
+    """DetSolver.params (solver/default_solver.py:83-94): drop bottom_up.conv1 / layer1 by name; FrozenBN
+    statistics and affine terms never receive gradients (configs/extra_cfg.py:55)."""
+    out = []
+    for k in params:
+        if ".bn" in k or "downsample.1" in k or "running_" in k:
+            continue
+        if "bottom_up.conv1" in k and freeze_at >= 1:
+            continue
+        if "bottom_up.layer1" in k and freeze_at >= 2:
+            continue
+        out.append(k)
+    return out
+
+
+def oracle_arch(cfg):
+    m = cfg.MODEL
+    return dict(backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
+                num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),
+                strides=list(m.FPN.STRIDES), anchor_scales=[list(s) for s in m.ANCHOR.SCALES],
+                anchor_ratios=[list(r) for r in m.ANCHOR.RATIOS], anchor_offset=m.ANCHOR.OFFSET,
+                focal_alpha=m.LOSSES.FOCAL_LOSS_ALPHA, focal_gamma=m.LOSSES.FOCAL_LOSS_GAMMA,
+                smooth_l1_beta=m.LOSSES.SMOOTH_L1_BETA, reg_loss_weight=m.LOSSES.REG_LOSS_WEIGHT)

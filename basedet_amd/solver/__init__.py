@@ -1,0 +1,129 @@
+"""DetSolver (basedet/solver/default_solver.py:79-124) + the basecore `Solver.minimize` step it returns.
+
+lr = BASIC_LR * BATCHSIZE * world_size for MEAN reduction (:99-106); SGD(momentum, weight_decay) over the
+trainable parameter arena in ONE fused launch; gradients are all-reduced (mean) over RCCL in arena buckets that
+follow the backward order (head -> FPN -> layer4 -> ... -> layer2) on a side stream, overlapped with backward.
+"""
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..utils.registry import registers
+
+
+class _ParamGroupView(dict):
+    pass
+
+
+class SGD:
+    """megengine.optimizer.SGD semantics: g' = g + wd*w; v = momentum*v + g'; w -= lr*v (fused HIP kernel)."""
+
+    def __init__(self, model, lr, weight_decay, momentum=0.9):
+        self.model = model
+        self.param_groups = [_ParamGroupView(lr=lr, weight_decay=weight_decay, momentum=momentum)]
+
+    def step(self, grad_scale=1.0):
+        a = self.model.arena
+        g = self.param_groups[0]
+        ops.sgd_momentum_step(a.w, a.v, a.g, g["lr"], g["momentum"], g["weight_decay"], grad_scale)
+        self.model.repack_trainable()
+        return self
+
+    def clear_grad(self):
+        return self   # every gradient slot is overwritten by the next backward (no accumulation across steps)
+
+
+class GradBuckets:
+    """Asynchronous bucketed all-reduce of the gradient arena (replaces dist.make_allreduce_cb,
+    solver/default_solver.py:121).  Buckets = contiguous arena ranges closed in backward order."""
+
+    def __init__(self, model, mode="MEAN"):
+        self.model = model
+        self.mode = mode
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.enabled else 1
+        self.comm_stream = torch.cuda.Stream() if (self.enabled and torch.cuda.is_available()) else None
+        self.ranges = self._ranges()
+        self.pending = []
+
+    def _ranges(self):
+        """name of the backward phase -> (start, end) element range of the arena."""
+        ent = self.model.arena.entries
+        groups = {}
+        for name, _, off, n in ent:
+            if name.startswith("head."):
+                k = "head"
+            elif "fpn_" in name or "top_block" in name:
+                k = "fpn"
+            else:
+                k = name.split(".")[2]     # backbone.bottom_up.layerX...
+            lo, hi = groups.get(k, (off, off))
+            groups[k] = (min(lo, off), max(hi, (off + n + 63) // 64 * 64))
+        return groups
+
+    def on_ready(self, phase):
+        if not self.enabled or phase not in self.ranges:
+            return
+        lo, hi = self.ranges[phase]
+        buf = self.model.arena.g[lo:hi]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        self.pending.append(work)
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        return 1.0 / self.world if (self.enabled and self.mode == "MEAN") else 1.0
+
+
+class Solver:
+    """basecore.engine.Solver protocol used by DetTrainer (engine/trainer.py:55-61,98)."""
+
+    def __init__(self, optimizer, buckets, grad_scaler=None, grad_clip_fn=None):
+        self.optimizer = optimizer
+        self.buckets = buckets
+        self.grad_scaler = grad_scaler
+        self.grad_clip_fn = grad_clip_fn
+
+    def minimize(self, model, inputs):
+        losses = model(inputs)
+        model.backward(on_bucket_ready=self.buckets.on_ready)
+        scale = self.buckets.wait()
+        self.optimizer.step(grad_scale=scale)
+        self.optimizer.clear_grad()
+        return losses
+
+
+@registers.solvers.register()
+class DetSolver:
+    @classmethod
+    def build(cls, cfg, model):
+        solver_cfg = cfg.SOLVER
+        mode = solver_cfg.get("REDUCE_MODE", "MEAN")
+        assert mode in ["MEAN", "SUM"]
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        lr = solver_cfg.BASIC_LR * cfg.MODEL.BATCHSIZE
+        wd = solver_cfg.WEIGHT_DECAY
+        if mode == "MEAN":
+            lr = lr * world
+        else:
+            wd = wd * world
+        extra = dict(solver_cfg.get("EXTRA_OPT_ARGS", {}))
+        opt = SGD(model, lr=lr, weight_decay=wd, momentum=extra.get("momentum", 0.0))
+        return Solver(opt, GradBuckets(model, mode))
+
+
+def broadcast_parameters(model, src=0):
+    """configs/detection_cfg.py:80-82 (dist.bcast_list_ of params and buffers) as one flat broadcast."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(model.arena.w, src=src)
+        model.repack_trainable()
