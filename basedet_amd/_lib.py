@@ -45,7 +45,7 @@ SIGNATURES = {
     "bd_stem_weight_pack": (_I, [_P, _P, _P, _P]),
     "bd_weight_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "bd_colsum_workspace_bytes": (_Z, [_I]),
-    "bd_colsum_bf16": (_I, [_P, _L, _I, _P, _I, _P, _Z, _P]),
+    "bd_colsum_bf16": (_I, [_P, _I, _L, _L, _L, _I, _P, _I, _P, _Z, _P]),
     "bd_pad_normalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "bd_pad_normalize_nchw": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "bd_maxpool3x3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),

@@ -258,6 +258,7 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
 // stage 2 sums the partials in block order.
 constexpr int COLSUM_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_raw* __restrict__ g, long long rows, int C,
+                                                             long long cnt, long long ppi, long long off,
                                                              float* __restrict__ partial) {
     __shared__ float red[256 * 8];
     const int cvec = C / 8;
@@ -266,7 +267,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_raw* __r
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ty < rif) {
         for (long long r = (long long)blockIdx.x * rif + ty; r < rows; r += (long long)gridDim.x * rif) {
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(g + r * C + tx * 8);
+            const long long img = r / cnt;
+            const long long row = img * ppi + off + (r - img * cnt);
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(g + row * C + tx * 8);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { acc[2 * k] += bf_lo(v[k]); acc[2 * k + 1] += bf_hi(v[k]); }
         }
@@ -412,16 +415,17 @@ extern "C" int bd_weight_pack(const float* w, const float* row_scale, void* w_fw
 }
 
 extern "C" size_t bd_colsum_workspace_bytes(int C) { return (size_t)COLSUM_BLOCKS * (size_t)C * sizeof(float); }
-extern "C" int bd_colsum_bf16(const void* g, int64_t rows, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
-                              bd_stream_t stream) {
-    BD_REQUIRE(g && out && ws && rows >= 0, "colsum: null pointer");
+extern "C" int bd_colsum_bf16(const void* g, int N, int64_t pix_per_img, int64_t off, int64_t cnt, int C, float* out,
+                              int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(g && out && ws && N >= 0 && cnt >= 0, "colsum: null pointer");
+    const long long rows = (long long)N * cnt;
     BD_REQUIRE(C > 0 && C % 8 == 0 && C <= 2048, "colsum: C=%d must be a multiple of 8 and <= 2048", C);
     if (ws_bytes < bd_colsum_workspace_bytes(C)) {
         bd_set_error("colsum: workspace %zu < required %zu bytes", ws_bytes, bd_colsum_workspace_bytes(C));
         return BD_EWORKSPACE;
     }
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(COLSUM_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)g,
-                       (long long)rows, C, (float*)ws);
+                       rows, C, (long long)(cnt > 0 ? cnt : 1), (long long)pix_per_img, (long long)off, (float*)ws);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
                        COLSUM_BLOCKS, C, out, accumulate);
     BD_CHECK_LAUNCH("bd_colsum_bf16");

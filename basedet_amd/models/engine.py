@@ -132,7 +132,11 @@ class ConvLayer:
         d = self.desc(gin, gout)
         ops.conv2d_wgrad(d, x, g, self.gw, ws, row_scale=self.row_scale)
         if self.gb is not None:
-            ops.colsum_bf16(g, gout.pixels, self.cout, self.gb, colsum_ws)
+            if gout.nlev == 1:
+                ops.colsum_bf16(g, 0, self.cout, self.gb, colsum_ws, geom=gout)
+            else:   # all levels of a dense pyramid buffer
+                assert gout.pix_per_img == sum(h * w for h, w in zip(gout.H, gout.W))
+                ops.colsum_bf16(g, gout.pixels, self.cout, self.gb, colsum_ws)
 
     def wgrad_ws_bytes(self, gin, gout):
         return ops.conv2d_wgrad_workspace_bytes(self.desc(gin, gout))

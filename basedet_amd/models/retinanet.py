@@ -170,6 +170,42 @@ class RetinaNet:
         out.update({k: v.copy() for k, v in self._bn_params.items()})
         return out
 
+    def debug_activations(self):
+        """Stored activations of the last forward as NCHW fp32 CPU tensors, keyed like oracle/model.py `_act`
+        (parity tests inject them into the oracle so that both backward passes see identical ReLU gates)."""
+        pl = self._cur
+        N = pl.N
+        out = {}
+
+        def nchw(t, g, c=None):
+            v = t.float().cpu().view(N, g.H[0], g.W[0], -1).permute(0, 3, 1, 2).contiguous()
+            return v if c is None else v[:, :c].contiguous()
+
+        def lvl(t, i, c=None):
+            g = pl.pyr
+            v = t.float().cpu().view(N, g.pix_per_img, -1)[:, g.off[i]: g.off[i] + g.H[i] * g.W[i]]
+            v = v.reshape(N, g.H[i], g.W[i], -1).permute(0, 3, 1, 2).contiguous()
+            return v if c is None else v[:, :c].contiguous()
+
+        out["pool"] = nchw(pl.pool_out, pl.g_pool)
+        for blk, b in zip(self.blocks, pl.blk):
+            pre = blk["prefix"]
+            for i, (t, g) in enumerate(zip(b.mids, b.mid_geo)):
+                out[f"{pre}.a{i}"] = nchw(t, g)
+            if b.idt is not None:
+                out[pre + ".idt"] = nchw(b.idt, b.gout)
+            out[pre + ".out"] = nchw(b.out, b.gout)
+        for s in self.fpn_stages:
+            out[f"lat{s}"] = nchw(pl.lat[s], pl.blk[pl.res[s]].gout)
+        for i in range(pl.pyr.nlev):
+            out[f"P{self.fpn_stages[0] + i}"] = lvl(pl.P, i)
+            for k in range(len(self.cls_tower)):
+                out[f"cls{k}_{i}"] = lvl(pl.cls_act[k], i)
+                out[f"box{k}_{i}"] = lvl(pl.box_act[k], i)
+            out[f"logits_{i}"] = lvl(pl.logits, i)
+            out[f"offs_{i}"] = lvl(pl.offsets, i, self.num_anchors * 4)
+        return out
+
     def trainable_parameter_names(self):
         return [e[0] for e in self.arena.entries]
 

@@ -108,8 +108,15 @@ def colsum_workspace_bytes(Cn):
     return int(L().bd_colsum_workspace_bytes(Cn))
 
 
-def colsum_bf16(g, rows, Cn, out, ws, accumulate=False):
-    check(L().bd_colsum_bf16(ptr(g), rows, Cn, ptr(out), int(accumulate), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_colsum_bf16")
+def colsum_bf16(g, rows, Cn, out, ws, accumulate=False, geom=None):
+    """geom: single-level Geom selecting the pixel rows of one pyramid level (default: all `rows` rows)."""
+    if geom is None:
+        n, ppi, off, cnt = 1, rows, 0, rows
+    else:
+        assert geom.nlev == 1
+        n, ppi, off, cnt = geom.N, geom.pix_per_img, geom.off[0], geom.H[0] * geom.W[0]
+    check(L().bd_colsum_bf16(ptr(g), n, ppi, off, cnt, Cn, ptr(out), int(accumulate), ptr(ws), ws.numel() * ws.element_size(),
+                             stream_ptr()), "bd_colsum_bf16")
     return out
 
 

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, training RetinaNet-R50-FPN on synthetic 1333x800 (padded 800x1344) images.
+
+Protocol = the reference's own harness (basedet/tools/benchmark.py:125-140): device sync, K full training steps
+(pre-process, forward, target assignment, losses, backward, gradient all-reduce, SGD + weight repack), device sync;
+inputs are DummyLoader-shaped (basedet/utils/dummy.py:8-63) and already resident in HBM.  One process per GPU;
+for N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RCCL over xGMI).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     -- the dominant kernel (MFMA implicit-GEMM conv, forward + dgrad launches): algorithmic FLOPs of those
+                  launches / their summed duration measured with HIP events on the launch stream during the timed steps
+  cpu_baseline -- the CPU oracle's (oracle/model.py, torch-CPU fp32) training step on the host cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense")
+TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): convs only, 1 MAC = 2 FLOP
+    "retinanet_r50_800x1344": 1435.6,
+    "retinanet_r18_512x512": 277.2,
+}
+
+
+class ConvTimer:
+    """HIP-event timing + algorithmic FLOP accounting of every conv launch (fwd / dgrad / wgrad)."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.records = {"igemm": [], "wgrad": []}
+        self.enabled = False
+        self._orig = (ops.conv2d_fwd, ops.conv2d_dgrad, ops.conv2d_wgrad)
+
+        def flops(d):
+            m = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
+            return 2.0 * m * d.Cin * d.Cout * d.R * d.S
+
+        def wrap(fn, kind):
+            def inner(d, *a, **k):
+                if not self.enabled:
+                    return fn(d, *a, **k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = fn(d, *a, **k)
+                e.record()
+                self.records[kind].append((s, e, flops(d)))
+                return r
+            return inner
+
+        ops.conv2d_fwd = wrap(ops.conv2d_fwd, "igemm")
+        ops.conv2d_dgrad = wrap(ops.conv2d_dgrad, "igemm")
+        ops.conv2d_wgrad = wrap(ops.conv2d_wgrad, "wgrad")
+
+    def summary(self, kind):
+        rec = self.records[kind]
+        if not rec:
+            return None
+        ms = sum(s.elapsed_time(e) for s, e, _ in rec)
+        fl = sum(f for _, _, f in rec)
+        return dict(launches=len(rec), ms=ms, flops=fl)
+
+
+def cpu_baseline(cfg, params, seconds=20.0, batch=2, size=(800, 1344)):
+    """Oracle training step (fwd + bwd + SGD) on the host cores, bounded sample of the same workload."""
+    from basedet_amd.models import params as P
+    from basedet_amd.utils import DummyLoader
+    from oracle.model import Oracle
+    names = P.trainable_names(params, cfg.MODEL.BACKBONE.FREEZE_AT)
+    orc = Oracle(params, P.oracle_arch(cfg), trainable=names)
+    b = next(DummyLoader(batch, size, seed=0))
+    b["data"] = b["data"].astype(np.float32)
+    state = {}
+    lr = cfg.SOLVER.BASIC_LR * batch
+    t_all, iters = [], 0
+    t_start = time.time()
+    while True:
+        t0 = time.time()
+        losses, _ = orc.retinanet_losses(b)
+        g = orc.grads(losses["total_loss"])
+        orc.sgd_step(g, state, lr, 0.9, cfg.SOLVER.WEIGHT_DECAY)
+        dt = time.time() - t0
+        iters += 1
+        if iters > 1:
+            t_all.append(dt)          # first iteration = warm-up
+        if (time.time() - t_start > seconds and t_all) or iters >= 4:
+            break
+    mean = float(np.mean(t_all))
+    return dict(value=batch / mean, unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/model.py torch-CPU fp32 RetinaNet-R50 step, batch {batch} x {size[0]}x{size[1]}, "
+                       f"{len(t_all)} timed iteration(s) after 1 warm-up, {mean:.2f} s/iter")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--workload", default="retinanet_r50_800x1344", choices=sorted(TRAIN_GFLOP_PER_IMG))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the basedet_amd path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from basedet_amd import ops
+    from basedet_amd.configs import RetinaNetConfig, retinanet_r18_config
+    from basedet_amd.models import RetinaNet, params as P
+    from basedet_amd.solver import DetSolver, broadcast_parameters
+    from basedet_amd.utils import DummyLoader
+
+    if args.workload == "retinanet_r50_800x1344":
+        cfg, size = RetinaNetConfig(), (800, 1344)
+    else:
+        cfg, size = retinanet_r18_config(), (512, 512)
+    cfg.MODEL.BATCHSIZE = args.batch
+    params = P.init_retinanet_params(cfg, seed=0)
+    model = RetinaNet(cfg, params=params)
+    broadcast_parameters(model)
+    solver = DetSolver.build(cfg, model)
+
+    loader = DummyLoader(args.batch, size, seed=rank)
+    b = next(loader)
+    batch = {
+        "data": torch.from_numpy(b["data"].astype(np.float32)).cuda(),      # resident in HBM before the timed region
+        "gt_boxes": torch.from_numpy(b["gt_boxes"]).cuda(),
+        "im_info": torch.from_numpy(b["im_info"]).cuda(),
+    }
+    timer = None if args.no_roofline else ConvTimer(ops)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        last = solver.minimize(model, batch)
+    sync()
+    if timer:
+        timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = solver.minimize(model, batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if timer:
+        timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(last["total_loss"])
+    assert np.isfinite(loss), "training diverged"
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / elapsed
+        out = {
+            "metric": "images/sec training RetinaNet-R50-FPN 1333x800" if "r50" in args.workload else "images/sec training " + args.workload,
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload} train step (fwd+bwd+allreduce+SGD), DummyLoader boxes, random-init weights",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "final_loss": round(loss, 4)},
+        }
+        gf = TRAIN_GFLOP_PER_IMG[args.workload]
+        out["config"]["train_gflop_per_img"] = gf
+        out["config"]["whole_step_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+        if timer:
+            ig, wg = timer.summary("igemm"), timer.summary("wgrad")
+            ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (conv forward + dgrad launches)",
+                               "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": ig["launches"] // args.steps,
+                               "ms_per_step": round(ig["ms"] / args.steps, 3),
+                               "gflop_per_step": round(ig["flops"] / args.steps / 1e9, 1)}
+            if wg:
+                achw = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
+                out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv_wgrad_kernel + slab reduce", "achieved": round(achw, 2),
+                                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achw / PEAK_BF16_TFLOPS, 4),
+                                         "launches_per_step": wg["launches"] // args.steps,
+                                         "ms_per_step": round(wg["ms"] / args.steps, 3)}
+        if world == 1 and not args.no_cpu_baseline and "r50" in args.workload:
+            out["cpu_baseline"] = cpu_baseline(cfg, params)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

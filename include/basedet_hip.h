@@ -100,11 +100,12 @@ int bd_stem_weight_pack(const float* w /*[64][7][7][3] fp32*/, const float* row_
 int bd_weight_pack(const float* w, const float* row_scale, void* w_fwd, void* w_dgrad, int Cout, int RS,
                    int Cin, bd_stream_t stream);
 
-/* column sums of a bf16 [rows][C] matrix into fp32 out[C] (bias gradients); accumulate != 0 adds.
- * C % 8 == 0, C <= 2048; two-stage fixed-order reduction through ws (bitwise reproducible). */
+/* bias gradient: column sums over the pixel rows {n*pix_per_img + off + i : n < N, i < cnt} of a bf16
+ * [.][C] activation gradient (one pyramid level, or the whole tensor with N=1, off=0) into fp32 out[C];
+ * accumulate != 0 adds.  C % 8 == 0, C <= 2048; two-stage fixed-order reduction through ws (reproducible). */
 size_t bd_colsum_workspace_bytes(int C);
-int bd_colsum_bf16(const void* g, int64_t rows, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
-                   bd_stream_t stream);
+int bd_colsum_bf16(const void* g, int N, int64_t pix_per_img, int64_t off, int64_t cnt, int C, float* out,
+                   int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Memory-bound image ops.

@@ -35,10 +35,34 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).float()
 
 
+class _Inject(torch.autograd.Function):
+    """Forward: return the injected activation (taken from the HIP run); backward: the ReLU gate of that
+    activation.  Turns the oracle backward into the exact linear map the HIP backward must implement."""
+
+    @staticmethod
+    def forward(ctx, x, inj, relu):
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(inj > 0)
+        return inj.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.relu:
+            (m,) = ctx.saved_tensors
+            g = g * m
+        return g, None, None
+
+
 class Oracle:
     """Functional model over a parameter dict.  ``trainable`` names get requires_grad."""
 
-    def __init__(self, params, arch, trainable=()):
+    def __init__(self, params, arch, trainable=(), sim_bf16=False, inject=None):
+        """sim_bf16: round weights (after folding the FrozenBN scale) and every stored activation to bf16 with a
+        straight-through gradient -- the rounding points of the HIP path -- while all arithmetic stays fp32.
+        With it the ReLU masks of both sides coincide, which makes the gradient comparison tight."""
+        self.sim_bf16 = sim_bf16
+        self.inject = inject      # dict key -> NCHW tensor: stored activations of the HIP run (see _act)
         self.arch = dict(arch)
         self.p = {}
         tset = set(trainable)
@@ -50,40 +74,65 @@ class Oracle:
         self.trainable = [k for k in params if k in tset]
 
     # ---- primitives -------------------------------------------------------------------------
-    def _bn(self, x, prefix):
+    def _act(self, key, x, relu):
+        """Every tensor the HIP path stores goes through here: (ReLU), bf16 rounding, optional injection."""
+        if self.inject is not None and key in self.inject:
+            return _Inject.apply(x, self.inject[key], relu)
+        return self._q(TF.relu(x) if relu else x)
+
+    def _q(self, x):
+        if not self.sim_bf16:
+            return x
+        return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach()
+
+    def _bn_scale_shift(self, prefix):
         p = self.p
         scale = p[prefix + ".weight"] / torch.sqrt(p[prefix + ".running_var"] + BN_EPS)
         shift = p[prefix + ".bias"] - p[prefix + ".running_mean"] * scale
+        return scale, shift
+
+    def _bn(self, x, prefix):
+        scale, shift = self._bn_scale_shift(prefix)
         return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
 
     def _conv(self, x, name, stride=1, pad=0):
         b = self.p.get(name + ".bias")
-        return TF.conv2d(x, self.p[name + ".weight"], b, stride=stride, padding=pad)
+        return TF.conv2d(x, self._q(self.p[name + ".weight"]), b, stride=stride, padding=pad)
+
+    def _conv_bn(self, x, name, bn, stride=1, pad=0):
+        """conv + FrozenBN; in sim_bf16 mode the scale is folded into the weight before rounding (HIP path)."""
+        if not self.sim_bf16:
+            return self._bn(self._conv(x, name, stride, pad), bn)
+        scale, shift = self._bn_scale_shift(bn)
+        w = self._q(self.p[name + ".weight"] * scale.view(-1, 1, 1, 1))
+        return TF.conv2d(x, w, shift, stride=stride, padding=pad)
 
     # ---- backbone (models/cls/resnet.py) -----------------------------------------------------
     def _bottleneck(self, x, pre, stride, has_ds):
         idt = x
-        y = TF.relu(self._bn(self._conv(x, pre + ".conv1"), pre + ".bn1"))
-        y = TF.relu(self._bn(self._conv(y, pre + ".conv2", stride, 1), pre + ".bn2"))   # stride on the 3x3 (:72-81)
-        y = self._bn(self._conv(y, pre + ".conv3"), pre + ".bn3")
+        y = self._act(pre + ".a0", self._conv_bn(x, pre + ".conv1", pre + ".bn1"), True)
+        y = self._act(pre + ".a1", self._conv_bn(y, pre + ".conv2", pre + ".bn2", stride, 1), True)   # stride on the 3x3 (:72-81)
+        y = self._conv_bn(y, pre + ".conv3", pre + ".bn3")
         if has_ds:
-            idt = self._bn(self._conv(x, pre + ".downsample.0", stride), pre + ".downsample.1")
-        return TF.relu(y + idt)
+            idt = self._act(pre + ".idt", self._conv_bn(x, pre + ".downsample.0", pre + ".downsample.1", stride), False)
+        return self._act(pre + ".out", y + idt, True)
 
     def _basic(self, x, pre, stride, has_ds):
         idt = x
-        y = TF.relu(self._bn(self._conv(x, pre + ".conv1", stride, 1), pre + ".bn1"))
-        y = self._bn(self._conv(y, pre + ".conv2", 1, 1), pre + ".bn2")
+        y = self._act(pre + ".a0", self._conv_bn(x, pre + ".conv1", pre + ".bn1", stride, 1), True)
+        y = self._conv_bn(y, pre + ".conv2", pre + ".bn2", 1, 1)
         if has_ds:
-            idt = self._bn(self._conv(x, pre + ".downsample.0", stride), pre + ".downsample.1")
-        return TF.relu(y + idt)
+            idt = self._act(pre + ".idt", self._conv_bn(x, pre + ".downsample.0", pre + ".downsample.1", stride), False)
+        return self._act(pre + ".out", y + idt, True)
 
     def backbone(self, x):
         """ResNet.extract_features (resnet.py:236-252)."""
         bu = "backbone.bottom_up"
         kind, layers = RESNET_SPECS[self.arch["backbone"]]
-        x = TF.relu(self._bn(self._conv(x, bu + ".conv1", 2, 3), bu + ".bn1"))
+        x = self._q(TF.relu(self._conv_bn(self._q(x), bu + ".conv1", bu + ".bn1", 2, 3)))
         x = TF.max_pool2d(x, 3, 2, 1)
+        if self.inject is not None and "pool" in self.inject:
+            x = self.inject["pool"].clone()
         outs = {"stem": x}
         block = self._bottleneck if kind == "bottleneck" else self._basic
         for li, nblk in enumerate(layers):
@@ -100,14 +149,16 @@ class Oracle:
         stages = [int(n[-1]) for n in names]
         x = [feats[n] for n in names[::-1]]
         st = stages[::-1]
-        prev = self._conv(x[0], f"backbone.fpn_lateral{st[0]}")
-        results = [self._conv(prev, f"backbone.fpn_output{st[0]}", 1, 1)]
+        q, act = self._q, self._act
+        prev = act(f"lat{st[0]}", self._conv(x[0], f"backbone.fpn_lateral{st[0]}"), False)
+        results = [act(f"P{st[0]}", self._conv(prev, f"backbone.fpn_output{st[0]}", 1, 1), False)]
         for f, s in zip(x[1:], st[1:]):
             td = TF.interpolate(prev, scale_factor=2, mode="bilinear", align_corners=False)
-            prev = self._conv(f, f"backbone.fpn_lateral{s}") + td
-            results.insert(0, self._conv(prev, f"backbone.fpn_output{s}", 1, 1))
-        p6 = self._conv(feats["res5"], "backbone.top_block.p6", 2, 1)
-        p7 = self._conv(TF.relu(p6), "backbone.top_block.p7", 2, 1)
+            prev = act(f"lat{s}", q(self._conv(f, f"backbone.fpn_lateral{s}")) + td, False)
+            results.insert(0, act(f"P{s}", self._conv(prev, f"backbone.fpn_output{s}", 1, 1), False))
+        top = stages[-1]
+        p6 = act(f"P{top + 1}", self._conv(feats["res5"], "backbone.top_block.p6", 2, 1), False)
+        p7 = act(f"P{top + 2}", self._conv(TF.relu(p6), "backbone.top_block.p7", 2, 1), False)
         return results + [p6, p7]
 
     # ---- heads --------------------------------------------------------------------------------
@@ -115,14 +166,14 @@ class Oracle:
         """RetinaNetHead.forward (retina_head.py:103-112); Sequential indices 0,2,4,6 are the convs."""
         logits, offsets = [], []
         nconv = self.arch.get("num_convs", 4)
-        for f in feats:
+        for li, f in enumerate(feats):
             c = f
             b = f
             for i in range(nconv):
-                c = TF.relu(self._conv(c, f"head.cls_subnet.{2 * i}", 1, 1))
-                b = TF.relu(self._conv(b, f"head.bbox_subnet.{2 * i}", 1, 1))
-            logits.append(self._conv(c, "head.cls_score", 1, 1))
-            offsets.append(self._conv(b, "head.bbox_pred", 1, 1))
+                c = self._act(f"cls{i}_{li}", self._conv(c, f"head.cls_subnet.{2 * i}", 1, 1), True)
+                b = self._act(f"box{i}_{li}", self._conv(b, f"head.bbox_subnet.{2 * i}", 1, 1), True)
+            logits.append(self._act(f"logits_{li}", self._conv(c, "head.cls_score", 1, 1), False))
+            offsets.append(self._act(f"offs_{li}", self._conv(b, "head.bbox_pred", 1, 1), False))
         return logits, offsets
 
     @staticmethod

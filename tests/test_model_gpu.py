@@ -1,8 +1,9 @@
 """End-to-end GPU parity of the RetinaNet training step (forward losses, target assignment, parameter gradients,
 SGD update) against the torch-CPU fp32 oracle (oracle/model.py) on the same parameters and the same batch.
 
-Tolerances (bf16 activations/weights on the HIP side, fp32 oracle): losses 2e-2 relative; per-group gradient
-rel-L2 <= 6e-2 and cosine >= 0.995; labels / matched anchors bit-exact."""
+Tolerances (bf16 activations/weights on the HIP side, fp32 oracle): losses and logits 2e-2 relative; labels /
+matched anchors bit-exact; parameter gradients: cosine >= 0.99 against the plain fp32 oracle, and rel-L2 <= 1e-2
+per parameter against the oracle evaluated on the same stored activations (identical ReLU gates)."""
 import numpy as np
 import pytest
 import torch
@@ -24,14 +25,23 @@ def _setup(backbone, N, size, seed=0):
         elif k.endswith("running_mean"):
             params[k] = rng.normal(0, 0.1, params[k].shape).astype(np.float32)
         elif (".bn" in k or "downsample.1" in k) and k.endswith(".weight"):
-            params[k] = rng.uniform(0.7, 1.3, params[k].shape).astype(np.float32)
+            # last BN of every residual branch is damped so that random-init activations stay O(1-10) at res5
+            last = (".bn3." in k) or (backbone in ("resnet18", "resnet34") and ".bn2." in k)
+            lo, hi = (0.15, 0.35) if last else (0.7, 1.3)
+            params[k] = rng.uniform(lo, hi, params[k].shape).astype(np.float32)
         elif (".bn" in k or "downsample.1" in k) and k.endswith(".bias"):
             params[k] = rng.normal(0, 0.1, params[k].shape).astype(np.float32)
-        elif k.startswith("head.") and k.endswith(".weight"):
-            params[k] = (params[k] * 3).astype(np.float32)      # livelier logits than the N(0, 0.01) init
     batch = next(DummyLoader(N, size, seed=seed))
     batch["data"] = (batch["data"] * 255).astype(np.float32)
     return cfg, params, batch
+
+
+def _grad_of(model, name, like):
+    ent = [e[0] for e in model.arena.entries]
+    g = model.arena.view("g", ent.index(name)).detach().cpu()
+    if g.ndim == 4:
+        g = g.permute(0, 3, 1, 2)
+    return g[: like.shape[0]].double().reshape(-1)
 
 
 @pytest.mark.parametrize("backbone,N,size", [("resnet18", 2, (128, 160)), ("resnet50", 3, (96, 128))])
@@ -43,19 +53,18 @@ def test_training_step_matches_oracle(backbone, N, size):
     model = RetinaNet(cfg, params=params)
     names = P.trainable_names(params, cfg.MODEL.BACKBONE.FREEZE_AT)
     assert sorted(names) == sorted(model.trainable_parameter_names())
+
+    # ---- (1) forward vs the plain fp32 oracle -------------------------------------------------------------
     orc = Oracle(params, P.oracle_arch(cfg), trainable=names)
     ref_losses, aux = orc.retinanet_losses(batch)
     ref_grads = orc.grads(ref_losses["total_loss"])
-
     losses = model(batch)
     pl = model._cur
-    # target assignment: bit-exact labels (anchors identical by construction of the kernels' parity tests)
-    assert np.array_equal(pl.labels.cpu().numpy(), aux["labels"])
+    assert np.array_equal(pl.labels.cpu().numpy(), aux["labels"])            # target assignment: bit-exact
     assert int(pl.num_fg.item()) == aux["num_fg"]
     for k in ("cls_loss", "reg_loss", "total_loss"):
-        got, ref = float(losses[k]), float(ref_losses[k])
-        assert abs(got - ref) / abs(ref) < 2e-2, (k, got, ref)
-    # logits parity
+        got, ref = float(losses[k]), float(ref_losses[k].detach())
+        assert abs(got - ref) / abs(ref) < 2e-2, (k, got, ref)               # bf16 tolerance (observed ~1e-5)
     K = cfg.DATA.NUM_CLASSES
     got_logits = pl.logits.float().cpu().view(-1, K)
     ref_logits = aux["logits"].detach()
@@ -63,40 +72,39 @@ def test_training_step_matches_oracle(backbone, N, size):
 
     model.backward()
     torch.cuda.synchronize()
-    groups = {}
-    for name in names:
-        idx = [e[0] for e in model.arena.entries].index(name)
-        g = model.arena.view("g", idx).detach().cpu()
-        r = ref_grads[name].detach()
-        if g.ndim == 4:
-            g = g.permute(0, 3, 1, 2)
-        g = g[: r.shape[0]]
-        key = name.split(".")[0] + "." + (name.split(".")[2] if name.startswith("backbone.bottom_up") else name.split(".")[1])
-        a, b = groups.setdefault(key, ([], []))
-        a.append(g.reshape(-1).double()); b.append(r.reshape(-1).double())
-    for key, (a, b) in groups.items():
-        a, b = torch.cat(a), torch.cat(b)
-        rel = float((a - b).norm() / b.norm())
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-        assert rel < 6e-2 and cos > 0.995, (key, rel, cos)
+    # ---- (2) gradients vs the fp32 oracle: loose (bf16 forward differences flip ReLU gates) ------------------
+    a = torch.cat([_grad_of(model, n, ref_grads[n]) for n in names])
+    b = torch.cat([ref_grads[n].detach().double().reshape(-1) for n in names])
+    assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99
+    # ---- (3) gradients vs the oracle evaluated on the SAME stored activations: tight ------------------------
+    # (the backward pass is then the same linear map on both sides; only bf16 rounding of gradient tensors differs)
+    orc2 = Oracle(params, P.oracle_arch(cfg), trainable=names, sim_bf16=True, inject=model.debug_activations())
+    l2, _ = orc2.retinanet_losses(batch)
+    g2 = orc2.grads(l2["total_loss"])
+    for n in names:
+        r = g2[n].detach().double().reshape(-1)
+        g = _grad_of(model, n, g2[n])
+        rel = float((g - r).norm() / (r.norm() + 1e-30))
+        assert rel < 1e-2, (n, rel)
 
-    # one optimizer step (solver/default_solver.py:96-114): w -= lr * (g + wd*w)
+    # ---- (4) one optimizer step (solver/default_solver.py:96-114) -------------------------------------------
     solver = DetSolver.build(cfg, model)
     lr = solver.optimizer.param_groups[0]["lr"]
     assert abs(lr - cfg.SOLVER.BASIC_LR * N) < 1e-12
     w_before = model.arena.w.clone()
     solver.optimizer.step()
-    state = orc.sgd_step(ref_grads, {}, lr, 0.9, cfg.SOLVER.WEIGHT_DECAY)
+    state = orc2.sgd_step(g2, {}, lr, 0.9, cfg.SOLVER.WEIGHT_DECAY)
     delta_ref, delta_got = [], []
     for name in names:
         idx = [e[0] for e in model.arena.entries].index(name)
-        d = (model.arena.view("w", idx) - w_before[model.arena.entries[idx][2]: model.arena.entries[idx][2] + model.arena.entries[idx][3]].view(model.arena.entries[idx][1])).cpu()
+        _, shape, off, n = model.arena.entries[idx]
+        d = (model.arena.view("w", idx) - w_before[off: off + n].view(shape)).cpu()
         if d.ndim == 4:
             d = d.permute(0, 3, 1, 2)
         d = d[: state[name].shape[0]]
         delta_got.append(d.reshape(-1).double()); delta_ref.append((-lr * state[name]).reshape(-1).double())
     a, b = torch.cat(delta_got), torch.cat(delta_ref)
-    assert float((a - b).norm() / b.norm()) < 6e-2
+    assert float((a - b).norm() / b.norm()) < 1e-2
 
 
 def test_minimize_runs_and_loss_decreases():
