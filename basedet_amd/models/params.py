@@ -50,7 +50,10 @@ def _bn(p, prefix, c):
     p[prefix + ".running_var"] = np.ones(c, np.float32)
 
 
-def init_resnet(p, rng, name):
+def init_resnet(p, rng, name, residual_gamma=None):
+    """residual_gamma: optional FrozenBN gamma for the last BN of every residual branch.  The reference always
+    starts from ImageNet statistics (retinanet_cfg.py:8); with identity BN a random-init ResNet-50 overflows, so the
+    benchmark's synthetic weights use a damped value (same FLOPs / bytes, finite activations)."""
     bu = "backbone.bottom_up"
     p[bu + ".conv1.weight"] = _msra_normal(rng, (64, 3, 7, 7), "fan_out")
     _bn(p, bu + ".bn1", 64)
@@ -63,6 +66,8 @@ def init_resnet(p, rng, name):
         for i, (cn, ci, co, k) in enumerate(specs):
             p[f"{pre}.{cn}.weight"] = _msra_normal(rng, (co, ci, k, k), "fan_out")
             _bn(p, f"{pre}.bn{i + 1}", co)
+            if residual_gamma is not None and i + 1 == len(specs):
+                p[f"{pre}.bn{i + 1}.weight"][:] = residual_gamma
         if blk["has_ds"]:
             p[f"{pre}.downsample.0.weight"] = _msra_normal(rng, (blk["cout"], blk["cin"], 1, 1), "fan_out")
             _bn(p, f"{pre}.downsample.1", blk["cout"])
@@ -90,11 +95,11 @@ def init_retina_head(p, rng, ch, num_anchors, num_classes, num_convs, prior_prob
     p["head.bbox_pred.bias"] = np.zeros(num_anchors * 4, np.float32)
 
 
-def init_retinanet_params(cfg, seed=0):
+def init_retinanet_params(cfg, seed=0, residual_gamma=None):
     rng = np.random.default_rng(seed)
     m = cfg.MODEL
     p = {}
-    init_resnet(p, rng, m.BACKBONE.NAME)
+    init_resnet(p, rng, m.BACKBONE.NAME, residual_gamma)
     stages = [int(f[-1]) for f in m.BACKBONE.OUT_FEATURES]
     init_fpn(p, rng, m.BACKBONE.OUT_FEATURE_CHANNELS, stages, m.FPN.OUT_CHANNELS, m.FPN.TOP_BLOCK_IN_CHANNELS)
     na = len(m.ANCHOR.SCALES[0]) * len(m.ANCHOR.RATIOS[0])

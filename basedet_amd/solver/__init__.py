@@ -103,6 +103,30 @@ class Solver:
         return losses
 
 
+class WarmupMultiStepLR:
+    """LRSchedulerHook.build_lr_scheduler (engine/hooks.py:222-248): MultiStepLR with iteration-wise milestones
+    (epochs * iters_per_epoch) wrapped in basecore's WarmUpScheduler (un-vendored; restated as a linear ramp
+    lr * (it + 1) / WARM_ITERS over the first WARM_ITERS iterations)."""
+
+    def __init__(self, optimizer, cfg, world_size=1):
+        s = cfg.SOLVER
+        self.optimizer = optimizer
+        self.base_lr = optimizer.param_groups[0]["lr"]
+        iters_per_epoch = int(s.NUM_IMAGE_PER_EPOCH / world_size / cfg.MODEL.BATCHSIZE)     # engine/trainer.py:48
+        self.milestones = [int(e) * iters_per_epoch for e in s.LR_DECAY_STAGES]
+        self.gamma = s.LR_DECAY_RATE
+        self.warm_iters = s.get("WARM_ITERS", 0)
+
+    def lr_at(self, it):
+        lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if it >= m)
+        if it < self.warm_iters:
+            lr *= (it + 1) / self.warm_iters
+        return lr
+
+    def step(self, it):
+        self.optimizer.param_groups[0]["lr"] = self.lr_at(it)
+
+
 @registers.solvers.register()
 class DetSolver:
     @classmethod

@@ -124,7 +124,7 @@ def main():
     from basedet_amd import ops
     from basedet_amd.configs import RetinaNetConfig, retinanet_r18_config
     from basedet_amd.models import RetinaNet, params as P
-    from basedet_amd.solver import DetSolver, broadcast_parameters
+    from basedet_amd.solver import DetSolver, WarmupMultiStepLR, broadcast_parameters
     from basedet_amd.utils import DummyLoader
 
     if args.workload == "retinanet_r50_800x1344":
@@ -132,10 +132,13 @@ def main():
     else:
         cfg, size = retinanet_r18_config(), (512, 512)
     cfg.MODEL.BATCHSIZE = args.batch
-    params = P.init_retinanet_params(cfg, seed=0)
+    # random-init weights of the named architecture; the last FrozenBN gamma of every residual branch is 0.2
+    # (stand-in for ImageNet statistics: identity BN overflows a random ResNet-50; same FLOPs and bytes)
+    params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
     model = RetinaNet(cfg, params=params)
     broadcast_parameters(model)
     solver = DetSolver.build(cfg, model)
+    sched = WarmupMultiStepLR(solver.optimizer, cfg, world)     # LRSchedulerHook.before_iter (engine/hooks.py:218)
 
     loader = DummyLoader(args.batch, size, seed=rank)
     b = next(loader)
@@ -153,13 +156,16 @@ def main():
             torch.cuda.synchronize()
 
     last = None
+    it = 0
     for _ in range(args.warmup):
+        sched.step(it); it += 1
         last = solver.minimize(model, batch)
     sync()
     if timer:
         timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        sched.step(it); it += 1
         last = solver.minimize(model, batch)
     sync()
     elapsed = time.perf_counter() - t0
