@@ -230,6 +230,14 @@ struct Plan { int ci_tiles, co_tiles, splits, steps_per_split, total_steps; long
 
 constexpr int BKP_DEFAULT = 64;
 int g_wgrad_use_tr = 1;
+int g_wgrad_use_3x3 = 1;
+
+bool is_3x3s1(const bd_conv_desc* d) {
+    if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return false;
+    for (int s = 0; s < d->nseg; ++s)
+        if (d->Hi[s] != d->Ho[s] || d->Wi[s] != d->Wo[s]) return false;
+    return true;
+}
 
 Plan make_plan(const bd_conv_desc* d) {
     Plan pl;
@@ -251,12 +259,27 @@ Plan make_plan(const bd_conv_desc* d) {
 
 }  // namespace
 
-extern "C" int bd_wgrad_set_transpose_read(int use_tr) { g_wgrad_use_tr = use_tr; return BD_OK; }
+int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patches_per_img_out);
+int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream);
+
+// use_tr: 1 = transposing LDS reads (default), 0 = scalar-read reference path of the generic kernel.
+// bit 1 (value 2) additionally disables the nine-tap 3x3 kernel (forces the generic per-tap kernel).
+extern "C" int bd_wgrad_set_transpose_read(int use_tr) {
+    g_wgrad_use_tr = use_tr & 1;
+    g_wgrad_use_3x3 = (use_tr & 2) ? 0 : 1;
+    if (!(use_tr & 1)) g_wgrad_use_3x3 = 0;
+    return BD_OK;
+}
 
 extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
     if (!d || d->nseg < 1 || d->nseg > BD_MAX_SEGS) return 0;
     const Plan pl = make_plan(d);
-    return (size_t)pl.splits * d->Cout * d->R * d->S * d->Cin * sizeof(float);
+    size_t splits = (size_t)pl.splits;
+    if (is_3x3s1(d)) {
+        const size_t s3 = (size_t)bd_wgrad3x3_splits(d, nullptr, nullptr);
+        if (s3 > splits) splits = s3;
+    }
+    return splits * d->Cout * d->R * d->S * d->Cin * sizeof(float);
 }
 
 extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale,
@@ -270,6 +293,16 @@ extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void*
     if (ws_bytes < need) {
         bd_set_error("conv2d_wgrad: workspace %zu < required %zu bytes", ws_bytes, need);
         return BD_EWORKSPACE;
+    }
+    if (g_wgrad_use_3x3 && is_3x3s1(d)) {
+        int splits3 = 1;
+        bd_wgrad3x3_launch(d, x, g, (float*)ws, &splits3, (hipStream_t)stream);
+        BD_CHECK_LAUNCH("bd_conv2d_wgrad(3x3)");
+        const long long n3 = (long long)d->Cout * 9 * d->Cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n3 / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)ws, splits3, n3, 9 * d->Cin, row_scale, dw, accumulate);
+        BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
+        return BD_OK;
     }
     WgradParams p{};
     p.x = (const bf16_raw*)x; p.g = (const bf16_raw*)g; p.slab = (float*)ws;

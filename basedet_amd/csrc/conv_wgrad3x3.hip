@@ -1,0 +1,234 @@
+// Weight gradient of 3x3 / stride-1 / pad-1 convolutions (RetinaNet head towers, FPN output convs, bottleneck
+// conv2): all nine taps from ONE staged activation patch.
+//
+//   dW[co][tap][ci] = sum_pix G[pix][co] * X[pix + shift(tap)][ci]
+//
+// The generic wgrad kernel (conv_wgrad.hip) re-reads both operands once per tap and per opposite tile
+// (64 FLOP per staged byte -> L2-bandwidth bound at ~250 TFLOP/s).  Here a workgroup stages, per K step, an
+// 8x8 output patch of G (64 pixels x 64 co) and the 10x10 input patch of X around it (100 pixels x 64 ci) and
+// accumulates the nine 64x64 tap products from them: ~225 FLOP per staged byte.  Each wave owns 16 ci x 64 co
+// of all nine taps (144 fp32 accumulator registers), two workgroups per CU; the next patch is prefetched into
+// registers under the 72 MFMAs of the current one.
+//
+// Both MFMA operands are pixel-major in LDS and are fetched with ds_read_b64_tr_b16 (see conv_wgrad.hip).  A tap
+// only shifts the LDS row of the X fragment by (r*10 + s) rows -- a compile-time address immediate.
+// MFMA k -> pixel map (same for A and B): k = 8*g4 + j  <->  patch row 4*kk + 2*(g4>>1) + (j>>2),
+// column 4*(g4&1) + (j&3); a half-wave therefore reads 8 consecutive LDS rows = all 64 banks (conflict-free).
+#include "common.h"
+
+namespace {
+
+constexpr int PATCH = 8;                 // output patch edge
+constexpr int XP = PATCH + 2;            // input patch edge
+constexpr int TILE_CI = 64, TILE_CO = 64;
+constexpr int X_PITCH = 160;             // 128 B data + 32 B pad  (40 dwords: 8 consecutive rows hit all 64 banks)
+constexpr int G_PITCH = 160;             // 128 B data + 32 B pad
+constexpr int X_BYTES = XP * XP * X_PITCH;
+constexpr int G_BYTES = PATCH * PATCH * G_PITCH;
+constexpr int BUF_BYTES = X_BYTES + G_BYTES;
+constexpr int X_CHUNKS = XP * XP * 8;    // 16-byte chunks in the X tile
+constexpr int X_PASSES = (X_CHUNKS + 255) / 256;   // 4
+constexpr int G_PASSES = 2;              // 64 rows x 8 chunks / 256 threads
+
+struct PSeg { int patch_start, H, W, pw, in_off, out_off; };
+
+struct W3Params {
+    const bf16_raw* x;
+    const bf16_raw* g;
+    float* slab;
+    int Cin, Cout, N, nseg;
+    int in_ppi, out_ppi;
+    int patches_per_img, total_patches, patches_per_split;
+    int ci_tiles, co_tiles;
+    PSeg seg[BD_MAX_SEGS];
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int tiles = p.ci_tiles * p.co_tiles;
+    const int split = bid / tiles;
+    bid -= split * tiles;
+    const int ci_tile = bid / p.co_tiles, co_tile = bid - ci_tile * p.co_tiles;
+    const int ci0 = ci_tile * TILE_CI, co0 = co_tile * TILE_CO;
+    const int pbeg = split * p.patches_per_split;
+    int pend = pbeg + p.patches_per_split;
+    if (pend > p.total_patches) pend = p.total_patches;
+
+    // per-thread staging slots
+    int x_iy[X_PASSES], x_ix[X_PASSES];      // position inside the 10x10 input patch, -1 = unused slot
+    const int x_chunk = tid & 7;
+    const bool x_cok = ci0 + x_chunk * 8 < p.Cin;
+#pragma unroll
+    for (int k = 0; k < X_PASSES; ++k) {
+        const int c = tid + 256 * k;
+        const int row = c >> 3;
+        x_iy[k] = row < XP * XP ? row / XP : -1;
+        x_ix[k] = row - (row / XP) * XP;
+    }
+    const int g_chunk = tid & 7;
+    const bool g_cok = co0 + g_chunk * 8 < p.Cout;
+
+    u32x4_t rx[X_PASSES], rg[G_PASSES];
+
+    auto stage_load = [&](int pid) {
+        const int n = pid / p.patches_per_img;
+        const int rem = pid - n * p.patches_per_img;
+        int s = 0;
+#pragma unroll
+        for (int k = 1; k < BD_MAX_SEGS; ++k)
+            if (k < p.nseg && rem >= p.seg[k].patch_start) s = k;
+        const PSeg sg = p.seg[s];
+        const int local = rem - sg.patch_start;
+        const int by = local / sg.pw, bx = local - by * sg.pw;
+        const int y0 = by * PATCH, x0 = bx * PATCH;
+        const long long xbase = (long long)n * p.in_ppi + sg.in_off;
+        const long long gbase = (long long)n * p.out_ppi + sg.out_off;
+#pragma unroll
+        for (int k = 0; k < X_PASSES; ++k) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            const int y = y0 - 1 + x_iy[k], x = x0 - 1 + x_ix[k];
+            if (x_iy[k] >= 0 && x_cok && y >= 0 && x >= 0 && y < sg.H && x < sg.W)
+                v = *reinterpret_cast<const u32x4_t*>(p.x + (xbase + (long long)y * sg.W + x) * p.Cin + ci0 + x_chunk * 8);
+            rx[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < G_PASSES; ++k) {
+            const int row = (tid >> 3) + 32 * k;
+            const int y = y0 + (row >> 3), x = x0 + (row & 7);
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (g_cok && y < sg.H && x < sg.W)
+                v = *reinterpret_cast<const u32x4_t*>(p.g + (gbase + (long long)y * sg.W + x) * p.Cout + co0 + g_chunk * 8);
+            rg[k] = v;
+        }
+    };
+    auto stage_write = [&](int buf) {
+        unsigned char* Xt = smem + buf * BUF_BYTES;
+        unsigned char* Gt = Xt + X_BYTES;
+#pragma unroll
+        for (int k = 0; k < X_PASSES; ++k) {
+            const int c = tid + 256 * k;
+            if (c < X_CHUNKS) *reinterpret_cast<u32x4_t*>(Xt + (c >> 3) * X_PITCH + x_chunk * 16) = rx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < G_PASSES; ++k) {
+            const int row = (tid >> 3) + 32 * k;
+            *reinterpret_cast<u32x4_t*>(Gt + row * G_PITCH + g_chunk * 16) = rg[k];
+        }
+    };
+
+    f32x4_t acc[9][4];     // wave tile: 16 ci x 64 co per tap
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int g4 = lane >> 4, idx = lane & 15;
+    const int tr_q = idx >> 2, tr_p = idx & 3;
+    // lane-constant parts of the fragment addresses
+    const int prow_hi = 2 * (g4 >> 1);            // patch row inside the 4-row sub-step
+    const int pcol = 4 * (g4 & 1) + tr_q;         // patch column supplied by this lane
+    const int x_lane_off = (prow_hi * XP + pcol) * X_PITCH + (wave * 16 + 4 * tr_p) * 2;
+    const int g_lane_off = (prow_hi * PATCH + pcol) * G_PITCH + (4 * tr_p) * 2;
+
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    auto tr_frag = [&](const unsigned char* a0, int row_pitch_bytes) -> bf16x8_t {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + row_pitch_bytes));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v);
+    };
+
+    auto compute = [&](int buf) {
+        const unsigned char* Xt = smem + buf * BUF_BYTES + x_lane_off;
+        const unsigned char* Gt = smem + buf * BUF_BYTES + X_BYTES + g_lane_off;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = tr_frag(Gt + (4 * kk * PATCH) * G_PITCH + j * 32, PATCH * G_PITCH);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s = t % 3;
+                const bf16x8_t a = tr_frag(Xt + ((4 * kk + r) * XP + s) * X_PITCH, XP * X_PITCH);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[t][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (pbeg < pend) {
+        stage_load(pbeg);
+        stage_write(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int pid = pbeg; pid < pend; ++pid) {
+        const bool more = pid + 1 < pend;
+        if (more) stage_load(pid + 1);
+        compute(cur);
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* slab = p.slab + (long long)split * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + j * 16 + idx;
+        if (co >= p.Cout) continue;
+        const int ci = ci0 + wave * 16 + g4 * 4;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            *reinterpret_cast<f32x4_t*>(slab + ((long long)co * 9 + t) * p.Cin + ci) = acc[t][j];
+    }
+}
+
+}  // namespace
+
+// plan shared with conv_wgrad.hip
+int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patches_per_img_out) {
+    int ppi = 0;
+    for (int s = 0; s < d->nseg; ++s) ppi += cdiv(d->Ho[s], PATCH) * cdiv(d->Wo[s], PATCH);
+    const int total = ppi * d->N;
+    const int tiles = cdiv(d->Cin, TILE_CI) * cdiv(d->Cout, TILE_CO);
+    int splits = 512 / tiles;
+    if (splits < 1) splits = 1;
+    if (splits > total) splits = total;
+    const int per = cdiv(total, splits);
+    splits = cdiv(total, per);
+    if (total_patches_out) *total_patches_out = total;
+    if (patches_per_img_out) *patches_per_img_out = ppi;
+    return splits;
+}
+
+int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream) {
+    W3Params p{};
+    p.x = (const bf16_raw*)x; p.g = (const bf16_raw*)g; p.slab = slab;
+    p.Cin = d->Cin; p.Cout = d->Cout; p.N = d->N; p.nseg = d->nseg;
+    p.in_ppi = d->in_pix_per_img; p.out_ppi = d->out_pix_per_img;
+    int total, ppi;
+    const int splits = bd_wgrad3x3_splits(d, &total, &ppi);
+    p.total_patches = total; p.patches_per_img = ppi; p.patches_per_split = cdiv(total, splits);
+    p.ci_tiles = cdiv(d->Cin, TILE_CI); p.co_tiles = cdiv(d->Cout, TILE_CO);
+    int ps = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        PSeg& sg = p.seg[s];
+        sg.patch_start = ps; sg.H = d->Ho[s]; sg.W = d->Wo[s]; sg.pw = cdiv(d->Wo[s], PATCH);
+        sg.in_off = d->in_off[s]; sg.out_off = d->out_off[s];
+        ps += cdiv(d->Ho[s], PATCH) * sg.pw;
+    }
+    const size_t lds = 2 * BUF_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = splits * p.ci_tiles * p.co_tiles;
+    hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3(grid), dim3(256), lds, stream, p);
+    *splits_out = splits;
+    return 0;
+}

@@ -284,12 +284,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_raw* __r
         partial[(long long)blockIdx.x * C + c] = s;
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// stage 2: block = 8 channels x 32 partial lanes; each lane sums every 32nd partial, LDS tree over the lanes
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int b = lane; b < nblocks; b += 32) s += partial[(long long)b * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && c < C) {
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[k * 8 + cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 __global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ v, const float* __restrict__ g, long long n,
@@ -426,7 +436,7 @@ extern "C" int bd_colsum_bf16(const void* g, int N, int64_t pix_per_img, int64_t
     }
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(COLSUM_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)g,
                        rows, C, (long long)(cnt > 0 ? cnt : 1), (long long)pix_per_img, (long long)off, (float*)ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
                        COLSUM_BLOCKS, C, out, accumulate);
     BD_CHECK_LAUNCH("bd_colsum_bf16");
     return BD_OK;
