@@ -1,0 +1,100 @@
+"""N > 1 path on CPU: world-size-2 gloo run of the solver's bucketed gradient all-reduce (GradBuckets), the
+world-size LR scaling of DetSolver.build (solver/default_solver.py:99-106) and the flat parameter broadcast
+(configs/detection_cfg.py:80-82).  No kernels are launched: the arenas are plain CPU tensors."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _FakeArena:
+    def __init__(self, names_sizes):
+        self.entries, off = [], 0
+        for n, s in names_sizes:
+            self.entries.append((n, (s,), off, s))
+            off += (s + 63) // 64 * 64
+        self.total = off
+        self.w = torch.zeros(off); self.g = torch.zeros(off); self.v = torch.zeros(off)
+
+
+class _FakeModel:
+    def __init__(self):
+        self.arena = _FakeArena([
+            ("backbone.bottom_up.layer2.0.conv1.weight", 100), ("backbone.bottom_up.layer3.0.conv1.weight", 70),
+            ("backbone.bottom_up.layer4.0.conv1.weight", 130), ("backbone.fpn_lateral3.weight", 64),
+            ("backbone.top_block.p6.weight", 10), ("head.cls_score.weight", 200), ("head.cls_score.bias", 8)])
+        self.repacked = 0
+
+    def repack_trainable(self):
+        self.repacked += 1
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basedet_amd.configs import RetinaNetConfig
+    from basedet_amd.solver import DetSolver, GradBuckets, broadcast_parameters
+    model = _FakeModel()
+    cfg = RetinaNetConfig()
+    cfg.MODEL.BATCHSIZE = 16
+    solver = DetSolver.build(cfg, model)
+    lr = solver.optimizer.param_groups[0]["lr"]
+    # parameter broadcast from rank 0
+    model.arena.w.fill_(float(rank + 1))
+    broadcast_parameters(model)
+    ok_bcast = bool((model.arena.w == 1.0).all()) and model.repacked == 1
+    # bucketed all-reduce in backward order; every bucket covers its parameters, buckets are disjoint
+    gb = GradBuckets(model, "MEAN")
+    model.arena.g.copy_(torch.arange(model.arena.total, dtype=torch.float32) * (rank + 1))
+    for phase in ("head", "fpn", "layer4", "layer3", "layer2"):
+        gb.on_ready(phase)
+    scale = gb.wait()
+    expect = torch.arange(model.arena.total, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    covered = torch.zeros(model.arena.total, dtype=torch.bool)
+    for lo, hi in gb.ranges.values():
+        assert not covered[lo:hi].any(), "buckets overlap"
+        covered[lo:hi] = True
+    for _, _, off, n in model.arena.entries:
+        assert covered[off:off + n].all(), "parameter outside every bucket"
+    ok_reduce = bool(torch.equal(model.arena.g[covered], expect[covered]))
+    if rank == 0:
+        out.put((lr, scale, ok_bcast, ok_reduce, sorted(gb.ranges)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_bucketed_allreduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    lr, scale, ok_bcast, ok_reduce, phases = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert abs(lr - 0.01 / 16 * 16 * world) < 1e-12          # BASIC_LR * BATCHSIZE * world (MEAN reduce)
+    assert scale == 0.5 and ok_bcast and ok_reduce
+    assert phases == ["fpn", "head", "layer2", "layer3", "layer4"]
+
+
+def test_lr_schedule_restates_reference_hook():
+    from basedet_amd.configs import RetinaNetConfig
+    from basedet_amd.solver import SGD, WarmupMultiStepLR
+    cfg = RetinaNetConfig()
+    cfg.MODEL.BATCHSIZE = 16
+    opt = SGD(_FakeModel(), lr=0.01, weight_decay=1e-4, momentum=0.9)
+    s = WarmupMultiStepLR(opt, cfg, world_size=1)
+    ipe = 80000 // 16
+    assert s.milestones == [12 * ipe, 16 * ipe]
+    assert np.isclose(s.lr_at(0), 0.01 / 500) and np.isclose(s.lr_at(499), 0.01) and np.isclose(s.lr_at(5000), 0.01)
+    assert np.isclose(s.lr_at(12 * ipe), 0.001) and np.isclose(s.lr_at(16 * ipe + 3), 0.0001)
