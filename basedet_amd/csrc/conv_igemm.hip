@@ -156,7 +156,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
         // A: weights [co][tap][ck]
 #pragma unroll
         for (int i = 0; i < C::PASSES; ++i) {
-            const int co = co0 + row0 + i * C::ROWS_PER_PASS;
+            // LDS row (h*64 + t*16 + rho) holds output channel h*64 + 16*(rho>>2) + 4*t + (rho&3): after the MFMAs a
+            // lane then owns 16 CONSECUTIVE channels of a pixel (4 tiles x 4 registers) -> 32-byte NHWC pieces,
+            // 128 contiguous bytes per pixel and wave-instruction in the epilogue
+            const int lrow = row0 + i * C::ROWS_PER_PASS;
+            const int rho = lrow & 15;
+            const int co = co0 + (lrow & 64) + 16 * (rho >> 2) + 4 * ((lrow >> 4) & 3) + (rho & 3);
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (cvalid && co < p.CO) {
                 const bf16_raw* g = p.w + ((long long)co * RS + cur_tap) * p.CK + c0;
@@ -242,12 +247,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane holds channels (cg*4 .. cg*4+3) of pixel (lane & 15) for each (i, j) ----
+    // ---- epilogue: lane (cg = lane>>4) holds channels co0 + wc*64 + 16*cg + (4*i + r) of pixel (lane & 15) ----
     const int cg = lane >> 4;
     const bool do_relu = p.flags & BD_EPI_RELU;
     const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
     const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
     const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
+    const int cbase = co0 + wc * 64 + 16 * cg;
+    float bias[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bias[k] = 0.f;
+    if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (cbase + 4 * q < p.CO) {
+                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 4 * q);
+                bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
+            }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wp * 64 + j * 16 + (lane & 15);
@@ -267,39 +284,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
             const int xx = rem - yy * ss.Ws;
             dstpix = n * p.dst_pix_per_img + ss.dst_off + (ss.y0 + ss.step * yy) * ss.Wd + ss.x0 + ss.step * xx;
         }
+        const long long base = (long long)dstpix * p.CO + cbase;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = co0 + wc * 64 + i * 16 + cg * 4;
-            if (co >= p.CO) continue;
-            const long long idx = (long long)dstpix * p.CO + co;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + co);
-                v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
-            }
+        for (int half = 0; half < 2; ++half) {       // 8 channels = 16 bytes per half
+            if (cbase + 8 * half >= p.CO) continue;  // CO % 8 == 0
+            const long long idx = base + 8 * half;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];
             if (add_before) {
-                const u32x2_t av = *reinterpret_cast<const u32x2_t*>(p.add + idx);
-                v[0] += bf_lo(av[0]); v[1] += bf_hi(av[0]); v[2] += bf_lo(av[1]); v[3] += bf_hi(av[1]);
+                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
             }
             if (do_relu) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
             }
             if (do_mask) {
-                const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(p.mask + idx);
-                if (!(bf_lo(mv[0]) > 0.f)) v[0] = 0.f;
-                if (!(bf_hi(mv[0]) > 0.f)) v[1] = 0.f;
-                if (!(bf_lo(mv[1]) > 0.f)) v[2] = 0.f;
-                if (!(bf_hi(mv[1]) > 0.f)) v[3] = 0.f;
+                const u32x4_t mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!(bf_lo(mv[k]) > 0.f)) v[2 * k] = 0.f;
+                    if (!(bf_hi(mv[k]) > 0.f)) v[2 * k + 1] = 0.f;
+                }
             }
             if (add_after) {
-                const u32x2_t av = *reinterpret_cast<const u32x2_t*>(p.add + idx);
-                v[0] += bf_lo(av[0]); v[1] += bf_hi(av[0]); v[2] += bf_lo(av[1]); v[3] += bf_hi(av[1]);
+                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
             }
-            u32x2_t o;
-            o[0] = pack_bf2(v[0], v[1]);
-            o[1] = pack_bf2(v[2], v[3]);
-            *reinterpret_cast<u32x2_t*>(p.dst + idx) = o;
+            u32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+            *reinterpret_cast<u32x4_t*>(p.dst + idx) = o;
         }
     }
 }
@@ -340,7 +358,7 @@ extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w
     if (int e = check_desc(d)) return e;
     BD_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_fwd: Cin=%d must be a multiple of 8", d->Cin);
-    BD_REQUIRE(d->Cout % 4 == 0, "conv2d_fwd: Cout=%d must be a multiple of 4", d->Cout);
+    BD_REQUIRE(d->Cout % 8 == 0, "conv2d_fwd: Cout=%d must be a multiple of 8", d->Cout);
     BD_REQUIRE(!(flags & BD_EPI_MASK), "conv2d_fwd: BD_EPI_MASK is a dgrad-only flag");
     IgemmParams p{};
     p.src = (const bf16_raw*)x; p.w = (const bf16_raw*)w_packed; p.bias = bias;
@@ -372,7 +390,7 @@ extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void*
     if (int e = check_desc(d)) return e;
     BD_REQUIRE(g && w_packed_t && dx, "conv2d_dgrad: null pointer");
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_dgrad: Cout=%d must be a multiple of 8 (pad the gradient)", d->Cout);
-    BD_REQUIRE(d->Cin % 4 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 4", d->Cin);
+    BD_REQUIRE(d->Cin % 8 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad: BD_EPI_RELU is a forward-only flag");
     IgemmParams p{};
     p.src = (const bf16_raw*)g; p.w = (const bf16_raw*)w_packed_t; p.bias = nullptr;

@@ -37,6 +37,7 @@ class ConvTimer:
         self.ops = ops
         self.records = {"igemm": [], "wgrad": []}
         self.enabled = False
+        self.meta = {}
         self._orig = (ops.conv2d_fwd, ops.conv2d_dgrad, ops.conv2d_wgrad)
 
         def flops(d):
@@ -52,12 +53,26 @@ class ConvTimer:
                 r = fn(d, *a, **k)
                 e.record()
                 self.records[kind].append((s, e, flops(d)))
+                self.meta.setdefault(kind, []).append((fn.__name__, d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0]))
                 return r
             return inner
 
         ops.conv2d_fwd = wrap(ops.conv2d_fwd, "igemm")
         ops.conv2d_dgrad = wrap(ops.conv2d_dgrad, "igemm")
         ops.conv2d_wgrad = wrap(ops.conv2d_wgrad, "wgrad")
+
+    def dump(self, steps):
+        agg = {}
+        for kind, rec in self.records.items():
+            for (s, e, f), m in zip(rec, self.meta.get(kind, [])):
+                k = (kind,) + m
+                a = agg.setdefault(k, [0, 0.0, 0.0])
+                a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        print("# per-shape conv time per step (ms), TFLOP/s", file=sys.stderr)
+        for k, (n, ms, fl) in rows:
+            print(f"# {k[0]:6s} {k[1]:14s} Cin={k[2]:5d} Cout={k[3]:5d} R={k[4]} s={k[5]} nseg={k[6]} HxW={k[7]}x{k[8]} "
+                  f"launches/step={n // steps:3d} ms/step={ms / steps:7.3f} TF/s={fl / (ms * 1e-3) / 1e12:7.1f}", file=sys.stderr)
 
     def summary(self, kind):
         rec = self.records[kind]
@@ -107,6 +122,7 @@ def main():
     ap.add_argument("--workload", default="retinanet_r50_800x1344", choices=sorted(TRAIN_GFLOP_PER_IMG))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-convs", action="store_true", help="per-shape conv timing table on stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,6 +209,8 @@ def main():
         gf = TRAIN_GFLOP_PER_IMG[args.workload]
         out["config"]["train_gflop_per_img"] = gf
         out["config"]["whole_step_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+        if timer and args.dump_convs:
+            timer.dump(args.steps)
         if timer:
             ig, wg = timer.summary("igemm"), timer.summary("wgrad")
             ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12

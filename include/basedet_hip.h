@@ -68,12 +68,12 @@ int bd_version(void);
  * ------------------------------------------------------------------------------------------------------- */
 
 /* y = epi(conv(x, w) + bias [+ add]); w_packed = [Cout][R][S][Cin] bf16 (bd_weight_pack fwd layout).
- * Requires Cin % 8 == 0 and Cout % 4 == 0. bias may be NULL. add/mask per flags (same shape as y). */
+ * Requires Cin % 8 == 0 and Cout % 8 == 0. bias may be NULL. add/mask per flags (same shape as y). */
 int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                   const void* add, void* y, int flags, bd_stream_t stream);
 
 /* dx = epi(conv_transpose(g, w) [+ add]) ; w_packed_t = [Cin][R][S][Cout] bf16 (bd_weight_pack dgrad layout).
- * g has the conv's OUTPUT geometry, dx/add/mask the INPUT geometry. Requires Cout % 8 == 0, Cin % 4 == 0. */
+ * g has the conv's OUTPUT geometry, dx/add/mask the INPUT geometry. Requires Cout % 8 == 0, Cin % 8 == 0. */
 int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add,
                     const void* mask, void* dx, int flags, bd_stream_t stream);
 
