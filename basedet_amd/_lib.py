@@ -69,6 +69,7 @@ SIGNATURES = {
     "bd_bce_logits_fwd_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P]),
     "bd_sgd_momentum_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _P]),
     "bd_wgrad_set_transpose_read": (_I, [_I]),
+    "bd_conv_set_patch3x3": (_I, [_I]),
 }
 
 _lib = None

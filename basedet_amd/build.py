@@ -15,6 +15,7 @@ ARCH = "gfx950"
 SOURCES = {
     "image_ops.hip": [],
     "conv_igemm.hip": [],
+    "conv3x3.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad3x3.hip": [],
     "stem.hip": [],

@@ -1,0 +1,308 @@
+// 3x3 / stride-1 / pad-1 convolution forward and data-gradient: "patch" implicit GEMM.
+//
+// The generic kernel (conv_igemm.hip) stages the activation tile once per filter tap; with 128x128 tiles that is
+// 64 FLOP per staged byte and the LDS store/load pipe, not the MFMA pipe, bounds it (~600 TFLOP/s).  Here a
+// workgroup owns 256 output pixels = two 8x16 patches and, per 64-channel K block, stages their two 10x18 input
+// patches ONCE; the nine taps then read shifted rows of that image while only the 128x64 weight tile of each tap is
+// re-staged:  ~225 FLOP per staged byte, LDS traffic per MFMA down ~1.7x, MFMA-bound.
+//
+// 512 threads = 8 waves = 2 (channel halves of 64) x 4 (pixel quarters of 64 = 4 patch rows of 16 px).
+// LDS (unpadded, XOR-swizzled 128-byte rows: chunk position = chunk ^ (row & 7), conflict-free for ds_read_b128 of
+// 16 consecutive rows): 2 x 45 KB activation images + 2 x 16 KB weight tiles.
+// dgrad = the same kernel on dY with the mirrored tap and the [Cin][tap][Cout] packed weights.
+#include "common.h"
+
+namespace {
+
+constexpr int PH = 8, PW = 16;                 // output patch
+constexpr int IH = PH + 2, IW = PW + 2;        // input patch
+constexpr int NPATCH = 2;                      // patches per workgroup
+constexpr int XROWS = NPATCH * IH * IW;        // 360 LDS rows
+constexpr int X_BYTES = XROWS * 128;           // 46080
+constexpr int W_BYTES = 128 * 128;             // 16384
+constexpr int XCHUNKS = XROWS * 8;             // 2880 16-byte chunks
+constexpr int XPASSES = (XCHUNKS + 511) / 512; // 6
+constexpr int TILE_CO = 128;
+constexpr int MAX_SEG = BD_MAX_SEGS;
+
+struct CSeg { int patch_start, H, W, pw, src_off, dst_off; };
+
+struct C3Params {
+    const bf16_raw* src;
+    const bf16_raw* w;       // [CO][9][CK]
+    const float* bias;
+    const bf16_raw* add;
+    const bf16_raw* mask;
+    bf16_raw* dst;
+    int CK, CO, mode, flags, N, nseg;
+    int src_ppi, dst_ppi;
+    int patches_per_img, total_patches, n_tiles;
+    CSeg seg[MAX_SEG];
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xbuf = smem;                       // [2][X_BYTES]
+    unsigned char* wbuf = smem + 2 * X_BYTES;         // [2][W_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 2, wp = wave & 3;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int pt = bid / p.n_tiles;              // pixel tile (pair of patches)
+    const int ct = bid - pt * p.n_tiles;
+    const int co0 = ct * TILE_CO;
+
+    // ---- geometry of the two patches (workgroup-uniform) ----
+    int pn[NPATCH], py0[NPATCH], px0[NPATCH], pH[NPATCH], pWd[NPATCH];
+    long long psrc[NPATCH], pdst[NPATCH];
+#pragma unroll
+    for (int k = 0; k < NPATCH; ++k) {
+        const int pid = pt * NPATCH + k;
+        pH[k] = 0; pWd[k] = 0; pn[k] = 0; py0[k] = 0; px0[k] = 0; psrc[k] = 0; pdst[k] = 0;
+        if (pid < p.total_patches) {
+            const int n = pid / p.patches_per_img;
+            const int rem = pid - n * p.patches_per_img;
+            int s = 0;
+#pragma unroll
+            for (int q = 1; q < MAX_SEG; ++q)
+                if (q < p.nseg && rem >= p.seg[q].patch_start) s = q;
+            const CSeg sg = p.seg[s];
+            const int local = rem - sg.patch_start;
+            const int by = local / sg.pw, bx = local - by * sg.pw;
+            pn[k] = n; py0[k] = by * PH; px0[k] = bx * PW; pH[k] = sg.H; pWd[k] = sg.W;
+            psrc[k] = (long long)n * p.src_ppi + sg.src_off;
+            pdst[k] = (long long)n * p.dst_ppi + sg.dst_off;
+        }
+    }
+
+    // ---- per-thread activation staging slots: chunk id c = tid + 512*k -> (row, chunk) ----
+    long long x_off[XPASSES];   // element offset of the source pixel (without channel), -1 = zero-fill
+    int x_lds[XPASSES];
+    const int x_chunk = tid & 7;
+#pragma unroll
+    for (int k = 0; k < XPASSES; ++k) {
+        const int c = tid + 512 * k;
+        const int row = c >> 3;
+        x_off[k] = -1; x_lds[k] = -1;
+        if (row < XROWS) {
+            const int pk = row / (IH * IW);
+            const int rr = row - pk * (IH * IW);
+            const int iy = rr / IW, ix = rr - iy * IW;
+            const int y = (pk == 0 ? py0[0] : py0[1]) - 1 + iy, x = (pk == 0 ? px0[0] : px0[1]) - 1 + ix;
+            const int H = pk == 0 ? pH[0] : pH[1], W = pk == 0 ? pWd[0] : pWd[1];
+            x_lds[k] = swz(row, x_chunk);
+            if (y >= 0 && x >= 0 && y < H && x < W) x_off[k] = ((pk == 0 ? psrc[0] : psrc[1]) + (long long)y * W + x) * p.CK;
+        }
+    }
+    // weight staging: 128 rows x 8 chunks = 1024 chunks -> 2 per thread; LDS row lrow holds the permuted channel
+    int w_co[2], w_lds[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 512 * k;
+        const int lrow = c >> 3;
+        const int rho = lrow & 15;
+        w_co[k] = co0 + (lrow & 64) + 16 * (rho >> 2) + 4 * ((lrow >> 4) & 3) + (rho & 3);
+        w_lds[k] = swz(lrow, tid & 7);
+    }
+
+    const int kblocks = (p.CK + 63) / 64;
+    const int nsteps = kblocks * 9;
+    u32x4_t rw[2], rx[XPASSES];
+
+    auto load_w = [&](int step) {
+        const int cb = step / 9, tap = step - cb * 9;
+        const int c0 = cb * 64 + (tid & 7) * 8;
+        const bool cvalid = c0 + 8 <= p.CK;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (cvalid && w_co[k] < p.CO)
+                v = *reinterpret_cast<const u32x4_t*>(p.w + ((long long)w_co[k] * 9 + tap) * p.CK + c0);
+            rw[k] = v;
+        }
+    };
+    auto write_w = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4_t*>(wbuf + buf * W_BYTES + w_lds[k]) = rw[k];
+    };
+    auto load_x = [&](int cb) {
+        const int c0 = cb * 64 + x_chunk * 8;
+        const bool cvalid = c0 + 8 <= p.CK;
+#pragma unroll
+        for (int k = 0; k < XPASSES; ++k) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (cvalid && x_off[k] >= 0) v = *reinterpret_cast<const u32x4_t*>(p.src + x_off[k] + c0);
+            rx[k] = v;
+        }
+    };
+    auto write_x = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < XPASSES; ++k)
+            if (x_lds[k] >= 0) *reinterpret_cast<u32x4_t*>(xbuf + buf * X_BYTES + x_lds[k]) = rx[k];
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int a_off[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) a_off[i][kk] = swz(wc * 64 + i * 16 + frow, kk * 4 + fchunk);
+    // B rows: patch (wp>>1), output rows 4*(wp&1) + j, column frow; input row = (orow + dy)*IW + frow + dx
+    const int b_row0 = (wp >> 1) * (IH * IW) + (4 * (wp & 1)) * IW + frow;
+
+    auto compute = [&](int xb, int wb, int tap) {
+        int dy = tap / 3, dx = tap - dy * 3;
+        if (p.mode == 1) { dy = 2 - dy; dx = 2 - dx; }     // dgrad: mirrored tap
+        const unsigned char* Xt = xbuf + xb * X_BYTES;
+        const unsigned char* Wt = wbuf + wb * W_BYTES;
+        const int shift = dy * IW + dx;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(Wt + a_off[i][kk]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = b_row0 + j * IW + shift;
+                b[j] = *reinterpret_cast<const bf16x8_t*>(Xt + swz(row, kk * 4 + fchunk));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // prologue: activation image of K block 0 and weights of step 0
+    load_x(0);
+    load_w(0);
+    write_x(0);
+    write_w(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int cb = step / 9, tap = step - cb * 9;
+        const bool more = step + 1 < nsteps;
+        const bool prefetch_x = (tap == 5) && (cb + 1 < kblocks);
+        if (more) load_w(step + 1);
+        if (prefetch_x) load_x(cb + 1);
+        compute(cb & 1, step & 1, tap);
+        if (more) write_w((step + 1) & 1);
+        if (prefetch_x) write_x((cb + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (same permuted-channel scheme as conv_igemm.hip) ----
+    const int cg = lane >> 4;
+    const bool do_relu = p.flags & BD_EPI_RELU;
+    const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
+    const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
+    const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
+    const int cbase = co0 + wc * 64 + 16 * cg;
+    float bias[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bias[k] = 0.f;
+    if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (cbase + 4 * q < p.CO) {
+                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 4 * q);
+                bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
+            }
+    }
+    const int pk = wp >> 1;
+    const int oy0 = (pk == 0 ? py0[0] : py0[1]) + 4 * (wp & 1);
+    const int ox = (pk == 0 ? px0[0] : px0[1]) + frow;
+    const int H = pk == 0 ? pH[0] : pH[1], W = pk == 0 ? pWd[0] : pWd[1];
+    const long long dbase = pk == 0 ? pdst[0] : pdst[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oy = oy0 + j;
+        if (oy >= H || ox >= W) continue;
+        const long long base = (dbase + (long long)oy * W + ox) * p.CO + cbase;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (cbase + 8 * half >= p.CO) continue;
+            const long long idx = base + 8 * half;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];
+            if (add_before) {
+                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
+            }
+            if (do_relu) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (do_mask) {
+                const u32x4_t mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!(bf_lo(mv[k]) > 0.f)) v[2 * k] = 0.f;
+                    if (!(bf_hi(mv[k]) > 0.f)) v[2 * k + 1] = 0.f;
+                }
+            }
+            if (add_after) {
+                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
+            }
+            u32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+            *reinterpret_cast<u32x4_t*>(p.dst + idx) = o;
+        }
+    }
+}
+
+}  // namespace
+
+// called from conv_igemm.hip for 3x3 / stride 1 / pad 1 descriptors; mode 0 fwd (src = x, geometry in == out),
+// mode 1 dgrad (src = dY).  CK = reduction channels, CO = produced channels.
+int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias,
+                            const void* add, const void* mask, void* dst, int flags, hipStream_t stream) {
+    C3Params p{};
+    p.src = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias;
+    p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)dst;
+    p.CK = mode == 0 ? d->Cin : d->Cout;
+    p.CO = mode == 0 ? d->Cout : d->Cin;
+    p.mode = mode; p.flags = flags; p.N = d->N; p.nseg = d->nseg;
+    p.src_ppi = mode == 0 ? d->in_pix_per_img : d->out_pix_per_img;
+    p.dst_ppi = mode == 0 ? d->out_pix_per_img : d->in_pix_per_img;
+    int ps = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        CSeg& sg = p.seg[s];
+        sg.patch_start = ps; sg.H = d->Ho[s]; sg.W = d->Wo[s]; sg.pw = cdiv(d->Wo[s], PW);
+        sg.src_off = mode == 0 ? d->in_off[s] : d->out_off[s];
+        sg.dst_off = mode == 0 ? d->out_off[s] : d->in_off[s];
+        ps += cdiv(d->Ho[s], PH) * sg.pw;
+    }
+    p.patches_per_img = ps;
+    p.total_patches = ps * d->N;
+    p.n_tiles = cdiv(p.CO, TILE_CO);
+    const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
+    const size_t lds = 2 * X_BYTES + 2 * W_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_patch_kernel, dim3(grid), dim3(512), lds, stream, p);
+    return 0;
+}

@@ -351,7 +351,21 @@ int check_desc(const bd_conv_desc* d) {
     return 0;
 }
 
+bool is_3x3s1(const bd_conv_desc* d) {
+    if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return false;
+    for (int s = 0; s < d->nseg; ++s)
+        if (d->Hi[s] != d->Ho[s] || d->Wi[s] != d->Wo[s]) return false;
+    return true;
+}
+int g_use_patch3x3 = 1;
+
 }  // namespace
+
+int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias,
+                            const void* add, const void* mask, void* dst, int flags, hipStream_t stream);
+
+// debug/measurement knob: 0 forces the generic per-tap kernel for 3x3 stride-1 convolutions
+extern "C" int bd_conv_set_patch3x3(int enable) { g_use_patch3x3 = enable; return BD_OK; }
 
 extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* add, void* y, int flags, bd_stream_t stream) {
@@ -360,6 +374,11 @@ extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_fwd: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_fwd: Cout=%d must be a multiple of 8", d->Cout);
     BD_REQUIRE(!(flags & BD_EPI_MASK), "conv2d_fwd: BD_EPI_MASK is a dgrad-only flag");
+    if (g_use_patch3x3 && is_3x3s1(d)) {
+        bd_conv3x3_patch_launch(d, 0, x, w_packed, bias, add, nullptr, y, flags, (hipStream_t)stream);
+        BD_CHECK_LAUNCH("bd_conv2d_fwd(3x3 patch)");
+        return BD_OK;
+    }
     IgemmParams p{};
     p.src = (const bf16_raw*)x; p.w = (const bf16_raw*)w_packed; p.bias = bias;
     p.add = (const bf16_raw*)add; p.mask = nullptr; p.dst = (bf16_raw*)y;
@@ -392,6 +411,11 @@ extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void*
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_dgrad: Cout=%d must be a multiple of 8 (pad the gradient)", d->Cout);
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad: BD_EPI_RELU is a forward-only flag");
+    if (g_use_patch3x3 && is_3x3s1(d)) {
+        bd_conv3x3_patch_launch(d, 1, g, w_packed_t, nullptr, add, mask, dx, flags, (hipStream_t)stream);
+        BD_CHECK_LAUNCH("bd_conv2d_dgrad(3x3 patch)");
+        return BD_OK;
+    }
     IgemmParams p{};
     p.src = (const bf16_raw*)g; p.w = (const bf16_raw*)w_packed_t; p.bias = nullptr;
     p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)dx;

@@ -83,6 +83,10 @@ size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d);
 int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
                     int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
+/* debug/measurement knob: 1 (default) = 3x3/stride-1 forward and dgrad use the patch kernel (conv3x3.hip),
+ * 0 = the generic per-tap implicit GEMM (conv_igemm.hip). */
+int bd_conv_set_patch3x3(int enable);
+
 /* debug/measurement knob: 1 (default) = operand transposes through ds_read_b64_tr_b16, 0 = scalar 16-bit LDS reads
  * (slow reference path used by the parity tests to validate the transposing read). */
 int bd_wgrad_set_transpose_read(int use_tr);
