@@ -8,7 +8,8 @@
 //
 // 512 threads = 8 waves = 2 (channel halves of 64) x 4 (pixel quarters of 64 = 4 patch rows of 16 px).
 // LDS (unpadded, XOR-swizzled 128-byte rows: chunk position = chunk ^ (row & 7), conflict-free for ds_read_b128 of
-// 16 consecutive rows): 2 x 45 KB activation images + 2 x 16 KB weight tiles.
+// 16 consecutive rows): one 45 KB activation image + 2 x 48 KB weight buffers (three taps = one filter row per
+// barrier step: 96 MFMAs per wave between barriers).
 // dgrad = the same kernel on dY with the mirrored tap and the [Cin][tap][Cout] packed weights.
 #include "common.h"
 
@@ -19,7 +20,10 @@ constexpr int IH = PH + 2, IW = PW + 2;        // input patch
 constexpr int NPATCH = 2;                      // patches per workgroup
 constexpr int XROWS = NPATCH * IH * IW;        // 360 LDS rows
 constexpr int X_BYTES = XROWS * 128;           // 46080
-constexpr int W_BYTES = 128 * 128;             // 16384
+constexpr int TAPS_PER_STEP = 3;               // one filter row per barrier step
+constexpr int W_TAP_BYTES = 128 * 128;         // 16384: one tap's 128 x 64 weight tile
+constexpr int W_BYTES = TAPS_PER_STEP * W_TAP_BYTES;   // 49152
+constexpr int WPASSES = TAPS_PER_STEP * 2;     // 16-byte chunks per thread and step
 constexpr int XCHUNKS = XROWS * 8;             // 2880 16-byte chunks
 constexpr int XPASSES = (XCHUNKS + 511) / 512; // 6
 constexpr int TILE_CO = 128;
@@ -44,8 +48,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xbuf = smem;                       // [2][X_BYTES]
-    unsigned char* wbuf = smem + 2 * X_BYTES;         // [2][W_BYTES]
+    unsigned char* xbuf = smem;                       // [X_BYTES]      (single buffer, swapped between K blocks)
+    unsigned char* wbuf = smem + X_BYTES;             // [2][W_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 2, wp = wave & 3;
@@ -113,24 +117,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     }
 
     const int kblocks = (p.CK + 63) / 64;
-    const int nsteps = kblocks * 9;
-    u32x4_t rw[2], rx[XPASSES];
+    const int nsteps = kblocks * 3;
+    u32x4_t rw[WPASSES], rx[XPASSES];
 
     auto load_w = [&](int step) {
-        const int cb = step / 9, tap = step - cb * 9;
+        const int cb = step / 3, r = step - cb * 3;
         const int c0 = cb * 64 + (tid & 7) * 8;
         const bool cvalid = c0 + 8 <= p.CK;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if (cvalid && w_co[k] < p.CO)
-                v = *reinterpret_cast<const u32x4_t*>(p.w + ((long long)w_co[k] * 9 + tap) * p.CK + c0);
-            rw[k] = v;
-        }
+        for (int t = 0; t < TAPS_PER_STEP; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                u32x4_t v = {0u, 0u, 0u, 0u};
+                if (cvalid && w_co[k] < p.CO)
+                    v = *reinterpret_cast<const u32x4_t*>(p.w + ((long long)w_co[k] * 9 + r * 3 + t) * p.CK + c0);
+                rw[t * 2 + k] = v;
+            }
     };
     auto write_w = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4_t*>(wbuf + buf * W_BYTES + w_lds[k]) = rw[k];
+        for (int t = 0; t < TAPS_PER_STEP; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                *reinterpret_cast<u32x4_t*>(wbuf + buf * W_BYTES + t * W_TAP_BYTES + w_lds[k]) = rw[t * 2 + k];
     };
     auto load_x = [&](int cb) {
         const int c0 = cb * 64 + x_chunk * 8;
@@ -142,10 +151,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
             rx[k] = v;
         }
     };
-    auto write_x = [&](int buf) {
+    auto write_x = [&]() {
 #pragma unroll
         for (int k = 0; k < XPASSES; ++k)
-            if (x_lds[k] >= 0) *reinterpret_cast<u32x4_t*>(xbuf + buf * X_BYTES + x_lds[k]) = rx[k];
+            if (x_lds[k] >= 0) *reinterpret_cast<u32x4_t*>(xbuf + x_lds[k]) = rx[k];
     };
 
     f32x4_t acc[4][4];
@@ -164,46 +173,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     // B rows: patch (wp>>1), output rows 4*(wp&1) + j, column frow; input row = (orow + dy)*IW + frow + dx
     const int b_row0 = (wp >> 1) * (IH * IW) + (4 * (wp & 1)) * IW + frow;
 
-    auto compute = [&](int xb, int wb, int tap) {
-        int dy = tap / 3, dx = tap - dy * 3;
-        if (p.mode == 1) { dy = 2 - dy; dx = 2 - dx; }     // dgrad: mirrored tap
-        const unsigned char* Xt = xbuf + xb * X_BYTES;
-        const unsigned char* Wt = wbuf + wb * W_BYTES;
-        const int shift = dy * IW + dx;
+    auto compute = [&](int wb, int r) {
+        const unsigned char* Xt = xbuf;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t a[4], b[4];
+        for (int t = 0; t < TAPS_PER_STEP; ++t) {
+            int dy = r, dx = t;
+            if (p.mode == 1) { dy = 2 - dy; dx = 2 - dx; }     // dgrad: mirrored tap
+            const unsigned char* Wt = wbuf + wb * W_BYTES + t * W_TAP_BYTES;
+            const int shift = dy * IW + dx;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(Wt + a_off[i][kk]);
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t a[4], b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = b_row0 + j * IW + shift;
-                b[j] = *reinterpret_cast<const bf16x8_t*>(Xt + swz(row, kk * 4 + fchunk));
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(Wt + a_off[i][kk]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = b_row0 + j * IW + shift;
+                    b[j] = *reinterpret_cast<const bf16x8_t*>(Xt + swz(row, kk * 4 + fchunk));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
 
-    // prologue: activation image of K block 0 and weights of step 0
+    // prologue: activation image of K block 0 and the first filter row of weights
     load_x(0);
     load_w(0);
-    write_x(0);
+    write_x();
     write_w(0);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
-        const int cb = step / 9, tap = step - cb * 9;
+        const int cb = step / 3, r = step - cb * 3;
         const bool more = step + 1 < nsteps;
-        const bool prefetch_x = (tap == 5) && (cb + 1 < kblocks);
+        const bool next_x = (r == 2) && (cb + 1 < kblocks);
         if (more) load_w(step + 1);
-        if (prefetch_x) load_x(cb + 1);
-        compute(cb & 1, step & 1, tap);
+        if (next_x) load_x(cb + 1);          // in flight under this step's 96 MFMAs
+        compute(step & 1, r);
         if (more) write_w((step + 1) & 1);
-        if (prefetch_x) write_x((cb + 1) & 1);
         __syncthreads();
+        if (next_x) {                        // every wave is done with the old image: swap it
+            write_x();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue (same permuted-channel scheme as conv_igemm.hip) ----
@@ -297,7 +312,7 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
     p.total_patches = ps * d->N;
     p.n_tiles = cdiv(p.CO, TILE_CO);
     const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
-    const size_t lds = 2 * X_BYTES + 2 * W_BYTES;
+    const size_t lds = X_BYTES + 2 * W_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -16,35 +16,11 @@
 // mode 1 (dgrad):    pix = input pixel,  src = dY,          sy = (iy + pad - r)/stride when divisible.
 //   For stride 2 the pixels are enumerated parity-class-major so that a tile only visits the taps
 //   that can contribute to its class (no multiply-by-zero work).
-#include "common.h"
+#include "igemm_params.h"
+
+using namespace igemm;
 
 namespace {
-
-constexpr int TILE_C = 128;   // output channels per workgroup
-constexpr int TILE_P = 128;   // pixels per workgroup
-constexpr int MAX_SUB = 8;
-
-struct SubSeg {
-    int m_start;             // first GEMM column of this sub-segment
-    int Hs, Ws;              // enumeration extent per image
-    int y0, x0, step;        // dst pixel = (y0 + step*yy, x0 + step*xx)
-    int Wd, dst_off;         // dst row pitch (pixels) and pixel offset inside one image
-    int Hsrc, Wsrc, src_off; // src geometry
-};
-
-struct IgemmParams {
-    const bf16_raw* src;
-    const bf16_raw* w;
-    const float* bias;
-    const bf16_raw* add;
-    const bf16_raw* mask;
-    bf16_raw* dst;
-    int CK, CO, R, S, stride, pad, mode, flags;
-    int M, nsub;
-    int src_pix_per_img, dst_pix_per_img;
-    int m_tiles, n_tiles;
-    SubSeg sub[MAX_SUB];
-};
 
 template <int BK>
 struct Cfg {
@@ -358,6 +334,8 @@ bool is_3x3s1(const bd_conv_desc* d) {
     return true;
 }
 int g_use_patch3x3 = 1;
+int g_bk32_for_1x1 = 1;
+int g_stream_1x1 = 0;   // persistent 1x1 kernel (conv1x1.hip): correct, but 3 one-tile WGs/CU measured faster
 
 }  // namespace
 
@@ -365,7 +343,13 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
                             const void* add, const void* mask, void* dst, int flags, hipStream_t stream);
 
 // debug/measurement knob: 0 forces the generic per-tap kernel for 3x3 stride-1 convolutions
-extern "C" int bd_conv_set_patch3x3(int enable) { g_use_patch3x3 = enable; return BD_OK; }
+int bd_conv1x1_stream_launch(const IgemmParams& p, hipStream_t stream);
+
+// bit 0: 3x3 patch kernel, bit 1: BK=32 tiles for 1x1 in the generic kernel, bit 2: persistent streaming 1x1 kernel
+extern "C" int bd_conv_set_patch3x3(int enable) {
+    g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1; g_stream_1x1 = (enable >> 2) & 1;
+    return BD_OK;
+}
 
 extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* add, void* y, int flags, bd_stream_t stream) {
@@ -398,7 +382,8 @@ extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w
     p.M = (int)m;
     p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
-    if (p.CK > 32) launch_igemm<64>(p, (hipStream_t)stream);
+    if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
+    else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1)) launch_igemm<64>(p, (hipStream_t)stream);
     else launch_igemm<32>(p, (hipStream_t)stream);
     BD_CHECK_LAUNCH("bd_conv2d_fwd");
     return BD_OK;
@@ -443,7 +428,8 @@ extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void*
     p.M = (int)m;
     p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
-    if (p.CK > 32) launch_igemm<64>(p, (hipStream_t)stream);
+    if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
+    else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1)) launch_igemm<64>(p, (hipStream_t)stream);
     else launch_igemm<32>(p, (hipStream_t)stream);
     BD_CHECK_LAUNCH("bd_conv2d_dgrad");
     return BD_OK;

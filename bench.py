@@ -163,6 +163,8 @@ def main():
         "gt_boxes": torch.from_numpy(b["gt_boxes"]).cuda(),
         "im_info": torch.from_numpy(b["im_info"]).cuda(),
     }
+    if os.environ.get("BD_PATCH3X3"):
+        ops.L().bd_conv_set_patch3x3(int(os.environ["BD_PATCH3X3"]))
     timer = None if args.no_roofline else ConvTimer(ops)
 
     def sync():

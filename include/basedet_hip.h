@@ -83,8 +83,9 @@ size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d);
 int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
                     int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
-/* debug/measurement knob: 1 (default) = 3x3/stride-1 forward and dgrad use the patch kernel (conv3x3.hip),
- * 0 = the generic per-tap implicit GEMM (conv_igemm.hip). */
+/* debug/measurement knob, bit mask (default 3): bit 0 = 3x3/stride-1 forward and dgrad use the patch kernel
+ * (conv3x3.hip); bit 1 = BK=32 tiles for 1x1 convs in the generic kernel; bit 2 = persistent streaming 1x1 kernel
+ * (conv1x1.hip).  0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip). */
 int bd_conv_set_patch3x3(int enable);
 
 /* debug/measurement knob: 1 (default) = operand transposes through ds_read_b64_tr_b16, 0 = scalar 16-bit LDS reads

@@ -35,9 +35,8 @@ CASES = [
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops = _ops()
-    if patch3x3 == 0 and not (case[5] == 3 and case[6] == 1):
-        pytest.skip("generic kernel already covered")
-    ops.L().bd_conv_set_patch3x3(patch3x3)
+    # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel
+    ops.L().bd_conv_set_patch3x3(7 if patch3x3 else 0)
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -88,7 +87,7 @@ def test_conv_fwd_dgrad_wgrad(case, patch3x3):
         ops.conv2d_wgrad(d, xp, nchw_to_pm(gy), dw, ws, row_scale=scale.cuda(), accumulate=True)
         assert rel_l2(dw.cpu(), ref_dw * (1 + scale.view(-1, 1, 1, 1))) < 2e-3
     ops.L().bd_wgrad_set_transpose_read(1)
-    ops.L().bd_conv_set_patch3x3(1)
+    ops.L().bd_conv_set_patch3x3(7)
 
 
 def test_conv_multilevel_head_layout():
