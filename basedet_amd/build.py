@@ -19,6 +19,7 @@ SOURCES = {
     "conv1x1.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad3x3.hip": [],
+    "conv_wgrad1x1.hip": [],
     "stem.hip": [],
     "boxops.hip": ["-ffp-contract=off"],
     "losses.hip": [],

@@ -2,30 +2,30 @@
 //
 // The generic kernel (conv_igemm.hip) stages the activation tile once per filter tap; with 128x128 tiles that is
 // 64 FLOP per staged byte and the LDS store/load pipe, not the MFMA pipe, bounds it (~600 TFLOP/s).  Here a
-// workgroup owns 256 output pixels = two 8x16 patches and, per 64-channel K block, stages their two 10x18 input
-// patches ONCE; the nine taps then read shifted rows of that image while only the 128x64 weight tile of each tap is
+// workgroup owns 256 output pixels = four 4x16 patches (one per pixel-quarter wave pair) and, per 64-channel K
+// block, stages their four 6x18 input patches ONCE; the nine taps then read shifted rows of that image while only the 128x64 weight tile of each tap is
 // re-staged:  ~225 FLOP per staged byte, LDS traffic per MFMA down ~1.7x, MFMA-bound.
 //
 // 512 threads = 8 waves = 2 (channel halves of 64) x 4 (pixel quarters of 64 = 4 patch rows of 16 px).
 // LDS (unpadded, XOR-swizzled 128-byte rows: chunk position = chunk ^ (row & 7), conflict-free for ds_read_b128 of
-// 16 consecutive rows): one 45 KB activation image + 2 x 48 KB weight buffers (three taps = one filter row per
+// 16 consecutive rows): one 54 KB activation image + 2 x 48 KB weight buffers (three taps = one filter row per
 // barrier step: 96 MFMAs per wave between barriers).
 // dgrad = the same kernel on dY with the mirrored tap and the [Cin][tap][Cout] packed weights.
 #include "common.h"
 
 namespace {
 
-constexpr int PH = 8, PW = 16;                 // output patch
+constexpr int PH = 4, PW = 16;                 // output patch (4 rows of 16 px = the four pixel tiles of one wave)
 constexpr int IH = PH + 2, IW = PW + 2;        // input patch
-constexpr int NPATCH = 2;                      // patches per workgroup
-constexpr int XROWS = NPATCH * IH * IW;        // 360 LDS rows
-constexpr int X_BYTES = XROWS * 128;           // 46080
+constexpr int NPATCH = 4;                      // patches per workgroup
+constexpr int XROWS = NPATCH * IH * IW;        // 432 LDS rows
+constexpr int X_BYTES = XROWS * 128;           // 55296
 constexpr int TAPS_PER_STEP = 3;               // one filter row per barrier step
 constexpr int W_TAP_BYTES = 128 * 128;         // 16384: one tap's 128 x 64 weight tile
 constexpr int W_BYTES = TAPS_PER_STEP * W_TAP_BYTES;   // 49152
 constexpr int WPASSES = TAPS_PER_STEP * 2;     // 16-byte chunks per thread and step
-constexpr int XCHUNKS = XROWS * 8;             // 2880 16-byte chunks
-constexpr int XPASSES = (XCHUNKS + 511) / 512; // 6
+constexpr int XCHUNKS = XROWS * 8;             // 3456 16-byte chunks
+constexpr int XPASSES = (XCHUNKS + 511) / 512; // 7
 constexpr int TILE_CO = 128;
 constexpr int MAX_SEG = BD_MAX_SEGS;
 
@@ -99,10 +99,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
             const int pk = row / (IH * IW);
             const int rr = row - pk * (IH * IW);
             const int iy = rr / IW, ix = rr - iy * IW;
-            const int y = (pk == 0 ? py0[0] : py0[1]) - 1 + iy, x = (pk == 0 ? px0[0] : px0[1]) - 1 + ix;
-            const int H = pk == 0 ? pH[0] : pH[1], W = pk == 0 ? pWd[0] : pWd[1];
+            int qy = py0[0], qx = px0[0], H = pH[0], W = pWd[0];
+            long long qs = psrc[0];
+#pragma unroll
+            for (int q = 1; q < NPATCH; ++q)
+                if (pk == q) { qy = py0[q]; qx = px0[q]; H = pH[q]; W = pWd[q]; qs = psrc[q]; }
+            const int y = qy - 1 + iy, x = qx - 1 + ix;
             x_lds[k] = swz(row, x_chunk);
-            if (y >= 0 && x >= 0 && y < H && x < W) x_off[k] = ((pk == 0 ? psrc[0] : psrc[1]) + (long long)y * W + x) * p.CK;
+            if (y >= 0 && x >= 0 && y < H && x < W) x_off[k] = (qs + (long long)y * W + x) * p.CK;
         }
     }
     // weight staging: 128 rows x 8 chunks = 1024 chunks -> 2 per thread; LDS row lrow holds the permuted channel
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) a_off[i][kk] = swz(wc * 64 + i * 16 + frow, kk * 4 + fchunk);
-    // B rows: patch (wp>>1), output rows 4*(wp&1) + j, column frow; input row = (orow + dy)*IW + frow + dx
-    const int b_row0 = (wp >> 1) * (IH * IW) + (4 * (wp & 1)) * IW + frow;
+    // B rows: patch wp, output row j, column frow; input row = (j + dy)*IW + frow + dx
+    const int b_row0 = wp * (IH * IW) + frow;
 
     auto compute = [&](int wb, int r) {
         const unsigned char* Xt = xbuf;
@@ -239,11 +243,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
                 bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
             }
     }
-    const int pk = wp >> 1;
-    const int oy0 = (pk == 0 ? py0[0] : py0[1]) + 4 * (wp & 1);
-    const int ox = (pk == 0 ? px0[0] : px0[1]) + frow;
-    const int H = pk == 0 ? pH[0] : pH[1], W = pk == 0 ? pWd[0] : pWd[1];
-    const long long dbase = pk == 0 ? pdst[0] : pdst[1];
+    int oy0 = py0[0], ox = px0[0] + frow, H = pH[0], W = pWd[0];
+    long long dbase = pdst[0];
+#pragma unroll
+    for (int q = 1; q < NPATCH; ++q)
+        if (wp == q) { oy0 = py0[q]; ox = px0[q] + frow; H = pH[q]; W = pWd[q]; dbase = pdst[q]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int oy = oy0 + j;

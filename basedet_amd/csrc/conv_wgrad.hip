@@ -209,21 +209,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long long n, int row_len,
-                                    const float* __restrict__ row_scale, float* __restrict__ dw, int accumulate) {
-    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
+// slab reduce: block = 64 element-vectors x 4 split lanes; lane y sums splits y, y+4, ... (fixed order), then the four
+// partial sums are added in lane order -> bitwise reproducible, and short chains even for 256 splits.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long long n, int row_len,
+                                                           const float* __restrict__ row_scale, float* __restrict__ dw,
+                                                           int accumulate) {
+    __shared__ f32x4_t red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long i = ((long long)blockIdx.x * 64 + tx) * 4;
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < splits; ++k) {
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(slab + (long long)k * n + i);
-        s += v;
+    if (i < n) {
+        int k = ty;
+        for (; k + 12 < splits; k += 16) {
+            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(slab + (long long)k * n + i);
+            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(slab + (long long)(k + 4) * n + i);
+            const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(slab + (long long)(k + 8) * n + i);
+            const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(slab + (long long)(k + 12) * n + i);
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < splits; k += 4) s += *reinterpret_cast<const f32x4_t*>(slab + (long long)k * n + i);
     }
-    if (row_scale) {
-        const float sc = row_scale[i / row_len];
-        s *= sc;
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        f32x4_t t = red[0][tx];
+        t += red[1][tx]; t += red[2][tx]; t += red[3][tx];
+        if (row_scale) t *= row_scale[i / row_len];
+        if (accumulate) t += *reinterpret_cast<const f32x4_t*>(dw + i);
+        *reinterpret_cast<f32x4_t*>(dw + i) = t;
     }
-    if (accumulate) s += *reinterpret_cast<const f32x4_t*>(dw + i);
-    *reinterpret_cast<f32x4_t*>(dw + i) = s;
 }
 
 struct Plan { int ci_tiles, co_tiles, splits, steps_per_split, total_steps; long long M; };
@@ -259,6 +273,8 @@ Plan make_plan(const bd_conv_desc* d) {
 
 }  // namespace
 
+int bd_wgrad1x1_splits(const bd_conv_desc* d);
+int bd_wgrad1x1_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream);
 int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patches_per_img_out);
 int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream);
 
@@ -278,6 +294,10 @@ extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
     if (is_3x3s1(d)) {
         const size_t s3 = (size_t)bd_wgrad3x3_splits(d, nullptr, nullptr);
         if (s3 > splits) splits = s3;
+    }
+    if (d->R == 1 && d->S == 1 && d->pad == 0) {
+        const size_t s1 = (size_t)bd_wgrad1x1_splits(d);
+        if (s1 > splits) splits = s1;
     }
     return splits * d->Cout * d->R * d->S * d->Cin * sizeof(float);
 }
@@ -299,8 +319,18 @@ extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void*
         bd_wgrad3x3_launch(d, x, g, (float*)ws, &splits3, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(3x3)");
         const long long n3 = (long long)d->Cout * 9 * d->Cin;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n3 / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n3 / 4, 64)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)ws, splits3, n3, 9 * d->Cin, row_scale, dw, accumulate);
+        BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
+        return BD_OK;
+    }
+    if (g_wgrad_use_3x3 && d->R == 1 && d->S == 1 && d->pad == 0) {
+        int splits1 = 1;
+        bd_wgrad1x1_launch(d, x, g, (float*)ws, &splits1, (hipStream_t)stream);
+        BD_CHECK_LAUNCH("bd_conv2d_wgrad(1x1)");
+        const long long n1 = (long long)d->Cout * d->Cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n1 / 4, 64)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)ws, splits1, n1, d->Cin, row_scale, dw, accumulate);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
         return BD_OK;
     }
@@ -336,7 +366,7 @@ extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void*
         hipLaunchKernelGGL((conv_wgrad_kernel<BKP_DEFAULT, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     BD_CHECK_LAUNCH("bd_conv2d_wgrad");
     const long long n = (long long)d->Cout * d->R * d->S * d->Cin;
-    const int rblocks = (int)cdiv64(n / 4, 256);
+    const int rblocks = (int)cdiv64(n / 4, 64);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
                        pl.splits, n, d->R * d->S * d->Cin, row_scale, dw, accumulate);
     BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
