@@ -50,13 +50,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
             a_co[i] = l_co0 + (lrow & 64) + 16 * (rho >> 2) + 4 * ((lrow >> 4) & 3) + (rho & 3);
             const int m = m0 + lrow;
             b_src[i] = -1;
-            if (m < p.M) {
+            if (p.linear_src) {
+                if (m < p.M) b_src[i] = (long long)m * p.CK;
+            } else if (m < p.M) {
                 const SubSeg ss = p.sub[find_sub(p, m)];
                 const int local = m - ss.m_start;
-                const int per_img = ss.Hs * ss.Ws;
-                const int n = local / per_img;
-                const int rem = local - n * per_img;
-                const int yy = rem / ss.Ws, xx = rem - yy * ss.Ws;
+                int n, rem, yy, xx;
+                fast_divmod(local, ss.Hs * ss.Ws, ss.inv_per_img, n, rem);
+                fast_divmod(rem, ss.Ws, ss.inv_ws, yy, xx);
                 const int py = ss.y0 + ss.step * yy, px = ss.x0 + ss.step * xx;
                 int sy, sx;
                 bool ok = true;
@@ -143,13 +144,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + wp * 64 + j * 16 + (lane & 15);
             if (m >= p.M) continue;
-            const SubSeg ss = p.sub[find_sub(p, m)];
-            const int local = m - ss.m_start;
-            const int per_img = ss.Hs * ss.Ws;
-            const int n = local / per_img;
-            const int rem = local - n * per_img;
-            const int yy = rem / ss.Ws, xx = rem - yy * ss.Ws;
-            const int dstpix = n * p.dst_pix_per_img + ss.dst_off + (ss.y0 + ss.step * yy) * ss.Wd + ss.x0 + ss.step * xx;
+            int dstpix = m;
+            if (!p.linear_dst) {
+                const SubSeg ss = p.sub[find_sub(p, m)];
+                const int local = m - ss.m_start;
+                int n, rem, yy, xx;
+                fast_divmod(local, ss.Hs * ss.Ws, ss.inv_per_img, n, rem);
+                fast_divmod(rem, ss.Ws, ss.inv_ws, yy, xx);
+                dstpix = n * p.dst_pix_per_img + ss.dst_off + (ss.y0 + ss.step * yy) * ss.Wd + ss.x0 + ss.step * xx;
+            }
             const long long base = (long long)dstpix * p.CO + cbase;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {

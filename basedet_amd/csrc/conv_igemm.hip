@@ -71,18 +71,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
         const int row = row0 + i * C::ROWS_PER_PASS;
         const int m = m0 + row;
         b_base[i] = -1; b_py[i] = 0; b_px[i] = 0; b_hs[i] = 0; b_ws[i] = 0;
-        if (m < p.M) {
+        if (p.linear_src) {
+            // 1x1 / stride 1 on a dense level: the source pixel IS column m; encode it as row 0, column m of a 1 x M image
+            if (m < p.M) { b_base[i] = 0; b_px[i] = m; b_hs[i] = 1; b_ws[i] = p.M; }
+        } else if (m < p.M) {
             int s = 0;
 #pragma unroll
             for (int k = 1; k < MAX_SUB; ++k)
                 if (k < p.nsub && m >= p.sub[k].m_start) s = k;
             const SubSeg ss = p.sub[s];
             const int local = m - ss.m_start;
-            const int per_img = ss.Hs * ss.Ws;
-            const int n = local / per_img;
-            const int rem = local - n * per_img;
-            const int yy = rem / ss.Ws;
-            const int xx = rem - yy * ss.Ws;
+            int n, rem, yy, xx;
+            fast_divmod(local, ss.Hs * ss.Ws, ss.inv_per_img, n, rem);
+            fast_divmod(rem, ss.Ws, ss.inv_ws, yy, xx);
             const int py = ss.y0 + ss.step * yy;
             const int px = ss.x0 + ss.step * xx;
             b_base[i] = (long long)n * p.src_pix_per_img + ss.src_off;
@@ -246,18 +247,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
         const int m = m0 + wp * 64 + j * 16 + (lane & 15);
         if (m >= p.M) continue;
         int dstpix;
-        {
+        if (p.linear_dst) dstpix = m;
+        else {
             int s = 0;
 #pragma unroll
             for (int k = 1; k < MAX_SUB; ++k)
                 if (k < p.nsub && m >= p.sub[k].m_start) s = k;
             const SubSeg ss = p.sub[s];
             const int local = m - ss.m_start;
-            const int per_img = ss.Hs * ss.Ws;
-            const int n = local / per_img;
-            const int rem = local - n * per_img;
-            const int yy = rem / ss.Ws;
-            const int xx = rem - yy * ss.Ws;
+            int n, rem, yy, xx;
+            fast_divmod(local, ss.Hs * ss.Ws, ss.inv_per_img, n, rem);
+            fast_divmod(rem, ss.Ws, ss.inv_ws, yy, xx);
             dstpix = n * p.dst_pix_per_img + ss.dst_off + (ss.y0 + ss.step * yy) * ss.Wd + ss.x0 + ss.step * xx;
         }
         const long long base = (long long)dstpix * p.CO + cbase;
@@ -376,9 +376,13 @@ extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w
         ss.Hs = d->Ho[s]; ss.Ws = d->Wo[s]; ss.y0 = 0; ss.x0 = 0; ss.step = 1;
         ss.Wd = d->Wo[s]; ss.dst_off = d->out_off[s];
         ss.Hsrc = d->Hi[s]; ss.Wsrc = d->Wi[s]; ss.src_off = d->in_off[s];
+        ss.inv_per_img = 1.0f / (float)(ss.Hs * ss.Ws); ss.inv_ws = 1.0f / (float)ss.Ws;
         m += (long long)d->N * d->Ho[s] * d->Wo[s];
     }
-    BD_REQUIRE(m < (1ll << 31) / 4, "conv2d_fwd: too many pixels");
+    BD_REQUIRE(m < (1ll << 24), "conv2d_fwd: too many pixels (2^24 limit of the fast index decode)");
+    p.linear_dst = (d->nseg == 1 && d->out_off[0] == 0 && d->out_pix_per_img == d->Ho[0] * d->Wo[0]) ? 1 : 0;
+    p.linear_src = (p.linear_dst && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->in_off[0] == 0 &&
+                    d->in_pix_per_img == d->Hi[0] * d->Wi[0]) ? 1 : 0;
     p.M = (int)m;
     p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
@@ -420,11 +424,15 @@ extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void*
                 ss.Hs = Hs; ss.Ws = Ws; ss.y0 = qy; ss.x0 = qx; ss.step = st;
                 ss.Wd = d->Wi[s]; ss.dst_off = d->in_off[s];
                 ss.Hsrc = d->Ho[s]; ss.Wsrc = d->Wo[s]; ss.src_off = d->out_off[s];
+                ss.inv_per_img = 1.0f / (float)(Hs * Ws); ss.inv_ws = 1.0f / (float)Ws;
                 m += (long long)d->N * Hs * Ws;
             }
     }
     p.nsub = ns;
-    BD_REQUIRE(m < (1ll << 31) / 4, "conv2d_dgrad: too many pixels");
+    BD_REQUIRE(m < (1ll << 24), "conv2d_dgrad: too many pixels (2^24 limit of the fast index decode)");
+    p.linear_dst = (d->nseg == 1 && st == 1 && d->in_off[0] == 0 && d->in_pix_per_img == d->Hi[0] * d->Wi[0]) ? 1 : 0;
+    p.linear_src = (p.linear_dst && d->R == 1 && d->S == 1 && d->pad == 0 && d->out_off[0] == 0 &&
+                    d->out_pix_per_img == d->Ho[0] * d->Wo[0]) ? 1 : 0;
     p.M = (int)m;
     p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);

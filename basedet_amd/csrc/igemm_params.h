@@ -14,7 +14,15 @@ struct SubSeg {
     int y0, x0, step;        // dst pixel = (y0 + step*yy, x0 + step*xx)
     int Wd, dst_off;         // dst row pitch (pixels) and pixel offset inside one image
     int Hsrc, Wsrc, src_off; // src geometry
+    float inv_per_img, inv_ws; // reciprocals of Hs*Ws and Ws for the float-based divmod (valid for m < 2^24)
 };
+
+__device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
 
 struct IgemmParams {
     const bf16_raw* src;
@@ -27,6 +35,8 @@ struct IgemmParams {
     int M, nsub;
     int src_pix_per_img, dst_pix_per_img;
     int m_tiles, n_tiles;
+    int linear_dst;   // 1: destination pixel index == GEMM column m (single dense level, unit step)
+    int linear_src;   // 1: additionally 1x1 / stride 1 with the same source geometry: source pixel index == m
     SubSeg sub[MAX_SUB];
 };
 
