@@ -138,12 +138,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
                 rw[t * 2 + k] = v;
             }
     };
-    auto write_w = [&](int buf) {
+    auto write_w_tap = [&](int buf, int t) {
 #pragma unroll
-        for (int t = 0; t < TAPS_PER_STEP; ++t)
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-                *reinterpret_cast<u32x4_t*>(wbuf + buf * W_BYTES + t * W_TAP_BYTES + w_lds[k]) = rw[t * 2 + k];
+        for (int k = 0; k < 2; ++k)
+            *reinterpret_cast<u32x4_t*>(wbuf + buf * W_BYTES + t * W_TAP_BYTES + w_lds[k]) = rw[t * 2 + k];
     };
     auto load_x = [&](int cb) {
         const int c0 = cb * 64 + x_chunk * 8;
@@ -177,47 +175,56 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     // B rows: patch wp, output row j, column frow; input row = (j + dy)*IW + frow + dx
     const int b_row0 = wp * (IH * IW) + frow;
 
-    auto compute = [&](int wb, int r) {
-        const unsigned char* Xt = xbuf;
+    // one barrier step = one filter row = 6 sub-steps (3 taps x 2 K halves) of 16 MFMAs.  Fragments are double
+    // buffered: the ds_reads of sub-step u+1 are issued before the MFMAs of sub-step u, so LDS latency hides under the
+    // MFMA pipe; after each tap the wave stores one tap of the NEXT step's weights (in registers since the end of the
+    // previous step), so the LDS stores overlap the MFMAs as well.
+    bf16x8_t fa[2][4], fb[2][4];
+    auto load_frags = [&](int wb, int r, int u, bf16x8_t (&a)[4], bf16x8_t (&b)[4]) {
+        const int t = u >> 1, kk = u & 1;
+        int dy = r, dx = t;
+        if (p.mode == 1) { dy = 2 - dy; dx = 2 - dx; }     // dgrad: mirrored tap
+        const unsigned char* Wt = wbuf + wb * W_BYTES + t * W_TAP_BYTES;
+        const int shift = dy * IW + dx;
 #pragma unroll
-        for (int t = 0; t < TAPS_PER_STEP; ++t) {
-            int dy = r, dx = t;
-            if (p.mode == 1) { dy = 2 - dy; dx = 2 - dx; }     // dgrad: mirrored tap
-            const unsigned char* Wt = wbuf + wb * W_BYTES + t * W_TAP_BYTES;
-            const int shift = dy * IW + dx;
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(Wt + a_off[i][kk]);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t a[4], b[4];
+        for (int j = 0; j < 4; ++j) {
+            const int row = b_row0 + j * IW + shift;
+            b[j] = *reinterpret_cast<const bf16x8_t*>(xbuf + swz(row, kk * 4 + fchunk));
+        }
+    };
+    auto mfma16 = [&](const bf16x8_t (&a)[4], const bf16x8_t (&b)[4]) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(Wt + a_off[i][kk]);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = b_row0 + j * IW + shift;
-                    b[j] = *reinterpret_cast<const bf16x8_t*>(Xt + swz(row, kk * 4 + fchunk));
-                }
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    auto compute = [&](int wb, int r, bool write_next) {
+        load_frags(wb, r, 0, fa[0], fb[0]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+        for (int u = 0; u < 2 * TAPS_PER_STEP; ++u) {
+            if (u + 1 < 2 * TAPS_PER_STEP) load_frags(wb, r, u + 1, fa[(u + 1) & 1], fb[(u + 1) & 1]);
+            mfma16(fa[u & 1], fb[u & 1]);
+            if ((u & 1) && write_next) write_w_tap(wb ^ 1, u >> 1);
         }
     };
 
-    // prologue: activation image of K block 0 and the first filter row of weights
+    // prologue: activation image of K block 0, weights of step 0 (to LDS) and step 1 (in registers)
     load_x(0);
     load_w(0);
     write_x();
-    write_w(0);
+#pragma unroll
+    for (int t = 0; t < TAPS_PER_STEP; ++t) write_w_tap(0, t);
+    if (nsteps > 1) load_w(1);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int cb = step / 3, r = step - cb * 3;
-        const bool more = step + 1 < nsteps;
         const bool next_x = (r == 2) && (cb + 1 < kblocks);
-        if (more) load_w(step + 1);
         if (next_x) load_x(cb + 1);          // in flight under this step's 96 MFMAs
-        compute(step & 1, r);
-        if (more) write_w((step + 1) & 1);
+        compute(step & 1, r, step + 1 < nsteps);
+        if (step + 2 < nsteps) load_w(step + 2);   // registers are free again: they were stored during this step
         __syncthreads();
         if (next_x) {                        // every wave is done with the old image: swap it
             write_x();
