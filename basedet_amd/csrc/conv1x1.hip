@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
         for (int i = 0; i < PASSES; ++i) {
             const int lrow = row0 + i * 64;
             const int rho = lrow & 15;
-            a_co[i] = l_co0 + (lrow & 64) + 16 * (rho >> 2) + 4 * ((lrow >> 4) & 3) + (rho & 3);
+            a_co[i] = l_co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
             const int m = m0 + lrow;
             b_src[i] = -1;
             if (p.linear_src) {
@@ -128,15 +128,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
         const int tile_m = tile / p.n_tiles;
         const int co0 = (tile - tile_m * p.n_tiles) * TILE_C;
         const int m0 = tile_m * TILE_P;
-        const int cbase = co0 + wc * 64 + 16 * cg;
+        const int cbase = co0 + wc * 64 + 8 * cg;      // + 32 * half below
         float bias[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) bias[k] = 0.f;
         if (p.bias) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (cbase + 4 * q < p.CO) {
-                    const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 4 * q);
+                if (cbase + 32 * (q >> 1) + 4 * (q & 1) < p.CO) {
+                    const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 32 * (q >> 1) + 4 * (q & 1));
                     bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
                 }
         }
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
             const long long base = (long long)dstpix * p.CO + cbase;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                if (cbase + 8 * half >= p.CO) continue;
-                const long long idx = base + 8 * half;
+                if (cbase + 32 * half >= p.CO) continue;
+                const long long idx = base + 32 * half;
                 float v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];

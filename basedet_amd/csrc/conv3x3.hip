@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
         const int c = tid + 512 * k;
         const int lrow = c >> 3;
         const int rho = lrow & 15;
-        w_co[k] = co0 + (lrow & 64) + 16 * (rho >> 2) + 4 * ((lrow >> 4) & 3) + (rho & 3);
+        w_co[k] = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
         w_lds[k] = swz(lrow, tid & 7);
     }
 
@@ -238,15 +238,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
     const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
     const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
-    const int cbase = co0 + wc * 64 + 16 * cg;
+    const int cbase = co0 + wc * 64 + 8 * cg;      // + 32 * half below
     float bias[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) bias[k] = 0.f;
     if (p.bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (cbase + 4 * q < p.CO) {
-                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 4 * q);
+            if (cbase + 32 * (q >> 1) + 4 * (q & 1) < p.CO) {
+                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 32 * (q >> 1) + 4 * (q & 1));
                 bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
             }
     }
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
         const long long base = (dbase + (long long)oy * W + ox) * p.CO + cbase;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (cbase + 8 * half >= p.CO) continue;
-            const long long idx = base + 8 * half;
+            if (cbase + 32 * half >= p.CO) continue;
+            const long long idx = base + 32 * half;
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];

@@ -27,8 +27,15 @@ struct Cfg {
     static constexpr int CHUNKS = BK / 8;             // 16-byte chunks per row
     static constexpr int ROWS_PER_PASS = 256 / CHUNKS;
     static constexpr int PASSES = 128 / ROWS_PER_PASS;
-    static constexpr int LDS_STRIDE = BK * 2 + 32;    // bytes per row (conflict-free for b128 reads)
+    // BK = 64: 128-byte rows padded to 160 B (conflict-free ds_read_b128, measured SQ_LDS_BANK_CONFLICT = 0).
+    // BK = 32: unpadded 64-byte rows with the chunk XOR-swizzled by (row >> 1) & 3: conflict-free reads AND
+    //          stores (the 96-byte padded pitch showed 33 % conflict cycles), and only 32 KB per workgroup.
+    static constexpr int LDS_STRIDE = BK == 64 ? 160 : 64;
     static constexpr int TILE_BYTES = 128 * LDS_STRIDE;
+    __device__ static __forceinline__ int off(int row, int chunk) {
+        if constexpr (BK == 64) return row * LDS_STRIDE + chunk * 16;
+        else return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4);
+    }
 };
 
 template <int BK>
@@ -133,12 +140,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
         // A: weights [co][tap][ck]
 #pragma unroll
         for (int i = 0; i < C::PASSES; ++i) {
-            // LDS row (h*64 + t*16 + rho) holds output channel h*64 + 16*(rho>>2) + 4*t + (rho&3): after the MFMAs a
-            // lane then owns 16 CONSECUTIVE channels of a pixel (4 tiles x 4 registers) -> 32-byte NHWC pieces,
-            // 128 contiguous bytes per pixel and wave-instruction in the epilogue
+            // LDS row (h*64 + t*16 + rho) holds output channel h*64 + 32*(t>>1) + 8*(rho>>2) + 4*(t&1) + (rho&3): after
+            // the MFMAs lane group cg = rho>>2 owns channels 8*cg..8*cg+7 of each 32-channel half, so one epilogue
+            // instruction moves 16 B per lane = 64 contiguous bytes per pixel (4 lanes), two instructions per 128-B line
             const int lrow = row0 + i * C::ROWS_PER_PASS;
             const int rho = lrow & 15;
-            const int co = co0 + (lrow & 64) + 16 * (rho >> 2) + 4 * ((lrow >> 4) & 3) + (rho & 3);
+            const int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (cvalid && co < p.CO) {
                 const bf16_raw* g = p.w + ((long long)co * RS + cur_tap) * p.CK + c0;
@@ -176,8 +183,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < C::PASSES; ++i) {
             const int row = row0 + i * C::ROWS_PER_PASS;
-            *reinterpret_cast<u32x4_t*>(At + row * C::LDS_STRIDE + chunk * 16) = ra[i];
-            *reinterpret_cast<u32x4_t*>(Bt + row * C::LDS_STRIDE + chunk * 16) = rb[i];
+            *reinterpret_cast<u32x4_t*>(At + C::off(row, chunk)) = ra[i];
+            *reinterpret_cast<u32x4_t*>(Bt + C::off(row, chunk)) = rb[i];
         }
     };
 
@@ -191,16 +198,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
     const int frag_chunk = lane >> 4;
 
     auto compute = [&](int buf) {
-        const unsigned char* At = tiles + buf * 2 * C::TILE_BYTES + (wc * 64 + frag_row) * C::LDS_STRIDE;
-        const unsigned char* Bt = tiles + buf * 2 * C::TILE_BYTES + C::TILE_BYTES + (wp * 64 + frag_row) * C::LDS_STRIDE;
+        const unsigned char* At = tiles + buf * 2 * C::TILE_BYTES;
+        const unsigned char* Bt = At + C::TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8_t a[4], b[4];
-            const int off = (kk * 4 + frag_chunk) * 16;
+            const int ch = kk * 4 + frag_chunk;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(At + i * 16 * C::LDS_STRIDE + off);
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(At + C::off(wc * 64 + i * 16 + frag_row, ch));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bt + j * 16 * C::LDS_STRIDE + off);
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bt + C::off(wp * 64 + j * 16 + frag_row, ch));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -230,15 +237,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
     const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
     const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
     const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
-    const int cbase = co0 + wc * 64 + 16 * cg;
+    const int cbase = co0 + wc * 64 + 8 * cg;      // + 32 * half below
     float bias[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) bias[k] = 0.f;
     if (p.bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (cbase + 4 * q < p.CO) {
-                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 4 * q);
+            if (cbase + 32 * (q >> 1) + 4 * (q & 1) < p.CO) {
+                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 32 * (q >> 1) + 4 * (q & 1));
                 bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
             }
     }
@@ -263,8 +270,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
         const long long base = (long long)dstpix * p.CO + cbase;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {       // 8 channels = 16 bytes per half
-            if (cbase + 8 * half >= p.CO) continue;  // CO % 8 == 0
-            const long long idx = base + 8 * half;
+            if (cbase + 32 * half >= p.CO) continue;  // CO % 8 == 0
+            const long long idx = base + 32 * half;
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];
