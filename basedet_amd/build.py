@@ -23,6 +23,7 @@ SOURCES = {
     "stem.hip": [],
     "boxops.hip": ["-ffp-contract=off"],
     "losses.hip": [],
+    "norm.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
 

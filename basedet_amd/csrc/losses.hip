@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void giou_ltrb_kernel(const bf16_raw* __restri
 }
 
 // binary_cross_entropy with logits on fg rows (layers/losses/cross_entropy.py:26)
-__global__ __launch_bounds__(256) void bce_kernel(const bf16_raw* __restrict__ pred, const float* __restrict__ target,
+__global__ __launch_bounds__(256) void bce_kernel(const bf16_raw* __restrict__ pred, int ld, int off, const float* __restrict__ target,
                                                   const int* __restrict__ labels, long long rows, const float* __restrict__ norm,
                                                   float* __restrict__ loss_sum, bf16_raw* __restrict__ dpred) {
     __shared__ float red[4];
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bce_kernel(const bf16_raw* __restrict__ p
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows; i += (long long)gridDim.x * 256) {
         float g = 0.f;
         if (labels[i] > 0) {
-            const float x = bf2f(pred[i]), t = target[i];
+            const float x = bf2f(pred[i * ld + off]), t = target[i];
             const float e = __expf(-fabsf(x));
             const float l1p = log1pf(e);
             const float ls_pos = fminf(x, 0.f) - l1p, ls_neg = fminf(-x, 0.f) - l1p;
@@ -244,11 +244,12 @@ extern "C" int bd_giou_ltrb_fwd_bwd(const void* pred, const float* target, const
     return BD_OK;
 }
 
-extern "C" int bd_bce_logits_fwd_bwd(const void* pred, const float* target, const int32_t* labels, int64_t rows,
+extern "C" int bd_bce_logits_fwd_bwd(const void* pred, int ld, int off, const float* target, const int32_t* labels, int64_t rows,
                                      const float* norm, float* loss_sum, void* dpred, bd_stream_t stream) {
     BD_REQUIRE(pred && target && labels && norm && loss_sum && dpred, "bce_logits: null pointer");
+    BD_REQUIRE(ld >= 1 && off >= 0 && off < ld, "bce_logits: bad ld/off");
     if (rows == 0) return BD_OK;
-    hipLaunchKernelGGL(bce_kernel, dim3(loss_grid(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)pred, target,
+    hipLaunchKernelGGL(bce_kernel, dim3(loss_grid(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)pred, ld, off, target,
                        labels, (long long)rows, norm, loss_sum, (bf16_raw*)dpred);
     BD_CHECK_LAUNCH("bd_bce_logits_fwd_bwd");
     return BD_OK;

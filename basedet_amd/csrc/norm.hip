@@ -1,0 +1,374 @@
+// GroupNorm(32, C) + ReLU forward / backward for the FCOS PointHead towers (layers/head/point_head.py:47-58), and
+// the per-level "relu(bbox_pred * scale_l) * stride_l" transform (:143) with its gradient.
+//
+// Activations are pixel-major NHWC bf16 with several pyramid levels per image; one GroupNorm instance (shared weights)
+// normalises every (image, level, group) independently over H_l*W_l pixels x C/32 channels.  With C = 256 a group is
+// exactly 8 channels = one 16-byte chunk per pixel, so every lane moves one chunk.  All four passes are HBM-bound:
+//   fwd: stats (read y) -> apply (read y, write z)            bwd: sums (read dz, y, z) -> apply (read dz, y, z, write dy)
+// Reductions are two-stage with a fixed partial order (no float atomics): bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_CHUNKS = 16;     // pixel chunks per (image, level) in the partial stage
+constexpr int MAXL = BD_MAX_SEGS;
+
+struct GnLevels { int L; int off[MAXL]; int cnt[MAXL]; };
+
+// block = 256 threads = 32 groups x 8 pixel lanes; grid = (GN_CHUNKS, L, N)
+// partial[((n*L + l)*GN_CHUNKS + chunk)*32 + g][2] = (sum, sumsq)
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const bf16_raw* __restrict__ y, GnLevels lv, int ppi, int C,
+                                                               float* __restrict__ partial) {
+    __shared__ float red[256][2];
+    const int g = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int chunk = blockIdx.x, l = blockIdx.y, n = blockIdx.z;
+    const int cnt = lv.cnt[l];
+    const int per = (cnt + GN_CHUNKS - 1) / GN_CHUNKS;
+    const int p0 = chunk * per;
+    int p1 = p0 + per;
+    if (p1 > cnt) p1 = cnt;
+    const bf16_raw* base = y + ((long long)n * ppi + lv.off[l]) * C + g * 8;
+    float s = 0.f, ss = 0.f;
+    for (int p = p0 + pl; p < p1; p += 8) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + (long long)p * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = bf_lo(v[k]), b = bf_hi(v[k]);
+            s += a + b; ss += a * a + b * b;
+        }
+    }
+    red[threadIdx.x][0] = s; red[threadIdx.x][1] = ss;
+    __syncthreads();
+    if (pl == 0) {
+        float ts = 0.f, tss = 0.f;
+        for (int k = 0; k < 8; ++k) { ts += red[k * 32 + g][0]; tss += red[k * 32 + g][1]; }
+        float* o = partial + ((((long long)n * lv.L + l) * GN_CHUNKS + chunk) * 32 + g) * 2;
+        o[0] = ts; o[1] = tss;
+    }
+}
+
+// stats[(n*L + l)*32 + g] = (mean, rstd)
+__global__ void gn_stats_final_kernel(const float* __restrict__ partial, GnLevels lv, int N, int cpg, float eps,
+                                      float* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * lv.L * 32) return;
+    const int g = i & 31, nl = i >> 5, l = nl % lv.L;
+    float s = 0.f, ss = 0.f;
+    for (int c = 0; c < GN_CHUNKS; ++c) {
+        const float* o = partial + (((long long)nl * GN_CHUNKS + c) * 32 + g) * 2;
+        s += o[0]; ss += o[1];
+    }
+    const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
+    const float mean = s * inv;
+    const float var = fmaxf(ss * inv - mean * mean, 0.f);
+    stats[i * 2] = mean;
+    stats[i * 2 + 1] = rsqrtf(var + eps);
+}
+
+__device__ __forceinline__ int level_of(const GnLevels& lv, int p) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < MAXL; ++k)
+        if (k < lv.L && p >= lv.off[k]) l = k;
+    return l;
+}
+
+// z = relu((y - mean) * rstd * gamma + beta); thread per (pixel, group)
+__global__ void gn_apply_kernel(const bf16_raw* __restrict__ y, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, GnLevels lv, int N, int ppi, int relu, bf16_raw* __restrict__ z) {
+    const long long total = (long long)N * ppi * 32;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i & 31);
+        const long long pix = i >> 5;
+        const int n = (int)(pix / ppi), p = (int)(pix - (long long)n * ppi);
+        const int l = level_of(lv, p);
+        const float mean = stats[((n * lv.L + l) * 32 + g) * 2], rstd = stats[((n * lv.L + l) * 32 + g) * 2 + 1];
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(y + i * 8);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xv = (k & 1) ? bf_hi(v[k >> 1]) : bf_lo(v[k >> 1]);
+            o[k] = (xv - mean) * rstd * gamma[g * 8 + k] + beta[g * 8 + k];
+        }
+        u32x4_t w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            w[k] = relu ? pack_bf2(fmaxf(o[2 * k], 0.f), fmaxf(o[2 * k + 1], 0.f)) : pack_bf2(o[2 * k], o[2 * k + 1]);
+        *reinterpret_cast<u32x4_t*>(z + i * 8) = w;
+    }
+}
+
+// backward sums per (n, l, chunk, g): A = sum dzm*gamma*xhat, B = sum dzm*gamma ; and per channel dgamma / dbeta partials
+// pg[((n*L + l)*GN_CHUNKS + chunk)*32 + g][2], pc[(((n*L + l)*GN_CHUNKS + chunk)*C + c)][2]
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
+                                                             const bf16_raw* __restrict__ z, const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, GnLevels lv, int ppi, int C,
+                                                             int relu, float* __restrict__ pg, float* __restrict__ pc) {
+    __shared__ float red[256][18];
+    const int g = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int chunk = blockIdx.x, l = blockIdx.y, n = blockIdx.z;
+    const int cnt = lv.cnt[l];
+    const int per = (cnt + GN_CHUNKS - 1) / GN_CHUNKS;
+    const int p0 = chunk * per;
+    int p1 = p0 + per;
+    if (p1 > cnt) p1 = cnt;
+    const long long base = ((long long)n * ppi + lv.off[l]) * C + g * 8;
+    const float mean = stats[((n * lv.L + l) * 32 + g) * 2], rstd = stats[((n * lv.L + l) * 32 + g) * 2 + 1];
+    float gm[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gm[k] = gamma[g * 8 + k];
+    float A = 0.f, B = 0.f, dg[8], db[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dg[k] = 0.f; db[k] = 0.f; }
+    for (int p = p0 + pl; p < p1; p += 8) {
+        const long long o = base + (long long)p * C;
+        const u32x4_t vd = *reinterpret_cast<const u32x4_t*>(dz + o);
+        const u32x4_t vy = *reinterpret_cast<const u32x4_t*>(y + o);
+        const u32x4_t vz = *reinterpret_cast<const u32x4_t*>(z + o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int w = k >> 1;
+            float d = (k & 1) ? bf_hi(vd[w]) : bf_lo(vd[w]);
+            const float yy = (k & 1) ? bf_hi(vy[w]) : bf_lo(vy[w]);
+            const float zz = (k & 1) ? bf_hi(vz[w]) : bf_lo(vz[w]);
+            if (relu && !(zz > 0.f)) d = 0.f;
+            const float xh = (yy - mean) * rstd;
+            A += d * gm[k] * xh; B += d * gm[k];
+            dg[k] += d * xh; db[k] += d;
+        }
+    }
+    red[threadIdx.x][0] = A; red[threadIdx.x][1] = B;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[threadIdx.x][2 + k] = dg[k]; red[threadIdx.x][10 + k] = db[k]; }
+    __syncthreads();
+    if (pl == 0) {
+        float t[18];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) t[q] = 0.f;
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int q = 0; q < 18; ++q) t[q] += red[k * 32 + g][q];
+        const long long slot = ((long long)n * lv.L + l) * GN_CHUNKS + chunk;
+        pg[(slot * 32 + g) * 2] = t[0]; pg[(slot * 32 + g) * 2 + 1] = t[1];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { pc[(slot * C + g * 8 + k) * 2] = t[2 + k]; pc[(slot * C + g * 8 + k) * 2 + 1] = t[10 + k]; }
+    }
+}
+
+// ab[(n*L + l)*32 + g] = (A, B) / count ; dgamma[c], dbeta[c] (+)= sums over every (n, l, chunk)
+__global__ void gn_bwd_final_kernel(const float* __restrict__ pg, const float* __restrict__ pc, GnLevels lv, int N, int C, int cpg,
+                                    float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ngl = N * lv.L * 32;
+    if (i < ngl) {
+        const int g = i & 31, nl = i >> 5, l = nl % lv.L;
+        float A = 0.f, B = 0.f;
+        for (int c = 0; c < GN_CHUNKS; ++c) {
+            const float* o = pg + (((long long)nl * GN_CHUNKS + c) * 32 + g) * 2;
+            A += o[0]; B += o[1];
+        }
+        const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
+        ab[i * 2] = A * inv; ab[i * 2 + 1] = B * inv;
+    } else if (i < ngl + C) {
+        const int c = i - ngl;
+        float dg = 0.f, db = 0.f;
+        const int slots = N * lv.L * GN_CHUNKS;
+        for (int s = 0; s < slots; ++s) { dg += pc[((long long)s * C + c) * 2]; db += pc[((long long)s * C + c) * 2 + 1]; }
+        dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+        dbeta[c] = accumulate ? dbeta[c] + db : db;
+    }
+}
+
+// dy = rstd * (dzm*gamma - B - xhat*A)
+__global__ void gn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y, const bf16_raw* __restrict__ z,
+                                    const float* __restrict__ stats, const float* __restrict__ ab, const float* __restrict__ gamma,
+                                    GnLevels lv, int N, int ppi, int relu, bf16_raw* __restrict__ dy) {
+    const long long total = (long long)N * ppi * 32;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i & 31);
+        const long long pix = i >> 5;
+        const int n = (int)(pix / ppi), p = (int)(pix - (long long)n * ppi);
+        const int l = level_of(lv, p);
+        const int si = ((n * lv.L + l) * 32 + g) * 2;
+        const float mean = stats[si], rstd = stats[si + 1], A = ab[si], B = ab[si + 1];
+        const u32x4_t vd = *reinterpret_cast<const u32x4_t*>(dz + i * 8);
+        const u32x4_t vy = *reinterpret_cast<const u32x4_t*>(y + i * 8);
+        const u32x4_t vz = *reinterpret_cast<const u32x4_t*>(z + i * 8);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int w = k >> 1;
+            float d = (k & 1) ? bf_hi(vd[w]) : bf_lo(vd[w]);
+            const float yy = (k & 1) ? bf_hi(vy[w]) : bf_lo(vy[w]);
+            const float zz = (k & 1) ? bf_hi(vz[w]) : bf_lo(vz[w]);
+            if (relu && !(zz > 0.f)) d = 0.f;
+            const float xh = (yy - mean) * rstd;
+            o[k] = rstd * (d * gamma[g * 8 + k] - B - xh * A);
+        }
+        u32x4_t w4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w4[k] = pack_bf2(o[2 * k], o[2 * k + 1]);
+        *reinterpret_cast<u32x4_t*>(dy + i * 8) = w4;
+    }
+}
+
+// ---- FCOS offsets: off[p][k] = relu(raw[p][k] * scale_l) * stride_l (k < 4); raw rows have `ld` channels -------------
+struct OffLevels { int L; int off[MAXL]; int cnt[MAXL]; float stride[MAXL]; };
+
+__global__ void fcos_offsets_fwd_kernel(const bf16_raw* __restrict__ raw, int ld, const float* __restrict__ scales, OffLevels lv,
+                                        int N, int ppi, bf16_raw* __restrict__ out) {
+    const long long total = (long long)N * ppi;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % ppi);
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < MAXL; ++k)
+            if (k < lv.L && p >= lv.off[k]) l = k;
+        const float sc = scales[l], st = lv.stride[l];
+        const u32x2_t v = *reinterpret_cast<const u32x2_t*>(raw + i * ld);
+        u32x2_t o;
+        o[0] = pack_bf2(fmaxf(bf_lo(v[0]) * sc, 0.f) * st, fmaxf(bf_hi(v[0]) * sc, 0.f) * st);
+        o[1] = pack_bf2(fmaxf(bf_lo(v[1]) * sc, 0.f) * st, fmaxf(bf_hi(v[1]) * sc, 0.f) * st);
+        *reinterpret_cast<u32x2_t*>(out + i * 4) = o;
+    }
+}
+
+// d_raw[p][k] = d_off[p][k] * stride * scale * (raw*scale > 0) (k < 4), d_raw[p][4] = d_ctr[p], rest 0;
+// dscale partial per block: one fixed-order partial per (block, level)
+__global__ __launch_bounds__(256) void fcos_offsets_bwd_kernel(const bf16_raw* __restrict__ raw, int ld, const float* __restrict__ scales,
+                                                               OffLevels lv, int N, int ppi, const bf16_raw* __restrict__ d_off,
+                                                               const bf16_raw* __restrict__ d_ctr, bf16_raw* __restrict__ d_raw,
+                                                               float* __restrict__ dscale_partial) {
+    __shared__ float red[4][MAXL];
+    float ds[MAXL];
+#pragma unroll
+    for (int k = 0; k < MAXL; ++k) ds[k] = 0.f;
+    const long long total = (long long)N * ppi;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % ppi);
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < MAXL; ++k)
+            if (k < lv.L && p >= lv.off[k]) l = k;
+        const float sc = scales[l], st = lv.stride[l];
+        const u32x2_t v = *reinterpret_cast<const u32x2_t*>(raw + i * ld);
+        const u32x2_t g = *reinterpret_cast<const u32x2_t*>(d_off + i * 4);
+        const float r[4] = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+        const float go[4] = {bf_lo(g[0]), bf_hi(g[0]), bf_lo(g[1]), bf_hi(g[1])};
+        float dr[4], acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = r[k] * sc > 0.f;
+            dr[k] = on ? go[k] * st * sc : 0.f;
+            acc += on ? go[k] * st * r[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < MAXL; ++k) if (k == l) ds[k] += acc;
+        u32x4_t o = {pack_bf2(dr[0], dr[1]), pack_bf2(dr[2], dr[3]), (unsigned int)d_ctr[i], 0u};
+        *reinterpret_cast<u32x4_t*>(d_raw + i * ld) = o;       // ld == 8
+    }
+#pragma unroll
+    for (int k = 0; k < MAXL; ++k) ds[k] = wave_sum(ds[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < MAXL; ++k) red[threadIdx.x >> 6][k] = ds[k];
+    __syncthreads();
+    if (threadIdx.x < MAXL)
+        dscale_partial[(long long)blockIdx.x * MAXL + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void fcos_dscale_final_kernel(const float* __restrict__ partial, int nblocks, int L, float* __restrict__ dscale) {
+    const int l = threadIdx.x;
+    if (l >= L) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * MAXL + l];
+    dscale[l] = s;
+}
+
+inline GnLevels make_levels(int L, const int32_t* off, const int32_t* cnt) {
+    GnLevels lv{};
+    lv.L = L;
+    for (int i = 0; i < L; ++i) { lv.off[i] = off[i]; lv.cnt[i] = cnt[i]; }
+    return lv;
+}
+inline int egrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+constexpr int OFF_BLOCKS = 512;
+
+}  // namespace
+
+extern "C" size_t bd_groupnorm_workspace_bytes(int N, int L, int C) {
+    return (size_t)N * L * GN_CHUNKS * (32 * 2 + (size_t)C * 2) * sizeof(float) + (size_t)N * L * 32 * 2 * sizeof(float);
+}
+
+extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* beta, int N, int L, const int32_t* lvl_off_host,
+                                const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, float eps, int relu, float* stats,
+                                void* z, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(y && gamma && beta && stats && z && ws && lvl_off_host && lvl_cnt_host, "groupnorm_fwd: null pointer");
+    BD_REQUIRE(C == 256, "groupnorm_fwd: C=%d unsupported (32 groups x 8 channels only)", C);
+    BD_REQUIRE(L >= 1 && L <= MAXL && N >= 1, "groupnorm_fwd: bad N/L");
+    if (ws_bytes < bd_groupnorm_workspace_bytes(N, L, C)) { bd_set_error("groupnorm_fwd: workspace too small"); return BD_EWORKSPACE; }
+    const GnLevels lv = make_levels(L, lvl_off_host, lvl_cnt_host);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(GN_CHUNKS, L, N), dim3(256), 0, st, (const bf16_raw*)y, lv, (int)pix_per_img, C, (float*)ws);
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(cdiv(N * L * 32, 256)), dim3(256), 0, st, (const float*)ws, lv, N, C / 32, eps, stats);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(egrid((long long)N * pix_per_img * 32)), dim3(256), 0, st, (const bf16_raw*)y,
+                       (const float*)stats, gamma, beta, lv, N, (int)pix_per_img, relu, (bf16_raw*)z);
+    BD_CHECK_LAUNCH("bd_groupnorm_fwd");
+    return BD_OK;
+}
+
+extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const void* z, const float* gamma, const float* stats, int N, int L,
+                                const int32_t* lvl_off_host, const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, int relu,
+                                void* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(dz && y && z && gamma && stats && dy && dgamma && dbeta && ws, "groupnorm_bwd: null pointer");
+    BD_REQUIRE(C == 256, "groupnorm_bwd: C=%d unsupported", C);
+    BD_REQUIRE(L >= 1 && L <= MAXL && N >= 1, "groupnorm_bwd: bad N/L");
+    if (ws_bytes < bd_groupnorm_workspace_bytes(N, L, C)) { bd_set_error("groupnorm_bwd: workspace too small"); return BD_EWORKSPACE; }
+    const GnLevels lv = make_levels(L, lvl_off_host, lvl_cnt_host);
+    hipStream_t st = (hipStream_t)stream;
+    float* pg = (float*)ws;
+    float* pc = pg + (size_t)N * L * GN_CHUNKS * 32 * 2;
+    float* ab = pc + (size_t)N * L * GN_CHUNKS * C * 2;
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(GN_CHUNKS, L, N), dim3(256), 0, st, (const bf16_raw*)dz, (const bf16_raw*)y,
+                       (const bf16_raw*)z, stats, gamma, lv, (int)pix_per_img, C, relu, pg, pc);
+    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * L * 32 + C, 256)), dim3(256), 0, st, (const float*)pg, (const float*)pc, lv, N,
+                       C, C / 32, ab, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(egrid((long long)N * pix_per_img * 32)), dim3(256), 0, st, (const bf16_raw*)dz,
+                       (const bf16_raw*)y, (const bf16_raw*)z, stats, (const float*)ab, gamma, lv, N, (int)pix_per_img, relu, (bf16_raw*)dy);
+    BD_CHECK_LAUNCH("bd_groupnorm_bwd");
+    return BD_OK;
+}
+
+extern "C" int bd_fcos_offsets_fwd(const void* raw, int ld, const float* scales, int N, int L, const int32_t* lvl_off_host,
+                                   const int32_t* lvl_cnt_host, const int32_t* strides_host, int64_t pix_per_img, void* out,
+                                   bd_stream_t stream) {
+    BD_REQUIRE(raw && scales && out && lvl_off_host && lvl_cnt_host && strides_host, "fcos_offsets_fwd: null pointer");
+    BD_REQUIRE(ld == 8 && L >= 1 && L <= MAXL, "fcos_offsets_fwd: ld must be 8");
+    OffLevels lv{};
+    lv.L = L;
+    for (int i = 0; i < L; ++i) { lv.off[i] = lvl_off_host[i]; lv.cnt[i] = lvl_cnt_host[i]; lv.stride[i] = (float)strides_host[i]; }
+    hipLaunchKernelGGL(fcos_offsets_fwd_kernel, dim3(egrid((long long)N * pix_per_img)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_raw*)raw, ld, scales, lv, N, (int)pix_per_img, (bf16_raw*)out);
+    BD_CHECK_LAUNCH("bd_fcos_offsets_fwd");
+    return BD_OK;
+}
+
+extern "C" size_t bd_fcos_offsets_workspace_bytes(void) { return (size_t)OFF_BLOCKS * MAXL * sizeof(float); }
+
+extern "C" int bd_fcos_offsets_bwd(const void* raw, int ld, const float* scales, int N, int L, const int32_t* lvl_off_host,
+                                   const int32_t* lvl_cnt_host, const int32_t* strides_host, int64_t pix_per_img, const void* d_off,
+                                   const void* d_ctr, void* d_raw, float* dscale, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(raw && scales && d_off && d_ctr && d_raw && dscale && ws, "fcos_offsets_bwd: null pointer");
+    BD_REQUIRE(ld == 8 && L >= 1 && L <= MAXL, "fcos_offsets_bwd: ld must be 8");
+    if (ws_bytes < bd_fcos_offsets_workspace_bytes()) { bd_set_error("fcos_offsets_bwd: workspace too small"); return BD_EWORKSPACE; }
+    OffLevels lv{};
+    lv.L = L;
+    for (int i = 0; i < L; ++i) { lv.off[i] = lvl_off_host[i]; lv.cnt[i] = lvl_cnt_host[i]; lv.stride[i] = (float)strides_host[i]; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fcos_offsets_bwd_kernel, dim3(OFF_BLOCKS), dim3(256), 0, st, (const bf16_raw*)raw, ld, scales, lv, N,
+                       (int)pix_per_img, (const bf16_raw*)d_off, (const bf16_raw*)d_ctr, (bf16_raw*)d_raw, (float*)ws);
+    hipLaunchKernelGGL(fcos_dscale_final_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, OFF_BLOCKS, L, dscale);
+    BD_CHECK_LAUNCH("bd_fcos_offsets_bwd");
+    return BD_OK;
+}

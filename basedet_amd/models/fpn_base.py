@@ -1,0 +1,442 @@
+"""Shared ResNet + FPN trunk of the one-stage detectors (RetinaNet, FCOS) on the HIP path.
+
+Same protocol as the reference's BaseNet (models/base_net.py:50-71): ``model(batch)`` in training mode returns
+``{"total_loss", "cls_loss", "reg_loss"}``; the batch dict is the collator contract
+(data/collators/pad_collator.py:38-49): ``data`` (N,3,H,W), ``gt_boxes`` (N,G,5), ``im_info`` (N,5).
+There is no autograd: ``get_losses`` runs the forward kernels and the fused loss fwd+bwd kernels, ``backward()``
+runs the explicit dgrad/wgrad schedule in reverse order and leaves fp32 gradients in the parameter arena.
+
+Gradient convention: the gradient buffer of a post-ReLU activation T holds dL/d(pre-activation) (already masked
+by T > 0).  When T has several consumers, all but the last dgrad accumulate unmasked and the last one applies the
+mask in its epilogue -- so ReLU backward, residual fan-in and FrozenBN never cost a separate pass over HBM.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..ops import Geom
+from . import params as P
+from .engine import ConvLayer, ParamArena
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class _Plan:
+    """Shape-dependent buffers (activations, gradients, anchors, workspaces) for one (N, Hp, Wp)."""
+
+
+class VecParam:
+    """A 1-D trainable fp32 parameter that is not a conv weight (GroupNorm affine, FCOS level scales)."""
+
+    def __init__(self, name, numel):
+        self.name, self.numel = name, numel
+        self.w = self.g = None
+
+    def reserve(self, arena):
+        self._i = arena.reserve(self.name, (self.numel,))
+
+    def bind(self, arena, params):
+        self.w = arena.view("w", self._i)
+        self.g = arena.view("g", self._i)
+        self.w.copy_(torch.from_numpy(np.asarray(params[self.name], np.float32).reshape(-1)))
+
+    def export(self, out):
+        out[self.name] = self.w.cpu().numpy().copy()
+
+
+class FPNDetector:
+    """Backbone + FPN forward/backward and the BaseNet module protocol; heads and losses live in subclasses."""
+
+    def __init__(self, cfg, params=None, device="cuda", seed=0):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        m = cfg.MODEL
+        self.training = True
+        self.num_classes = cfg.DATA.NUM_CLASSES
+        self.strides = list(m.FPN.STRIDES)
+        self.fpn_ch = m.FPN.OUT_CHANNELS
+        self.freeze_at = m.BACKBONE.FREEZE_AT
+        self.img_mean, self.img_std = list(m.BACKBONE.IMG_MEAN), list(m.BACKBONE.IMG_STD)
+        if params is None:
+            params = self.init_params(cfg, seed)
+        self._build_layers(params)
+        self._plans = {}
+        self._cur = None
+        self.extra_meter = {}
+
+    # ------------------------------------------------------------------------------------------------
+    # construction
+    # ------------------------------------------------------------------------------------------------
+    def _build_layers(self, params):
+        dev = self.device
+        m = self.cfg.MODEL
+        self.arena = ParamArena(dev)
+        bu = "backbone.bottom_up"
+        self.blocks = P.resnet_conv_table(m.BACKBONE.NAME)
+        self.convs = {}
+
+        def add(name, cin, cout, k, stride, pad, bn=None, bias=False, trainable=True, cout_pad=None):
+            c = ConvLayer(name, cin, cout, k, stride, pad, dev, bn_prefix=bn, has_bias=bias, trainable=trainable, cout_pad=cout_pad)
+            self.convs[name] = c
+            return c
+
+        # stem (frozen when FREEZE_AT >= 1; the dedicated 7x7 kernel is forward-only)
+        assert self.freeze_at >= 1, "the 7x7 stem kernel is forward-only: FREEZE_AT must be >= 1 (reference default 2)"
+        self.stem_w = torch.from_numpy(params[bu + ".conv1.weight"]).permute(0, 2, 3, 1).contiguous().to(dev)
+        g, b = params[bu + ".bn1.weight"], params[bu + ".bn1.bias"]
+        mu, var = params[bu + ".bn1.running_mean"], params[bu + ".bn1.running_var"]
+        sc = g / np.sqrt(var + 1e-5)
+        self.stem_scale = torch.from_numpy(sc.astype(np.float32)).to(dev)
+        self.stem_shift = torch.from_numpy((b - mu * sc).astype(np.float32)).to(dev)
+        self.stem_packed = torch.empty((64, 7, 8, 4), dtype=torch.bfloat16, device=dev)
+
+        for blk in self.blocks:
+            pre = blk["prefix"]
+            tr = not (blk["layer"] == 1 and self.freeze_at >= 2)
+            blk["trainable"] = tr
+            if blk["kind"] == "bottleneck":
+                blk["convs"] = [
+                    add(pre + ".conv1", blk["cin"], blk["ch"], 1, 1, 0, bn=pre + ".bn1", trainable=tr),
+                    add(pre + ".conv2", blk["ch"], blk["ch"], 3, blk["stride"], 1, bn=pre + ".bn2", trainable=tr),
+                    add(pre + ".conv3", blk["ch"], blk["cout"], 1, 1, 0, bn=pre + ".bn3", trainable=tr),
+                ]
+            else:
+                blk["convs"] = [
+                    add(pre + ".conv1", blk["cin"], blk["ch"], 3, blk["stride"], 1, bn=pre + ".bn1", trainable=tr),
+                    add(pre + ".conv2", blk["ch"], blk["cout"], 3, 1, 1, bn=pre + ".bn2", trainable=tr),
+                ]
+            blk["ds"] = add(pre + ".downsample.0", blk["cin"], blk["cout"], 1, blk["stride"], 0, bn=pre + ".downsample.1",
+                            trainable=tr) if blk["has_ds"] else None
+
+        self.fpn_stages = [int(f[-1]) for f in m.BACKBONE.OUT_FEATURES]          # [3, 4, 5]
+        ch = self.fpn_ch
+        self.lateral, self.output = {}, {}
+        for s, ci in zip(self.fpn_stages, m.BACKBONE.OUT_FEATURE_CHANNELS):
+            self.lateral[s] = add(f"backbone.fpn_lateral{s}", ci, ch, 1, 1, 0, bias=True)
+            self.output[s] = add(f"backbone.fpn_output{s}", ch, ch, 3, 1, 1, bias=True)
+        self.p6 = add("backbone.top_block.p6", m.FPN.TOP_BLOCK_IN_CHANNELS, ch, 3, 2, 1, bias=True)
+        self.p7 = add("backbone.top_block.p7", ch, ch, 3, 2, 1, bias=True)
+        self.vparams = {}
+        self._build_head(add, params)
+
+        for c in list(self.convs.values()) + list(self.vparams.values()):
+            c.reserve(self.arena)
+        self.arena.allocate()
+        for c in list(self.convs.values()) + list(self.vparams.values()):
+            c.bind(self.arena, params)
+        self._bn_params = {k: v.copy() for k, v in params.items() if (".bn" in k or "downsample.1" in k)}
+        self.repack_weights()
+
+    def repack_weights(self):
+        """Refresh the bf16 packed copies from the fp32 masters (after load_weights / every optimizer step)."""
+        ops.stem_weight_pack(self.stem_w, self.stem_scale, self.stem_packed)
+        for c in self.convs.values():
+            c.pack()
+
+    def repack_trainable(self):
+        for c in self.convs.values():
+            if c.trainable:
+                c.pack()
+
+    # reference module protocol ------------------------------------------------------------------------
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def __call__(self, inputs):
+        return self.forward(inputs)
+
+    def forward(self, inputs):
+        """BaseNet.forward (models/base_net.py:50-54)."""
+        if self.training:
+            return self.get_losses(inputs)
+        return self.inference(inputs)
+
+    def state_dict(self):
+        out = {}
+        for c in list(self.convs.values()) + list(self.vparams.values()):
+            c.export(out)
+        out["backbone.bottom_up.conv1.weight"] = self.stem_w.permute(0, 3, 1, 2).contiguous().cpu().numpy()
+        out.update({k: v.copy() for k, v in self._bn_params.items()})
+        return out
+
+    def debug_activations(self):
+        """Stored activations of the last forward as NCHW fp32 CPU tensors, keyed like oracle/model.py `_act`
+        (parity tests inject them into the oracle so that both backward passes see identical ReLU gates)."""
+        pl = self._cur
+        N = pl.N
+        out = {}
+
+        def nchw(t, g, c=None):
+            v = t.float().cpu().view(N, g.H[0], g.W[0], -1).permute(0, 3, 1, 2).contiguous()
+            return v if c is None else v[:, :c].contiguous()
+
+        def lvl(t, i, c=None):
+            g = pl.pyr
+            v = t.float().cpu().view(N, g.pix_per_img, -1)[:, g.off[i]: g.off[i] + g.H[i] * g.W[i]]
+            v = v.reshape(N, g.H[i], g.W[i], -1).permute(0, 3, 1, 2).contiguous()
+            return v if c is None else v[:, :c].contiguous()
+
+        out["pool"] = nchw(pl.pool_out, pl.g_pool)
+        for blk, b in zip(self.blocks, pl.blk):
+            pre = blk["prefix"]
+            for i, (t, g) in enumerate(zip(b.mids, b.mid_geo)):
+                out[f"{pre}.a{i}"] = nchw(t, g)
+            if b.idt is not None:
+                out[pre + ".idt"] = nchw(b.idt, b.gout)
+            out[pre + ".out"] = nchw(b.out, b.gout)
+        for s in self.fpn_stages:
+            out[f"lat{s}"] = nchw(pl.lat[s], pl.blk[pl.res[s]].gout)
+        for i in range(pl.pyr.nlev):
+            out[f"P{self.fpn_stages[0] + i}"] = lvl(pl.P, i)
+        self._debug_head(pl, out, lvl)
+        return out
+
+    def trainable_parameter_names(self):
+        return [e[0] for e in self.arena.entries]
+
+    # ------------------------------------------------------------------------------------------------
+    # shape plan
+    # ------------------------------------------------------------------------------------------------
+    def _plan(self, N, Hp, Wp):
+        key = (N, Hp, Wp)
+        pl = self._plans.get(key)
+        if pl is not None:
+            return pl
+        dev = self.device
+        pl = _Plan()
+        pl.N, pl.Hp, pl.Wp = N, Hp, Wp
+        bf = dict(dtype=torch.bfloat16, device=dev)
+
+        def act(g, c):
+            return torch.empty((g.pixels, c), **bf)
+
+        pl.x_halo = torch.empty((N, Hp + 6, Wp + 8, 4), **bf)
+        g2 = ops.single(N, Hp // 2, Wp // 2)
+        g4 = ops.single(N, (Hp // 2 - 1) // 2 + 1, (Wp // 2 - 1) // 2 + 1)
+        pl.g_stem, pl.g_pool = g2, g4
+        pl.stem_out, pl.pool_out = act(g2, 64), act(g4, 64)
+        # backbone
+        pl.blk = []
+        gin = g4
+        for blk in self.blocks:
+            b = _Plan()
+            b.gin = gin
+            b.gout = gin.conv_out(1, blk["stride"], 0) if blk["stride"] == 2 else gin
+            if blk["kind"] == "bottleneck":
+                b.mid_geo = [gin, b.gout]
+                b.mids = [act(gin, blk["ch"]), act(b.gout, blk["ch"])]
+            else:
+                b.mid_geo = [b.gout]
+                b.mids = [act(b.gout, blk["ch"])]
+            b.idt = act(b.gout, blk["cout"]) if blk["has_ds"] else None
+            b.out = act(b.gout, blk["cout"])
+            if blk["trainable"]:
+                b.g_mids = [torch.empty_like(t) for t in b.mids]
+                b.g_out = torch.empty_like(b.out)
+            pl.blk.append(b)
+            gin = b.gout
+        # feature taps (last block of layer 2..4 -> res3..res5)
+        pl.res = {}
+        for i, blk in enumerate(self.blocks):
+            last = i + 1 == len(self.blocks) or self.blocks[i + 1]["layer"] != blk["layer"]
+            if last:
+                pl.res[blk["layer"] + 1] = i
+        # pyramid
+        sizes = [(pl.blk[pl.res[s]].gout.H[0], pl.blk[pl.res[s]].gout.W[0]) for s in self.fpn_stages]
+        h5, w5 = sizes[-1]
+        h6, w6 = (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1
+        h7, w7 = (h6 - 1) // 2 + 1, (w6 - 1) // 2 + 1
+        sizes = sizes + [(h6, w6), (h7, w7)]
+        pl.sizes = sizes
+        pl.pyr = Geom(N, [s[0] for s in sizes], [s[1] for s in sizes])
+        ch = self.fpn_ch
+        pl.P = act(pl.pyr, ch)
+        pl.g_P = act(pl.pyr, ch)
+        pl.lat = {s: act(pl.blk[pl.res[s]].gout, ch) for s in self.fpn_stages}
+        pl.g_lat = {s: torch.empty_like(pl.lat[s]) for s in self.fpn_stages}
+        g6 = pl.pyr.level(len(self.fpn_stages))
+        pl.p6_relu = torch.empty((N * h6 * w6, ch), **bf)
+        pl.g_p6r = ops.single(N, h6, w6)
+        self._plan_head(pl)
+        # workspaces
+        need = 0
+        for blk, b in zip(self.blocks, pl.blk):
+            if not blk["trainable"]:
+                continue
+            geos = [b.gin] + b.mid_geo + [b.gout]
+            for ci, c in enumerate(blk["convs"]):
+                need = max(need, c.wgrad_ws_bytes(geos[ci], geos[ci + 1]))
+            if blk["ds"] is not None:
+                need = max(need, blk["ds"].wgrad_ws_bytes(b.gin, b.gout))
+        for s in self.fpn_stages:
+            gl = pl.blk[pl.res[s]].gout
+            need = max(need, self.lateral[s].wgrad_ws_bytes(gl, gl), self.output[s].wgrad_ws_bytes(gl, gl))
+        g5 = pl.blk[pl.res[self.fpn_stages[-1]]].gout
+        need = max(need, self.p6.wgrad_ws_bytes(g5, g6), self.p7.wgrad_ws_bytes(pl.g_p6r, pl.pyr.level(len(self.fpn_stages) + 1)))
+        for c in self._head_convs():
+            need = max(need, c.wgrad_ws_bytes(pl.pyr, pl.pyr))
+        pl.wgrad_ws = torch.empty((need // 4 + 64,), dtype=torch.float32, device=dev)
+        pl.colsum_ws = torch.empty((ops.colsum_workspace_bytes(2048) // 4,), dtype=torch.float32, device=dev)
+        self._plans[key] = pl
+        return pl
+
+    # ------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------
+    def pre_process(self, inputs):
+        """RetinaNet.pre_process (retinanet.py:90-107): H2D copy + pad to x32 + normalise (fused kernel)."""
+        image = inputs["data"] if isinstance(inputs, dict) else inputs
+        if not torch.is_tensor(image):
+            image = torch.as_tensor(np.asarray(image), dtype=torch.float32)
+        image = image.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        N, _, H, W = image.shape
+        Hp, Wp = _round_up(H, 32), _round_up(W, 32)
+        pl = self._plan(N, Hp, Wp)
+        ops.pad_normalize(image, Hp, Wp, self.img_mean, self.img_std, pl.x_halo)
+        out = {"plan": pl}
+        if isinstance(inputs, dict) and "gt_boxes" in inputs:
+            gt = torch.as_tensor(np.asarray(inputs["gt_boxes"]), dtype=torch.float32) if not torch.is_tensor(inputs["gt_boxes"]) else inputs["gt_boxes"]
+            out["gt_boxes"] = gt.to(self.device, dtype=torch.float32).contiguous()
+        if isinstance(inputs, dict) and "im_info" in inputs:
+            info = torch.as_tensor(np.asarray(inputs["im_info"]), dtype=torch.float32) if not torch.is_tensor(inputs["im_info"]) else inputs["im_info"]
+        else:
+            info = torch.tensor([[Hp, Wp, H, W, 0]] * N, dtype=torch.float32)
+        out["img_info"] = info.to(self.device, dtype=torch.float32).contiguous()
+        return out
+
+    def _block_forward(self, blk, b, x):
+        convs = blk["convs"]
+        idt = x
+        if blk["ds"] is not None:
+            blk["ds"].forward(x, b.gin, b.gout, b.idt)
+            idt = b.idt
+        geos = [b.gin] + b.mid_geo + [b.gout]
+        t = x
+        for ci, c in enumerate(convs[:-1]):
+            c.forward(t, geos[ci], geos[ci + 1], b.mids[ci], relu=True)
+            t = b.mids[ci]
+        convs[-1].forward(t, geos[-2], geos[-1], b.out, add=idt, relu=True)
+        return b.out
+
+    def network_forward(self, pl):
+        """RetinaNet.network_forward (retinanet.py:109-118): backbone + FPN + head; logits/offsets come out already
+        in the (N, sum HWA, K) layout of permute_to_N_Any_K + concat (function.py:26-32, retinanet.py:127-132)."""
+        N = pl.N
+        ops.stem_conv7x7_fwd(N, pl.Hp, pl.Wp, pl.x_halo, self.stem_packed, self.stem_shift, pl.stem_out)
+        ops.maxpool3x3s2_fwd(pl.stem_out, N, pl.g_stem.H[0], pl.g_stem.W[0], 64, pl.pool_out)
+        x = pl.pool_out
+        for blk, b in zip(self.blocks, pl.blk):
+            x = self._block_forward(blk, b, x)
+        # FPN (fpn_backbone.py:123-160): top-down from the coarsest level
+        st = self.fpn_stages
+        nl = len(st)
+        prev, prev_geo = None, None
+        for li in range(nl - 1, -1, -1):
+            s = st[li]
+            b = pl.blk[pl.res[s]]
+            self.lateral[s].forward(b.out, b.gout, b.gout, pl.lat[s])
+            if prev is not None:
+                ops.upsample2x_add_fwd(prev, prev_geo, pl.lat[s], b.gout, self.fpn_ch)
+            self.output[s].forward(pl.lat[s], b.gout, pl.pyr.level(li), pl.P)
+            prev, prev_geo = pl.lat[s], b.gout
+        b5 = pl.blk[pl.res[st[-1]]]
+        g6, g7 = pl.pyr.level(nl), pl.pyr.level(nl + 1)
+        self.p6.forward(b5.out, b5.gout, g6, pl.P)                                 # LastLevelP6P7 (:198-204)
+        self._relu_level(pl.P, g6, pl.p6_relu)
+        self.p7.forward(pl.p6_relu, pl.g_p6r, g7, pl.P)
+        self.head_forward(pl)
+
+    def _relu_level(self, src, geo, dst):
+        """dst (dense, per level) = relu(one pyramid level of src); the level is contiguous per image."""
+        C = src.shape[1]
+        n = geo.H[0] * geo.W[0]
+        sv = src.view(geo.N, geo.pix_per_img, C)
+        dv = dst.view(geo.N, n, C)
+        for i in range(geo.N):
+            ops.relu_bf16(sv[i, geo.off[0]: geo.off[0] + n], dv[i])
+
+    # ------------------------------------------------------------------------------------------------
+    # backward (replaces GradManager.backward, solver/default_solver.py:118-124)
+    # ------------------------------------------------------------------------------------------------
+    def backward(self, on_bucket_ready=None):
+        pl = self._cur
+        ws, cws = pl.wgrad_ws, pl.colsum_ws
+        pyr = pl.pyr
+        self.head_backward(pl, ws, cws)
+        if on_bucket_ready:
+            on_bucket_ready("head")
+        # ---- FPN
+        st = self.fpn_stages
+        nl = len(st)
+        g6, g7 = pyr.level(nl), pyr.level(nl + 1)
+        b5 = pl.blk[pl.res[st[-1]]]
+        # P7 = conv(relu(P6)): d P6 = dgrad(g_P7) * (P6 > 0) + g_P6(head), written in place into g_P's P6 level
+        self.p7.wgrad(pl.p6_relu, pl.g_P, pl.g_p6r, g7, ws, cws)
+        self.p7.dgrad(pl.g_P, g6, g7, pl.g_P, mask=pl.P, add_after=pl.g_P)
+        self.p6.wgrad(b5.out, pl.g_P, b5.gout, g6, ws, cws)
+        self.p6.dgrad(pl.g_P, b5.gout, g6, b5.g_out, first=True)
+        for li in range(nl):
+            s = st[li]
+            b = pl.blk[pl.res[s]]
+            lvl = pyr.level(li)
+            self.output[s].wgrad(pl.lat[s], pl.g_P, b.gout, lvl, ws, cws)
+            self.output[s].dgrad(pl.g_P, b.gout, lvl, pl.g_lat[s], first=True)
+            if li > 0:   # gradient arriving through the top-down path from the finer level
+                sf = st[li - 1]
+                ops.upsample2x_add_bwd(pl.g_lat[sf], pl.blk[pl.res[sf]].gout, pl.g_lat[s], b.gout, self.fpn_ch, accumulate=True)
+            self.lateral[s].wgrad(b.out, pl.g_lat[s], b.gout, b.gout, ws, cws)
+            # res_s gradient: first contribution for res3/res4, second (after P6) and final for res5 -> mask there
+            is_top = li == nl - 1
+            if is_top:
+                self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=False, mask=b.out)
+            else:
+                self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=True)
+        if on_bucket_ready:
+            on_bucket_ready("fpn")
+        # ---- backbone, last block first.  g_out of a block holds the masked gradient once all consumers are done:
+        # res5: done above.  res3/res4 (and every inner block output): the next block's dgrads finish it.
+        nb = len(self.blocks)
+        for bi in range(nb - 1, -1, -1):
+            blk, b = self.blocks[bi], pl.blk[bi]
+            if not blk["trainable"]:
+                break
+            convs = blk["convs"]
+            geos = [b.gin] + b.mid_geo + [b.gout]
+            xin = pl.blk[bi - 1].out if bi > 0 else pl.pool_out
+            prev_tr = bi > 0 and self.blocks[bi - 1]["trainable"]
+            G = b.g_out
+            # main branch, last conv backwards
+            g = G
+            for ci in range(len(convs) - 1, 0, -1):
+                convs[ci].wgrad(b.mids[ci - 1], g, geos[ci], geos[ci + 1], ws)
+                convs[ci].dgrad(g, geos[ci], geos[ci + 1], b.g_mids[ci - 1], mask=b.mids[ci - 1])
+                g = b.g_mids[ci - 1]
+            convs[0].wgrad(xin, g, geos[0], geos[1], ws)
+            if blk["ds"] is not None:
+                blk["ds"].wgrad(xin, G, b.gin, b.gout, ws)
+            if prev_tr:
+                gx = pl.blk[bi - 1].g_out
+                # has the input already received a contribution (FPN lateral of res3/res4)?
+                tapped = any(pl.res[s] == bi - 1 for s in st)
+                if blk["ds"] is not None:
+                    blk["ds"].dgrad(G, b.gin, b.gout, gx, first=not tapped)
+                    convs[0].dgrad(g, geos[0], geos[1], gx, first=False, mask=xin)
+                else:
+                    if tapped:
+                        ops.add_bf16(gx, G, gx)
+                        convs[0].dgrad(g, geos[0], geos[1], gx, first=False, mask=xin)
+                    else:
+                        # identity skip: gx = (dgrad + G) * mask
+                        ops.conv2d_dgrad(convs[0].desc(geos[0], geos[1]), g, convs[0].w_dgrad, gx, add=G, mask=xin,
+                                         flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
+            if on_bucket_ready and (bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]):
+                on_bucket_ready(f"layer{blk['layer']}")
+

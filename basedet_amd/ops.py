@@ -205,7 +205,7 @@ def fcos_assign(points, lvl_start, soi, strides, radius, gt_boxes, num_gt, label
     P = points.shape[0]
     N, Gmax = gt_boxes.shape[0], gt_boxes.shape[1]
     Ln = len(strides)
-    soi_flat = [min(max(float(v), -3.0e38), 3.0e38) if v not in (float("inf"), float("-inf")) else v for s in soi for v in s]
+    soi_flat = [float(v) for s in soi for v in s]
     check(L().bd_fcos_assign(ptr(points), P, i32arr(lvl_start), f32arr(soi_flat), i32arr(strides), Ln, float(radius),
                              ptr(gt_boxes), ptr(num_gt), N, Gmax, ptr(labels), ptr(offsets), ptr(ctrness), ptr(stats),
                              stream_ptr()), "bd_fcos_assign")
@@ -244,9 +244,51 @@ def giou_ltrb_fwd_bwd(pred, target, weight, labels, rows, norm, loss_weight, los
                                    ptr(loss_sum), ptr(dpred), stream_ptr()), "bd_giou_ltrb_fwd_bwd")
 
 
-def bce_logits_fwd_bwd(pred, target, labels, rows, norm, loss_sum, dpred):
-    check(L().bd_bce_logits_fwd_bwd(ptr(pred), ptr(target), ptr(labels), rows, ptr(norm), ptr(loss_sum), ptr(dpred),
+def bce_logits_fwd_bwd(pred, target, labels, rows, norm, loss_sum, dpred, ld=1, off=0):
+    check(L().bd_bce_logits_fwd_bwd(ptr(pred), ld, off, ptr(target), ptr(labels), rows, ptr(norm), ptr(loss_sum), ptr(dpred),
                                     stream_ptr()), "bd_bce_logits_fwd_bwd")
+
+
+# ---- FCOS head pieces -------------------------------------------------------------------------------------
+def groupnorm_workspace_bytes(N, Ln, Cn):
+    return int(L().bd_groupnorm_workspace_bytes(N, Ln, Cn))
+
+
+def _lvl_arrays(geom: Geom):
+    return i32arr(geom.off), i32arr([h * w for h, w in zip(geom.H, geom.W)])
+
+
+def groupnorm_fwd(y, gamma, beta, geom: Geom, Cn, eps, relu, stats, z, ws):
+    off, cnt = _lvl_arrays(geom)
+    check(L().bd_groupnorm_fwd(ptr(y), ptr(gamma), ptr(beta), geom.N, geom.nlev, off, cnt, geom.pix_per_img, Cn, float(eps),
+                               int(relu), ptr(stats), ptr(z), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_groupnorm_fwd")
+    return z
+
+
+def groupnorm_bwd(dz, y, z, gamma, stats, geom: Geom, Cn, relu, dy, dgamma, dbeta, ws, accumulate=False):
+    off, cnt = _lvl_arrays(geom)
+    check(L().bd_groupnorm_bwd(ptr(dz), ptr(y), ptr(z), ptr(gamma), ptr(stats), geom.N, geom.nlev, off, cnt, geom.pix_per_img, Cn,
+                               int(relu), ptr(dy), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel() * ws.element_size(),
+                               stream_ptr()), "bd_groupnorm_bwd")
+    return dy
+
+
+def fcos_offsets_fwd(raw, ld, scales, geom: Geom, strides, out):
+    off, cnt = _lvl_arrays(geom)
+    check(L().bd_fcos_offsets_fwd(ptr(raw), ld, ptr(scales), geom.N, geom.nlev, off, cnt, i32arr(strides), geom.pix_per_img, ptr(out),
+                                  stream_ptr()), "bd_fcos_offsets_fwd")
+    return out
+
+
+def fcos_offsets_workspace_bytes():
+    return int(L().bd_fcos_offsets_workspace_bytes())
+
+
+def fcos_offsets_bwd(raw, ld, scales, geom: Geom, strides, d_off, d_ctr, d_raw, dscale, ws):
+    off, cnt = _lvl_arrays(geom)
+    check(L().bd_fcos_offsets_bwd(ptr(raw), ld, ptr(scales), geom.N, geom.nlev, off, cnt, i32arr(strides), geom.pix_per_img, ptr(d_off),
+                                  ptr(d_ctr), ptr(d_raw), ptr(dscale), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()),
+          "bd_fcos_offsets_bwd")
 
 
 def sgd_momentum_step(w, v, g, lr, momentum, wd, grad_scale=1.0):

@@ -219,9 +219,39 @@ int bd_giou_ltrb_fwd_bwd(const void* pred, const float* target, const float* wei
                          int64_t rows, const float* norm, float loss_weight, float* loss_sum, void* dpred,
                          bd_stream_t stream);
 
-/* binary_cross_entropy with logits over fg rows (layers/losses/cross_entropy.py:7-29, fcos.py:166-170). */
-int bd_bce_logits_fwd_bwd(const void* pred, const float* target, const int32_t* labels, int64_t rows,
+/* binary_cross_entropy with logits over fg rows (layers/losses/cross_entropy.py:7-29, fcos.py:166-170).
+ * Logit of row i at pred[i*ld + off] (the centre-ness channel of the fused bbox/ctrness conv output);
+ * dpred is a dense bf16 [rows] vector. */
+int bd_bce_logits_fwd_bwd(const void* pred, int ld, int off, const float* target, const int32_t* labels, int64_t rows,
                           const float* norm, float* loss_sum, void* dpred, bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * FCOS PointHead pieces (layers/head/point_head.py:47-58, 137-151).
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* GroupNorm(32, C=256) (+ReLU) over every (image, pyramid level, group) of a pixel-major multi-level tensor:
+ * level l of image n = pixel rows [n*pix_per_img + lvl_off[l], + lvl_cnt[l]).  stats: fp32 [N][L][32][2] = (mean, rstd),
+ * kept for the backward.  Two-stage fixed-order reductions (reproducible).  ws: bd_groupnorm_workspace_bytes. */
+size_t bd_groupnorm_workspace_bytes(int N, int L, int C);
+int bd_groupnorm_fwd(const void* y, const float* gamma, const float* beta, int N, int L, const int32_t* lvl_off_host,
+                     const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, float eps, int relu, float* stats,
+                     void* z, void* ws, size_t ws_bytes, bd_stream_t stream);
+/* dz = gradient w.r.t. the (ReLU'd) output z; relu != 0 gates it with z > 0.  dy: gradient w.r.t. the conv output y;
+ * dgamma/dbeta fp32 [C] (accumulate != 0 adds). */
+int bd_groupnorm_bwd(const void* dz, const void* y, const void* z, const float* gamma, const float* stats, int N, int L,
+                     const int32_t* lvl_off_host, const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, int relu,
+                     void* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
+
+/* offsets = relu(bbox_pred * scale_l) * stride_l (point_head.py:143).  raw: bf16 [pixels][ld = 8] (channels 0-3 =
+ * bbox_pred, 4 = ctrness logit, 5-7 = 0), scales: device fp32 [L]; out: bf16 [pixels][4]. */
+int bd_fcos_offsets_fwd(const void* raw, int ld, const float* scales, int N, int L, const int32_t* lvl_off_host,
+                        const int32_t* lvl_cnt_host, const int32_t* strides_host, int64_t pix_per_img, void* out,
+                        bd_stream_t stream);
+/* backward: d_raw[.][0..3] from d_off, d_raw[.][4] = d_ctr (dense bf16 [pixels]), d_raw[.][5..7] = 0; dscale fp32 [L]. */
+size_t bd_fcos_offsets_workspace_bytes(void);
+int bd_fcos_offsets_bwd(const void* raw, int ld, const float* scales, int N, int L, const int32_t* lvl_off_host,
+                        const int32_t* lvl_cnt_host, const int32_t* strides_host, int64_t pix_per_img, const void* d_off,
+                        const void* d_ctr, void* d_raw, float* dscale, void* ws, size_t ws_bytes, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Optimizer (megengine.optimizer.SGD as configured at solver/default_solver.py:96-114).
