@@ -94,3 +94,22 @@ def retinanet_r18_config():
     cfg.merge(dict(MODEL=dict(BACKBONE=dict(NAME="resnet18", OUT_FEATURE_CHANNELS=[128, 256, 512]),
                               FPN=dict(TOP_BLOCK_IN_CHANNELS=512))))
     return cfg
+
+
+class FCOSConfig(ConfigDict):
+    """basedet/configs/det_model/fcos_cfg.py:7-56."""
+
+    def __init__(self):
+        super().__init__(_base())
+        self.merge(dict(MODEL=dict(
+            NAME="FCOS",
+            ANCHOR=dict(NUM_ANCHORS=1, OFFSET=0.5),
+            BACKBONE=dict(OUT_FEATURES=["res3", "res4", "res5"], OUT_FEATURE_CHANNELS=[512, 1024, 2048]),
+            FPN=dict(OUT_FEATURES=["p3", "p4", "p5", "p6", "p7"], NORM=None, STRIDES=[8, 16, 32, 64, 128],
+                     TOP_BLOCK_IN_CHANNELS=2048, OUT_CHANNELS=256, TOP_BLOCK_IN_FEATURE="res5"),
+            LOSSES=dict(FOCAL_LOSS_ALPHA=0.25, FOCAL_LOSS_GAMMA=2, IOU_LOSS_TYPE="giou", REG_LOSS_WEIGHT=1.0),
+            BOX_REG=dict(MEAN=[0.0, 0.0, 0.0, 0.0], STD=[1.0, 1.0, 1.0, 1.0]),
+            HEAD=dict(NUM_CONVS=4, CLS_PRIOR_PROB=0.01,
+                      OBJECT_SIZES_OF_INTEREST=[[-1, 64], [64, 128], [128, 256], [256, 512], [512, float("inf")]],
+                      CENTER_SAMPLING_RADIUS=1.5),
+        ), TEST=dict(IOU_THRESHOLD=0.6)))

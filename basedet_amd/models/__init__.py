@@ -1,1 +1,2 @@
 from .retinanet import RetinaNet  # noqa: F401
+from .fcos import FCOS  # noqa: F401

@@ -97,6 +97,11 @@ class ConvLayer:
         if self.has_bias and not self.bn_prefix:
             out[self.name + ".bias"] = self.b[: self.cout_real].cpu().numpy().copy()
 
+    def export_grad(self, out):
+        out[self.name + ".weight"] = self.gw[: self.cout_real].permute(0, 3, 1, 2).contiguous().cpu()
+        if self.gb is not None:
+            out[self.name + ".bias"] = self.gb[: self.cout_real].cpu().clone()
+
     def pack(self):
         ops.weight_pack(self.w, self.row_scale, self.w_fwd, self.w_dgrad, self.cout, self.k * self.k, self.cin)
 
@@ -140,3 +145,32 @@ class ConvLayer:
 
     def wgrad_ws_bytes(self, gin, gout):
         return ops.conv2d_wgrad_workspace_bytes(self.desc(gin, gout))
+
+
+class FusedPredConv(ConvLayer):
+    """Several reference convs that read the same input, fused along Cout into one launch (FCOS bbox_pred [4] + ctrness [1]
+    -> 5 rows, padded to 8).  Parameters are bound from / exported to the reference's separate tensors."""
+
+    def __init__(self, name, parts, cin, k, stride, pad, device, cout_pad):
+        self.parts = parts   # [(reference conv name, cout)]
+        super().__init__(name, cin, sum(c for _, c in parts), k, stride, pad, device, has_bias=True, trainable=True, cout_pad=cout_pad)
+
+    def bind(self, arena, params):
+        merged = dict(params)
+        merged[self.name + ".weight"] = np.concatenate([params[n + ".weight"] for n, _ in self.parts], 0)
+        merged[self.name + ".bias"] = np.concatenate([params[n + ".bias"] for n, _ in self.parts], 0)
+        super().bind(arena, merged)
+
+    def export(self, out):
+        o = 0
+        for n, c in self.parts:
+            out[n + ".weight"] = self.w[o:o + c].permute(0, 3, 1, 2).contiguous().cpu().numpy()
+            out[n + ".bias"] = self.b[o:o + c].cpu().numpy().copy()
+            o += c
+
+    def export_grad(self, out):
+        o = 0
+        for n, c in self.parts:
+            out[n + ".weight"] = self.gw[o:o + c].permute(0, 3, 1, 2).contiguous().cpu()
+            out[n + ".bias"] = self.gb[o:o + c].cpu().clone()
+            o += c

@@ -1,0 +1,171 @@
+"""FCOS (basedet/models/det/fcos.py) on the HIP path: PointHead (GroupNorm towers, per-level scales, centre-ness) +
+point target assignment + focal / GIoU / BCE losses on the shared ResNet-FPN trunk.
+
+``model(batch)`` returns ``{"total_loss", "cls_loss", "reg_loss", "ctr_loss"}`` (fcos.py:173-178).
+Data-parallel detail (fcos.py:143-144): ``num_fg`` and ``sum_ctr`` are all-reduced (mean) across ranks before the losses
+are normalised -- one 2-float RCCL all-reduce in the forward pass.
+"""
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..utils.registry import registers
+from . import params as P
+from .engine import FusedPredConv
+from .fpn_base import FPNDetector, VecParam
+
+GN_EPS = 1e-5   # megengine.module.normalization.GroupNorm default
+
+
+@registers.models.register()
+class FCOS(FPNDetector):
+    @staticmethod
+    def init_params(cfg, seed=0):
+        return P.init_fcos_params(cfg, seed)
+
+    # ---- construction ------------------------------------------------------------------------------------
+    def _build_head(self, add, params):
+        """PointHead (layers/head/point_head.py:40-105)."""
+        m = self.cfg.MODEL
+        ch = self.fpn_ch
+        assert m.ANCHOR.NUM_ANCHORS == 1, "the HIP PointHead path supports one anchor point per location"
+        assert ch == 256, "GroupNorm kernel: 32 groups x 8 channels"
+        nc = m.HEAD.NUM_CONVS
+        self.towers = {}
+        for tower in ("cls_subnet", "bbox_subnet"):
+            convs, gammas, betas = [], [], []
+            for i in range(nc):
+                convs.append(add(f"head.{tower}.{3 * i}", ch, ch, 3, 1, 1, bias=True))
+                g = VecParam(f"head.{tower}.{3 * i + 1}.weight", ch)
+                b = VecParam(f"head.{tower}.{3 * i + 1}.bias", ch)
+                self.vparams[g.name] = g
+                self.vparams[b.name] = b
+                gammas.append(g); betas.append(b)
+            self.towers[tower] = (convs, gammas, betas)
+        self.cls_score = add("head.cls_score", ch, self.num_classes, 3, 1, 1, bias=True)
+        # bbox_pred (4) and ctrness (1) read the same tower output: one conv with 5 (padded to 8) output channels
+        self.pred = FusedPredConv("head.bbox_ctr", [("head.bbox_pred", 4), ("head.ctrness", 1)], ch, 3, 1, 1, self.device, cout_pad=8)
+        self.convs[self.pred.name] = self.pred
+        self.scales = VecParam("head.scales", len(self.strides))
+        self.vparams[self.scales.name] = self.scales
+
+    def _head_convs(self):
+        return self.towers["cls_subnet"][0] + self.towers["bbox_subnet"][0] + [self.cls_score, self.pred]
+
+    def _plan_head(self, pl):
+        dev = self.device
+        ch = self.fpn_ch
+        N = pl.N
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def act(c):
+            return torch.empty((pl.pyr.pixels, c), **bf)
+
+        nc = len(self.towers["cls_subnet"][0])
+        L = pl.pyr.nlev
+        pl.tw = {}
+        for tower in self.towers:
+            pl.tw[tower] = dict(y=[act(ch) for _ in range(nc)], z=[act(ch) for _ in range(nc)],
+                                stats=[torch.empty((N, L, 32, 2), **f32) for _ in range(nc)])
+        pl.logits = act(self.num_classes)
+        pl.raw = act(8)
+        pl.offsets = act(4)
+        pl.d_logits = torch.empty_like(pl.logits)
+        pl.d_off = torch.empty_like(pl.offsets)
+        pl.d_ctr = torch.empty((pl.pyr.pixels,), **bf)
+        pl.d_raw = torch.empty_like(pl.raw)
+        pl.g_tower = [act(ch), act(ch)]
+        P_total = pl.pyr.pix_per_img
+        pl.points = torch.empty((P_total, 2), **f32)
+        o = 0
+        for (h, w), s in zip(pl.sizes, self.strides):
+            ops.points_generate(h, w, s, self.cfg.MODEL.ANCHOR.OFFSET, 1, pl.points[o:o + h * w])
+            o += h * w
+        pl.lvl_start = [0]
+        for (h, w) in pl.sizes:
+            pl.lvl_start.append(pl.lvl_start[-1] + h * w)
+        pl.labels = torch.empty((N, P_total), dtype=torch.int32, device=dev)
+        pl.gt_offsets = torch.empty((N, P_total, 4), **f32)
+        pl.gt_ctr = torch.empty((N, P_total), **f32)
+        pl.stats = torch.zeros((2,), **f32)          # (num_fg, sum_ctr)
+        pl.loss_buf = torch.zeros((3,), **f32)
+        pl.gn_ws = torch.empty((ops.groupnorm_workspace_bytes(N, L, ch) // 4 + 16,), **f32)
+        pl.off_ws = torch.empty((ops.fcos_offsets_workspace_bytes() // 4,), **f32)
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def head_forward(self, pl):
+        """PointHead.forward (point_head.py:137-151), all levels per launch."""
+        pyr, ch = pl.pyr, self.fpn_ch
+        for tower, (convs, gammas, betas) in self.towers.items():
+            t = pl.P
+            bufs = pl.tw[tower]
+            for i, c in enumerate(convs):
+                c.forward(t, pyr, pyr, bufs["y"][i])
+                ops.groupnorm_fwd(bufs["y"][i], gammas[i].w, betas[i].w, pyr, ch, GN_EPS, True, bufs["stats"][i], bufs["z"][i], pl.gn_ws)
+                t = bufs["z"][i]
+            if tower == "cls_subnet":
+                self.cls_score.forward(t, pyr, pyr, pl.logits)
+            else:
+                self.pred.forward(t, pyr, pyr, pl.raw)
+        ops.fcos_offsets_fwd(pl.raw, 8, self.scales.w, pyr, self.strides, pl.offsets)     # relu(x * scale_l) * stride_l (:143)
+
+    def get_losses(self, inputs):
+        """FCOS.get_losses (fcos.py:114-179)."""
+        assert self.training
+        pre = self.pre_process(inputs)
+        pl = pre["plan"]
+        self._cur = pl
+        self.network_forward(pl)
+        m = self.cfg.MODEL
+        gt = pre["gt_boxes"]
+        num_gt = pre["img_info"][:, 4].to(torch.int32).contiguous()
+        ops.fcos_assign(pl.points, pl.lvl_start, m.HEAD.OBJECT_SIZES_OF_INTEREST, self.strides, m.HEAD.CENTER_SAMPLING_RADIUS,
+                        gt, num_gt, pl.labels, pl.gt_offsets, pl.gt_ctr, pl.stats)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(pl.stats, op=dist.ReduceOp.SUM)            # all_reduce(mode="mean") of num_fg and sum_ctr
+            pl.stats.mul_(1.0 / dist.get_world_size())
+        pl.loss_buf.zero_()
+        rows = pl.N * pl.pyr.pix_per_img
+        assert m.LOSSES.IOU_LOSS_TYPE == "giou", "HIP FCOS path implements the giou ltrb loss"
+        ops.focal_loss_fwd_bwd(pl.logits, pl.labels, rows, self.num_classes, m.LOSSES.FOCAL_LOSS_ALPHA, m.LOSSES.FOCAL_LOSS_GAMMA,
+                               pl.stats[0:1], 1.0, pl.loss_buf[0:1], pl.d_logits)
+        ops.giou_ltrb_fwd_bwd(pl.offsets, pl.gt_offsets, pl.gt_ctr, pl.labels, rows, pl.stats[1:2], m.LOSSES.REG_LOSS_WEIGHT,
+                              pl.loss_buf[1:2], pl.d_off)
+        ops.bce_logits_fwd_bwd(pl.raw, pl.gt_ctr, pl.labels, rows, pl.stats[0:1], pl.loss_buf[2:3], pl.d_ctr, ld=8, off=4)
+        cls_loss, reg_loss, ctr_loss = pl.loss_buf[0], pl.loss_buf[1], pl.loss_buf[2]
+        return {"total_loss": cls_loss + reg_loss + ctr_loss, "cls_loss": cls_loss, "reg_loss": reg_loss, "ctr_loss": ctr_loss}
+
+    # ---- backward ----------------------------------------------------------------------------------------
+    def head_backward(self, pl, ws, cws):
+        pyr, ch = pl.pyr, self.fpn_ch
+        ops.fcos_offsets_bwd(pl.raw, 8, self.scales.w, pyr, self.strides, pl.d_off, pl.d_ctr, pl.d_raw, self.scales.g, pl.off_ws)
+        gA, gB = pl.g_tower
+        for ti, (tower, pred, dpred) in enumerate((("cls_subnet", self.cls_score, pl.d_logits), ("bbox_subnet", self.pred, pl.d_raw))):
+            convs, gammas, betas = self.towers[tower]
+            bufs = pl.tw[tower]
+            nc = len(convs)
+            pred.wgrad(bufs["z"][nc - 1], dpred, pyr, pyr, ws, cws)
+            pred.dgrad(dpred, pyr, pyr, gA)                 # gradient w.r.t. z (the ReLU gate is applied in the GroupNorm bwd)
+            for i in range(nc - 1, -1, -1):
+                # gA = dL/dz_i  ->  gB = dL/dy_i (conv output)
+                ops.groupnorm_bwd(gA, bufs["y"][i], bufs["z"][i], gammas[i].w, bufs["stats"][i], pyr, ch, True, gB,
+                                  gammas[i].g, betas[i].g, pl.gn_ws)
+                x = bufs["z"][i - 1] if i > 0 else pl.P
+                convs[i].wgrad(x, gB, pyr, pyr, ws, cws)
+                if i > 0:
+                    convs[i].dgrad(gB, pyr, pyr, gA)
+                else:
+                    convs[i].dgrad(gB, pyr, pyr, pl.g_P, first=(ti == 0))
+
+    def _debug_head(self, pl, out, lvl):
+        for i in range(pl.pyr.nlev):
+            for tower, tag in (("cls_subnet", "cls"), ("bbox_subnet", "box")):
+                for k in range(len(self.towers[tower][0])):
+                    out[f"{tag}y{k}_{i}"] = lvl(pl.tw[tower]["y"][k], i)
+                    out[f"{tag}{k}_{i}"] = lvl(pl.tw[tower]["z"][k], i)
+            out[f"logits_{i}"] = lvl(pl.logits, i)
+            out[f"raw_{i}"] = lvl(pl.raw, i, 5)
+
+    def inference(self, inputs):
+        raise NotImplementedError("FCOS.inference (fcos.py:181-216) is not built yet on the HIP path; training path only")

@@ -199,6 +199,35 @@ class FPNDetector:
         self._debug_head(pl, out, lvl)
         return out
 
+    def reference_grads(self):
+        """Gradients of the last backward() keyed by the reference's parameter names, in the reference's layouts
+        (conv weights OIHW, padding rows dropped) -- what megengine's GradManager would hand to the optimizer."""
+        out = {}
+        for c in self.convs.values():
+            if not c.trainable:
+                continue
+            c.export_grad(out)
+        for v in self.vparams.values():
+            out[v.name] = v.g.detach().cpu().clone()
+        return out
+
+    def state_dict_trainable_names(self):
+        """Trainable parameters under the reference's names (what DetSolver.params would collect)."""
+        return list(self.reference_grads_names())
+
+    def reference_grads_names(self):
+        names = []
+        for c in self.convs.values():
+            if not c.trainable:
+                continue
+            parts = getattr(c, "parts", None)
+            for n in ([p[0] for p in parts] if parts else [c.name]):
+                names.append(n + ".weight")
+                if c.has_bias and not c.bn_prefix:
+                    names.append(n + ".bias")
+        names += [v.name for v in self.vparams.values()]
+        return names
+
     def trainable_parameter_names(self):
         return [e[0] for e in self.arena.entries]
 

@@ -107,6 +107,36 @@ def init_retinanet_params(cfg, seed=0, residual_gamma=None):
     return p
 
 
+def init_point_head(p, rng, ch, num_anchors, num_classes, num_convs, prior_prob, num_levels):
+    """PointHead (layers/head/point_head.py:40-125): Sequential = [conv, GroupNorm(32), ReLU] x num_convs, so conv i sits at
+    index 3i and its GroupNorm at 3i+1; N(0, 0.01) conv weights, zero bias, GN gamma=1 beta=0, scales = 1."""
+    for tower in ("cls_subnet", "bbox_subnet"):
+        for i in range(num_convs):
+            p[f"head.{tower}.{3 * i}.weight"] = (rng.standard_normal((ch, ch, 3, 3)) * 0.01).astype(np.float32)
+            p[f"head.{tower}.{3 * i}.bias"] = np.zeros(ch, np.float32)
+            p[f"head.{tower}.{3 * i + 1}.weight"] = np.ones(ch, np.float32)
+            p[f"head.{tower}.{3 * i + 1}.bias"] = np.zeros(ch, np.float32)
+    p["head.cls_score.weight"] = (rng.standard_normal((num_anchors * num_classes, ch, 3, 3)) * 0.01).astype(np.float32)
+    p["head.cls_score.bias"] = np.full(num_anchors * num_classes, -math.log((1 - prior_prob) / prior_prob), np.float32)
+    p["head.bbox_pred.weight"] = (rng.standard_normal((num_anchors * 4, ch, 3, 3)) * 0.01).astype(np.float32)
+    p["head.bbox_pred.bias"] = np.zeros(num_anchors * 4, np.float32)
+    p["head.ctrness.weight"] = (rng.standard_normal((num_anchors, ch, 3, 3)) * 0.01).astype(np.float32)
+    p["head.ctrness.bias"] = np.zeros(num_anchors, np.float32)
+    p["head.scales"] = np.ones(num_levels, np.float32)
+
+
+def init_fcos_params(cfg, seed=0, residual_gamma=None):
+    rng = np.random.default_rng(seed)
+    m = cfg.MODEL
+    p = {}
+    init_resnet(p, rng, m.BACKBONE.NAME, residual_gamma)
+    stages = [int(f[-1]) for f in m.BACKBONE.OUT_FEATURES]
+    init_fpn(p, rng, m.BACKBONE.OUT_FEATURE_CHANNELS, stages, m.FPN.OUT_CHANNELS, m.FPN.TOP_BLOCK_IN_CHANNELS)
+    init_point_head(p, rng, m.FPN.OUT_CHANNELS, m.ANCHOR.NUM_ANCHORS, cfg.DATA.NUM_CLASSES, m.HEAD.NUM_CONVS,
+                    m.HEAD.CLS_PRIOR_PROB, len(m.FPN.STRIDES))
+    return p
+
+
 def trainable_names(params, freeze_at=2):
     """DetSolver.params (solver/default_solver.py:83-94): drop bottom_up.conv1 / layer1 by name; FrozenBN
     statistics and affine terms never receive gradients (configs/extra_cfg.py:55)."""
@@ -124,6 +154,14 @@ def trainable_names(params, freeze_at=2):
 
 def oracle_arch(cfg):
     m = cfg.MODEL
+    if m.NAME == "FCOS":
+        return dict(backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
+                    num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),
+                    strides=list(m.FPN.STRIDES), anchor_offset=m.ANCHOR.OFFSET,
+                    sizes_of_interest=[list(s) for s in m.HEAD.OBJECT_SIZES_OF_INTEREST],
+                    center_sampling_radius=m.HEAD.CENTER_SAMPLING_RADIUS,
+                    focal_alpha=m.LOSSES.FOCAL_LOSS_ALPHA, focal_gamma=m.LOSSES.FOCAL_LOSS_GAMMA,
+                    iou_loss_type=m.LOSSES.IOU_LOSS_TYPE, reg_loss_weight=m.LOSSES.REG_LOSS_WEIGHT)
     return dict(backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
                 num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),
                 strides=list(m.FPN.STRIDES), anchor_scales=[list(s) for s in m.ANCHOR.SCALES],

@@ -228,6 +228,81 @@ class Oracle:
         return {"total_loss": total, "cls_loss": cls_loss, "reg_loss": reg_loss}, {
             "labels": labels, "gt_offsets": gt_off, "anchors": anchors, "logits": logits, "offsets": offsets, "num_fg": num_fg}
 
+    # ---- FCOS (layers/head/point_head.py:137-151, models/det/fcos.py:114-179) ---------------------------------
+    def point_head(self, feats):
+        """PointHead.forward: conv -> GroupNorm(32) -> ReLU towers (Sequential indices 3i / 3i+1), cls_score, and
+        offsets = relu(bbox_pred * scale_l) * stride_l, ctrness from the BOX tower (:143-144)."""
+        nconv = self.arch.get("num_convs", 4)
+        logits, offsets, ctrs = [], [], []
+        for li, (f, stride) in enumerate(zip(feats, self.arch["strides"])):
+            c, b = f, f
+            for i in range(nconv):
+                y = self._act(f"clsy{i}_{li}", self._conv(c, f"head.cls_subnet.{3 * i}", 1, 1), False)
+                z = TF.group_norm(y, 32, self.p[f"head.cls_subnet.{3 * i + 1}.weight"], self.p[f"head.cls_subnet.{3 * i + 1}.bias"], 1e-5)
+                c = self._act(f"cls{i}_{li}", z, True)
+                y = self._act(f"boxy{i}_{li}", self._conv(b, f"head.bbox_subnet.{3 * i}", 1, 1), False)
+                z = TF.group_norm(y, 32, self.p[f"head.bbox_subnet.{3 * i + 1}.weight"], self.p[f"head.bbox_subnet.{3 * i + 1}.bias"], 1e-5)
+                b = self._act(f"box{i}_{li}", z, True)
+            logits.append(self._act(f"logits_{li}", self._conv(c, "head.cls_score", 1, 1), False))
+            raw = torch.cat([self._conv(b, "head.bbox_pred", 1, 1), self._conv(b, "head.ctrness", 1, 1)], dim=1)
+            raw = self._act(f"raw_{li}", raw, False)
+            offsets.append(self._q(TF.relu(raw[:, :4] * self.p["head.scales"][li]) * float(stride)))
+            ctrs.append(raw[:, 4:5])
+        return logits, offsets, ctrs
+
+    @staticmethod
+    def _giou_ltrb(p, t, eps=1e-8):
+        """get_ltrb_boxes_iou(iou_type="giou") (layers/losses/iou_loss.py:9-56) on torch tensors."""
+        b1 = torch.cat([-p[..., :2], p[..., 2:]], -1)
+        b2 = torch.cat([-t[..., :2], t[..., 2:]], -1)
+        a1 = (b1[..., 2] - b1[..., 0]).clamp(min=0) * (b1[..., 3] - b1[..., 1]).clamp(min=0)
+        a2 = (b2[..., 2] - b2[..., 0]).clamp(min=0) * (b2[..., 3] - b2[..., 1]).clamp(min=0)
+        wi = (torch.minimum(b1[..., 2], b2[..., 2]) - torch.maximum(b1[..., 0], b2[..., 0])).clamp(min=0)
+        hi = (torch.minimum(b1[..., 3], b2[..., 3]) - torch.maximum(b1[..., 1], b2[..., 1])).clamp(min=0)
+        ai = wi * hi
+        au = a1 + a2 - ai
+        iou = ai / au.clamp(min=eps)
+        gw = torch.maximum(b1[..., 2], b2[..., 2]) - torch.minimum(b1[..., 0], b2[..., 0])
+        gh = torch.maximum(b1[..., 3], b2[..., 3]) - torch.minimum(b1[..., 1], b2[..., 1])
+        ac = gw * gh
+        return iou - (ac - au) / ac.clamp(min=eps)
+
+    def fcos_losses(self, batch):
+        a = self.arch
+        image = _t(box_ops.data_to_input(batch["data"], a["img_mean"], a["img_std"]))
+        feats = self.fpn(self.backbone(image))
+        logits, offsets, ctrs = self.point_head(feats)
+        K = a["num_classes"]
+        sizes = [tuple(f.shape[-2:]) for f in feats]
+        logits = torch.cat([self._permute(x, K) for x in logits], dim=1).reshape(-1, K)
+        offsets = torch.cat([self._permute(x, 4) for x in offsets], dim=1).reshape(-1, 4)
+        ctrs = torch.cat([self._permute(x, 1) for x in ctrs], dim=1).reshape(-1)
+        pts = box_ops.point_anchors(sizes, a["strides"], a["anchor_offset"], 1)
+        num_valid = np.asarray(batch["im_info"])[:, 4].astype(np.int32)
+        labels, gt_off, gt_ctr = box_ops.fcos_ground_truth(pts, a["strides"], batch["gt_boxes"], num_valid, a["sizes_of_interest"],
+                                                           a["center_sampling_radius"])
+        labels_t = torch.from_numpy(labels.reshape(-1)).long()
+        gt_off_t, gt_ctr_t = _t(gt_off.reshape(-1, 4)), _t(gt_ctr.reshape(-1))
+        valid, fg = labels_t >= 0, labels_t > 0
+        num_fg = float(fg.sum())
+        sum_ctr = float(gt_ctr_t[fg].sum())
+        tgt = torch.zeros_like(logits)
+        tgt[fg, labels_t[fg] - 1] = 1
+        x, t = logits[valid], tgt[valid]
+        p = torch.sigmoid(x)
+        ce = -(t * TF.logsigmoid(x) + (1 - t) * TF.logsigmoid(-x))
+        al = a.get("focal_alpha", 0.25)
+        fl = ce * (t * (1 - p) + (1 - t) * p) ** a.get("focal_gamma", 2.0) * (t * al + (1 - t) * (1 - al))
+        cls_loss = fl.sum() / max(1.0, num_fg)
+        giou = self._giou_ltrb(offsets[fg], gt_off_t[fg])
+        reg_loss = ((1 - giou) * gt_ctr_t[fg]).sum() / max(1.0, sum_ctr) * a.get("reg_loss_weight", 1.0)
+        xc, tc = ctrs[fg], gt_ctr_t[fg]
+        ctr_loss = (-(tc * TF.logsigmoid(xc) + (1 - tc) * TF.logsigmoid(-xc))).sum() / max(1.0, num_fg)
+        total = cls_loss + reg_loss + ctr_loss
+        return {"total_loss": total, "cls_loss": cls_loss, "reg_loss": reg_loss, "ctr_loss": ctr_loss}, {
+            "labels": labels, "gt_offsets": gt_off, "gt_ctr": gt_ctr, "logits": logits, "offsets": offsets, "num_fg": num_fg,
+            "sum_ctr": sum_ctr}
+
     # ---- one training step: backward + SGD (solver/default_solver.py:96-124) --------------------
     def grads(self, loss):
         ps = [self.p[k] for k in self.trainable]
