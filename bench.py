@@ -27,6 +27,7 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, "Pe
 TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): convs only, 1 MAC = 2 FLOP
     "retinanet_r50_800x1344": 1435.6,
     "retinanet_r18_512x512": 277.2,
+    "fcos_r50_800x1344": 1227.8,
 }
 
 
@@ -152,20 +153,26 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from basedet_amd import ops
-    from basedet_amd.configs import RetinaNetConfig, retinanet_r18_config
-    from basedet_amd.models import RetinaNet, params as P
+    from basedet_amd.configs import FCOSConfig, RetinaNetConfig, retinanet_r18_config
+    from basedet_amd.models import FCOS, RetinaNet, params as P
     from basedet_amd.solver import DetSolver, WarmupMultiStepLR, broadcast_parameters
     from basedet_amd.utils import DummyLoader
 
     if args.workload == "retinanet_r50_800x1344":
         cfg, size = RetinaNetConfig(), (800, 1344)
+    elif args.workload == "fcos_r50_800x1344":
+        cfg, size = FCOSConfig(), (800, 1344)
     else:
         cfg, size = retinanet_r18_config(), (512, 512)
     cfg.MODEL.BATCHSIZE = args.batch
     # random-init weights of the named architecture; the last FrozenBN gamma of every residual branch is 0.2
     # (stand-in for ImageNet statistics: identity BN overflows a random ResNet-50; same FLOPs and bytes)
-    params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
-    model = RetinaNet(cfg, params=params)
+    if cfg.MODEL.NAME == "FCOS":
+        params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.2)
+        model = FCOS(cfg, params=params)
+    else:
+        params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
+        model = RetinaNet(cfg, params=params)
     broadcast_parameters(model)
     solver = DetSolver.build(cfg, model)
     sched = WarmupMultiStepLR(solver.optimizer, cfg, world)     # LRSchedulerHook.before_iter (engine/hooks.py:218)
@@ -216,7 +223,7 @@ def main():
         imgs = args.batch * world * args.steps
         value = imgs / elapsed
         out = {
-            "metric": "images/sec training RetinaNet-R50-FPN 1333x800" if "r50" in args.workload else "images/sec training " + args.workload,
+            "metric": "images/sec training RetinaNet-R50-FPN 1333x800" if args.workload == "retinanet_r50_800x1344" else "images/sec training " + args.workload,
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -244,7 +251,7 @@ def main():
             entries.sort(key=lambda e: -e["ms_per_step"])
             out["roofline"] = entries[0]                 # the dominant kernel of the step
             out["roofline_others"] = entries[1:]
-        if world == 1 and not args.no_cpu_baseline and "r50" in args.workload:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "retinanet_r50_800x1344":
             out["cpu_baseline"] = cpu_baseline(cfg, params)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
