@@ -75,7 +75,8 @@ class FCOS(FPNDetector):
         pl.d_off = torch.empty_like(pl.offsets)
         pl.d_ctr = torch.empty((pl.pyr.pixels,), **bf)
         pl.d_raw = torch.empty_like(pl.raw)
-        pl.g_tower = [act(ch), act(ch)]
+        pl.g_z = act(ch)                                                  # dL/dz scratch (consumed at once by the GN bwd)
+        pl.g_y = [[act(ch) for _ in range(nc)] for _ in range(2)]         # dL/dy per tower layer (read by async wgrads)
         P_total = pl.pyr.pix_per_img
         pl.points = torch.empty((P_total, 2), **f32)
         o = 0
@@ -140,23 +141,23 @@ class FCOS(FPNDetector):
     def head_backward(self, pl, ws, cws):
         pyr, ch = pl.pyr, self.fpn_ch
         ops.fcos_offsets_bwd(pl.raw, 8, self.scales.w, pyr, self.strides, pl.d_off, pl.d_ctr, pl.d_raw, self.scales.g, pl.off_ws)
-        gA, gB = pl.g_tower
         for ti, (tower, pred, dpred) in enumerate((("cls_subnet", self.cls_score, pl.d_logits), ("bbox_subnet", self.pred, pl.d_raw))):
             convs, gammas, betas = self.towers[tower]
             bufs = pl.tw[tower]
             nc = len(convs)
-            pred.wgrad(bufs["z"][nc - 1], dpred, pyr, pyr, ws, cws)
-            pred.dgrad(dpred, pyr, pyr, gA)                 # gradient w.r.t. z (the ReLU gate is applied in the GroupNorm bwd)
+            self._wgrad(pred, bufs["z"][nc - 1], dpred, pyr, pyr, ws, cws)
+            pred.dgrad(dpred, pyr, pyr, pl.g_z)             # gradient w.r.t. z (the ReLU gate is applied in the GroupNorm bwd)
             for i in range(nc - 1, -1, -1):
-                # gA = dL/dz_i  ->  gB = dL/dy_i (conv output)
-                ops.groupnorm_bwd(gA, bufs["y"][i], bufs["z"][i], gammas[i].w, bufs["stats"][i], pyr, ch, True, gB,
+                gy = pl.g_y[ti][i]
+                # g_z = dL/dz_i  ->  gy = dL/dy_i (conv output)
+                ops.groupnorm_bwd(pl.g_z, bufs["y"][i], bufs["z"][i], gammas[i].w, bufs["stats"][i], pyr, ch, True, gy,
                                   gammas[i].g, betas[i].g, pl.gn_ws)
                 x = bufs["z"][i - 1] if i > 0 else pl.P
-                convs[i].wgrad(x, gB, pyr, pyr, ws, cws)
+                self._wgrad(convs[i], x, gy, pyr, pyr, ws, cws)
                 if i > 0:
-                    convs[i].dgrad(gB, pyr, pyr, gA)
+                    convs[i].dgrad(gy, pyr, pyr, pl.g_z)
                 else:
-                    convs[i].dgrad(gB, pyr, pyr, pl.g_P, first=(ti == 0))
+                    convs[i].dgrad(gy, pyr, pyr, pl.g_P, first=(ti == 0))
 
     def _debug_head(self, pl, out, lvl):
         for i in range(pl.pyr.nlev):

@@ -67,6 +67,10 @@ class FPNDetector:
         self._plans = {}
         self._cur = None
         self.extra_meter = {}
+        # weight-gradient kernels run on a side stream, concurrently with the dgrad chain they do not feed: tails and
+        # barrier bubbles of one kernel are filled by the other (set False to serialise, e.g. for per-kernel timing)
+        self.async_wgrad = True
+        self._wstream = torch.cuda.Stream() if (torch.cuda.is_available() and self.device.type == "cuda") else None
 
     # ------------------------------------------------------------------------------------------------
     # construction
@@ -395,12 +399,27 @@ class FPNDetector:
     # ------------------------------------------------------------------------------------------------
     # backward (replaces GradManager.backward, solver/default_solver.py:118-124)
     # ------------------------------------------------------------------------------------------------
+    def _wgrad(self, conv, x, g, gin, gout, ws, cws=None):
+        """conv.wgrad on the side stream: it only needs x and g as they are NOW (everything enqueued so far on the main
+        stream), and nothing on the main stream reads its outputs before `_join_wgrads`.  Callers must not overwrite g/x
+        later in the same backward pass (the heads keep one gradient buffer per layer for that reason)."""
+        if not (self.async_wgrad and self._wstream is not None):
+            return conv.wgrad(x, g, gin, gout, ws, cws)
+        self._wstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._wstream):
+            conv.wgrad(x, g, gin, gout, ws, cws)
+
+    def _join_wgrads(self):
+        if self.async_wgrad and self._wstream is not None:
+            torch.cuda.current_stream().wait_stream(self._wstream)
+
     def backward(self, on_bucket_ready=None):
         pl = self._cur
         ws, cws = pl.wgrad_ws, pl.colsum_ws
         pyr = pl.pyr
         self.head_backward(pl, ws, cws)
         if on_bucket_ready:
+            self._join_wgrads()
             on_bucket_ready("head")
         # ---- FPN
         st = self.fpn_stages
@@ -408,20 +427,20 @@ class FPNDetector:
         g6, g7 = pyr.level(nl), pyr.level(nl + 1)
         b5 = pl.blk[pl.res[st[-1]]]
         # P7 = conv(relu(P6)): d P6 = dgrad(g_P7) * (P6 > 0) + g_P6(head), written in place into g_P's P6 level
-        self.p7.wgrad(pl.p6_relu, pl.g_P, pl.g_p6r, g7, ws, cws)
+        self._wgrad(self.p7, pl.p6_relu, pl.g_P, pl.g_p6r, g7, ws, cws)
         self.p7.dgrad(pl.g_P, g6, g7, pl.g_P, mask=pl.P, add_after=pl.g_P)
-        self.p6.wgrad(b5.out, pl.g_P, b5.gout, g6, ws, cws)
+        self._wgrad(self.p6, b5.out, pl.g_P, b5.gout, g6, ws, cws)
         self.p6.dgrad(pl.g_P, b5.gout, g6, b5.g_out, first=True)
         for li in range(nl):
             s = st[li]
             b = pl.blk[pl.res[s]]
             lvl = pyr.level(li)
-            self.output[s].wgrad(pl.lat[s], pl.g_P, b.gout, lvl, ws, cws)
+            self._wgrad(self.output[s], pl.lat[s], pl.g_P, b.gout, lvl, ws, cws)
             self.output[s].dgrad(pl.g_P, b.gout, lvl, pl.g_lat[s], first=True)
             if li > 0:   # gradient arriving through the top-down path from the finer level
                 sf = st[li - 1]
                 ops.upsample2x_add_bwd(pl.g_lat[sf], pl.blk[pl.res[sf]].gout, pl.g_lat[s], b.gout, self.fpn_ch, accumulate=True)
-            self.lateral[s].wgrad(b.out, pl.g_lat[s], b.gout, b.gout, ws, cws)
+            self._wgrad(self.lateral[s], b.out, pl.g_lat[s], b.gout, b.gout, ws, cws)
             # res_s gradient: first contribution for res3/res4, second (after P6) and final for res5 -> mask there
             is_top = li == nl - 1
             if is_top:
@@ -429,6 +448,7 @@ class FPNDetector:
             else:
                 self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=True)
         if on_bucket_ready:
+            self._join_wgrads()
             on_bucket_ready("fpn")
         # ---- backbone, last block first.  g_out of a block holds the masked gradient once all consumers are done:
         # res5: done above.  res3/res4 (and every inner block output): the next block's dgrads finish it.
@@ -445,12 +465,12 @@ class FPNDetector:
             # main branch, last conv backwards
             g = G
             for ci in range(len(convs) - 1, 0, -1):
-                convs[ci].wgrad(b.mids[ci - 1], g, geos[ci], geos[ci + 1], ws)
+                self._wgrad(convs[ci], b.mids[ci - 1], g, geos[ci], geos[ci + 1], ws)
                 convs[ci].dgrad(g, geos[ci], geos[ci + 1], b.g_mids[ci - 1], mask=b.mids[ci - 1])
                 g = b.g_mids[ci - 1]
-            convs[0].wgrad(xin, g, geos[0], geos[1], ws)
+            self._wgrad(convs[0], xin, g, geos[0], geos[1], ws)
             if blk["ds"] is not None:
-                blk["ds"].wgrad(xin, G, b.gin, b.gout, ws)
+                self._wgrad(blk["ds"], xin, G, b.gin, b.gout, ws)
             if prev_tr:
                 gx = pl.blk[bi - 1].g_out
                 # has the input already received a contribution (FPN lateral of res3/res4)?
@@ -467,5 +487,7 @@ class FPNDetector:
                         ops.conv2d_dgrad(convs[0].desc(geos[0], geos[1]), g, convs[0].w_dgrad, gx, add=G, mask=xin,
                                          flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
             if on_bucket_ready and (bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]):
+                self._join_wgrads()
                 on_bucket_ready(f"layer{blk['layer']}")
+        self._join_wgrads()
 

@@ -75,7 +75,7 @@ class RetinaNet(FPNDetector):
         pl.offsets = act(pl.pyr, self.box_ld)
         pl.d_logits = torch.empty_like(pl.logits)
         pl.d_offsets = torch.empty_like(pl.offsets)
-        pl.g_tower = [act(pl.pyr, ch), act(pl.pyr, ch)]
+        pl.g_tower = [[act(pl.pyr, ch) for _ in range(nc)] for _ in range(2)]   # one gradient buffer per tower layer
         # anchors (regenerated per forward in the reference, retinanet.py:116; cached per shape here)
         tot = pl.pyr.pix_per_img * A
         pl.anchors = torch.empty((tot, 4), dtype=torch.float32, device=dev)
@@ -130,22 +130,20 @@ class RetinaNet(FPNDetector):
     # ---- backward ----------------------------------------------------------------------------------------
     def head_backward(self, pl, ws, cws):
         pyr = pl.pyr
-        # ---- head: cls tower then box tower; both end in g_P
+        # ---- head: cls tower then box tower; both end in g_P.  g_tower[t][i] = dL/d(pre-activation of tower conv i)
         for ti, (tower, acts, pred, dpred) in enumerate(((self.cls_tower, pl.cls_act, self.cls_score, pl.d_logits),
                                                          (self.box_tower, pl.box_act, self.bbox_pred, pl.d_offsets))):
-            gA, gB = pl.g_tower
-            pred.wgrad(acts[-1], dpred, pyr, pyr, ws, cws)
-            pred.dgrad(dpred, pyr, pyr, gA, mask=acts[-1])
-            g = gA
-            for i in range(len(tower) - 1, -1, -1):
+            gbuf = pl.g_tower[ti]
+            n = len(tower)
+            self._wgrad(pred, acts[-1], dpred, pyr, pyr, ws, cws)
+            pred.dgrad(dpred, pyr, pyr, gbuf[n - 1], mask=acts[-1])
+            for i in range(n - 1, -1, -1):
                 x = acts[i - 1] if i > 0 else pl.P
-                tower[i].wgrad(x, g, pyr, pyr, ws, cws)
+                self._wgrad(tower[i], x, gbuf[i], pyr, pyr, ws, cws)
                 if i > 0:
-                    nxt = gB if g is gA else gA
-                    tower[i].dgrad(g, pyr, pyr, nxt, mask=acts[i - 1])
-                    g = nxt
+                    tower[i].dgrad(gbuf[i], pyr, pyr, gbuf[i - 1], mask=acts[i - 1])
                 else:
-                    tower[i].dgrad(g, pyr, pyr, pl.g_P, first=(ti == 0))
+                    tower[i].dgrad(gbuf[i], pyr, pyr, pl.g_P, first=(ti == 0))
 
     def _debug_head(self, pl, out, lvl):
         for i in range(pl.pyr.nlev):

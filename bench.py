@@ -207,6 +207,7 @@ def main():
         if timer:
             timer.enabled = (k % max(1, args.roofline_every) == 0)
             sampled += int(timer.enabled)
+            model.async_wgrad = not timer.enabled     # instrumented steps run serialised: clean per-kernel durations
         last = solver.minimize(model, batch)
     sync()
     elapsed = time.perf_counter() - t0
