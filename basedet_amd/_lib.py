@@ -73,6 +73,21 @@ SIGNATURES = {
     "bd_fcos_offsets_fwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _L, _P, _P]),
     "bd_fcos_offsets_workspace_bytes": (_Z, []),
     "bd_fcos_offsets_bwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _Z, _P]),
+    "bd_rpn_assign_encode": (_I, [_P, _I, _P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bd_sample_labels": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "bd_segment_topk": (_I, [_P, _I, _I, _L, _I, _I, _I, _I, _P, _P, _I, _F, _I, _P, _P, _P, _P]),
+    "bd_nms_batched_workspace_bytes": (_Z, [_I, _I]),
+    "bd_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    "bd_rpn_proposals_workspace_bytes": (_Z, [_I, _I, _P, _I, _I, _I]),
+    "bd_rpn_proposals": (_I, [_P, _I, _I, _I, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _I, _F, _I, _P, _P, _P, _Z, _P]),
+    "bd_rcnn_sample_targets": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "bd_roi_align_fwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "bd_roi_align_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "bd_subsample2x_fwd": (_I, [_P, _L, _L, _I, _I, _P, _L, _L, _I, _I, _P]),
+    "bd_subsample2x_bwd_add": (_I, [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _P]),
+    "bd_f32_to_bf16": (_I, [_P, _P, _L, _P]),
+    "bd_rpn_loss_fwd_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _L, _F, _P, _P, _P, _P]),
+    "bd_rcnn_loss_fwd_bwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P]),
     "bd_sgd_momentum_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _P]),
     "bd_wgrad_set_transpose_read": (_I, [_I]),
     "bd_conv_set_patch3x3": (_I, [_I]),

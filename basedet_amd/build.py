@@ -22,6 +22,7 @@ SOURCES = {
     "conv_wgrad1x1.hip": [],
     "stem.hip": [],
     "boxops.hip": ["-ffp-contract=off"],
+    "rcnn_ops.hip": ["-ffp-contract=off"],
     "losses.hip": [],
     "norm.hip": [],
 }

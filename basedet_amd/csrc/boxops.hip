@@ -3,7 +3,7 @@
 // fp32 division / sqrt, so that every decision taken on an IoU value (thresholds, equality with the per-gt row
 // maximum, NMS suppression) is bit-identical to the float32 numpy oracle (oracle/box_ops.py).
 #pragma clang fp contract(off)
-#include "common.h"
+#include "box_dev.h"
 
 namespace {
 
@@ -39,25 +39,6 @@ __global__ void points_kernel(int H, int W, int stride, float shift, int A, floa
 // ------------------------------------------------------------------------------------------------------------
 // pairwise ops (structures/op_patch.py:33-97, 170-227; structures/boxes.py:74-95, 114-130)
 // ------------------------------------------------------------------------------------------------------------
-struct Box { float x1, y1, x2, y2; };
-
-__device__ __forceinline__ Box ld_box(const float* p) {
-    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
-    return Box{v[0], v[1], v[2], v[3]};
-}
-__device__ __forceinline__ float box_area(const Box& b) { return (b.x2 - b.x1) * (b.y2 - b.y1); }
-__device__ __forceinline__ float box_inter(const Box& a, const Box& b) {
-    const float iw = fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1);
-    const float ih = fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1);
-    return fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
-}
-// op_patch.py:33-76: inter / (area1 + area2 - inter), max(., 0)   (fmaxf maps NaN -> 0)
-__device__ __forceinline__ float box_iou_dev(const Box& a, float area_a, const Box& b, float area_b) {
-    const float inter = box_inter(a, b);
-    const float uni = (area_a + area_b) - inter;
-    return fmaxf(inter / uni, 0.f);
-}
-
 __global__ void pairwise_kernel(const float* __restrict__ b1, int m, const float* __restrict__ b2, int n, int mode,
                                 float* __restrict__ out) {
     const long long total = (long long)m * n;
@@ -86,21 +67,6 @@ __global__ void pairwise_kernel(const float* __restrict__ b1, int m, const float
 // ------------------------------------------------------------------------------------------------------------
 // BoxCoder (structures/boxcoder.py:61-98)
 // ------------------------------------------------------------------------------------------------------------
-struct Coder { float m0, m1, m2, m3, s0, s1, s2, s3; };
-
-__device__ __forceinline__ f32x4_t encode_dev(const Box& a, const Box& g, const Coder& c) {
-    const float aw = a.x2 - a.x1, ah = a.y2 - a.y1;
-    const float acx = a.x1 + 0.5f * aw, acy = a.y1 + 0.5f * ah;
-    const float gw = g.x2 - g.x1, gh = g.y2 - g.y1;
-    const float gcx = g.x1 + 0.5f * gw, gcy = g.y1 + 0.5f * gh;
-    f32x4_t t;
-    t[0] = ((gcx - acx) / aw - c.m0) / c.s0;
-    t[1] = ((gcy - acy) / ah - c.m1) / c.s1;
-    t[2] = (logf(gw / aw) - c.m2) / c.s2;
-    t[3] = (logf(gh / ah) - c.m3) / c.s3;
-    return t;
-}
-
 __global__ void encode_kernel(const float* __restrict__ anchors, const float* __restrict__ gt, long long n, Coder c,
                               float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,16 +78,7 @@ __global__ void decode_kernel(const float* __restrict__ anchors, const float* __
                               float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Box a = ld_box(anchors + i * 4);
-    const f32x4_t d = *reinterpret_cast<const f32x4_t*>(deltas + i * 4);
-    const float d0 = d[0] * c.s0 + c.m0, d1 = d[1] * c.s1 + c.m1, d2 = d[2] * c.s2 + c.m2, d3 = d[3] * c.s3 + c.m3;
-    const float aw = a.x2 - a.x1, ah = a.y2 - a.y1;
-    const float acx = a.x1 + 0.5f * aw, acy = a.y1 + 0.5f * ah;
-    const float cx = acx + d0 * aw, cy = acy + d1 * ah;
-    const float w = aw * expf(d2), h = ah * expf(d3);
-    f32x4_t o;
-    o[0] = cx - 0.5f * w; o[1] = cy - 0.5f * h; o[2] = cx + 0.5f * w; o[3] = cy + 0.5f * h;
-    *reinterpret_cast<f32x4_t*>(out + i * 4) = o;
+    *reinterpret_cast<f32x4_t*>(out + i * 4) = decode_dev(ld_box(anchors + i * 4), *reinterpret_cast<const f32x4_t*>(deltas + i * 4), c);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -165,15 +122,13 @@ __global__ __launch_bounds__(256) void gt_rowmax_kernel(const float* __restrict_
     }
 }
 
-__device__ __forceinline__ Box ld_gt(const float* p) { return Box{p[0], p[1], p[2], p[3]}; }
-
 // pass 2: per-anchor max/argmax over gts, threshold bands, low-quality rule, class label, encode
 __global__ __launch_bounds__(256) void retina_assign_kernel(const float* __restrict__ anchors, int A,
                                                             const float* __restrict__ gt_boxes, const int* __restrict__ num_gt,
                                                             int Gmax, float thr_lo, float thr_hi, int allow_lq, Coder coder,
                                                             const unsigned int* __restrict__ gtmax, int* __restrict__ labels,
                                                             int* __restrict__ match_idx, float* __restrict__ offsets,
-                                                            int* __restrict__ num_fg) {
+                                                            int* __restrict__ num_fg, int class_agnostic) {
     const int n = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
     const int G = min(num_gt[n], Gmax);
@@ -197,7 +152,7 @@ __global__ __launch_bounds__(256) void retina_assign_kernel(const float* __restr
             lab = best < thr_lo ? 0 : (best < thr_hi ? -1 : 1);
             if (allow_lq && lq) lab = 1;
             const float* mg = gp + bi * 5;
-            if (lab == 1) lab = (int)mg[4];
+            if (lab == 1 && !class_agnostic) lab = (int)mg[4];
             off = encode_dev(ab, ld_gt(mg), coder);
         }
         const long long o = (long long)n * A + a;
@@ -274,12 +229,6 @@ __global__ __launch_bounds__(256) void fcos_assign_kernel(const float* __restric
 // batched NMS (layers/common/post_processing.py:17-47)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int NMS_MAX = 16384;
-
-__device__ __forceinline__ unsigned int float_desc_key(float f) {
-    unsigned int u = __float_as_uint(f);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable
-    return ~u;                                         // descending score
-}
 
 // one workgroup: max coordinate, class-offset boxes, bitonic sort of (score desc, index asc)
 __global__ __launch_bounds__(1024) void nms_prepare_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
@@ -364,13 +313,6 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
     if (lane == 0) *num_keep = cnt;
 }
 
-inline Coder make_coder(const float* mean4, const float* std4) {
-    Coder c{0, 0, 0, 0, 1, 1, 1, 1};
-    if (mean4) { c.m0 = mean4[0]; c.m1 = mean4[1]; c.m2 = mean4[2]; c.m3 = mean4[3]; }
-    if (std4) { c.s0 = std4[0]; c.s1 = std4[1]; c.s2 = std4[2]; c.s3 = std4[3]; }
-    return c;
-}
-
 }  // namespace
 
 extern "C" int bd_anchors_generate(int H, int W, int stride, float offset, const float* base, int A, float* out,
@@ -423,14 +365,14 @@ extern "C" int bd_box_decode(const float* anchors, const float* deltas, int64_t 
     return BD_OK;
 }
 
-extern "C" int bd_retina_assign_encode(const float* anchors, int A, const float* gt_boxes, const int32_t* num_gt, int N,
-                                       int Gmax, float thr_lo, float thr_hi, int allow_low_quality, const float* mean4,
-                                       const float* std4, int32_t* labels, int32_t* match_idx, float* offsets,
-                                       int32_t* num_fg, void* ws, size_t ws_bytes, bd_stream_t stream) {
-    BD_REQUIRE(anchors && gt_boxes && num_gt && labels && match_idx && offsets && num_fg && ws, "retina_assign: null pointer");
-    BD_REQUIRE(A > 0 && N > 0 && Gmax > 0, "retina_assign: bad sizes");
+static int assign_encode_impl(const char* who, const float* anchors, int A, const float* gt_boxes, const int32_t* num_gt, int N,
+                              int Gmax, float thr_lo, float thr_hi, int allow_low_quality, const float* mean4, const float* std4,
+                              int32_t* labels, int32_t* match_idx, float* offsets, int32_t* num_fg, void* ws, size_t ws_bytes,
+                              int class_agnostic, bd_stream_t stream) {
+    BD_REQUIRE(anchors && gt_boxes && num_gt && labels && match_idx && offsets && num_fg && ws, "%s: null pointer", who);
+    BD_REQUIRE(A > 0 && N > 0 && Gmax > 0, "%s: bad sizes", who);
     if (ws_bytes < (size_t)N * Gmax * sizeof(float)) {
-        bd_set_error("retina_assign: workspace %zu < %zu bytes", ws_bytes, (size_t)N * Gmax * sizeof(float));
+        bd_set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, (size_t)N * Gmax * sizeof(float));
         return BD_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -440,9 +382,25 @@ extern "C" int bd_retina_assign_encode(const float* anchors, int A, const float*
                        Gmax, (unsigned int*)ws);
     hipLaunchKernelGGL(retina_assign_kernel, dim3(cdiv(A, 256), N), dim3(256), 0, st, anchors, A, gt_boxes, num_gt, Gmax,
                        thr_lo, thr_hi, allow_low_quality, make_coder(mean4, std4), (const unsigned int*)ws, labels,
-                       match_idx, offsets, num_fg);
-    BD_CHECK_LAUNCH("bd_retina_assign_encode");
+                       match_idx, offsets, num_fg, class_agnostic);
+    BD_CHECK_LAUNCH(who);
     return BD_OK;
+}
+
+extern "C" int bd_retina_assign_encode(const float* anchors, int A, const float* gt_boxes, const int32_t* num_gt, int N,
+                                       int Gmax, float thr_lo, float thr_hi, int allow_low_quality, const float* mean4,
+                                       const float* std4, int32_t* labels, int32_t* match_idx, float* offsets,
+                                       int32_t* num_fg, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    return assign_encode_impl("bd_retina_assign_encode", anchors, A, gt_boxes, num_gt, N, Gmax, thr_lo, thr_hi, allow_low_quality,
+                              mean4, std4, labels, match_idx, offsets, num_fg, ws, ws_bytes, 0, stream);
+}
+
+extern "C" int bd_rpn_assign_encode(const float* anchors, int A, const float* gt_boxes, const int32_t* num_gt, int N,
+                                    int Gmax, float thr_lo, float thr_hi, int allow_low_quality, const float* mean4,
+                                    const float* std4, int32_t* labels, int32_t* match_idx, float* offsets,
+                                    int32_t* num_fg, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    return assign_encode_impl("bd_rpn_assign_encode", anchors, A, gt_boxes, num_gt, N, Gmax, thr_lo, thr_hi, allow_low_quality,
+                              mean4, std4, labels, match_idx, offsets, num_fg, ws, ws_bytes, 1, stream);
 }
 
 extern "C" int bd_fcos_assign(const float* points, int P, const int32_t* lvl_start, const float* soi, const int32_t* strides,

@@ -199,6 +199,121 @@ __global__ __launch_bounds__(256) void bce_kernel(const bf16_raw* __restrict__ p
     if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s * gs);
 }
 
+// RPN losses (models/det/rpn.py:113-131): binary cross entropy with logits, mean over the sampled (label >= 0) anchors,
+// and smooth-L1 over the positive anchors divided by max(num_valid, 1).  One thread per (pixel, cell anchor); the fused
+// prediction row holds [cls_off + a] logits and [box_off + 4a .. +3] offsets; padding channels are never written.
+__global__ __launch_bounds__(256) void rpn_loss_kernel(const bf16_raw* __restrict__ raw, int ldc, int A, int cls_off, int box_off,
+                                                       const int* __restrict__ labels, const float* __restrict__ targets,
+                                                       long long rows, float beta, const int* __restrict__ num_valid,
+                                                       float* __restrict__ loss, bf16_raw* __restrict__ draw) {
+    __shared__ float red[4];
+    const float gs = 1.f / fmaxf((float)*num_valid, 1.f);
+    float acc_c = 0.f, acc_b = 0.f;
+    const long long total = rows * A;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / A;
+        const int a = (int)(i - pix * A);
+        const int l = labels[i];
+        const bf16_raw* rp = raw + pix * ldc;
+        bf16_raw* dp = draw + pix * ldc;
+        float gc = 0.f;
+        float gb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (l >= 0) {
+            const float x = bf2f(rp[cls_off + a]), t = (float)l;
+            const float e = __expf(-fabsf(x));
+            const float l1p = log1pf(e);
+            const float ls_pos = fminf(x, 0.f) - l1p, ls_neg = fminf(-x, 0.f) - l1p;
+            acc_c += -(t * ls_pos + (1.f - t) * ls_neg);
+            const float inv = 1.f / (1.f + e);
+            const float p = x >= 0.f ? inv : e * inv;
+            gc = (p - t) * gs;
+        }
+        if (l > 0) {
+            const f32x4_t tv = *reinterpret_cast<const f32x4_t*>(targets + i * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = bf2f(rp[box_off + a * 4 + k]) - tv[k];
+                const float ax = fabsf(x);
+                float g;
+                if (beta < 1e-5f) { acc_b += ax; g = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+                else if (ax < beta) { acc_b += 0.5f * x * x / beta; g = x / beta; }
+                else { acc_b += ax - 0.5f * beta; g = x > 0.f ? 1.f : -1.f; }
+                gb[k] = g * gs;
+            }
+        }
+        dp[cls_off + a] = f2bf(gc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dp[box_off + a * 4 + k] = f2bf(gb[k]);
+    }
+    const float sc = block_sum_256(acc_c, red);
+    __syncthreads();
+    const float sb = block_sum_256(acc_b, red);
+    if (threadIdx.x == 0) {
+        if (sc != 0.f) atomicAdd(loss, sc * gs);
+        if (sb != 0.f) atomicAdd(loss + 1, sb * gs);
+    }
+}
+
+// RCNN losses (layers/head/rcnn.py:65-83): softmax cross entropy over K+1 classes (mean over the sampled RoIs) and
+// smooth-L1 on the deltas of the ground-truth class of the foreground RoIs, divided by the number of samples.
+// One wave per RoI row; the fused prediction row holds K+1 logits at [0, K] and K*4 deltas from `box_off`.
+// Rows with label < 0 are empty sample slots: zero gradient, no loss.
+__global__ __launch_bounds__(256) void rcnn_loss_kernel(const bf16_raw* __restrict__ raw, int ld, int K, int box_off,
+                                                        const int* __restrict__ labels, const float* __restrict__ targets,
+                                                        int R, float beta, const int* __restrict__ num_samples,
+                                                        float* __restrict__ loss, bf16_raw* __restrict__ draw) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float gs = 1.f / fmaxf((float)*num_samples, 1.f);
+    const bf16_raw* rp = raw + (long long)r * ld;
+    bf16_raw* dp = draw + (long long)r * ld;
+    const int l = labels[r];
+    if (l < 0) {
+        for (int c = lane; c < ld; c += 64) dp[c] = 0;
+        return;
+    }
+    const int nc = K + 1;
+    float mx = -INFINITY;
+    for (int c = lane; c < nc; c += 64) mx = fmaxf(mx, bf2f(rp[c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = 0.f;
+    for (int c = lane; c < nc; c += 64) se += expf(bf2f(rp[c]) - mx);
+    se = wave_sum(se);
+    const float lse = logf(se) + mx;
+    for (int c = lane; c < nc; c += 64) {
+        const float p = expf(bf2f(rp[c]) - lse);
+        dp[c] = f2bf((p - (c == l ? 1.f : 0.f)) * gs);
+    }
+    for (int c = nc + lane; c < ld; c += 64) {
+        float g = 0.f;
+        const int q = c - box_off;
+        if (l > 0 && q >= (l - 1) * 4 && q < l * 4) {
+            const float x = bf2f(rp[c]) - targets[(long long)r * 4 + (q & 3)];
+            if (beta < 1e-5f) g = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+            else if (fabsf(x) < beta) g = x / beta;
+            else g = x > 0.f ? 1.f : -1.f;
+            g *= gs;
+        }
+        dp[c] = f2bf(g);
+    }
+    if (lane == 0) {
+        atomicAdd(loss, (lse - bf2f(rp[l])) * gs);
+        if (l > 0) {
+            float sb = 0.f;
+            for (int k = 0; k < 4; ++k) {
+                const float x = bf2f(rp[box_off + (l - 1) * 4 + k]) - targets[(long long)r * 4 + k];
+                const float ax = fabsf(x);
+                if (beta < 1e-5f) sb += ax;
+                else if (ax < beta) sb += 0.5f * x * x / beta;
+                else sb += ax - 0.5f * beta;
+            }
+            atomicAdd(loss + 1, sb * gs);
+        }
+    }
+}
+
 inline int loss_grid(long long n) {
     long long g = (n + 255) / 256;
     if (g < 1) g = 1;
@@ -252,5 +367,28 @@ extern "C" int bd_bce_logits_fwd_bwd(const void* pred, int ld, int off, const fl
     hipLaunchKernelGGL(bce_kernel, dim3(loss_grid(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)pred, ld, off, target,
                        labels, (long long)rows, norm, loss_sum, (bf16_raw*)dpred);
     BD_CHECK_LAUNCH("bd_bce_logits_fwd_bwd");
+    return BD_OK;
+}
+
+extern "C" int bd_rpn_loss_fwd_bwd(const void* raw, int ldc, int A, int cls_off, int box_off, const int32_t* labels,
+                                   const float* targets, int64_t rows, float beta, const int32_t* num_valid, float* loss2,
+                                   void* draw, bd_stream_t stream) {
+    BD_REQUIRE(raw && labels && targets && num_valid && loss2 && draw, "rpn_loss: null pointer");
+    BD_REQUIRE(A > 0 && cls_off >= 0 && box_off >= 0 && cls_off + A <= ldc && box_off + 4 * A <= ldc, "rpn_loss: bad channel layout");
+    if (rows == 0) return BD_OK;
+    hipLaunchKernelGGL(rpn_loss_kernel, dim3(loss_grid(rows * A)), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)raw, ldc, A,
+                       cls_off, box_off, labels, targets, (long long)rows, beta, num_valid, loss2, (bf16_raw*)draw);
+    BD_CHECK_LAUNCH("bd_rpn_loss_fwd_bwd");
+    return BD_OK;
+}
+
+extern "C" int bd_rcnn_loss_fwd_bwd(const void* raw, int ld, int K, int box_off, const int32_t* labels, const float* targets, int R,
+                                    float beta, const int32_t* num_samples, float* loss2, void* draw, bd_stream_t stream) {
+    BD_REQUIRE(raw && labels && targets && num_samples && loss2 && draw, "rcnn_loss: null pointer");
+    BD_REQUIRE(K > 0 && box_off >= K + 1 && box_off + 4 * K <= ld, "rcnn_loss: bad channel layout");
+    if (R == 0) return BD_OK;
+    hipLaunchKernelGGL(rcnn_loss_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)raw, ld, K, box_off,
+                       labels, targets, R, beta, num_samples, loss2, (bf16_raw*)draw);
+    BD_CHECK_LAUNCH("bd_rcnn_loss_fwd_bwd");
     return BD_OK;
 }

@@ -226,6 +226,97 @@ def batched_nms(boxes, scores, idxs, iou_thresh, max_output=None):
     return keep[: int(num.item())]
 
 
+# ---- Faster R-CNN pieces ----------------------------------------------------------------------------------
+def rpn_assign_encode(anchors, gt_boxes, num_gt, thr_lo, thr_hi, allow_lq, mean, std, labels, match_idx, offsets, num_fg, ws):
+    A = anchors.shape[0]
+    N, Gmax = gt_boxes.shape[0], gt_boxes.shape[1]
+    check(L().bd_rpn_assign_encode(ptr(anchors), A, ptr(gt_boxes), ptr(num_gt), N, Gmax, float(thr_lo), float(thr_hi),
+                                   int(allow_lq), f32arr(mean), f32arr(std), ptr(labels), ptr(match_idx), ptr(offsets),
+                                   ptr(num_fg), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_rpn_assign_encode")
+
+
+def sample_labels(labels, keys_pos, keys_neg, num_pos_max, num_total, num_valid):
+    N, A = labels.shape
+    check(L().bd_sample_labels(ptr(labels), ptr(keys_pos), ptr(keys_neg), N, A, int(num_pos_max), int(num_total), ptr(num_valid),
+                               stream_ptr()), "bd_sample_labels")
+
+
+def segment_topk(scores, B, batch_stride, A, ldc, coff, seg_start, seg_rows, k, out_idx, out_score, out_cnt, min_score=None):
+    check(L().bd_segment_topk(ptr(scores), int(scores.dtype == torch.bfloat16), B, batch_stride, A, ldc, coff, len(seg_start),
+                              i32arr(seg_start), i32arr(seg_rows), k, float(min_score or 0.0), int(min_score is not None),
+                              ptr(out_idx), ptr(out_score), ptr(out_cnt), stream_ptr()), "bd_segment_topk")
+
+
+def nms_batched_workspace_bytes(B, Cn):
+    return int(L().bd_nms_batched_workspace_bytes(B, Cn))
+
+
+def nms_batched(boxes, scores, idxs, iou_thresh, max_output, keep, num_keep, ws):
+    B, Cn = scores.shape
+    check(L().bd_nms_batched(ptr(boxes), ptr(scores), ptr(idxs), B, Cn, float(iou_thresh), int(max_output or 0), keep.shape[1],
+                             ptr(keep), ptr(num_keep), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_nms_batched")
+
+
+def rpn_proposals_workspace_bytes(N, lvl_pixels, A, pre_k, post_k):
+    return int(L().bd_rpn_proposals_workspace_bytes(N, len(lvl_pixels), i32arr(lvl_pixels), A, pre_k, post_k))
+
+
+def rpn_proposals(raw, ldc, A, cls_off, box_off, geom: Geom, anchors, im_info, mean, std, pre_k, nms_thresh, post_k, rois, num_rois, ws):
+    lvl_pixels = [h * w for h, w in zip(geom.H, geom.W)]
+    check(L().bd_rpn_proposals(ptr(raw), ldc, A, cls_off, box_off, geom.N, geom.pix_per_img, geom.nlev, i32arr(geom.off),
+                               i32arr(lvl_pixels), ptr(anchors), ptr(im_info), im_info.shape[1], f32arr(mean), f32arr(std),
+                               int(pre_k), float(nms_thresh), int(post_k), ptr(rois), ptr(num_rois), ptr(ws),
+                               ws.numel() * ws.element_size(), stream_ptr()), "bd_rpn_proposals")
+
+
+def rcnn_sample_targets(rois, num_rois, gt_boxes, num_gt, keys_fg, keys_bg, num_samples, num_fg_max, fg_thresh, bg_hi, bg_lo,
+                        mean, std, out_rois, out_labels, out_targets, out_count, total_count):
+    N, post_k = rois.shape[0], rois.shape[1]
+    Gmax = gt_boxes.shape[1]
+    check(L().bd_rcnn_sample_targets(ptr(rois), ptr(num_rois), post_k, ptr(gt_boxes), ptr(num_gt), N, Gmax, ptr(keys_fg),
+                                     ptr(keys_bg), keys_fg.shape[1], int(num_samples), int(num_fg_max), float(fg_thresh),
+                                     float(bg_hi), float(bg_lo), f32arr(mean), f32arr(std), ptr(out_rois), ptr(out_labels),
+                                     ptr(out_targets), ptr(out_count), ptr(total_count), stream_ptr()), "bd_rcnn_sample_targets")
+
+
+def roi_align_fwd(feat, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_img, pool, sample_points, out):
+    R = rois.shape[0]
+    check(L().bd_roi_align_fwd(ptr(feat), geom.pix_per_img, Cn, nlev, i32arr(geom.off[:nlev]), i32arr(geom.H[:nlev]),
+                               i32arr(geom.W[:nlev]), i32arr(strides[:nlev]), ptr(rois), ptr(labels), R, rois_per_img, pool[0],
+                               pool[1], sample_points, ptr(out), stream_ptr()), "bd_roi_align_fwd")
+
+
+def roi_align_bwd(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_img, pool, sample_points, gfeat):
+    R = rois.shape[0]
+    check(L().bd_roi_align_bwd(ptr(gout), geom.pix_per_img, Cn, nlev, i32arr(geom.off[:nlev]), i32arr(geom.H[:nlev]),
+                               i32arr(geom.W[:nlev]), i32arr(strides[:nlev]), ptr(rois), ptr(labels), R, rois_per_img, pool[0],
+                               pool[1], sample_points, ptr(gfeat), stream_ptr()), "bd_roi_align_bwd")
+
+
+def subsample2x_fwd(src, gsrc: Geom, dst, gdst: Geom, Cn):
+    check(L().bd_subsample2x_fwd(ptr(src), gsrc.pix_per_img, gsrc.off[0], gsrc.H[0], gsrc.W[0], ptr(dst), gdst.pix_per_img,
+                                 gdst.off[0], Cn, gsrc.N, stream_ptr()), "bd_subsample2x_fwd")
+
+
+def subsample2x_bwd_add(g_dst, gdst: Geom, g_src, gsrc: Geom, Cn):
+    check(L().bd_subsample2x_bwd_add(ptr(g_dst), gdst.pix_per_img, gdst.off[0], ptr(g_src), gsrc.pix_per_img, gsrc.off[0],
+                                     gsrc.H[0], gsrc.W[0], Cn, gsrc.N, stream_ptr()), "bd_subsample2x_bwd_add")
+
+
+def f32_to_bf16(src, dst):
+    check(L().bd_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "bd_f32_to_bf16")
+
+
+def rpn_loss_fwd_bwd(raw, ldc, A, cls_off, box_off, labels, targets, rows, beta, num_valid, loss2, draw):
+    check(L().bd_rpn_loss_fwd_bwd(ptr(raw), ldc, A, cls_off, box_off, ptr(labels), ptr(targets), rows, float(beta), ptr(num_valid),
+                                  ptr(loss2), ptr(draw), stream_ptr()), "bd_rpn_loss_fwd_bwd")
+
+
+def rcnn_loss_fwd_bwd(raw, ld, K, box_off, labels, targets, R, beta, num_samples, loss2, draw):
+    check(L().bd_rcnn_loss_fwd_bwd(ptr(raw), ld, K, box_off, ptr(labels), ptr(targets), R, float(beta), ptr(num_samples),
+                                   ptr(loss2), ptr(draw), stream_ptr()), "bd_rcnn_loss_fwd_bwd")
+
+
 # ---- losses -----------------------------------------------------------------------------------------------
 def focal_loss_fwd_bwd(logits, labels, rows, K, alpha, gamma, norm, grad_scale, loss_sum, dlogits):
     check(L().bd_focal_loss_fwd_bwd(ptr(logits), ptr(labels), rows, K, float(alpha), float(gamma), ptr(norm),

@@ -254,6 +254,99 @@ int bd_fcos_offsets_bwd(const void* raw, int ld, const float* scales, int N, int
                         const void* d_ctr, void* d_raw, float* dscale, void* ws, size_t ws_bytes, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Faster R-CNN pieces (models/det/rpn.py, layers/head/rcnn.py, layers/common/roi_pool.py, sampling.py).
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* RPN.get_ground_truth (rpn.py:215-227) before the random subsampling: same IoU + Matcher + BoxCoder.encode as
+ * bd_retina_assign_encode, but class-agnostic labels in {-1, 0, 1}. */
+int bd_rpn_assign_encode(const float* anchors, int A, const float* gt_boxes, const int32_t* num_gt, int N,
+                         int Gmax, float thr_lo, float thr_hi, int allow_low_quality,
+                         const float* mean4_host, const float* std4_host, int32_t* labels,
+                         int32_t* match_idx, float* offsets, int32_t* num_fg, void* ws, size_t ws_bytes,
+                         bd_stream_t stream);
+
+/* sample_labels twice as at rpn.py:229-232 (layers/common/sampling.py:7-30), in place on labels [N][A]:
+ * at most num_pos_max labels stay 1, then at most num_total - (#kept positives) stay 0; the rest become -1.
+ * The reference draws megengine.random.uniform keys and drops the entries with the LARGEST keys (topk with negative
+ * k); here the keys are inputs (fp32 in [0,1), [N][A] each) so that the selection is reproducible: the entries with
+ * the smallest keys survive, ties broken by the lower index.  num_valid: int32[1] = number of labels >= 0 over the
+ * batch (zeroed inside). */
+int bd_sample_labels(int32_t* labels, const float* keys_pos, const float* keys_neg, int N, int A, int num_pos_max,
+                     int num_total, int32_t* num_valid, bd_stream_t stream);
+
+/* F.topk(descending=True) per (batch item, segment) (rpn.py:155; retinanet.py:188-192 at inference).
+ * Item i of segment s of batch b is the element scores[b*batch_stride + (seg_start[s] + i / A)*ldc + coff + i % A]
+ * (bf16 or fp32), i in [0, seg_rows[s]*A).  Optionally only items with score > min_score take part.
+ * Output order: score descending, then item index ascending.  out_idx/out_score [B][nseg][k] (idx -1 past the count),
+ * out_cnt [B][nseg].  k <= 2048. */
+int bd_segment_topk(const void* scores, int is_bf16, int B, int64_t batch_stride, int A, int ldc, int coff, int nseg,
+                    const int32_t* seg_start_host, const int32_t* seg_rows_host, int k, float min_score,
+                    int use_min_score, int32_t* out_idx, float* out_score, int32_t* out_cnt, bd_stream_t stream);
+
+/* batched_nms (post_processing.py:17-47) for B independent problems of capacity C (<= 16384) in three launches.
+ * boxes [B][C][4], scores [B][C] (-inf marks an absent item), idxs [B][C] or NULL.  keep [B][keep_ld] (indices into
+ * the problem's C items, descending score), num_keep [B]. */
+size_t bd_nms_batched_workspace_bytes(int B, int C);
+int bd_nms_batched(const float* boxes, const float* scores, const int32_t* idxs, int B, int C, float iou_thresh,
+                   int max_output, int keep_ld, int32_t* keep, int32_t* num_keep, void* ws, size_t ws_bytes,
+                   bd_stream_t stream);
+
+/* RPN.find_top_rpn_proposals (rpn.py:134-186) for the whole batch: per image and level top pre_k scores ->
+ * BoxCoder.decode -> clip to im_info[:, 0:2] -> drop empty boxes -> NMS across levels (level = NMS class) ->
+ * first post_k.  raw: bf16 [N*pix_per_img][ldc], objectness logit of cell anchor a at channel cls_off + a, its
+ * offsets at box_off + 4a.  anchors [pix_per_img*A][4].  rois [N][post_k][4] (zero past num_rois[n]). */
+size_t bd_rpn_proposals_workspace_bytes(int N, int L, const int32_t* lvl_pixels_host, int A, int pre_k, int post_k);
+int bd_rpn_proposals(const void* raw, int ldc, int A, int cls_off, int box_off, int N, int64_t pix_per_img, int L,
+                     const int32_t* lvl_pix_off_host, const int32_t* lvl_pixels_host, const float* anchors,
+                     const float* im_info, int info_ld, const float* mean4_host, const float* std4_host, int pre_k,
+                     float nms_thresh, int post_k, float* rois, int32_t* num_rois, void* ws, size_t ws_bytes,
+                     bd_stream_t stream);
+
+/* RCNN.get_ground_truth (rcnn.py:95-147) per image: candidates = proposals + gt boxes, IoU max/argmax over the gts,
+ * fg (>= fg_thresh) / bg ([bg_lo, bg_hi)) masks, random subsampling with caller-supplied keys (see
+ * bd_sample_labels; keys_fg/keys_bg [N][key_ld], key_ld >= post_k + Gmax), targets = BoxCoder.encode.
+ * Outputs use num_samples fixed slots per image (kept candidates in index order, label -1 marks an empty slot):
+ * out_rois [N][num_samples][4], out_labels [N][num_samples], out_targets [N][num_samples][4], out_count [N],
+ * total_count int32[1] (zeroed inside). */
+int bd_rcnn_sample_targets(const float* rois, const int32_t* num_rois, int post_k, const float* gt_boxes,
+                           const int32_t* num_gt, int N, int Gmax, const float* keys_fg, const float* keys_bg,
+                           int key_ld, int num_samples, int num_fg_max, float fg_thresh, float bg_thresh_hi,
+                           float bg_thresh_lo, const float* mean4_host, const float* std4_host, float* out_rois,
+                           int32_t* out_labels, float* out_targets, int32_t* out_count, int32_t* total_count,
+                           bd_stream_t stream);
+
+/* roi_pool(..., "roi_align") (roi_pool.py:35-78): level = clamp(floor(4 + log2(sqrt(area)/224))) (:12-25), then
+ * RoIAlign (average, sample_points^2 samples per bin, aligned) on that level of a pixel-major bf16 pyramid.
+ * RoI r belongs to image r / rois_per_img; labels (optional) < 0 marks an empty slot (output row zeroed).
+ * out: bf16 [R][PH*PW][C] (bin-major, channel-minor).  The backward scatters into an fp32 gradient pyramid of the
+ * same pixel layout with atomic adds (the caller zeroes it). */
+int bd_roi_align_fwd(const void* feat, int64_t pix_per_img, int C, int L, const int32_t* lvl_pix_off_host,
+                     const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
+                     const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
+                     int sample_points, void* out, bd_stream_t stream);
+int bd_roi_align_bwd(const void* gout, int64_t pix_per_img, int C, int L, const int32_t* lvl_pix_off_host,
+                     const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
+                     const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
+                     int sample_points, float* gfeat, bd_stream_t stream);
+
+/* FPNP6 (fpn_backbone.py:172-183): dst[n,y,x,:] = src[n,2y,2x,:]; backward adds gdst into gsrc at the even pixels. */
+int bd_subsample2x_fwd(const void* src, int64_t src_pix_per_img, int64_t src_off, int Hs, int Ws, void* dst,
+                       int64_t dst_pix_per_img, int64_t dst_off, int C, int N, bd_stream_t stream);
+int bd_subsample2x_bwd_add(const void* gdst, int64_t dst_pix_per_img, int64_t dst_off, void* gsrc,
+                           int64_t src_pix_per_img, int64_t src_off, int Hs, int Ws, int C, int N, bd_stream_t stream);
+int bd_f32_to_bf16(const float* src, void* dst, int64_t n, bd_stream_t stream);
+
+/* RPN losses (rpn.py:113-131): loss2[0] += mean BCE-with-logits over labels >= 0, loss2[1] += smooth-L1 sum over
+ * labels > 0 / max(num_valid, 1); d_raw gets both gradients at the channels of the fused prediction row. */
+int bd_rpn_loss_fwd_bwd(const void* raw, int ldc, int A, int cls_off, int box_off, const int32_t* labels,
+                        const float* targets, int64_t rows, float beta, const int32_t* num_valid, float* loss2,
+                        void* draw, bd_stream_t stream);
+/* RCNN losses (rcnn.py:65-83): softmax cross entropy over K+1 classes + smooth-L1 on the gt-class deltas, both
+ * divided by num_samples.  raw/draw bf16 [R][ld]: logits at [0, K], deltas at box_off + 4*(class-1). */
+int bd_rcnn_loss_fwd_bwd(const void* raw, int ld, int K, int box_off, const int32_t* labels, const float* targets, int R,
+                         float beta, const int32_t* num_samples, float* loss2, void* draw, bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Optimizer (megengine.optimizer.SGD as configured at solver/default_solver.py:96-114).
  * g' = g*grad_scale + wd*w ; v = momentum*v + g' ; w -= lr*v   (all fp32, n elements)
  * ------------------------------------------------------------------------------------------------------- */

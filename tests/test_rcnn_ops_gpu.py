@@ -1,0 +1,370 @@
+"""GPU parity of the Faster R-CNN operators (csrc/rcnn_ops.hip, RPN / RCNN losses) against oracle/rcnn_ops.py.
+Index-valued outputs (top-k order, NMS survivors, sampled labels / RoIs) are compared bit-exactly; RoIAlign within one
+bf16 ulp; the losses against a float64 restatement with the tolerance written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_ops as ob
+from oracle import rcnn_ops as orc
+
+pytestmark = pytest.mark.gpu
+
+STRIDES = [4, 8, 16, 32, 64]
+
+
+def _ops():
+    from basedet_amd import ops
+    return ops
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _bf16(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16)
+
+
+def _geom(N, sizes):
+    from basedet_amd.ops import Geom
+    return Geom(N, [s[0] for s in sizes], [s[1] for s in sizes])
+
+
+def _rand_boxes(rng, n, W, H, min_size=2.0, max_size=300.0):
+    cx = rng.uniform(0, W, n); cy = rng.uniform(0, H, n)
+    w = rng.uniform(min_size, max_size, n); h = rng.uniform(min_size, max_size, n)
+    b = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    b[:, 0::2] = np.clip(b[:, 0::2], 0, W); b[:, 1::2] = np.clip(b[:, 1::2], 0, H)
+    return b.astype(np.float32)
+
+
+def _gt(rng, N, Gmax, W, H):
+    gt = np.zeros((N, Gmax, 5), np.float32)
+    num = rng.integers(1, Gmax + 1, N).astype(np.int32)
+    for n in range(N):
+        b = _rand_boxes(rng, num[n], W, H, 20, 250)
+        gt[n, : num[n], :4] = b
+        gt[n, : num[n], 4] = rng.integers(1, 81, num[n])
+    return gt, num
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_segment_topk(dtype):
+    ops = _ops()
+    rng = np.random.default_rng(0)
+    B, A, ldc, coff, k = 3, 3, 16, 1, 2000
+    rows = [5000, 900, 300, 40]              # 15000, 2700, 900, 120 items
+    starts = np.concatenate([[0], np.cumsum(rows)[:-1]]).astype(np.int32)
+    ppi = int(sum(rows))
+    raw = rng.normal(0, 1, (B, ppi, ldc)).astype(np.float32)
+    if dtype == "bf16":
+        t = _bf16(raw)
+        raw = t.float().numpy()
+        dev = t.cuda()
+    else:
+        raw = np.round(raw * 64) / 64        # plenty of ties
+        dev = _dev(raw)
+    out_idx = torch.empty((B, len(rows), k), dtype=torch.int32, device="cuda")
+    out_sc = torch.empty((B, len(rows), k), dtype=torch.float32, device="cuda")
+    out_cnt = torch.empty((B, len(rows)), dtype=torch.int32, device="cuda")
+    for min_score in (None, 0.5):
+        ops.segment_topk(dev, B, ppi * ldc, A, ldc, coff, starts.tolist(), rows, k, out_idx, out_sc, out_cnt, min_score=min_score)
+        gi, gs, gc = out_idx.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy()
+        for b in range(B):
+            for s, (st, r) in enumerate(zip(starts, rows)):
+                sc = raw[b, st:st + r, coff:coff + A].reshape(-1)
+                ri, rs = orc.topk_desc(sc, k, min_score)
+                assert gc[b, s] == len(ri)
+                assert np.array_equal(gi[b, s, : len(ri)], ri)
+                assert np.array_equal(gs[b, s, : len(ri)], rs)
+                assert np.all(gi[b, s, len(ri):] == -1)
+
+
+def test_nms_batched():
+    ops = _ops()
+    rng = np.random.default_rng(1)
+    B, C = 3, 3000
+    boxes = np.stack([_rand_boxes(rng, C, 1344, 800, 8, 200) for _ in range(B)])
+    # clustered boxes so that a large fraction is suppressed
+    boxes[:, 1000:2000] = boxes[:, :1000] + rng.normal(0, 3, (B, 1000, 4)).astype(np.float32)
+    scores = rng.uniform(0, 1, (B, C)).astype(np.float32)
+    scores = np.round(scores * 512) / 512
+    scores[1, 100:400] = -np.inf
+    idxs = rng.integers(0, 5, (B, C)).astype(np.int32)
+    for max_out in (1000, 0, 17):
+        cap = max_out if max_out > 0 else C
+        keep = torch.full((B, cap), -1, dtype=torch.int32, device="cuda")
+        num = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ws = torch.empty((ops.nms_batched_workspace_bytes(B, C),), dtype=torch.uint8, device="cuda")
+        ops.nms_batched(_dev(boxes), _dev(scores), _dev(idxs), 0.7, max_out, keep, num, ws)
+        gk, gn = keep.cpu().numpy(), num.cpu().numpy()
+        for b in range(B):
+            valid = np.nonzero(scores[b] > -np.inf)[0]
+            ref = ob.batched_nms(boxes[b][valid], scores[b][valid], idxs[b][valid], 0.7, max_out if max_out > 0 else None)
+            ref = valid[ref]
+            assert gn[b] == len(ref)
+            assert np.array_equal(gk[b, : gn[b]], ref)
+
+
+def _pyramid_inputs(rng, N, sizes, A, ldc):
+    ppi = sum(h * w for h, w in sizes)
+    raw = np.zeros((N, ppi, ldc), np.float32)
+    raw[:, :, :A] = rng.normal(0, 2, (N, ppi, A))
+    raw[:, :, A:5 * A] = rng.normal(0, 0.5, (N, ppi, 4 * A))
+    t = _bf16(raw)
+    return t.float().numpy(), t.cuda().reshape(N * ppi, ldc).contiguous(), ppi
+
+
+def _anchors(sizes):
+    scales = [[x] for x in [32, 64, 128, 256, 512]]
+    ratios = [[0.5, 1, 2]]
+    return ob.default_anchors(sizes, STRIDES, scales, ratios, 0.5)
+
+
+def test_rpn_proposals():
+    ops = _ops()
+    rng = np.random.default_rng(2)
+    N, A, ldc = 2, 3, 16
+    sizes = [(48, 80), (24, 40), (12, 20), (6, 10), (3, 5)]
+    H, W = 192, 320
+    raw, raw_dev, ppi = _pyramid_inputs(rng, N, sizes, A, ldc)
+    anchors = _anchors(sizes)
+    anc_all = np.concatenate(anchors, 0)
+    im_info = np.array([[H, W, H, W, 3], [180, 300, 180, 300, 2]], np.float32)
+    pre_k, post_k, thr = 500, 300, 0.7
+    geom = _geom(N, sizes)
+    rois = torch.empty((N, post_k, 4), dtype=torch.float32, device="cuda")
+    num = torch.empty((N,), dtype=torch.int32, device="cuda")
+    ws = torch.empty((ops.rpn_proposals_workspace_bytes(N, [h * w for h, w in sizes], A, pre_k, post_k),), dtype=torch.uint8, device="cuda")
+    ops.rpn_proposals(raw_dev, ldc, A, 0, A, geom, _dev(anc_all), _dev(im_info), [0, 0, 0, 0], [1, 1, 1, 1], pre_k, thr, post_k, rois, num, ws)
+    gr, gn = rois.cpu().numpy(), num.cpu().numpy()
+    for n in range(N):
+        sc, of = [], []
+        o = 0
+        for (h, w) in sizes:
+            blk = raw[n, o:o + h * w]
+            sc.append(blk[:, :A].reshape(-1))
+            of.append(blk[:, A:5 * A].reshape(-1, 4))
+            o += h * w
+        ref_rois, _, _ = orc.rpn_proposals(sc, of, anchors, im_info[n, :2], pre_k, post_k, thr)
+        assert gn[n] == len(ref_rois)
+        # decode uses expf on the device and np.exp in the oracle: boxes within a few ulp, selection identical
+        np.testing.assert_allclose(gr[n, : gn[n]], ref_rois, rtol=1e-5, atol=1e-3)
+        assert np.all(gr[n, gn[n]:] == 0)
+
+
+def test_rpn_targets_and_sampling():
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    N, Gmax = 3, 12
+    sizes = [(48, 80), (24, 40), (12, 20), (6, 10), (3, 5)]
+    anchors = np.concatenate(_anchors(sizes), 0)
+    A = anchors.shape[0]
+    gt, num_gt = _gt(rng, N, Gmax, 320, 192)
+    num_gt[2] = 0
+    kp = rng.random((N, A), dtype=np.float32)
+    kn = rng.random((N, A), dtype=np.float32)
+    kn = (np.round(kn * 4096) / 4096).astype(np.float32)          # force key ties
+    labels = torch.empty((N, A), dtype=torch.int32, device="cuda")
+    match = torch.empty((N, A), dtype=torch.int32, device="cuda")
+    offs = torch.empty((N, A, 4), dtype=torch.float32, device="cuda")
+    nfg = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    nvalid = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    ws = torch.empty((N * Gmax,), dtype=torch.float32, device="cuda")
+    for num_total, num_pos in ((256, 128), (64, 8)):
+        ops.rpn_assign_encode(_dev(anchors), _dev(gt), _dev(num_gt), 0.3, 0.7, True, [0, 0, 0, 0], [1, 1, 1, 1], labels, match, offs, nfg, ws)
+        ops.sample_labels(labels, _dev(kp), _dev(kn), num_pos, num_total, nvalid)
+        ref_l, ref_o = orc.rpn_ground_truth(anchors, gt, num_gt, kp, kn, (0.3, 0.7), (0, -1, 1), True, num_total, num_pos)
+        gl = labels.cpu().numpy()
+        assert np.array_equal(gl, ref_l)
+        assert int(nvalid.item()) == int((ref_l >= 0).sum())
+        fg = ref_l > 0
+        np.testing.assert_allclose(offs.cpu().numpy()[fg], ref_o[fg], rtol=2e-6, atol=2e-6)
+        assert (gl == 1).sum(axis=1).max() <= num_pos and (gl >= 0).sum(axis=1).max() <= num_total
+
+
+def test_rcnn_sample_targets():
+    ops = _ops()
+    rng = np.random.default_rng(4)
+    N, Gmax, post_k = 4, 10, 600
+    gt, num_gt = _gt(rng, N, Gmax, 640, 480)
+    num_gt[3] = 0
+    rois = np.zeros((N, post_k, 4), np.float32)
+    num_rois = np.array([600, 350, 40, 500], np.int32)
+    for n in range(N):
+        b = _rand_boxes(rng, num_rois[n], 640, 480, 10, 300)
+        g = int(num_gt[n])
+        if g:   # jittered copies of the gts so that there are many foreground candidates
+            rep = gt[n, rng.integers(0, g, num_rois[n] // 2), :4] + rng.normal(0, 6, (num_rois[n] // 2, 4)).astype(np.float32)
+            b[: len(rep)] = rep
+        rois[n, : num_rois[n]] = b
+    key_ld = post_k + Gmax
+    kf = rng.random((N, key_ld), dtype=np.float32)
+    kb = rng.random((N, key_ld), dtype=np.float32)
+    kb = (np.round(kb * 256) / 256).astype(np.float32)             # force key ties
+    std = [0.1, 0.1, 0.2, 0.2]
+    for num_samples, fg_ratio in ((512, 0.5), (64, 0.25)):
+        nfg = int(num_samples * fg_ratio)
+        o_rois = torch.empty((N, num_samples, 4), dtype=torch.float32, device="cuda")
+        o_lab = torch.empty((N, num_samples), dtype=torch.int32, device="cuda")
+        o_tgt = torch.empty((N, num_samples, 4), dtype=torch.float32, device="cuda")
+        o_cnt = torch.empty((N,), dtype=torch.int32, device="cuda")
+        tot = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        ops.rcnn_sample_targets(_dev(rois), _dev(num_rois), _dev(gt), _dev(num_gt), _dev(kf), _dev(kb), num_samples, nfg, 0.5, 0.5, 0.0,
+                                [0, 0, 0, 0], std, o_rois, o_lab, o_tgt, o_cnt, tot)
+        total = 0
+        for n in range(N):
+            rr, rl, rt = orc.rcnn_ground_truth(rois[n, : num_rois[n]], gt[n, : num_gt[n]], kf[n], kb[n], num_samples, fg_ratio,
+                                               0.5, 0.5, 0.0, (0, 0, 0, 0), std)
+            m = len(rl)
+            total += m
+            assert int(o_cnt[n].item()) == m
+            assert np.array_equal(o_lab[n].cpu().numpy()[:m], rl)
+            assert np.all(o_lab[n].cpu().numpy()[m:] == -1)
+            assert np.array_equal(o_rois[n].cpu().numpy()[:m], rr)
+            np.testing.assert_allclose(o_tgt[n].cpu().numpy()[:m], rt, rtol=2e-5, atol=2e-5)
+        assert int(tot.item()) == total
+
+
+def test_roi_align_fwd_bwd():
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    N, C = 2, 64
+    sizes = [(48, 80), (24, 40), (12, 20), (6, 10), (3, 5)]
+    nlev = 4
+    geom = _geom(N, sizes)
+    ppi = geom.pix_per_img
+    feat = _bf16(rng.normal(0, 1, (N, ppi, C)).astype(np.float32))
+    feats = []
+    o = 0
+    for (h, w) in sizes[:nlev]:
+        feats.append(feat.float().numpy()[:, o:o + h * w].reshape(N, h, w, C))
+        o += h * w
+    rpi = 24
+    rois = np.concatenate([_rand_boxes(rng, rpi, 320, 192, 4, 400) for _ in range(N)], 0)
+    rois[3] = [10, 10, 10, 30]            # zero area
+    rois[5] = [-20, -30, 500, 400]        # far outside the image
+    labels = np.ones(N * rpi, np.int32)
+    labels[7] = -1
+    bidx = np.repeat(np.arange(N), rpi)
+    out = torch.empty((N * rpi, 49, C), dtype=torch.bfloat16, device="cuda")
+    ops.roi_align_fwd(feat.cuda().reshape(N * ppi, C), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, out)
+    ref = orc.roi_align(feats, rois, bidx, STRIDES[:nlev], 7, 7, 2)
+    ref[7] = 0
+    got = out.float().cpu().numpy()
+    # one bf16 ulp (2^-8 relative) on top of the fp32 accumulation-order difference
+    np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-3)
+    levels = orc.assign_roi_levels(rois, STRIDES[:nlev])
+    assert len(set(levels.tolist())) >= 3
+    # backward: adjoint
+    gout = _bf16(rng.normal(0, 1, (N * rpi, 49, C)).astype(np.float32))
+    gfeat = torch.zeros((N * ppi, C), dtype=torch.float32, device="cuda")
+    ops.roi_align_bwd(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gfeat)
+    g_in = gout.float().numpy().copy()
+    g_in[7] = 0
+    refg = orc.roi_align_backward(g_in, [f.shape for f in feats], rois, bidx, STRIDES[:nlev], 7, 7, 2)
+    gg = gfeat.cpu().numpy().reshape(N, ppi, C)
+    o = 0
+    for l, (h, w) in enumerate(sizes[:nlev]):
+        np.testing.assert_allclose(gg[:, o:o + h * w].reshape(N, h, w, C), refg[l], rtol=1e-4, atol=1e-4)
+        o += h * w
+    assert np.all(gg[:, o:] == 0)
+
+
+def test_subsample_and_convert():
+    ops = _ops()
+    rng = np.random.default_rng(6)
+    N, C = 2, 32
+    sizes = [(13, 21), (7, 11)]
+    geom = _geom(N, sizes)
+    ppi = geom.pix_per_img
+    buf = _bf16(rng.normal(0, 1, (N, ppi, C)).astype(np.float32))
+    dev = buf.cuda().reshape(N * ppi, C).contiguous()
+    ops.subsample2x_fwd(dev, geom.level(0), dev, geom.level(1), C)
+    got = dev.float().cpu().numpy().reshape(N, ppi, C)
+    src = buf.float().numpy()[:, : 13 * 21].reshape(N, 13, 21, C)
+    assert np.array_equal(got[:, 13 * 21:].reshape(N, 7, 11, C), src[:, ::2, ::2])
+    g = _bf16(rng.normal(0, 1, (N, ppi, C)).astype(np.float32))
+    gdev = g.cuda().reshape(N * ppi, C).contiguous()
+    ops.subsample2x_bwd_add(gdev, geom.level(1), gdev, geom.level(0), C)
+    gg = gdev.float().cpu().numpy().reshape(N, ppi, C)
+    g0 = g.float().numpy()
+    exp = g0[:, : 13 * 21].reshape(N, 13, 21, C).copy()
+    exp[:, ::2, ::2] = (torch.from_numpy(exp[:, ::2, ::2] + g0[:, 13 * 21:].reshape(N, 7, 11, C)).to(torch.bfloat16).float().numpy())
+    assert np.array_equal(gg[:, : 13 * 21].reshape(N, 13, 21, C), exp)
+    x = torch.randn(4096, device="cuda")
+    y = torch.empty(4096, dtype=torch.bfloat16, device="cuda")
+    ops.f32_to_bf16(x, y)
+    assert torch.equal(y, x.to(torch.bfloat16))
+
+
+def test_rpn_loss():
+    ops = _ops()
+    rng = np.random.default_rng(7)
+    rows, A, ldc = 5000, 3, 16
+    raw = _bf16(rng.normal(0, 2, (rows, ldc)).astype(np.float32))
+    labels = rng.choice([-1, 0, 1], size=rows * A, p=[0.9, 0.07, 0.03]).astype(np.int32)
+    targets = rng.normal(0, 1, (rows * A, 4)).astype(np.float32)
+    nv = torch.tensor([int((labels >= 0).sum())], dtype=torch.int32, device="cuda")
+    for beta in (0.0, 0.5):
+        loss = torch.zeros((2,), dtype=torch.float32, device="cuda")
+        draw = torch.zeros((rows, ldc), dtype=torch.bfloat16, device="cuda")
+        ops.rpn_loss_fwd_bwd(raw.cuda(), ldc, A, 0, A, _dev(labels), _dev(targets), rows, beta, nv, loss, draw)
+        r = raw.float().numpy()
+        logits = r[:, :A].reshape(-1)
+        offs = r[:, A:5 * A].reshape(-1, 4)
+        cls, box = orc.rpn_losses(logits, offs, labels, targets, beta)
+        got = loss.cpu().numpy()
+        assert abs(got[0] - cls) <= 1e-4 * abs(cls) + 1e-6
+        assert abs(got[1] - box) <= 1e-4 * abs(box) + 1e-6
+        # gradient: torch autograd on the same formula (fp64), compared at bf16 resolution
+        x = torch.tensor(r, dtype=torch.float64, requires_grad=True)
+        lab = torch.from_numpy(labels)
+        lg = x[:, :A].reshape(-1); of = x[:, A:5 * A].reshape(-1, 4)
+        valid = lab >= 0; fg = lab > 0
+        t = lab[valid].double()
+        ls = torch.nn.functional.logsigmoid
+        l_cls = (-(t * ls(lg[valid]) + (1 - t) * ls(-lg[valid]))).sum() / max(int(valid.sum()), 1)
+        d = of[fg] - torch.from_numpy(targets).double()[fg]
+        l_box = (d.abs() if beta < 1e-5 else torch.where(d.abs() < beta, 0.5 * d * d / beta, d.abs() - 0.5 * beta)).sum() / max(int(valid.sum()), 1)
+        (l_cls + l_box).backward()
+        ref_g = x.grad.float().numpy()
+        ref_g[:, 5 * A:] = 0
+        np.testing.assert_allclose(draw.float().cpu().numpy(), ref_g, rtol=2 ** -7, atol=1e-7)
+
+
+def test_rcnn_loss():
+    ops = _ops()
+    rng = np.random.default_rng(8)
+    R, K = 700, 80
+    ld = 408
+    box_off = K + 1
+    raw = _bf16(rng.normal(0, 1.5, (R, ld)).astype(np.float32))
+    labels = rng.integers(-1, K + 1, R).astype(np.int32)
+    labels[rng.random(R) < 0.5] = 0
+    targets = rng.normal(0, 1, (R, 4)).astype(np.float32)
+    ns = torch.tensor([int((labels >= 0).sum())], dtype=torch.int32, device="cuda")
+    for beta in (0.0, 1.0):
+        loss = torch.zeros((2,), dtype=torch.float32, device="cuda")
+        draw = torch.empty((R, ld), dtype=torch.bfloat16, device="cuda")
+        ops.rcnn_loss_fwd_bwd(raw.cuda(), ld, K, box_off, _dev(labels), _dev(targets), R, beta, ns, loss, draw)
+        r = raw.float().numpy()
+        v = labels >= 0
+        cls, box = orc.rcnn_losses(r[v, : K + 1], r[v, box_off: box_off + 4 * K].reshape(-1, K, 4), labels[v], targets[v], beta)
+        got = loss.cpu().numpy()
+        assert abs(got[0] - cls) <= 1e-4 * abs(cls) + 1e-6
+        assert abs(got[1] - box) <= 1e-4 * abs(box) + 1e-6
+        x = torch.tensor(r, dtype=torch.float64, requires_grad=True)
+        lab = torch.from_numpy(labels).long()
+        vm = lab >= 0
+        nsamp = max(int(vm.sum()), 1)
+        l_cls = torch.nn.functional.cross_entropy(x[vm, : K + 1], lab[vm], reduction="sum") / nsamp
+        fg = lab > 0
+        d = x[:, box_off: box_off + 4 * K].reshape(R, K, 4)[fg, lab[fg] - 1] - torch.from_numpy(targets).double()[fg]
+        l_box = (d.abs() if beta < 1e-5 else torch.where(d.abs() < beta, 0.5 * d * d / beta, d.abs() - 0.5 * beta)).sum() / nsamp
+        (l_cls + l_box).backward()
+        np.testing.assert_allclose(draw.float().cpu().numpy(), x.grad.float().numpy(), rtol=2 ** -7, atol=1e-7)
