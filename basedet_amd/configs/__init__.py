@@ -113,3 +113,26 @@ class FCOSConfig(ConfigDict):
                       OBJECT_SIZES_OF_INTEREST=[[-1, 64], [64, 128], [128, 256], [256, 512], [512, float("inf")]],
                       CENTER_SAMPLING_RADIUS=1.5),
         ), TEST=dict(IOU_THRESHOLD=0.6)))
+
+
+class FasterRCNNConfig(ConfigDict):
+    """basedet/configs/det_model/faster_rcnn_cfg.py:5-78."""
+
+    def __init__(self):
+        super().__init__(_base())
+        self.merge(dict(MODEL=dict(
+            NAME="FasterRCNN",
+            BACKBONE=dict(OUT_FEATURES=["res2", "res3", "res4", "res5"], OUT_FEATURE_CHANNELS=[256, 512, 1024, 2048]),
+            FPN=dict(OUT_FEATURES=["p2", "p3", "p4", "p5", "p6"], NORM=None, STRIDES=[4, 8, 16, 32, 64],
+                     TOP_BLOCK_IN_CHANNELS=2048, OUT_CHANNELS=256, TOP_BLOCK_IN_FEATURE="p5"),
+            RPN=dict(CHANNELS=256, NMS_THRESHOLD=0.7, NUM_SAMPLE_ANCHORS=256, POSITIVE_ANCHOR_RATIO=0.5,
+                     TRAIN_PREV_NMS_TOPK=2000, TRAIN_POST_NMS_TOPK=1000, TEST_PREV_NMS_TOPK=1000, TEST_POST_NMS_TOPK=1000),
+            ROI_POOLER=dict(METHOD="roi_align", SIZE=(7, 7)),
+            RCNN=dict(IN_FEATURES=["p2", "p3", "p4", "p5"], STRIDES=[4, 8, 16, 32], NUM_ROIS=512, FG_RATIO=0.5,
+                      FG_THRESHOLD=0.5, BG_THRESHOLD_HIGH=0.5, BG_THRESHOLD_LOW=0.0),
+            ANCHOR=dict(SCALES=[[x] for x in [32, 64, 128, 256, 512]], RATIOS=[[0.5, 1, 2]], OFFSET=0.5),
+            LOSSES=dict(RPN_SMOOTH_L1_BETA=0, RCNN_SMOOTH_L1_BETA=0),
+            RPN_BOX_REG=dict(MEAN=[0.0, 0.0, 0.0, 0.0], STD=[1.0, 1.0, 1.0, 1.0]),
+            RCNN_BOX_REG=dict(MEAN=[0.0, 0.0, 0.0, 0.0], STD=[0.1, 0.1, 0.2, 0.2]),
+            MATCHER=dict(THRESHOLDS=[0.3, 0.7], LABELS=[0, -1, 1], ALLOW_LOW_QUALITY=True),
+        ), SOLVER=dict(BASIC_LR=0.02 / 16, WARM_ITERS=500, MAX_EPOCH=18, LR_DECAY_STAGES=[12, 16])))

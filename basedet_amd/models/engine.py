@@ -174,3 +174,52 @@ class FusedPredConv(ConvLayer):
             out[n + ".weight"] = self.gw[o:o + c].permute(0, 3, 1, 2).contiguous().cpu()
             out[n + ".bias"] = self.gb[o:o + c].cpu().clone()
             o += c
+
+
+class FCLayer(ConvLayer):
+    """megengine.module.Linear (or several that read the same input, fused along the output dimension) as a 1x1 convolution
+    whose "pixels" are the rows.  The reference flattens RoI features as (c, h, w) (layers/head/rcnn.py:59); the HIP
+    RoIAlign writes (h, w, c), so for `in_chw` layers the master weight is kept with permuted columns -- an elementwise SGD
+    does not care -- and permuted back on export."""
+
+    def __init__(self, name, cin, cout, device, in_chw=None, parts=None, cout_pad=None):
+        self.in_chw = in_chw
+        self.parts = parts          # [(reference linear name, out features)]
+        super().__init__(name, cin, cout, 1, 1, 0, device, has_bias=True, trainable=True, cout_pad=cout_pad)
+
+    def _names(self):
+        return [n for n, _ in self.parts] if self.parts else [self.name]
+
+    def _to_ours(self, w):
+        if self.in_chw:
+            c, h, wd = self.in_chw
+            w = w.reshape(-1, c, h, wd).permute(0, 2, 3, 1).reshape(-1, c * h * wd)
+        return w.contiguous()
+
+    def _to_ref(self, w):
+        if self.in_chw:
+            c, h, wd = self.in_chw
+            w = w.reshape(-1, h, wd, c).permute(0, 3, 1, 2).reshape(-1, c * h * wd)
+        return w.contiguous()
+
+    def bind(self, arena, params):
+        w = np.concatenate([np.asarray(params[n + ".weight"], np.float32) for n in self._names()], 0)
+        b = np.concatenate([np.asarray(params[n + ".bias"], np.float32) for n in self._names()], 0)
+        w = self._to_ours(torch.from_numpy(w)).numpy().reshape(self.cout_real, self.cin, 1, 1)
+        super().bind(arena, {self.name + ".weight": w, self.name + ".bias": b})
+
+    def _split(self, w, b, out, to_numpy):
+        w = self._to_ref(w[: self.cout_real].reshape(self.cout_real, self.cin))
+        b = b[: self.cout_real]
+        o = 0
+        for n, c in (self.parts or [(self.name, self.cout_real)]):
+            wn, bn = w[o:o + c].cpu(), b[o:o + c].cpu()
+            out[n + ".weight"] = wn.numpy().copy() if to_numpy else wn.clone()
+            out[n + ".bias"] = bn.numpy().copy() if to_numpy else bn.clone()
+            o += c
+
+    def export(self, out):
+        self._split(self.w, self.b, out, True)
+
+    def export_grad(self, out):
+        self._split(self.gw, self.gb, out, False)

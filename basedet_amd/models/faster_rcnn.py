@@ -1,0 +1,254 @@
+"""Faster R-CNN (basedet/models/det/faster_rcnn.py, rpn.py, layers/head/rcnn.py) on the HIP path: ResNet-FPN trunk with
+P2-P6 (FPNP6), RPN head + proposal selection inside the training step, RoI sampling, multi-level RoIAlign and the
+two-FC box head (the FC layers run on the 1x1 implicit-GEMM kernels, RoIs as "pixels").
+
+``model(batch)`` returns ``{"total_loss", "rpn_cls_loss", "rpn_reg_loss", "rcnn_cls_loss", "rcnn_reg_loss"}``
+(faster_rcnn.py:84-96).  Static shapes: every image owns RPN.TRAIN_POST_NMS_TOPK proposal slots and RCNN.NUM_ROIS sample
+slots (label -1 = empty slot, zero loss / zero gradient); nothing is synchronised with the host inside the step.
+
+Randomness: the reference subsamples anchors and RoIs with megengine.random.uniform keys (layers/common/sampling.py:26).
+Here the keys come from a seeded device generator, or from ``batch["sample_keys"]`` (tests feed the same keys to the oracle).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..utils.registry import registers
+from . import params as P
+from .engine import FCLayer, FusedPredConv
+from .fpn_base import FPNDetector, _round_up
+
+
+@registers.models.register()
+class FasterRCNN(FPNDetector):
+    TOP_BLOCK = "pool"
+
+    @staticmethod
+    def init_params(cfg, seed=0):
+        return P.init_faster_rcnn_params(cfg, seed)
+
+    # ---- construction ------------------------------------------------------------------------------------
+    def _build_head(self, add, params):
+        m = self.cfg.MODEL
+        dev = self.device
+        ch = self.fpn_ch
+        A = self.num_anchors = len(m.ANCHOR.SCALES[0]) * len(m.ANCHOR.RATIOS[0])
+        rc = m.RPN.CHANNELS
+        # RPN (rpn.py:52-62): 3x3 conv + ReLU, then objectness (A) and offsets (4A) 1x1 convs fused into one launch
+        self.rpn_conv = add("rpn.rpn_conv", ch, rc, 3, 1, 1, bias=True)
+        self.rpn_ld = _round_up(5 * A, 8)
+        self.rpn_pred = FusedPredConv("rpn.pred", [("rpn.rpn_cls_score", A), ("rpn.rpn_bbox_offsets", 4 * A)], rc, 1, 1, 0, dev,
+                                      cout_pad=self.rpn_ld)
+        self.convs[self.rpn_pred.name] = self.rpn_pred
+        # RCNN (layers/head/rcnn.py:32-38)
+        self.pool = tuple(m.ROI_POOLER.SIZE)
+        assert m.ROI_POOLER.METHOD == "roi_align", "the HIP path implements roi_align"
+        self.rcnn_levels = len(m.RCNN.IN_FEATURES)
+        assert list(m.RCNN.STRIDES) == self.strides[: self.rcnn_levels]
+        K = self.num_classes
+        fin = ch * self.pool[0] * self.pool[1]
+        self.fc1 = FCLayer("rcnn.fc1", fin, 1024, dev, in_chw=(ch, self.pool[0], self.pool[1]))
+        self.fc2 = FCLayer("rcnn.fc2", 1024, 1024, dev)
+        self.rcnn_ld = _round_up(K + 1 + 4 * K, 8)
+        self.rcnn_pred = FCLayer("rcnn.pred", 1024, K + 1 + 4 * K, dev, parts=[("rcnn.pred_cls", K + 1), ("rcnn.pred_delta", 4 * K)],
+                                 cout_pad=self.rcnn_ld)
+        for c in (self.fc1, self.fc2, self.rcnn_pred):
+            self.convs[c.name] = c
+        scales = np.asarray(m.ANCHOR.SCALES, np.float32).tolist()
+        ratios = np.asarray(m.ANCHOR.RATIOS, np.float32).tolist()
+        if len(ratios) == 1:
+            ratios = ratios * len(self.strides)
+        if len(scales) == 1:
+            scales = scales * len(self.strides)
+        self.base_anchors = []
+        for sc_, ra_ in zip(scales, ratios):     # layers/common/anchor_generator.py:95-109
+            base = []
+            for s_ in sc_:
+                area = float(s_) ** 2.0
+                for r_ in ra_:
+                    w = math.sqrt(area / float(r_)); h = float(r_) * w
+                    base.append([-w / 2.0, -h / 2.0, w / 2.0, h / 2.0])
+            self.base_anchors.append(torch.tensor(base, dtype=torch.float32, device=dev))
+        self.pre_k = {True: m.RPN.TRAIN_PREV_NMS_TOPK, False: m.RPN.TEST_PREV_NMS_TOPK}
+        self.post_k = {True: m.RPN.TRAIN_POST_NMS_TOPK, False: m.RPN.TEST_POST_NMS_TOPK}
+        self._gen = torch.Generator(device=dev) if self.device.type == "cuda" else None
+        if self._gen is not None:
+            self._gen.manual_seed(0)
+
+    def _head_convs(self):
+        return [self.rpn_conv, self.rpn_pred, self.fc1, self.fc2, self.rcnn_pred]
+
+    def _head_wgrad_ws_bytes(self, pl):
+        need = max(self.rpn_conv.wgrad_ws_bytes(pl.pyr, pl.pyr), self.rpn_pred.wgrad_ws_bytes(pl.pyr, pl.pyr))
+        return max(need, *(c.wgrad_ws_bytes(pl.g_fc, pl.g_fc) for c in (self.fc1, self.fc2, self.rcnn_pred)))
+
+    def _plan_head(self, pl):
+        dev = self.device
+        m = self.cfg.MODEL
+        N = pl.N
+        A = self.num_anchors
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        pyr = pl.pyr
+        rc = m.RPN.CHANNELS
+        pl.rpn_t = torch.empty((pyr.pixels, rc), **bf)
+        pl.rpn_raw = torch.empty((pyr.pixels, self.rpn_ld), **bf)
+        pl.d_rpn_raw = torch.zeros((pyr.pixels, self.rpn_ld), **bf)        # padding channel stays zero
+        pl.g_rpn_t = torch.empty((pyr.pixels, rc), **bf)
+        tot = pyr.pix_per_img * A
+        pl.A_total = tot
+        pl.anchors = torch.empty((tot, 4), **f32)
+        o = 0
+        for (h, w), s, base in zip(pl.sizes, self.strides, self.base_anchors):
+            n = h * w * A
+            ops.anchors_generate(h, w, s, m.ANCHOR.OFFSET, base, pl.anchors[o:o + n])
+            o += n
+        pl.rpn_labels = torch.empty((N, tot), **i32)
+        pl.rpn_match = torch.empty((N, tot), **i32)
+        pl.rpn_offsets = torch.empty((N, tot, 4), **f32)
+        pl.rpn_num_fg = torch.zeros((1,), **i32)
+        pl.rpn_num_valid = torch.zeros((1,), **i32)
+        lvl_pixels = [h * w for h, w in pl.sizes]
+        post = self.post_k[True]
+        assert self.post_k[False] == post, "train / test post-NMS top-k share the proposal slots"
+        pl.rois = torch.empty((N, post, 4), **f32)
+        pl.num_rois = torch.zeros((N,), **i32)
+        pl.prop_ws = torch.empty((max(ops.rpn_proposals_workspace_bytes(N, lvl_pixels, A, k, post) for k in self.pre_k.values()),),
+                                 dtype=torch.uint8, device=dev)
+        S = m.RCNN.NUM_ROIS
+        R = N * S
+        pl.R = R
+        pl.s_rois = torch.empty((N, S, 4), **f32)
+        pl.s_labels = torch.empty((N, S), **i32)
+        pl.s_targets = torch.empty((N, S, 4), **f32)
+        pl.s_count = torch.zeros((N,), **i32)
+        pl.s_total = torch.zeros((1,), **i32)
+        ch = self.fpn_ch
+        fin = ch * self.pool[0] * self.pool[1]
+        pl.pooled = torch.empty((R, fin), **bf)
+        pl.fc1_out = torch.empty((R, 1024), **bf)
+        pl.fc2_out = torch.empty((R, 1024), **bf)
+        pl.rcnn_raw = torch.empty((R, self.rcnn_ld), **bf)
+        pl.d_rcnn_raw = torch.empty((R, self.rcnn_ld), **bf)
+        pl.g_fc2 = torch.empty((R, 1024), **bf)
+        pl.g_fc1 = torch.empty((R, 1024), **bf)
+        pl.g_pooled = torch.empty((R, fin), **bf)
+        pl.g_feat32 = torch.zeros((pyr.pixels, ch), **f32)
+        pl.g_fc = ops.single(1, R, 1)
+        pl.loss_buf = torch.zeros((4,), **f32)
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def head_forward(self, pl):
+        """RPN.forward predictions (rpn.py:78-100), all five levels per launch."""
+        self.rpn_conv.forward(pl.P, pl.pyr, pl.pyr, pl.rpn_t, relu=True)
+        self.rpn_pred.forward(pl.rpn_t, pl.pyr, pl.pyr, pl.rpn_raw)
+
+    def _keys(self, inputs, name, shape):
+        sk = inputs.get("sample_keys") if isinstance(inputs, dict) else None
+        if sk is not None and name in sk:
+            k = sk[name]
+            k = torch.as_tensor(np.asarray(k), dtype=torch.float32) if not torch.is_tensor(k) else k
+            k = k.to(self.device, dtype=torch.float32).contiguous()
+            assert tuple(k.shape) == tuple(shape), f"sample_keys[{name}] has shape {tuple(k.shape)}, expected {tuple(shape)}"
+            return k
+        return torch.rand(shape, generator=self._gen, device=self.device, dtype=torch.float32)
+
+    def _proposals(self, pl, img_info):
+        m = self.cfg.MODEL
+        A = self.num_anchors
+        ops.rpn_proposals(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.pyr, pl.anchors, img_info, m.RPN_BOX_REG.MEAN, m.RPN_BOX_REG.STD,
+                          self.pre_k[self.training], m.RPN.NMS_THRESHOLD, pl.rois.shape[1], pl.rois, pl.num_rois, pl.prop_ws)
+
+    def get_losses(self, inputs):
+        """FasterRCNN.get_losses (faster_rcnn.py:78-97) = RPN.forward (rpn.py:70-132) + RCNN.forward (rcnn.py:52-83)."""
+        assert self.training
+        pre = self.pre_process(inputs)
+        pl = pre["plan"]
+        self._cur = pl
+        self.network_forward(pl)
+        m = self.cfg.MODEL
+        A = self.num_anchors
+        N = pl.N
+        gt = pre["gt_boxes"]
+        info = pre["img_info"]
+        num_gt = info[:, 4].to(torch.int32).contiguous()
+        Gmax = gt.shape[1]
+        # ---- RPN: proposals (detached), targets, losses
+        self._proposals(pl, info)
+        thr = m.MATCHER.THRESHOLDS
+        ws = pl.wgrad_ws[: N * Gmax]
+        ops.rpn_assign_encode(pl.anchors, gt, num_gt, thr[0], thr[1], m.MATCHER.ALLOW_LOW_QUALITY, m.RPN_BOX_REG.MEAN,
+                              m.RPN_BOX_REG.STD, pl.rpn_labels, pl.rpn_match, pl.rpn_offsets, pl.rpn_num_fg, ws)
+        nsa = m.RPN.NUM_SAMPLE_ANCHORS
+        ops.sample_labels(pl.rpn_labels, self._keys(inputs, "rpn_pos", (N, pl.A_total)), self._keys(inputs, "rpn_neg", (N, pl.A_total)),
+                          int(m.RPN.POSITIVE_ANCHOR_RATIO * nsa), nsa, pl.rpn_num_valid)
+        pl.loss_buf.zero_()
+        ops.rpn_loss_fwd_bwd(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.rpn_labels, pl.rpn_offsets, pl.pyr.pixels,
+                             m.LOSSES.RPN_SMOOTH_L1_BETA, pl.rpn_num_valid, pl.loss_buf[0:2], pl.d_rpn_raw)
+        # ---- RCNN: sampling, RoIAlign, box head, losses
+        S = m.RCNN.NUM_ROIS
+        key_ld = pl.rois.shape[1] + Gmax
+        ops.rcnn_sample_targets(pl.rois, pl.num_rois, gt, num_gt, self._keys(inputs, "rcnn_fg", (N, key_ld)),
+                                self._keys(inputs, "rcnn_bg", (N, key_ld)), S, int(S * m.RCNN.FG_RATIO), m.RCNN.FG_THRESHOLD,
+                                m.RCNN.BG_THRESHOLD_HIGH, m.RCNN.BG_THRESHOLD_LOW, m.RCNN_BOX_REG.MEAN, m.RCNN_BOX_REG.STD,
+                                pl.s_rois, pl.s_labels, pl.s_targets, pl.s_count, pl.s_total)
+        self._box_head(pl)
+        ops.rcnn_loss_fwd_bwd(pl.rcnn_raw, self.rcnn_ld, self.num_classes, self.num_classes + 1, pl.s_labels, pl.s_targets, pl.R,
+                              m.LOSSES.RCNN_SMOOTH_L1_BETA, pl.s_total, pl.loss_buf[2:4], pl.d_rcnn_raw)
+        lb = pl.loss_buf
+        return {"total_loss": lb[0] + lb[1] + lb[2] + lb[3], "rpn_cls_loss": lb[0], "rpn_reg_loss": lb[1],
+                "rcnn_cls_loss": lb[2], "rcnn_reg_loss": lb[3]}
+
+    def _box_head(self, pl):
+        """roi_pool + fc1/fc2 + predictors (rcnn.py:55-63) on the sampled RoI slots."""
+        S = pl.s_rois.shape[1]
+        ops.roi_align_fwd(pl.P, pl.pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
+                          self.pool, 2, pl.pooled)
+        g = pl.g_fc
+        self.fc1.forward(pl.pooled, g, g, pl.fc1_out, relu=True)
+        self.fc2.forward(pl.fc1_out, g, g, pl.fc2_out, relu=True)
+        self.rcnn_pred.forward(pl.fc2_out, g, g, pl.rcnn_raw)
+
+    # ---- backward ----------------------------------------------------------------------------------------
+    def head_backward(self, pl, ws, cws):
+        pyr, g = pl.pyr, pl.g_fc
+        S = pl.s_rois.shape[1]
+        # box head
+        self._wgrad(self.rcnn_pred, pl.fc2_out, pl.d_rcnn_raw, g, g, ws, cws)
+        self.rcnn_pred.dgrad(pl.d_rcnn_raw, g, g, pl.g_fc2, mask=pl.fc2_out)
+        self._wgrad(self.fc2, pl.fc1_out, pl.g_fc2, g, g, ws, cws)
+        self.fc2.dgrad(pl.g_fc2, g, g, pl.g_fc1, mask=pl.fc1_out)
+        self._wgrad(self.fc1, pl.pooled, pl.g_fc1, g, g, ws, cws)
+        self.fc1.dgrad(pl.g_fc1, g, g, pl.g_pooled)
+        pl.g_feat32.zero_()
+        ops.roi_align_bwd(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
+                          self.pool, 2, pl.g_feat32)
+        ops.f32_to_bf16(pl.g_feat32, pl.g_P)                        # first contribution to dL/dP (P6 rows are zero)
+        # RPN head
+        self._wgrad(self.rpn_pred, pl.rpn_t, pl.d_rpn_raw, pyr, pyr, ws, cws)
+        self.rpn_pred.dgrad(pl.d_rpn_raw, pyr, pyr, pl.g_rpn_t, mask=pl.rpn_t)
+        self._wgrad(self.rpn_conv, pl.P, pl.g_rpn_t, pyr, pyr, ws, cws)
+        self.rpn_conv.dgrad(pl.g_rpn_t, pyr, pyr, pl.g_P, first=False)
+
+    def _debug_head(self, pl, out, lvl):
+        A = self.num_anchors
+        for i in range(pl.pyr.nlev):
+            out[f"rpn_t_{i}"] = lvl(pl.rpn_t, i)
+            out[f"rpn_raw_{i}"] = lvl(pl.rpn_raw, i, 5 * A)
+        out["pooled"] = pl.pooled.float().cpu()
+        out["fc1"] = pl.fc1_out.float().cpu()
+        out["fc2"] = pl.fc2_out.float().cpu()
+        out["rcnn_raw"] = pl.rcnn_raw.float().cpu()[:, : 5 * self.num_classes + 1]
+
+    def debug_samples(self):
+        """Proposals and sampled RoIs of the last forward (host copies, for the parity tests)."""
+        pl = self._cur
+        return dict(rois=pl.rois.cpu().numpy(), num_rois=pl.num_rois.cpu().numpy(), s_rois=pl.s_rois.cpu().numpy(),
+                    s_labels=pl.s_labels.cpu().numpy(), s_targets=pl.s_targets.cpu().numpy(), s_count=pl.s_count.cpu().numpy(),
+                    rpn_labels=pl.rpn_labels.cpu().numpy())
+
+    def inference(self, inputs):
+        raise NotImplementedError("FasterRCNN.inference (faster_rcnn.py:98-131) is not built yet on the HIP path; training path only")

@@ -51,6 +51,8 @@ class VecParam:
 class FPNDetector:
     """Backbone + FPN forward/backward and the BaseNet module protocol; heads and losses live in subclasses."""
 
+    TOP_BLOCK = "p6p7"      # LastLevelP6P7 (RetinaNet / FCOS); "pool" = FPNP6 (Faster R-CNN)
+
     def __init__(self, cfg, params=None, device="cuda", seed=0):
         self.cfg = cfg
         self.device = torch.device(device)
@@ -122,8 +124,9 @@ class FPNDetector:
         for s, ci in zip(self.fpn_stages, m.BACKBONE.OUT_FEATURE_CHANNELS):
             self.lateral[s] = add(f"backbone.fpn_lateral{s}", ci, ch, 1, 1, 0, bias=True)
             self.output[s] = add(f"backbone.fpn_output{s}", ch, ch, 3, 1, 1, bias=True)
-        self.p6 = add("backbone.top_block.p6", m.FPN.TOP_BLOCK_IN_CHANNELS, ch, 3, 2, 1, bias=True)
-        self.p7 = add("backbone.top_block.p7", ch, ch, 3, 2, 1, bias=True)
+        if self.TOP_BLOCK == "p6p7":
+            self.p6 = add("backbone.top_block.p6", m.FPN.TOP_BLOCK_IN_CHANNELS, ch, 3, 2, 1, bias=True)
+            self.p7 = add("backbone.top_block.p7", ch, ch, 3, 2, 1, bias=True)
         self.vparams = {}
         self._build_head(add, params)
 
@@ -287,7 +290,7 @@ class FPNDetector:
         h5, w5 = sizes[-1]
         h6, w6 = (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1
         h7, w7 = (h6 - 1) // 2 + 1, (w6 - 1) // 2 + 1
-        sizes = sizes + [(h6, w6), (h7, w7)]
+        sizes = sizes + ([(h6, w6), (h7, w7)] if self.TOP_BLOCK == "p6p7" else [(h6, w6)])
         pl.sizes = sizes
         pl.pyr = Geom(N, [s[0] for s in sizes], [s[1] for s in sizes])
         ch = self.fpn_ch
@@ -313,13 +316,16 @@ class FPNDetector:
             gl = pl.blk[pl.res[s]].gout
             need = max(need, self.lateral[s].wgrad_ws_bytes(gl, gl), self.output[s].wgrad_ws_bytes(gl, gl))
         g5 = pl.blk[pl.res[self.fpn_stages[-1]]].gout
-        need = max(need, self.p6.wgrad_ws_bytes(g5, g6), self.p7.wgrad_ws_bytes(pl.g_p6r, pl.pyr.level(len(self.fpn_stages) + 1)))
-        for c in self._head_convs():
-            need = max(need, c.wgrad_ws_bytes(pl.pyr, pl.pyr))
+        if self.TOP_BLOCK == "p6p7":
+            need = max(need, self.p6.wgrad_ws_bytes(g5, g6), self.p7.wgrad_ws_bytes(pl.g_p6r, pl.pyr.level(len(self.fpn_stages) + 1)))
+        need = max(need, self._head_wgrad_ws_bytes(pl))
         pl.wgrad_ws = torch.empty((need // 4 + 64,), dtype=torch.float32, device=dev)
         pl.colsum_ws = torch.empty((ops.colsum_workspace_bytes(2048) // 4,), dtype=torch.float32, device=dev)
         self._plans[key] = pl
         return pl
+
+    def _head_wgrad_ws_bytes(self, pl):
+        return max(c.wgrad_ws_bytes(pl.pyr, pl.pyr) for c in self._head_convs())
 
     # ------------------------------------------------------------------------------------------------
     # forward
@@ -381,10 +387,13 @@ class FPNDetector:
             self.output[s].forward(pl.lat[s], b.gout, pl.pyr.level(li), pl.P)
             prev, prev_geo = pl.lat[s], b.gout
         b5 = pl.blk[pl.res[st[-1]]]
-        g6, g7 = pl.pyr.level(nl), pl.pyr.level(nl + 1)
-        self.p6.forward(b5.out, b5.gout, g6, pl.P)                                 # LastLevelP6P7 (:198-204)
-        self._relu_level(pl.P, g6, pl.p6_relu)
-        self.p7.forward(pl.p6_relu, pl.g_p6r, g7, pl.P)
+        if self.TOP_BLOCK == "p6p7":
+            g6, g7 = pl.pyr.level(nl), pl.pyr.level(nl + 1)
+            self.p6.forward(b5.out, b5.gout, g6, pl.P)                             # LastLevelP6P7 (:198-204)
+            self._relu_level(pl.P, g6, pl.p6_relu)
+            self.p7.forward(pl.p6_relu, pl.g_p6r, g7, pl.P)
+        else:
+            ops.subsample2x_fwd(pl.P, pl.pyr.level(nl - 1), pl.P, pl.pyr.level(nl), self.fpn_ch)   # FPNP6 (:172-183)
         self.head_forward(pl)
 
     def _relu_level(self, src, geo, dst):
@@ -424,13 +433,17 @@ class FPNDetector:
         # ---- FPN
         st = self.fpn_stages
         nl = len(st)
-        g6, g7 = pyr.level(nl), pyr.level(nl + 1)
         b5 = pl.blk[pl.res[st[-1]]]
-        # P7 = conv(relu(P6)): d P6 = dgrad(g_P7) * (P6 > 0) + g_P6(head), written in place into g_P's P6 level
-        self._wgrad(self.p7, pl.p6_relu, pl.g_P, pl.g_p6r, g7, ws, cws)
-        self.p7.dgrad(pl.g_P, g6, g7, pl.g_P, mask=pl.P, add_after=pl.g_P)
-        self._wgrad(self.p6, b5.out, pl.g_P, b5.gout, g6, ws, cws)
-        self.p6.dgrad(pl.g_P, b5.gout, g6, b5.g_out, first=True)
+        pool_top = self.TOP_BLOCK != "p6p7"
+        if not pool_top:
+            g6, g7 = pyr.level(nl), pyr.level(nl + 1)
+            # P7 = conv(relu(P6)): d P6 = dgrad(g_P7) * (P6 > 0) + g_P6(head), written in place into g_P's P6 level
+            self._wgrad(self.p7, pl.p6_relu, pl.g_P, pl.g_p6r, g7, ws, cws)
+            self.p7.dgrad(pl.g_P, g6, g7, pl.g_P, mask=pl.P, add_after=pl.g_P)
+            self._wgrad(self.p6, b5.out, pl.g_P, b5.gout, g6, ws, cws)
+            self.p6.dgrad(pl.g_P, b5.gout, g6, b5.g_out, first=True)
+        else:
+            ops.subsample2x_bwd_add(pl.g_P, pyr.level(nl), pl.g_P, pyr.level(nl - 1), self.fpn_ch)      # P6 = P5[::2, ::2]
         for li in range(nl):
             s = st[li]
             b = pl.blk[pl.res[s]]
@@ -443,8 +456,10 @@ class FPNDetector:
             self._wgrad(self.lateral[s], b.out, pl.g_lat[s], b.gout, b.gout, ws, cws)
             # res_s gradient: first contribution for res3/res4, second (after P6) and final for res5 -> mask there
             is_top = li == nl - 1
+            if not self.blocks[pl.res[s]]["trainable"]:
+                continue                                   # res2 of a FREEZE_AT=2 backbone: nothing below needs the gradient
             if is_top:
-                self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=False, mask=b.out)
+                self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=pool_top, mask=b.out)
             else:
                 self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=True)
         if on_bucket_ready:

@@ -73,12 +73,14 @@ def init_resnet(p, rng, name, residual_gamma=None):
             _bn(p, f"{pre}.downsample.1", blk["cout"])
 
 
-def init_fpn(p, rng, in_channels, stages, out_ch, top_in):
+def init_fpn(p, rng, in_channels, stages, out_ch, top_in, top_convs=True):
     for s, ci in zip(stages, in_channels):
         p[f"backbone.fpn_lateral{s}.weight"] = _msra_normal(rng, (out_ch, ci, 1, 1), "fan_in")
         p[f"backbone.fpn_lateral{s}.bias"] = np.zeros(out_ch, np.float32)
         p[f"backbone.fpn_output{s}.weight"] = _msra_normal(rng, (out_ch, out_ch, 3, 3), "fan_in")
         p[f"backbone.fpn_output{s}.bias"] = np.zeros(out_ch, np.float32)
+    if not top_convs:      # FPNP6 (fpn_backbone.py:172-183) has no parameters
+        return
     for nm, ci in (("p6", top_in), ("p7", out_ch)):
         p[f"backbone.top_block.{nm}.weight"] = (rng.standard_normal((out_ch, ci, 3, 3)) * math.sqrt(1.0 / (ci * 9))).astype(np.float32)
         p[f"backbone.top_block.{nm}.bias"] = np.zeros(out_ch, np.float32)
@@ -137,6 +139,37 @@ def init_fcos_params(cfg, seed=0, residual_gamma=None):
     return p
 
 
+def init_faster_rcnn_params(cfg, seed=0, residual_gamma=None):
+    """FasterRCNN (models/det/faster_rcnn.py:19-44): ResNet + FPN(p2-p5, FPNP6) + RPN (rpn.py:52-68: N(0, 0.01), zero bias)
+    + RCNN (layers/head/rcnn.py:32-50: fc1/fc2/pred_cls N(0, 0.01), pred_delta N(0, 0.001), zero bias)."""
+    rng = np.random.default_rng(seed)
+    m = cfg.MODEL
+    p = {}
+    init_resnet(p, rng, m.BACKBONE.NAME, residual_gamma)
+    stages = [int(f[-1]) for f in m.BACKBONE.OUT_FEATURES]
+    ch = m.FPN.OUT_CHANNELS
+    init_fpn(p, rng, m.BACKBONE.OUT_FEATURE_CHANNELS, stages, ch, m.FPN.TOP_BLOCK_IN_CHANNELS, top_convs=False)
+    na = len(m.ANCHOR.SCALES[0]) * len(m.ANCHOR.RATIOS[0])
+    rc = m.RPN.CHANNELS
+    p["rpn.rpn_conv.weight"] = (rng.standard_normal((rc, ch, 3, 3)) * 0.01).astype(np.float32)
+    p["rpn.rpn_conv.bias"] = np.zeros(rc, np.float32)
+    p["rpn.rpn_cls_score.weight"] = (rng.standard_normal((na, rc, 1, 1)) * 0.01).astype(np.float32)
+    p["rpn.rpn_cls_score.bias"] = np.zeros(na, np.float32)
+    p["rpn.rpn_bbox_offsets.weight"] = (rng.standard_normal((na * 4, rc, 1, 1)) * 0.01).astype(np.float32)
+    p["rpn.rpn_bbox_offsets.bias"] = np.zeros(na * 4, np.float32)
+    ph, pw = m.ROI_POOLER.SIZE
+    K = cfg.DATA.NUM_CLASSES
+    p["rcnn.fc1.weight"] = (rng.standard_normal((1024, ch * ph * pw)) * 0.01).astype(np.float32)
+    p["rcnn.fc1.bias"] = np.zeros(1024, np.float32)
+    p["rcnn.fc2.weight"] = (rng.standard_normal((1024, 1024)) * 0.01).astype(np.float32)
+    p["rcnn.fc2.bias"] = np.zeros(1024, np.float32)
+    p["rcnn.pred_cls.weight"] = (rng.standard_normal((K + 1, 1024)) * 0.01).astype(np.float32)
+    p["rcnn.pred_cls.bias"] = np.zeros(K + 1, np.float32)
+    p["rcnn.pred_delta.weight"] = (rng.standard_normal((K * 4, 1024)) * 0.001).astype(np.float32)
+    p["rcnn.pred_delta.bias"] = np.zeros(K * 4, np.float32)
+    return p
+
+
 def trainable_names(params, freeze_at=2):
     """DetSolver.params (solver/default_solver.py:83-94): drop bottom_up.conv1 / layer1 by name; FrozenBN
     statistics and affine terms never receive gradients (configs/extra_cfg.py:55)."""
@@ -154,6 +187,16 @@ def trainable_names(params, freeze_at=2):
 
 def oracle_arch(cfg):
     m = cfg.MODEL
+    if m.NAME == "FasterRCNN":
+        return dict(backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), top_block="pool",
+                    num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),
+                    strides=list(m.FPN.STRIDES), anchor_scales=[list(s) for s in m.ANCHOR.SCALES],
+                    anchor_ratios=[list(r) for r in m.ANCHOR.RATIOS], anchor_offset=m.ANCHOR.OFFSET,
+                    rpn=dict(m.RPN), rcnn=dict(m.RCNN), pool_size=tuple(m.ROI_POOLER.SIZE),
+                    rpn_box_reg=(list(m.RPN_BOX_REG.MEAN), list(m.RPN_BOX_REG.STD)),
+                    rcnn_box_reg=(list(m.RCNN_BOX_REG.MEAN), list(m.RCNN_BOX_REG.STD)),
+                    matcher=(list(m.MATCHER.THRESHOLDS), list(m.MATCHER.LABELS), m.MATCHER.ALLOW_LOW_QUALITY),
+                    rpn_beta=m.LOSSES.RPN_SMOOTH_L1_BETA, rcnn_beta=m.LOSSES.RCNN_SMOOTH_L1_BETA)
     if m.NAME == "FCOS":
         return dict(backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
                     num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),

@@ -53,7 +53,7 @@ class GradBuckets:
         ent = self.model.arena.entries
         groups = {}
         for name, _, off, n in ent:
-            if name.startswith("head."):
+            if name.startswith(("head.", "rpn.", "rcnn.")):
                 k = "head"
             elif "fpn_" in name or "top_block" in name:
                 k = "fpn"

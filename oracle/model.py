@@ -157,6 +157,8 @@ class Oracle:
             prev = act(f"lat{s}", q(self._conv(f, f"backbone.fpn_lateral{s}")) + td, False)
             results.insert(0, act(f"P{s}", self._conv(prev, f"backbone.fpn_output{s}", 1, 1), False))
         top = stages[-1]
+        if self.arch.get("top_block") == "pool":          # FPNP6 (fpn_backbone.py:172-183)
+            return results + [TF.max_pool2d(results[-1], kernel_size=1, stride=2, padding=0)]
         p6 = act(f"P{top + 1}", self._conv(feats["res5"], "backbone.top_block.p6", 2, 1), False)
         p7 = act(f"P{top + 2}", self._conv(TF.relu(p6), "backbone.top_block.p7", 2, 1), False)
         return results + [p6, p7]
@@ -302,6 +304,130 @@ class Oracle:
         return {"total_loss": total, "cls_loss": cls_loss, "reg_loss": reg_loss, "ctr_loss": ctr_loss}, {
             "labels": labels, "gt_offsets": gt_off, "gt_ctr": gt_ctr, "logits": logits, "offsets": offsets, "num_fg": num_fg,
             "sum_ctr": sum_ctr}
+
+    # ---- Faster R-CNN (models/det/faster_rcnn.py:64-97, rpn.py:70-132, layers/head/rcnn.py:52-83) ---------------
+    def rpn_head(self, feats):
+        """rpn.py:78-100: per level relu(rpn_conv) -> cls (A) / offsets (4A)."""
+        scores, offsets, A = [], [], None
+        for li, f in enumerate(feats):
+            t = self._act(f"rpn_t_{li}", self._conv(f, "rpn.rpn_conv", 1, 1), True)
+            s = self._conv(t, "rpn.rpn_cls_score")
+            o = self._conv(t, "rpn.rpn_bbox_offsets")
+            A = s.shape[1]
+            raw = self._act(f"rpn_raw_{li}", torch.cat([s, o], 1), False)      # the HIP path stores both in one fused row
+            scores.append(raw[:, :A]); offsets.append(raw[:, A:])
+        return scores, offsets
+
+    def _linear(self, x, name):
+        return TF.linear(x, self._q(self.p[name + ".weight"]), self.p[name + ".bias"])
+
+    def roi_align_torch(self, feats, rois, batch_idx, strides, pool):
+        """Differentiable roi_pool(..., "roi_align") built from oracle/rcnn_ops.py sample tables.
+        feats[l]: (N, C, H, W).  Returns (R, C, PH, PW) like F.nn.roi_align."""
+        from . import rcnn_ops
+        PH, PW = pool
+        lv = rcnn_ops.assign_roi_levels(rois, strides)
+        C = feats[0].shape[1]
+        outs = []
+        for r in range(len(rois)):
+            l, n = int(lv[r]), int(batch_idx[r])
+            f = feats[l][n]                                   # (C, H, W)
+            H, W = f.shape[1], f.shape[2]
+            table = rcnn_ops.roi_align_sample_table(rois[r], 1.0 / strides[l], H, W, PH, PW, 2)
+            idx, wts = [], []
+            for pts in table:
+                ii, ww = [], []
+                for p in pts:
+                    if p is None:
+                        ii += [0, 0, 0, 0]; ww += [0.0, 0.0, 0.0, 0.0]
+                    else:
+                        y0, y1, x0, x1, w00, w01, w10, w11 = p
+                        ii += [y0 * W + x0, y0 * W + x1, y1 * W + x0, y1 * W + x1]
+                        ww += [float(w00), float(w01), float(w10), float(w11)]
+                idx.append(ii); wts.append(ww)
+            idx = torch.tensor(idx, dtype=torch.long)         # (PH*PW, 16)
+            wts = torch.tensor(wts, dtype=torch.float32)
+            g = f.reshape(C, H * W)[:, idx.reshape(-1)].reshape(C, PH * PW, -1)
+            outs.append((g * wts[None]).sum(-1).reshape(C, PH, PW) * 0.25)
+        return torch.stack(outs) if outs else torch.zeros((0, C, PH, PW))
+
+    def faster_rcnn_losses(self, batch, keys, forced=None):
+        """keys: dict rpn_pos / rpn_neg (N, A_total), rcnn_fg / rcnn_bg (N, post_k + Gmax) float32 in [0, 1).
+        forced: optional dict(rois=list of (n_i, 4)) replacing the RPN proposals (to decouple the RCNN parity from the
+        discrete proposal selection)."""
+        from . import rcnn_ops
+        a = self.arch
+        image = _t(box_ops.data_to_input(batch["data"], a["img_mean"], a["img_std"]))
+        feats = self.fpn(self.backbone(image))
+        scores, offsets = self.rpn_head(feats)
+        N = image.shape[0]
+        sizes = [tuple(f.shape[-2:]) for f in feats]
+        anchors_list = box_ops.default_anchors(sizes, a["strides"], a["anchor_scales"], a["anchor_ratios"], a["anchor_offset"])
+        anchors = np.concatenate(anchors_list, 0)
+        info = np.asarray(batch["im_info"], np.float32)
+        num_valid = info[:, 4].astype(np.int32)
+        rpn, rc = a["rpn"], a["rcnn"]
+        A = scores[0].shape[1]
+        # per level (N, HWA) / (N, HWA, 4) in the reference's (h, w, a) order (rpn.py:149-153)
+        sc_l = [s.permute(0, 2, 3, 1).reshape(N, -1) for s in scores]
+        of_l = [o.reshape(N, A, 4, o.shape[2], o.shape[3]).permute(0, 3, 4, 1, 2).reshape(N, -1, 4) for o in offsets]
+        mean_r, std_r = a["rpn_box_reg"]
+        rois_list = []
+        for n in range(N):
+            if forced is not None:
+                rois_list.append(np.asarray(forced["rois"][n], np.float32))
+                continue
+            r, _, _ = rcnn_ops.rpn_proposals([s[n].detach().numpy() for s in sc_l], [o[n].detach().numpy() for o in of_l], anchors_list,
+                                             info[n, :2], rpn["TRAIN_PREV_NMS_TOPK"], rpn["TRAIN_POST_NMS_TOPK"], rpn["NMS_THRESHOLD"],
+                                             mean_r, std_r)
+            rois_list.append(r)
+        thr, labs, lq = a["matcher"]
+        nsa = rpn["NUM_SAMPLE_ANCHORS"]
+        rpn_labels, rpn_off = rcnn_ops.rpn_ground_truth(anchors, batch["gt_boxes"], num_valid, keys["rpn_pos"], keys["rpn_neg"], thr, labs,
+                                                        lq, nsa, int(rpn["POSITIVE_ANCHOR_RATIO"] * nsa), mean_r, std_r)
+        logits = torch.cat(sc_l, 1).reshape(-1)
+        offs = torch.cat(of_l, 1).reshape(-1, 4)
+        lab_t = torch.from_numpy(rpn_labels.reshape(-1)).long()
+        valid, fg = lab_t >= 0, lab_t > 0
+        nv = max(int(valid.sum()), 1)
+        t = lab_t[valid].float()
+        x = logits[valid]
+        rpn_cls = (-(t * TF.logsigmoid(x) + (1 - t) * TF.logsigmoid(-x))).sum() / nv
+        d = offs[fg] - _t(rpn_off.reshape(-1, 4))[fg]
+        beta = a.get("rpn_beta", 0.0)
+        l1 = d.abs() if beta < 1e-5 else torch.where(d.abs() < beta, 0.5 * d ** 2 / beta, d.abs() - 0.5 * beta)
+        rpn_box = l1.sum() / nv
+        # RCNN
+        mean_c, std_c = a["rcnn_box_reg"]
+        s_rois, s_labels, s_targets, s_bidx = [], [], [], []
+        gtb = np.asarray(batch["gt_boxes"], np.float32)
+        for n in range(N):
+            rr, rl, rt = rcnn_ops.rcnn_ground_truth(rois_list[n], gtb[n, : num_valid[n]], keys["rcnn_fg"][n], keys["rcnn_bg"][n],
+                                                    rc["NUM_ROIS"], rc["FG_RATIO"], rc["FG_THRESHOLD"], rc["BG_THRESHOLD_HIGH"],
+                                                    rc["BG_THRESHOLD_LOW"], mean_c, std_c)
+            s_rois.append(rr); s_labels.append(rl); s_targets.append(rt); s_bidx.append(np.full(len(rl), n))
+        s_rois = np.concatenate(s_rois); s_labels = np.concatenate(s_labels); s_targets = np.concatenate(s_targets)
+        s_bidx = np.concatenate(s_bidx)
+        nl = len(rc["STRIDES"])
+        pooled = self.roi_align_torch(feats[:nl], s_rois, s_bidx, list(rc["STRIDES"]), a["pool_size"])
+        pooled = self._act("pooled", pooled.flatten(1), False)
+        h1 = self._act("fc1", self._linear(pooled, "rcnn.fc1"), True)
+        h2 = self._act("fc2", self._linear(h1, "rcnn.fc2"), True)
+        raw = self._act("rcnn_raw", torch.cat([self._linear(h2, "rcnn.pred_cls"), self._linear(h2, "rcnn.pred_delta")], 1), False)
+        K = a["num_classes"]
+        cls_logits, deltas = raw[:, : K + 1], raw[:, K + 1:].reshape(-1, K, 4)
+        R = max(len(s_labels), 1)
+        lt = torch.from_numpy(s_labels).long()
+        rcnn_cls = TF.cross_entropy(cls_logits, lt, reduction="sum") / R
+        fgm = lt > 0
+        d2 = deltas[fgm, lt[fgm] - 1] - _t(s_targets)[fgm]
+        beta2 = a.get("rcnn_beta", 0.0)
+        l2 = d2.abs() if beta2 < 1e-5 else torch.where(d2.abs() < beta2, 0.5 * d2 ** 2 / beta2, d2.abs() - 0.5 * beta2)
+        rcnn_box = l2.sum() / R
+        total = rpn_cls + rpn_box + rcnn_cls + rcnn_box
+        return {"total_loss": total, "rpn_cls_loss": rpn_cls, "rpn_reg_loss": rpn_box, "rcnn_cls_loss": rcnn_cls,
+                "rcnn_reg_loss": rcnn_box}, {"rois": rois_list, "s_rois": s_rois, "s_labels": s_labels, "s_targets": s_targets,
+                                             "s_bidx": s_bidx, "rpn_labels": rpn_labels, "rpn_offsets": rpn_off}
 
     # ---- one training step: backward + SGD (solver/default_solver.py:96-124) --------------------
     def grads(self, loss):

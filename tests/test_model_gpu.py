@@ -179,3 +179,102 @@ def test_fcos_training_step_matches_oracle():
         g = got[n].double().reshape(-1)
         rel = float((g - r).norm() / (r.norm() + 1e-30))
         assert rel < 2e-2, (n, rel)
+
+
+def _frcnn_setup(N, size, seed=0):
+    from basedet_amd.configs import FasterRCNNConfig
+    from basedet_amd.models import params as P
+    from basedet_amd.utils import DummyLoader
+    cfg = FasterRCNNConfig()
+    cfg.merge(dict(MODEL=dict(BATCHSIZE=N, BACKBONE=dict(NAME="resnet18", OUT_FEATURE_CHANNELS=[64, 128, 256, 512]),
+                              FPN=dict(TOP_BLOCK_IN_CHANNELS=512),
+                              RPN=dict(TRAIN_PREV_NMS_TOPK=300, TRAIN_POST_NMS_TOPK=120, TEST_PREV_NMS_TOPK=300, TEST_POST_NMS_TOPK=120,
+                                       NUM_SAMPLE_ANCHORS=64),
+                              RCNN=dict(NUM_ROIS=48))))
+    params = P.init_faster_rcnn_params(cfg, seed, residual_gamma=0.25)
+    rng = np.random.default_rng(seed + 11)
+    # larger head weights than the N(0, 0.01) init so that scores / deltas are not all ~0 (non-trivial top-k, NMS, sampling)
+    for k in ("rpn.rpn_cls_score.weight", "rpn.rpn_bbox_offsets.weight", "rcnn.pred_cls.weight", "rcnn.pred_delta.weight",
+              "rcnn.fc1.weight", "rcnn.fc2.weight", "rpn.rpn_conv.weight"):
+        params[k] = (params[k] * 3).astype(np.float32)
+    batch = next(DummyLoader(N, size, seed=seed))
+    batch["data"] = (batch["data"] * 255).astype(np.float32)
+    return cfg, params, batch
+
+
+def test_faster_rcnn_training_step_matches_oracle():
+    """Faster R-CNN (models/det/faster_rcnn.py): RPN targets bit-exact with the same sampling keys; proposals, sampled RoIs,
+    labels and the four losses against the oracle evaluated on the stored activations of the HIP run (so that the discrete
+    proposal / sample selection sees identical scores); parameter gradients rel-L2 <= 2e-2 per parameter."""
+    from basedet_amd.models import FasterRCNN, params as P
+    from oracle.model import Oracle
+    N, size = 2, (128, 160)
+    cfg, params, batch = _frcnn_setup(N, size)
+    model = FasterRCNN(cfg, params=params)
+    names = P.trainable_names(params, cfg.MODEL.BACKBONE.FREEZE_AT)
+    assert sorted(names) == sorted(model.state_dict_trainable_names())
+    pl = model._plan(N, size[0], size[1])
+    Gmax = batch["gt_boxes"].shape[1]
+    rng = np.random.default_rng(5)
+    keys = dict(rpn_pos=rng.random((N, pl.A_total), dtype=np.float32), rpn_neg=rng.random((N, pl.A_total), dtype=np.float32),
+                rcnn_fg=rng.random((N, pl.rois.shape[1] + Gmax), dtype=np.float32),
+                rcnn_bg=rng.random((N, pl.rois.shape[1] + Gmax), dtype=np.float32))
+    batch = dict(batch, sample_keys=keys)
+    out = model(batch)
+    model.backward()
+    torch.cuda.synchronize()
+    dbg = model.debug_samples()
+
+    # (1) plain fp32 oracle: RPN targets are independent of the network output -> bit-exact; RPN losses within bf16 tolerance
+    orc = Oracle(params, P.oracle_arch(cfg), trainable=names)
+    ref, aux = orc.faster_rcnn_losses(batch, keys)
+    assert np.array_equal(dbg["rpn_labels"], aux["rpn_labels"])
+    for k in ("rpn_cls_loss", "rpn_reg_loss"):
+        got, want = float(out[k]), float(ref[k].detach())
+        assert abs(got - want) / abs(want) < 2e-2, (k, got, want)
+
+    # (2) oracle on the stored activations of the HIP run: identical scores -> identical proposals and samples
+    acts = model.debug_activations()
+    valid = dbg["s_labels"].reshape(-1) >= 0
+    ch = cfg.MODEL.FPN.OUT_CHANNELS
+    pooled = acts.pop("pooled")[valid]
+    acts["pooled"] = pooled.reshape(-1, 49, ch).permute(0, 2, 1).reshape(-1, ch * 49).contiguous()
+    for k in ("fc1", "fc2", "rcnn_raw"):
+        acts[k] = acts[k][valid].contiguous()
+    orc2 = Oracle(params, P.oracle_arch(cfg), trainable=names, sim_bf16=True, inject=acts)
+    l2, aux2 = orc2.faster_rcnn_losses(batch, keys)
+    for n in range(N):
+        m = int(dbg["num_rois"][n])
+        assert m == len(aux2["rois"][n])
+        np.testing.assert_allclose(dbg["rois"][n, :m], aux2["rois"][n], rtol=1e-5, atol=1e-3)
+    assert int(valid.sum()) == len(aux2["s_labels"])
+    assert np.array_equal(dbg["s_labels"].reshape(-1)[valid], aux2["s_labels"])
+    np.testing.assert_allclose(dbg["s_rois"].reshape(-1, 4)[valid], aux2["s_rois"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(dbg["s_targets"].reshape(-1, 4)[valid], aux2["s_targets"], rtol=1e-3, atol=1e-3)
+    assert (aux2["s_labels"] > 0).sum() >= N                    # the gt boxes themselves are foreground candidates
+    for k in ("rpn_cls_loss", "rpn_reg_loss", "rcnn_cls_loss", "rcnn_reg_loss", "total_loss"):
+        got, want = float(out[k]), float(l2[k].detach())
+        assert abs(got - want) / abs(want) < 2e-2, (k, got, want)
+    g2 = orc2.grads(l2["total_loss"])
+    got = model.reference_grads()
+    for n in names:
+        r = g2[n].detach().double().reshape(-1)
+        g = got[n].double().reshape(-1)
+        rel = float((g - r).norm() / (r.norm() + 1e-30))
+        assert rel < 2e-2, (n, rel)
+
+
+def test_faster_rcnn_minimize_runs():
+    from basedet_amd.models import FasterRCNN
+    from basedet_amd.solver import DetSolver
+    cfg, params, batch = _frcnn_setup(2, (128, 160), seed=3)
+    model = FasterRCNN(cfg, params=params)
+    solver = DetSolver.build(cfg, model)
+    solver.optimizer.param_groups[0]["lr"] = 0.0005         # the sampled anchors / RoIs change every step: keep the steps small
+    first = None
+    for it in range(10):
+        out = solver.minimize(model, batch)
+        v = float(out["total_loss"])
+        assert np.isfinite(v)
+        first = v if first is None else first
+    assert v < first, (first, v)
