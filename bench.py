@@ -28,6 +28,9 @@ TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): 
     "retinanet_r50_800x1344": 1435.6,
     "retinanet_r18_512x512": 277.2,
     "fcos_r50_800x1344": 1227.8,
+    # Faster R-CNN R50-FPN (P2-P6): fwd 208.9 GMAC/img (backbone 87.6, FPN 60.9, RPN 53.1, box head 512 RoIs x 14.3 MMAC = 7.3);
+    # stem + layer1 frozen, lateral2 needs no dgrad
+    "faster_rcnn_r50_800x1344": 1177.2,
 }
 
 
@@ -153,8 +156,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from basedet_amd import ops
-    from basedet_amd.configs import FCOSConfig, RetinaNetConfig, retinanet_r18_config
-    from basedet_amd.models import FCOS, RetinaNet, params as P
+    from basedet_amd.configs import FasterRCNNConfig, FCOSConfig, RetinaNetConfig, retinanet_r18_config
+    from basedet_amd.models import FCOS, FasterRCNN, RetinaNet, params as P
     from basedet_amd.solver import DetSolver, WarmupMultiStepLR, broadcast_parameters
     from basedet_amd.utils import DummyLoader
 
@@ -162,6 +165,8 @@ def main():
         cfg, size = RetinaNetConfig(), (800, 1344)
     elif args.workload == "fcos_r50_800x1344":
         cfg, size = FCOSConfig(), (800, 1344)
+    elif args.workload == "faster_rcnn_r50_800x1344":
+        cfg, size = FasterRCNNConfig(), (800, 1344)
     else:
         cfg, size = retinanet_r18_config(), (512, 512)
     cfg.MODEL.BATCHSIZE = args.batch
@@ -170,6 +175,9 @@ def main():
     if cfg.MODEL.NAME == "FCOS":
         params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.2)
         model = FCOS(cfg, params=params)
+    elif cfg.MODEL.NAME == "FasterRCNN":
+        params = P.init_faster_rcnn_params(cfg, seed=0, residual_gamma=0.2)
+        model = FasterRCNN(cfg, params=params)
     else:
         params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
         model = RetinaNet(cfg, params=params)
