@@ -88,6 +88,10 @@ SIGNATURES = {
     "bd_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "bd_rpn_loss_fwd_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _L, _F, _P, _P, _P, _P]),
     "bd_rcnn_loss_fwd_bwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P]),
+    "bd_det_scores": (_I, [_P, _P, _I, _I, _L, _I, _P, _P]),
+    "bd_rcnn_predict": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "bd_det_candidates": (_I, [_I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "bd_det_finalize": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "bd_sgd_momentum_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _P]),
     "bd_wgrad_set_transpose_read": (_I, [_I]),
     "bd_conv_set_patch3x3": (_I, [_I]),

@@ -23,6 +23,7 @@ SOURCES = {
     "stem.hip": [],
     "boxops.hip": ["-ffp-contract=off"],
     "rcnn_ops.hip": ["-ffp-contract=off"],
+    "postprocess.hip": ["-ffp-contract=off"],
     "losses.hip": [],
     "norm.hip": [],
 }

@@ -251,4 +251,34 @@ class FasterRCNN(FPNDetector):
                     rpn_labels=pl.rpn_labels.cpu().numpy())
 
     def inference(self, inputs):
-        raise NotImplementedError("FasterRCNN.inference (faster_rcnn.py:98-131) is not built yet on the HIP path; training path only")
+        """FasterRCNN.inference (faster_rcnn.py:98-131): RPN proposals (test top-k) -> RoIAlign + box head on every proposal ->
+        softmax scores / per-class decode (rcnn.py:84-93) -> score threshold -> NMS by class -> rescale.
+        The reference thresholds all R*K scores without a cap; here the NMS input is the 2048 best of them."""
+        assert not self.training
+        pre = self.pre_process(inputs)
+        pl = pre["plan"]
+        assert pl.N == 1, "inference supports batch size 1"
+        self._cur = pl
+        self.network_forward(pl)
+        m = self.cfg.MODEL
+        info = pre["img_info"]
+        self._proposals(pl, info)
+        R = pl.rois.shape[1]
+        K = self.num_classes
+        dev = self.device
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        if not hasattr(pl, "inf"):
+            fin = self.fpn_ch * self.pool[0] * self.pool[1]
+            pl.inf = dict(pooled=torch.empty((R, fin), **bf), fc1=torch.empty((R, 1024), **bf), fc2=torch.empty((R, 1024), **bf),
+                          raw=torch.empty((R, self.rcnn_ld), **bf), g=ops.single(1, R, 1),
+                          scores=torch.empty((R * K,), dtype=torch.float32, device=dev),
+                          boxes=torch.empty((R * K, 4), dtype=torch.float32, device=dev))
+        b = pl.inf
+        ops.roi_align_fwd(pl.P, pl.pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.rois.view(-1, 4), None, R, self.pool, 2, b["pooled"])
+        g = b["g"]
+        self.fc1.forward(b["pooled"], g, g, b["fc1"], relu=True)
+        self.fc2.forward(b["fc1"], g, g, b["fc2"], relu=True)
+        self.rcnn_pred.forward(b["fc2"], g, g, b["raw"])
+        ops.rcnn_predict(b["raw"], self.rcnn_ld, K, K + 1, pl.rois.view(-1, 4), pl.num_rois, R, m.RCNN_BOX_REG.MEAN, m.RCNN_BOX_REG.STD,
+                         b["scores"], b["boxes"])
+        return self._detect(b["scores"], [R], K, 2, info, k=2048, item_boxes=b["boxes"])

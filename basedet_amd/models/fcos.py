@@ -169,4 +169,15 @@ class FCOS(FPNDetector):
             out[f"raw_{i}"] = lvl(pl.raw, i, 5)
 
     def inference(self, inputs):
-        raise NotImplementedError("FCOS.inference (fcos.py:181-216) is not built yet on the HIP path; training path only")
+        """FCOS.inference (fcos.py:181-216): score = sqrt(sigmoid(cls) * sigmoid(ctrness)), PointCoder.decode."""
+        assert not self.training
+        pre = self.pre_process(inputs)
+        pl = pre["plan"]
+        assert pl.N == 1, "inference supports batch size 1 (fcos.py:183)"
+        self.network_forward(pl)
+        K = self.num_classes
+        rows = pl.pyr.pix_per_img
+        scores = torch.empty((rows * K,), dtype=torch.float32, device=self.device)
+        ops.det_scores(pl.logits, rows, K, scores, ctr=pl.raw, ctr_ld=8, ctr_off=4)
+        return self._detect(scores, [h * w for h, w in pl.sizes], K, 1, pre["img_info"], anchors=pl.points, offsets=pl.offsets,
+                            off_ld=4, A=1)

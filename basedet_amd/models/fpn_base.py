@@ -406,6 +406,42 @@ class FPNDetector:
             ops.relu_bf16(sv[i, geo.off[0]: geo.off[0] + n], dv[i])
 
     # ------------------------------------------------------------------------------------------------
+    # inference post-processing shared by the heads (layers/common/post_processing.py:50-103)
+    # ------------------------------------------------------------------------------------------------
+    def _detect(self, scores, lvl_rows, K, mode, info, k=1000, anchors=None, offsets=None, off_ld=4, A=1, mean=(0, 0, 0, 0),
+                std=(1, 1, 1, 1), item_boxes=None):
+        """scores: fp32 [sum(lvl_rows) * K] on the device.  Per level: score > TEST.CLS_THRESHOLD -> top-k (descending) ->
+        label = idx % K, box of row idx // K; then batched NMS by label, keep MAX_BOXES_PER_IMAGE, rescale + clip.
+        Everything stays on the device; the only host read is the final detection count."""
+        from ..structures import Boxes, Container
+        t = self.cfg.TEST
+        dev = self.device
+        Ln = len(lvl_rows)
+        row_off = [0]
+        for r in lvl_rows[:-1]:
+            row_off.append(row_off[-1] + r)
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        tk_idx = torch.empty((Ln, k), **i32); tk_sc = torch.empty((Ln, k), **f32); tk_cnt = torch.empty((Ln,), **i32)
+        ops.segment_topk(scores, 1, 0, 1, 1, 0, [r * K for r in row_off], [r * K for r in lvl_rows], k, tk_idx, tk_sc, tk_cnt,
+                         min_score=t.CLS_THRESHOLD)
+        C = Ln * k
+        boxes = torch.empty((C, 4), **f32); sc = torch.empty((1, C), **f32); labels = torch.empty((1, C), **i32)
+        ops.det_candidates(mode, tk_idx, tk_sc, tk_cnt, Ln, k, row_off, K, anchors, offsets, off_ld, A, mean, std, item_boxes,
+                           boxes, sc, labels)
+        max_out = t.MAX_BOXES_PER_IMAGE
+        keep = torch.empty((1, max_out), **i32); num = torch.zeros((1,), **i32)
+        ws = torch.empty((ops.nms_batched_workspace_bytes(1, C),), dtype=torch.uint8, device=dev)
+        ops.nms_batched(boxes, sc, labels, t.IOU_THRESHOLD, max_out, keep, num, ws)
+        ob = torch.empty((max_out, 4), **f32); osc = torch.empty((max_out,), **f32); ol = torch.empty((max_out,), **i32)
+        ops.det_finalize(boxes, sc, labels, keep, num, max_out, info[0].contiguous(), ob, osc, ol)
+        n = int(num.item())
+        if n == 0:
+            e = torch.zeros((0,))
+            return Container(boxes=e, box_scores=e, box_labels=e)
+        return Container(boxes=Boxes(ob[:n]), box_scores=osc[:n], box_labels=ol[:n])
+
+    # ------------------------------------------------------------------------------------------------
     # backward (replaces GradManager.backward, solver/default_solver.py:118-124)
     # ------------------------------------------------------------------------------------------------
     def _wgrad(self, conv, x, g, gin, gout, ws, cws=None):

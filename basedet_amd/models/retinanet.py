@@ -157,32 +157,15 @@ class RetinaNet(FPNDetector):
     # inference (retinanet.py:172-201) -- single image, like the reference
     # ------------------------------------------------------------------------------------------------
     def inference(self, inputs):
-        from ..layers import post_process_with_empty_input
         assert not self.training
         pre = self.pre_process(inputs)
         pl = pre["plan"]
         assert pl.N == 1, "inference supports batch size 1 (retinanet.py:174)"
         self.network_forward(pl)
         K, A = self.num_classes, self.num_anchors
-        logits = pl.logits.view(-1).float()
-        offsets = pl.offsets.view(pl.pyr.pix_per_img, self.box_ld)[:, : A * 4].reshape(-1, 4).float().contiguous()
         m = self.cfg.MODEL
-        boxes_all = ops.box_decode(pl.anchors, offsets, m.BOX_REG.MEAN, m.BOX_REG.STD)
-        scores_all = torch.sigmoid(logits)
-        total_boxes, total_scores, total_labels = [], [], []
-        o = 0
-        for (h, w) in pl.sizes:
-            n = h * w * A * K
-            sc = scores_all[o:o + n]
-            keep = torch.nonzero(sc > self.cfg.TEST.CLS_THRESHOLD).flatten()
-            if keep.numel():
-                k = min(keep.numel(), 1000)
-                top = torch.topk(sc[keep], k).indices
-                keep = keep[top]
-                total_scores.append(sc[keep])
-                total_labels.append((keep % K).to(torch.int32))
-                total_boxes.append(boxes_all[(o // K) + keep // K])
-            o += n
-        return post_process_with_empty_input(total_boxes, total_scores, total_labels, pre["img_info"],
-                                             iou_threshold=self.cfg.TEST.IOU_THRESHOLD,
-                                             max_detections_per_image=self.cfg.TEST.MAX_BOXES_PER_IMAGE)
+        rows = pl.pyr.pix_per_img * A                               # anchors
+        scores = torch.empty((rows * K,), dtype=torch.float32, device=self.device)
+        ops.det_scores(pl.logits, rows, K, scores)                  # F.sigmoid(F.flatten(logits)) (:184)
+        return self._detect(scores, [h * w * A for h, w in pl.sizes], K, 0, pre["img_info"], anchors=pl.anchors, offsets=pl.offsets,
+                            off_ld=self.box_ld, A=A, mean=m.BOX_REG.MEAN, std=m.BOX_REG.STD)

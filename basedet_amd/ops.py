@@ -317,6 +317,29 @@ def rcnn_loss_fwd_bwd(raw, ld, K, box_off, labels, targets, R, beta, num_samples
                                    ptr(loss2), ptr(draw), stream_ptr()), "bd_rcnn_loss_fwd_bwd")
 
 
+# ---- inference post-processing ----------------------------------------------------------------------------
+def det_scores(logits, rows, K, scores, ctr=None, ctr_ld=1, ctr_off=0):
+    check(L().bd_det_scores(ptr(logits), ptr(ctr), ctr_ld, ctr_off, rows, K, ptr(scores), stream_ptr()), "bd_det_scores")
+
+
+def rcnn_predict(raw, ld, K, box_off, rois, num_rois, rois_per_img, mean, std, scores, boxes):
+    R = raw.shape[0]
+    check(L().bd_rcnn_predict(ptr(raw), ld, K, box_off, ptr(rois), ptr(num_rois), rois_per_img, R, f32arr(mean), f32arr(std),
+                              ptr(scores), ptr(boxes), stream_ptr()), "bd_rcnn_predict")
+
+
+def det_candidates(mode, topk_idx, topk_score, topk_cnt, Ln, k, lvl_row_off, K, anchors, offsets, off_ld, A, mean, std, item_boxes,
+                   boxes, scores, labels):
+    check(L().bd_det_candidates(mode, ptr(topk_idx), ptr(topk_score), ptr(topk_cnt), Ln, k, i32arr(lvl_row_off), K, ptr(anchors),
+                                ptr(offsets), off_ld, A, f32arr(mean), f32arr(std), ptr(item_boxes), ptr(boxes), ptr(scores),
+                                ptr(labels), stream_ptr()), "bd_det_candidates")
+
+
+def det_finalize(boxes, scores, labels, keep, num_keep, max_out, im_info, out_boxes, out_scores, out_labels):
+    check(L().bd_det_finalize(ptr(boxes), ptr(scores), ptr(labels), ptr(keep), ptr(num_keep), max_out, ptr(im_info), ptr(out_boxes),
+                              ptr(out_scores), ptr(out_labels), stream_ptr()), "bd_det_finalize")
+
+
 # ---- losses -----------------------------------------------------------------------------------------------
 def focal_loss_fwd_bwd(logits, labels, rows, K, alpha, gamma, norm, grad_scale, loss_sum, dlogits):
     check(L().bd_focal_loss_fwd_bwd(ptr(logits), ptr(labels), rows, K, float(alpha), float(gamma), ptr(norm),

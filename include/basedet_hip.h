@@ -347,6 +347,35 @@ int bd_rcnn_loss_fwd_bwd(const void* raw, int ld, int K, int box_off, const int3
                          float beta, const int32_t* num_samples, float* loss2, void* draw, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Inference post-processing (retinanet.py:172-209, fcos.py:181-216, rcnn.py:84-93, post_processing.py:50-103):
+ * bd_det_scores -> bd_segment_topk(min_score = TEST.CLS_THRESHOLD) -> bd_det_candidates -> bd_nms_batched ->
+ * bd_det_finalize.  One image per call, like the reference.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* scores[r*K + k] = sigmoid(logits[r*K + k]), or sqrt(sigmoid(logit) * sigmoid(ctr[r*ctr_ld + ctr_off])) when ctr != NULL
+ * (fcos.py:194).  logits/ctr bf16, scores fp32. */
+int bd_det_scores(const void* logits, const void* ctr, int ctr_ld, int ctr_off, int64_t rows, int K, float* scores,
+                  bd_stream_t stream);
+/* RCNN test branch (rcnn.py:84-93): scores [R][K] = softmax(logits)[:, 1:] (-inf for empty RoI slots),
+ * boxes [R][K][4] = BoxCoder.decode(roi, deltas of class k).  raw: bf16 [R][ld] as in bd_rcnn_loss_fwd_bwd. */
+int bd_rcnn_predict(const void* raw, int ld, int K, int box_off, const float* rois, const int32_t* num_rois,
+                    int rois_per_img, int R, const float* mean4_host, const float* std4_host, float* scores, float* boxes,
+                    bd_stream_t stream);
+/* Candidate list from the per-level top-k (topk_* as written by bd_segment_topk with B = 1, nseg = L): item index i of
+ * level l -> label = i % K, row = lvl_row_off[l] + i / K.  mode 0: box = BoxCoder.decode(anchors[row], offsets of row)
+ * with offsets bf16 at (row / A)*off_ld + (row % A)*4; mode 1: anchors are points [rows][2], box = PointCoder.decode;
+ * mode 2: box = item_boxes[row*K + label].  Outputs [L*k] (score -inf past the per-level count). */
+int bd_det_candidates(int mode, const int32_t* topk_idx, const float* topk_score, const int32_t* topk_cnt, int L, int k,
+                      const int32_t* lvl_row_off_host, int K, const float* anchors, const void* offsets, int off_ld, int A,
+                      const float* mean4_host, const float* std4_host, const float* item_boxes, float* boxes, float* scores,
+                      int32_t* labels, bd_stream_t stream);
+/* post_processing.py:93-101: out[j] = candidate keep[j] scaled by (im_info[2]/im_info[0], im_info[3]/im_info[1]) and
+ * clipped to (im_info[2], im_info[3]); slots past num_keep[0]: zero box, label -1. */
+int bd_det_finalize(const float* boxes, const float* scores, const int32_t* labels, const int32_t* keep,
+                    const int32_t* num_keep, int max_out, const float* im_info, float* out_boxes, float* out_scores,
+                    int32_t* out_labels, bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Optimizer (megengine.optimizer.SGD as configured at solver/default_solver.py:96-114).
  * g' = g*grad_scale + wd*w ; v = momentum*v + g' ; w -= lr*v   (all fp32, n elements)
  * ------------------------------------------------------------------------------------------------------- */

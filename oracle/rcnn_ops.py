@@ -256,3 +256,34 @@ def rcnn_losses(logits, deltas, labels, targets, beta=0.0):
     else:
         l = np.where(np.abs(d) < beta, 0.5 * d * d / beta, np.abs(d) - 0.5 * beta)
     return cls, float(l.sum() / max(R, 1))
+
+
+# --------------------------------------------------------------------------------------------
+# inference post-processing (models/det/retinanet.py:172-209, fcos.py:181-216, layers/common/post_processing.py:50-103)
+# --------------------------------------------------------------------------------------------
+def sigmoid(x):
+    x = np.asarray(x, F32)
+    return (F32(1) / (F32(1) + np.exp(-x).astype(F32))).astype(F32)
+
+
+def detect_postprocess(scores_per_level, boxes_per_level, num_classes, im_info, cls_threshold=0.05, iou_threshold=0.5,
+                       max_detections=100, topk=1000):
+    """scores_per_level[l]: flat (rows_l * K,) scores; boxes_per_level[l]: (rows_l, 4) decoded boxes -- or (rows_l * K, 4)
+    per-item boxes (RCNN).  Returns (boxes, scores, labels) after NMS, rescaled to the original image and clipped."""
+    tb, ts, tl = [], [], []
+    for sc, bx in zip(scores_per_level, boxes_per_level):
+        idx, top = topk_desc(sc, topk, cls_threshold)
+        if len(idx) == 0:
+            continue
+        ts.append(top)
+        tl.append((idx % num_classes).astype(np.int32))
+        bx = np.asarray(bx, F32)
+        tb.append(bx[idx] if bx.shape[0] == len(sc) else bx[idx // num_classes])
+    if not tb:
+        return np.zeros((0, 4), F32), np.zeros((0,), F32), np.zeros((0,), np.int32)
+    boxes = np.concatenate(tb); scores = np.concatenate(ts); labels = np.concatenate(tl)
+    keep = B.batched_nms(boxes, scores, labels, iou_threshold, max_detections)
+    info = np.asarray(im_info, F32).reshape(-1)
+    out = B.box_scale(boxes[keep], (F32(info[2] / info[0]), F32(info[3] / info[1])))
+    out = B.box_clip(out, info[2:4])
+    return out, scores[keep], labels[keep]

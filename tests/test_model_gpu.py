@@ -124,13 +124,101 @@ def test_minimize_runs_and_loss_decreases():
     assert v < first, (first, v)
 
 
-def test_inference_smoke():
+def _level_split(t, sizes, per_pixel):
+    out, o = [], 0
+    for (h, w) in sizes:
+        n = h * w * per_pixel
+        out.append(t[o:o + n]); o += n
+    return out
+
+
+def test_retinanet_inference_matches_oracle():
+    """retinanet.py:172-209 on the HIP kernels (scores, per-level top-k, decode, NMS, rescale) against the numpy restatement
+    evaluated on the same bf16 logits / offsets."""
     from basedet_amd.models import RetinaNet
+    from oracle import box_ops as ob, rcnn_ops as orc
     cfg, params, batch = _setup("resnet18", 1, (128, 160), seed=5)
+    params["head.cls_score.bias"] = np.full_like(params["head.cls_score.bias"], -2.5)      # scores around the 0.05 threshold
+    params["head.cls_score.weight"] = params["head.cls_score.weight"] * 8
+    params["head.bbox_pred.weight"] = params["head.bbox_pred.weight"] * 8
+    batch["im_info"][0, 2:4] = (100, 141)                                                    # a rescale different from 1
     model = RetinaNet(cfg, params=params).eval()
     out = model({"data": batch["data"], "im_info": batch["im_info"]})
     assert set(out.keys()) == {"boxes", "box_scores", "box_labels"}
-    assert out["boxes"].shape[0] <= cfg.TEST.MAX_BOXES_PER_IMAGE
+    pl = model._plan(1, 128, 160)
+    K, A = model.num_classes, model.num_anchors
+    logits = pl.logits.float().cpu().numpy().reshape(-1)
+    offs = pl.offsets.float().cpu().numpy()[:, : A * 4].reshape(-1, 4)
+    boxes_all = ob.box_decode(pl.anchors.cpu().numpy(), offs)
+    sc_l = _level_split(orc.sigmoid(logits), pl.sizes, A * K)
+    bx_l = _level_split(boxes_all, pl.sizes, A)
+    rb, rs, rl = orc.detect_postprocess(sc_l, bx_l, K, batch["im_info"][0], cfg.TEST.CLS_THRESHOLD, cfg.TEST.IOU_THRESHOLD,
+                                        cfg.TEST.MAX_BOXES_PER_IMAGE)
+    assert len(rs) > 10
+    assert out["boxes"].shape[0] == len(rs)
+    assert np.array_equal(out["box_labels"].cpu().numpy(), rl)
+    np.testing.assert_allclose(out["box_scores"].cpu().numpy(), rs, rtol=1e-5)
+    np.testing.assert_allclose(out["boxes"].float().cpu().numpy(), rb, rtol=1e-5, atol=1e-3)
+
+
+def test_fcos_inference_matches_oracle():
+    from basedet_amd.configs import FCOSConfig
+    from basedet_amd.models import FCOS, params as P
+    from basedet_amd.utils import DummyLoader
+    from oracle import box_ops as ob, rcnn_ops as orc
+    cfg = FCOSConfig()
+    cfg.MODEL.BATCHSIZE = 1
+    params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.25)
+    params["head.cls_score.bias"] = np.full_like(params["head.cls_score.bias"], -1.0)
+    params["head.cls_score.weight"] = params["head.cls_score.weight"] * 8
+    params["head.bbox_pred.bias"] = np.full_like(params["head.bbox_pred.bias"], 1.5)
+    batch = next(DummyLoader(1, (128, 160), seed=0))
+    batch["data"] = (batch["data"] * 255).astype(np.float32)
+    model = FCOS(cfg, params=params).eval()
+    out = model({"data": batch["data"], "im_info": batch["im_info"]})
+    pl = model._plan(1, 128, 160)
+    K = model.num_classes
+    logits = pl.logits.float().cpu().numpy()
+    ctr = pl.raw.float().cpu().numpy()[:, 4:5]
+    scores = np.sqrt(orc.sigmoid(logits) * orc.sigmoid(ctr)).astype(np.float32).reshape(-1)
+    boxes_all = ob.point_decode(pl.points.cpu().numpy(), pl.offsets.float().cpu().numpy())
+    rb, rs, rl = orc.detect_postprocess(_level_split(scores, pl.sizes, K), _level_split(boxes_all, pl.sizes, 1), K, batch["im_info"][0],
+                                        cfg.TEST.CLS_THRESHOLD, cfg.TEST.IOU_THRESHOLD, cfg.TEST.MAX_BOXES_PER_IMAGE)
+    assert len(rs) > 10
+    assert out["boxes"].shape[0] == len(rs)
+    assert np.array_equal(out["box_labels"].cpu().numpy(), rl)
+    np.testing.assert_allclose(out["box_scores"].cpu().numpy(), rs, rtol=1e-5)
+    np.testing.assert_allclose(out["boxes"].float().cpu().numpy(), rb, rtol=1e-5, atol=1e-3)
+
+
+def test_faster_rcnn_inference_matches_oracle():
+    """faster_rcnn.py:98-131: proposals (test top-k) -> box head on every proposal -> softmax / per-class decode -> threshold
+    -> NMS; the oracle restates the post-processing on the box-head outputs of the HIP run."""
+    from basedet_amd.models import FasterRCNN
+    from oracle import box_ops as ob, rcnn_ops as orc
+    cfg, params, batch = _frcnn_setup(1, (128, 160), seed=2)
+    params["rcnn.pred_cls.weight"] = params["rcnn.pred_cls.weight"] * 5      # confident but unsaturated softmax scores
+    model = FasterRCNN(cfg, params=params).eval()
+    out = model({"data": batch["data"], "im_info": batch["im_info"]})
+    pl = model._cur
+    K = model.num_classes
+    R = pl.rois.shape[1]
+    nr = int(pl.num_rois[0].item())
+    assert 0 < nr <= R
+    raw = pl.inf["raw"].float().cpu().numpy()
+    rois = pl.rois[0].cpu().numpy()
+    lg = raw[:nr, : K + 1].astype(np.float32)
+    e = np.exp(lg - lg.max(axis=1, keepdims=True)).astype(np.float32)
+    scores = (e / e.sum(axis=1, keepdims=True))[:, 1:].astype(np.float32)
+    deltas = raw[:nr, K + 1: K + 1 + 4 * K].reshape(nr * K, 4)
+    boxes = ob.box_decode(np.repeat(rois[:nr], K, axis=0), deltas, cfg.MODEL.RCNN_BOX_REG.MEAN, cfg.MODEL.RCNN_BOX_REG.STD)
+    rb, rs, rl = orc.detect_postprocess([scores.reshape(-1)], [boxes], K, batch["im_info"][0], cfg.TEST.CLS_THRESHOLD,
+                                        cfg.TEST.IOU_THRESHOLD, cfg.TEST.MAX_BOXES_PER_IMAGE, topk=2048)
+    assert len(rs) > 5
+    assert out["boxes"].shape[0] == len(rs)
+    assert np.array_equal(out["box_labels"].cpu().numpy(), rl)
+    np.testing.assert_allclose(out["box_scores"].cpu().numpy(), rs, rtol=1e-4)
+    np.testing.assert_allclose(out["boxes"].float().cpu().numpy(), rb, rtol=1e-4, atol=1e-2)
 
 
 def test_fcos_training_step_matches_oracle():
