@@ -724,6 +724,125 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// deterministic RoIAlign backward: per (image, level) RoI lists, then one workgroup per 8x8 pixel tile gathers the
+// contributions of every RoI sample whose bilinear footprint touches the tile.  One thread per channel owns a private
+// column of the LDS accumulator, so there are no atomics and the summation order is fixed (list order = slot order).
+// The result is written as bf16 straight into the feature-gradient pyramid (every level, zeros where no RoI lands).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void roi_level_lists_kernel(const float* __restrict__ rois, const int* __restrict__ labels, int S,
+                                                               RoiLevels lv, int* __restrict__ lists, int* __restrict__ counts) {
+    __shared__ int wcnt[16];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int l = 0; l < lv.L; ++l) {
+        int base = 0;
+        for (int s0 = 0; s0 < S; s0 += 1024) {
+            const int slot = s0 + tid;
+            bool flag = false;
+            if (slot < S) {
+                const int r = n * S + slot;
+                if (!labels || labels[r] >= 0) flag = roi_level(ld_box(rois + r * 4ll), lv) == l;
+            }
+            int tot;
+            const int rank = block_rank_1024(flag, wcnt, tot);
+            if (flag) lists[((long long)n * lv.L + l) * S + base + rank] = slot;
+            base += tot;
+        }
+        if (tid == 0) counts[n * lv.L + l] = base;
+    }
+}
+
+constexpr int RT = 8;     // tile side in pixels
+struct PyrTiles { int pix_off[BD_MAX_SEGS]; int H[BD_MAX_SEGS]; int W[BD_MAX_SEGS]; int tile_start[BD_MAX_SEGS + 1]; int tiles_x[BD_MAX_SEGS]; int L; };
+
+__device__ __forceinline__ void sample_range(float lo, float hi, float start, float step, int nsamp, int& j0, int& j1) {
+    j0 = 0; j1 = nsamp - 1;
+    if (step > 1e-6f) {
+        const float a = (lo - start) / step - 0.5f, b = (hi - start) / step - 0.5f;
+        if (a == a && b == b) {
+            const float fa = floorf(a) - 1.f, fb = ceilf(b) + 1.f;
+            if (fa > (float)j0) j0 = fa > (float)nsamp ? nsamp : (int)fa;
+            if (fb < (float)j1) j1 = fb < -1.f ? -1 : (int)fb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv,
+                                                                   PyrTiles pt, const float* __restrict__ rois, int S, int PH, int PW,
+                                                                   int SP, const int* __restrict__ lists,
+                                                                   const int* __restrict__ counts, bf16_raw* __restrict__ gfeat) {
+    __shared__ float acc[RT * RT * 256];
+    const int tid = threadIdx.x;
+    const int tiles_per_img = pt.tile_start[pt.L];
+    const int n = blockIdx.x / tiles_per_img;
+    const int t = blockIdx.x - n * tiles_per_img;
+    int la = 0;
+    for (int q = 1; q < pt.L; ++q) if (t >= pt.tile_start[q]) la = q;
+    const int tt = t - pt.tile_start[la];
+    const int ty0 = (tt / pt.tiles_x[la]) * RT, tx0 = (tt % pt.tiles_x[la]) * RT;
+    const int H = pt.H[la], W = pt.W[la];
+    const int nb = PH * PW;
+    const float inv = 1.f / (float)(SP * SP);
+    const int cnt = la < lv.L ? counts[n * lv.L + la] : 0;
+    const int* lst = lists + ((long long)n * lv.L + (la < lv.L ? la : 0)) * S;
+    const float sc = la < lv.L ? lv.scale[la] : 1.f;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + tid;
+        const bool cok = c < C;
+#pragma unroll
+        for (int p = 0; p < RT * RT; ++p) acc[p * 256 + tid] = 0.f;
+        for (int q = 0; q < cnt; ++q) {
+            const int slot = lst[q];
+            const long long r = (long long)n * S + slot;
+            const Box b = ld_box(rois + r * 4);
+            const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
+            const float rw = (b.x2 * sc - 0.5f) - sw, rh = (b.y2 * sc - 0.5f) - sh_;
+            // cheap cull first: the sample footprint [start - 1, start + extent + 1] against the tile (degenerate or reversed
+            // boxes have all samples inside [min, max] of the two ends)
+            const float fx0 = fminf(sw, sw + rw) - 1.f, fx1 = fmaxf(sw, sw + rw) + 1.f;
+            const float fy0 = fminf(sh_, sh_ + rh) - 1.f, fy1 = fmaxf(sh_, sh_ + rh) + 1.f;
+            if (fx1 < (float)tx0 || fx0 > (float)(tx0 + RT) || fy1 < (float)ty0 || fy0 > (float)(ty0 + RT)) {
+                // rows / columns clamped into the map (y <= 0 -> row 0, y >= H-1 -> row H-1) still lie within one pixel of the
+                // footprint unless the footprint is outside the map, where only the border tiles can be touched
+                const bool border = (ty0 == 0 && fy1 >= -1.f) || (ty0 + RT >= H && fy0 <= (float)H) || (tx0 == 0 && fx1 >= -1.f) ||
+                                    (tx0 + RT >= W && fx0 <= (float)W);
+                if (!border) continue;
+            }
+            const float bw = rw / (float)PW, bh = rh / (float)PH;
+            int jy0, jy1, jx0, jx1;
+            sample_range((float)(ty0 - 1), (float)(ty0 + RT), sh_, bh / (float)SP, PH * SP, jy0, jy1);
+            sample_range((float)(tx0 - 1), (float)(tx0 + RT), sw, bw / (float)SP, PW * SP, jx0, jx1);
+            if (jy0 > jy1 || jx0 > jx1) continue;
+            const bf16_raw* go = gout + r * nb * C + c;
+            for (int jy = jy0; jy <= jy1; ++jy) {
+                const int ph = jy / SP, iy = jy - ph * SP;
+                const float y = sh_ + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)SP;
+                for (int jx = jx0; jx <= jx1; ++jx) {
+                    const int pw = jx / SP, ix = jx - pw * SP;
+                    const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)SP;
+                    const Bilinear bl = bilinear_setup(y, x, H, W);
+                    if (!bl.ok) continue;
+                    const int ya = bl.y0 - ty0, yb = bl.y1 - ty0, xa = bl.x0 - tx0, xb = bl.x1 - tx0;
+                    const bool ya_in = (unsigned)ya < RT, yb_in = (unsigned)yb < RT, xa_in = (unsigned)xa < RT, xb_in = (unsigned)xb < RT;
+                    if (!((ya_in || yb_in) && (xa_in || xb_in))) continue;
+                    const float g = cok ? bf2f(go[(long long)(ph * PW + pw) * C]) * inv : 0.f;
+                    if (ya_in && xa_in) acc[(ya * RT + xa) * 256 + tid] += bl.w00 * g;
+                    if (ya_in && xb_in) acc[(ya * RT + xb) * 256 + tid] += bl.w01 * g;
+                    if (yb_in && xa_in) acc[(yb * RT + xa) * 256 + tid] += bl.w10 * g;
+                    if (yb_in && xb_in) acc[(yb * RT + xb) * 256 + tid] += bl.w11 * g;
+                }
+            }
+        }
+        if (cok) {
+            bf16_raw* gp = gfeat + ((long long)n * ppi + pt.pix_off[la]) * C + c;
+            for (int p = 0; p < RT * RT; ++p) {
+                const int y = ty0 + p / RT, x = tx0 + p % RT;
+                if (y < H && x < W) gp[((long long)y * W + x) * C] = f2bf(acc[p * 256 + tid]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // FPNP6 (fpn_backbone.py:172-183): max_pool2d(kernel 1, stride 2) == take every other pixel
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void subsample_fwd_kernel(const bf16_raw* __restrict__ src, long long src_ppi, long long src_off,
@@ -1044,5 +1163,43 @@ extern "C" int bd_f32_to_bf16(const float* src, void* dst, int64_t n, bd_stream_
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (bf16_raw*)dst, (long long)(n / 8));
     BD_CHECK_LAUNCH("bd_f32_to_bf16");
+    return BD_OK;
+}
+
+extern "C" size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L, int rois_per_img) {
+    if (N <= 0 || L <= 0 || rois_per_img <= 0) return 256;
+    return align256((size_t)N * L * rois_per_img * 4) + align256((size_t)N * L * 4);
+}
+
+extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int C, int L, int L_all, const int32_t* lvl_pix_off_host,
+                                     const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
+                                     const float* rois, const int32_t* labels, int N, int rois_per_img, int PH, int PW,
+                                     int sample_points, void* gfeat, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(gout && lvl_pix_off_host && lvl_h_host && lvl_w_host && strides_host && rois && gfeat && ws, "roi_align_bwd_bf16: null pointer");
+    BD_REQUIRE(L > 0 && L <= L_all && L_all <= BD_MAX_SEGS && C > 0 && PH > 0 && PW > 0 && sample_points > 0 && rois_per_img > 0 && N > 0,
+               "roi_align_bwd_bf16: bad sizes");
+    if (ws_bytes < bd_roi_align_bwd_bf16_workspace_bytes(N, L, rois_per_img)) {
+        bd_set_error("roi_align_bwd_bf16: workspace %zu < %zu bytes", ws_bytes, bd_roi_align_bwd_bf16_workspace_bytes(N, L, rois_per_img));
+        return BD_EWORKSPACE;
+    }
+    RoiLevels lv{};
+    BD_REQUIRE(fill_roi_levels(lv, L, lvl_pix_off_host, lvl_h_host, lvl_w_host, strides_host) == 0, "roi_align_bwd_bf16: strides must be powers of two");
+    PyrTiles pt{};
+    pt.L = L_all;
+    int ts = 0;
+    for (int l = 0; l < L_all; ++l) {
+        pt.pix_off[l] = lvl_pix_off_host[l]; pt.H[l] = lvl_h_host[l]; pt.W[l] = lvl_w_host[l];
+        pt.tiles_x[l] = cdiv(lvl_w_host[l], RT);
+        pt.tile_start[l] = ts;
+        ts += pt.tiles_x[l] * cdiv(lvl_h_host[l], RT);
+    }
+    pt.tile_start[L_all] = ts;
+    int* lists = (int*)ws;
+    int* counts = (int*)((unsigned char*)ws + align256((size_t)N * L * rois_per_img * 4));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(roi_level_lists_kernel, dim3(N), dim3(1024), 0, st, rois, labels, rois_per_img, lv, lists, counts);
+    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3(N * ts), dim3(256), 0, st, (const bf16_raw*)gout, (long long)pix_per_img, C, lv,
+                       pt, rois, rois_per_img, PH, PW, sample_points, lists, counts, (bf16_raw*)gfeat);
+    BD_CHECK_LAUNCH("bd_roi_align_bwd_bf16");
     return BD_OK;
 }

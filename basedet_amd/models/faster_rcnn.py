@@ -73,6 +73,7 @@ class FasterRCNN(FPNDetector):
             self.base_anchors.append(torch.tensor(base, dtype=torch.float32, device=dev))
         self.pre_k = {True: m.RPN.TRAIN_PREV_NMS_TOPK, False: m.RPN.TEST_PREV_NMS_TOPK}
         self.post_k = {True: m.RPN.TRAIN_POST_NMS_TOPK, False: m.RPN.TEST_POST_NMS_TOPK}
+        self.deterministic_roi_bwd = False
         self._gen = torch.Generator(device=dev) if self.device.type == "cuda" else None
         if self._gen is not None:
             self._gen.manual_seed(0)
@@ -137,6 +138,7 @@ class FasterRCNN(FPNDetector):
         pl.g_fc1 = torch.empty((R, 1024), **bf)
         pl.g_pooled = torch.empty((R, fin), **bf)
         pl.g_feat32 = torch.zeros((pyr.pixels, ch), **f32)
+        pl.roi_bwd_ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(N, self.rcnn_levels, S),), dtype=torch.uint8, device=dev)
         pl.g_fc = ops.single(1, R, 1)
         pl.loss_buf = torch.zeros((4,), **f32)
 
@@ -223,10 +225,15 @@ class FasterRCNN(FPNDetector):
         self.fc2.dgrad(pl.g_fc2, g, g, pl.g_fc1, mask=pl.fc1_out)
         self._wgrad(self.fc1, pl.pooled, pl.g_fc1, g, g, ws, cws)
         self.fc1.dgrad(pl.g_fc1, g, g, pl.g_pooled)
-        pl.g_feat32.zero_()
-        ops.roi_align_bwd(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
-                          self.pool, 2, pl.g_feat32)
-        ops.f32_to_bf16(pl.g_feat32, pl.g_P)                        # first contribution to dL/dP (P6 rows are zero)
+        # first contribution to dL/dP: every pyramid level is written (zeros where no RoI sample lands, all of P6)
+        if self.deterministic_roi_bwd:      # gather kernel: fixed summation order, ~2x slower than the atomic scatter
+            ops.roi_align_bwd_bf16(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4),
+                                   pl.s_labels.view(-1), S, self.pool, 2, pl.g_P, pl.roi_bwd_ws)
+        else:
+            pl.g_feat32.zero_()
+            ops.roi_align_bwd(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
+                              self.pool, 2, pl.g_feat32)
+            ops.f32_to_bf16(pl.g_feat32, pl.g_P)
         # RPN head
         self._wgrad(self.rpn_pred, pl.rpn_t, pl.d_rpn_raw, pyr, pyr, ws, cws)
         self.rpn_pred.dgrad(pl.d_rpn_raw, pyr, pyr, pl.g_rpn_t, mask=pl.rpn_t)

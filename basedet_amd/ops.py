@@ -293,6 +293,16 @@ def roi_align_bwd(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_im
                                pool[1], sample_points, ptr(gfeat), stream_ptr()), "bd_roi_align_bwd")
 
 
+def roi_align_bwd_bf16_workspace_bytes(N, nlev, rois_per_img):
+    return int(L().bd_roi_align_bwd_bf16_workspace_bytes(N, nlev, rois_per_img))
+
+
+def roi_align_bwd_bf16(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_img, pool, sample_points, gfeat, ws):
+    check(L().bd_roi_align_bwd_bf16(ptr(gout), geom.pix_per_img, Cn, nlev, geom.nlev, i32arr(geom.off), i32arr(geom.H), i32arr(geom.W),
+                                    i32arr(strides[:nlev]), ptr(rois), ptr(labels), geom.N, rois_per_img, pool[0], pool[1], sample_points,
+                                    ptr(gfeat), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_roi_align_bwd_bf16")
+
+
 def subsample2x_fwd(src, gsrc: Geom, dst, gdst: Geom, Cn):
     check(L().bd_subsample2x_fwd(ptr(src), gsrc.pix_per_img, gsrc.off[0], gsrc.H[0], gsrc.W[0], ptr(dst), gdst.pix_per_img,
                                  gdst.off[0], Cn, gsrc.N, stream_ptr()), "bd_subsample2x_fwd")

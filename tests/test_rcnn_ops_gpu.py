@@ -273,6 +273,19 @@ def test_roi_align_fwd_bwd():
         np.testing.assert_allclose(gg[:, o:o + h * w].reshape(N, h, w, C), refg[l], rtol=1e-4, atol=1e-4)
         o += h * w
     assert np.all(gg[:, o:] == 0)
+    # deterministic gather variant: bf16 output over the whole pyramid, bitwise reproducible
+    gbf = torch.full((N * ppi, C), 7.0, dtype=torch.bfloat16, device="cuda")
+    ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(N, nlev, rpi),), dtype=torch.uint8, device="cuda")
+    ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gbf, ws)
+    g1 = gbf.float().cpu().numpy().reshape(N, ppi, C)
+    o = 0
+    for l, (h, w) in enumerate(sizes[:nlev]):
+        np.testing.assert_allclose(g1[:, o:o + h * w].reshape(N, h, w, C), refg[l], rtol=2 ** -7, atol=1e-3)
+        o += h * w
+    assert np.all(g1[:, o:] == 0)
+    gbf2 = torch.empty_like(gbf)
+    ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gbf2, ws)
+    assert torch.equal(gbf, gbf2)
 
 
 def test_subsample_and_convert():
