@@ -247,11 +247,19 @@ def main():
             timer.dump(sampled)
         if timer:
             entries = []
+            # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the bench):
+            # valid for the workload / batch they were collected on, null otherwise
+            pmc = {}
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if args.workload == "retinanet_r50_800x1344" and args.batch == 16 and os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    pmc = json.load(f).get("kernels", {})
             for kern in timer.records:
                 sm = timer.summary(kern)
                 ach = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
                 entries.append({"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                                "traffic": pmc.get(kern, {}).get("hbm_bytes_per_launch"),
                                 "launches_per_step": sm["launches"] // sampled,
                                 "avg_launch_us": round(sm["ms"] * 1e3 / sm["launches"], 2),
                                 "ms_per_step": round(sm["ms"] / sampled, 3),
