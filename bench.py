@@ -28,6 +28,7 @@ TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): 
     "retinanet_r50_800x1344": 1435.6,
     "retinanet_r18_512x512": 277.2,
     "fcos_r50_800x1344": 1227.8,
+    "retinanet_r101_800x1344": 1912.8,
     # Faster R-CNN R50-FPN (P2-P6): fwd 208.9 GMAC/img (backbone 87.6, FPN 60.9, RPN 53.1, box head 512 RoIs x 14.3 MMAC = 7.3);
     # stem + layer1 frozen, lateral2 needs no dgrad
     "faster_rcnn_r50_800x1344": 1177.2,
@@ -165,6 +166,9 @@ def main():
         cfg, size = RetinaNetConfig(), (800, 1344)
     elif args.workload == "fcos_r50_800x1344":
         cfg, size = FCOSConfig(), (800, 1344)
+    elif args.workload == "retinanet_r101_800x1344":
+        cfg, size = RetinaNetConfig(), (800, 1344)
+        cfg.MODEL.BACKBONE.NAME = "resnet101"
     elif args.workload == "faster_rcnn_r50_800x1344":
         cfg, size = FasterRCNNConfig(), (800, 1344)
     else:
