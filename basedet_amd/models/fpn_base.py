@@ -92,12 +92,6 @@ class FPNDetector:
 
         # stem (frozen when FREEZE_AT >= 1; the dedicated 7x7 kernel is forward-only)
         assert self.freeze_at >= 1, "the 7x7 stem kernel is forward-only: FREEZE_AT must be >= 1 (reference default 2)"
-        self.stem_w = torch.from_numpy(params[bu + ".conv1.weight"]).permute(0, 2, 3, 1).contiguous().to(dev)
-        g, b = params[bu + ".bn1.weight"], params[bu + ".bn1.bias"]
-        mu, var = params[bu + ".bn1.running_mean"], params[bu + ".bn1.running_var"]
-        sc = g / np.sqrt(var + 1e-5)
-        self.stem_scale = torch.from_numpy(sc.astype(np.float32)).to(dev)
-        self.stem_shift = torch.from_numpy((b - mu * sc).astype(np.float32)).to(dev)
         self.stem_packed = torch.empty((64, 7, 8, 4), dtype=torch.bfloat16, device=dev)
 
         for blk in self.blocks:
@@ -133,10 +127,28 @@ class FPNDetector:
         for c in list(self.convs.values()) + list(self.vparams.values()):
             c.reserve(self.arena)
         self.arena.allocate()
+        self._bind_params(params)
+
+    def _bind_params(self, params):
+        """(Re)load every parameter from a reference-layout dict (name -> numpy) and refresh the packed bf16 copies."""
+        dev = self.device
+        bu = "backbone.bottom_up"
+        self.stem_w = torch.from_numpy(np.asarray(params[bu + ".conv1.weight"], np.float32)).permute(0, 2, 3, 1).contiguous().to(dev)
+        g, b = params[bu + ".bn1.weight"], params[bu + ".bn1.bias"]
+        mu, var = params[bu + ".bn1.running_mean"], params[bu + ".bn1.running_var"]
+        sc = g / np.sqrt(var + 1e-5)
+        self.stem_scale = torch.from_numpy(sc.astype(np.float32)).to(dev)
+        self.stem_shift = torch.from_numpy((b - mu * sc).astype(np.float32)).to(dev)
         for c in list(self.convs.values()) + list(self.vparams.values()):
             c.bind(self.arena, params)
-        self._bn_params = {k: v.copy() for k, v in params.items() if (".bn" in k or "downsample.1" in k)}
+        self._bn_params = {k: np.asarray(v, np.float32).copy() for k, v in params.items() if (".bn" in k or "downsample.1" in k)}
         self.repack_weights()
+
+    def load_weights(self, weights, strict=False):
+        """BaseNet.load_weights (models/base_net.py:83-89) -> utils/checkpoint.py load_matched_weights: `weights` is a dict
+        or the path of a .pkl / .npz checkpoint; names are matched exactly, then by suffix, then by shape."""
+        from ..utils.checkpoint import load_matched_weights
+        return load_matched_weights(self, weights, strict)
 
     def repack_weights(self):
         """Refresh the bf16 packed copies from the fp32 masters (after load_weights / every optimizer step)."""

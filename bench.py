@@ -68,7 +68,11 @@ class ConvTimer:
                 e.record()
                 kern = kernel_of(d, kind)
                 self.records.setdefault(kern, []).append((s, e, flops(d)))
-                self.meta.setdefault(kern, []).append((fn.__name__, d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0]))
+                # lower bound of the HBM bytes: both activations once + weights (epilogue add / mask operands not counted)
+                mi = sum(d.Hi[i] * d.Wi[i] for i in range(d.nseg)) * d.N
+                mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
+                nbytes = 2.0 * (mi * d.Cin + mo * d.Cout) + (4.0 if kind == "wgrad" else 2.0) * d.Cin * d.Cout * d.R * d.S
+                self.meta.setdefault(kern, []).append((fn.__name__, d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
                 return r
             return inner
 
@@ -80,14 +84,15 @@ class ConvTimer:
         agg = {}
         for kind, rec in self.records.items():
             for (s, e, f), m in zip(rec, self.meta.get(kind, [])):
-                k = (kind,) + m
-                a = agg.setdefault(k, [0, 0.0, 0.0])
-                a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f
+                k = (kind,) + m[:8]
+                a = agg.setdefault(k, [0, 0.0, 0.0, 0.0])
+                a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f; a[3] += m[8]
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
         print("# per-shape conv time per step (ms), TFLOP/s", file=sys.stderr)
-        for k, (n, ms, fl) in rows:
+        for k, (n, ms, fl, nb) in rows:
             print(f"# {k[0]:22s} {k[1]:14s} Cin={k[2]:5d} Cout={k[3]:5d} R={k[4]} s={k[5]} nseg={k[6]} HxW={k[7]}x{k[8]} "
-                  f"launches/step={n // steps:3d} ms/step={ms / steps:7.3f} TF/s={fl / (ms * 1e-3) / 1e12:7.1f}", file=sys.stderr)
+                  f"launches/step={n // steps:3d} ms/step={ms / steps:7.3f} TF/s={fl / (ms * 1e-3) / 1e12:7.1f} "
+                  f"minGB/s={nb / (ms * 1e-3) / 1e9:7.0f}", file=sys.stderr)
 
     def summary(self, kind):
         rec = self.records[kind]

@@ -366,3 +366,26 @@ def test_faster_rcnn_minimize_runs():
         assert np.isfinite(v)
         first = v if first is None else first
     assert v < first, (first, v)
+
+
+def test_state_dict_roundtrip_and_load_weights(tmp_path):
+    """state_dict() returns the reference layouts bit-exactly (incl. the permuted fc1 columns and the fused predictors of
+    Faster R-CNN); load_weights (models/base_net.py:83-89) of a saved checkpoint reproduces the losses."""
+    from basedet_amd.models import FasterRCNN, RetinaNet
+    from basedet_amd.utils import save_checkpoint
+    cfg, params, batch = _frcnn_setup(1, (128, 160), seed=4)
+    m = FasterRCNN(cfg, params=params)
+    sd = m.state_dict()
+    for k, v in params.items():
+        assert np.array_equal(sd[k], v), k
+    cfg, params, batch = _setup("resnet18", 2, (128, 160), seed=6)
+    a = RetinaNet(cfg, params=params)
+    ref = {k: float(v) for k, v in a(batch).items()}
+    path = tmp_path / "ck.pkl"
+    save_checkpoint(path, a.state_dict())
+    b = RetinaNet(cfg, seed=9)
+    assert abs(float(b(batch)["total_loss"]) - ref["total_loss"]) > 1e-3
+    b.load_weights(str(path))
+    got = {k: float(v) for k, v in b(batch).items()}
+    for k in ref:                     # loss sums are block-atomic fp32 adds: equal up to summation order
+        assert abs(got[k] - ref[k]) <= 1e-5 * abs(ref[k]), (k, got[k], ref[k])
