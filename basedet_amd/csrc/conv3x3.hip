@@ -46,6 +46,13 @@ struct C3Params {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// DMA = true: the weight tiles go global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass); a
+// wave-instruction writes 1 KiB = 8 swizzled rows, the swizzle is applied on the per-lane SOURCE address.  Needs
+// CK % 64 == 0 (no zero-filled K tail) -- other shapes use the register-staged variant.
+template <bool DMA>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xbuf = smem;                       // [X_BYTES]      (single buffer, swapped between K blocks)
@@ -120,11 +127,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
         w_lds[k] = swz(lrow, tid & 7);
     }
 
+    // DMA pieces of this wave: piece pc = wave + 8k (k = 0..5) -> tap pc / 16, rows 8 (pc % 16) .. +7; lane -> (row, position)
+    int dma_src[WPASSES];
+    if (DMA) {
+#pragma unroll
+        for (int k = 0; k < WPASSES; ++k) {
+            const int pc = wave + 8 * k;
+            const int lrow = 8 * (pc & 15) + (lane >> 3);
+            const int chunk = (lane & 7) ^ (lane >> 3);               // (lrow & 7) == lane >> 3
+            const int rho = lrow & 15;
+            int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
+            if (co >= p.CO) co = p.CO - 1;                             // rows past CO are never stored: any finite data will do
+            dma_src[k] = (co * 9 + (pc >> 4)) * p.CK + chunk * 8;
+        }
+    }
+
     const int kblocks = (p.CK + 63) / 64;
     const int nsteps = kblocks * 3;
-    u32x4_t rw[WPASSES], rx[XPASSES];
+    u32x4_t rw[DMA ? 1 : WPASSES], rx[XPASSES];
+    auto dma_w = [&](int step, int buf, int k) {
+        const int cb = step / 3, r = step - cb * 3;
+        const int pc = wave + 8 * k;
+        const bf16_raw* g = p.w + dma_src[k] + r * 3 * p.CK + cb * 64;
+        unsigned char* l = wbuf + buf * W_BYTES + (pc >> 4) * W_TAP_BYTES + (pc & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+    };
 
     auto load_w = [&](int step) {
+        if (DMA) return;
         const int cb = step / 3, r = step - cb * 3;
         const int c0 = cb * 64 + (tid & 7) * 8;
         const bool cvalid = c0 + 8 <= p.CK;
@@ -139,6 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
             }
     };
     auto write_w_tap = [&](int buf, int t) {
+        if (DMA) return;
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             *reinterpret_cast<u32x4_t*>(wbuf + buf * W_BYTES + t * W_TAP_BYTES + w_lds[k]) = rw[t * 2 + k];
@@ -201,11 +232,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
-    auto compute = [&](int wb, int r, bool write_next) {
+    auto compute = [&](int wb, int r, bool write_next, int next_step) {
         load_frags(wb, r, 0, fa[0], fb[0]);
 #pragma unroll
         for (int u = 0; u < 2 * TAPS_PER_STEP; ++u) {
             if (u + 1 < 2 * TAPS_PER_STEP) load_frags(wb, r, u + 1, fa[(u + 1) & 1], fb[(u + 1) & 1]);
+            if (DMA && write_next && u < 3) {                       // all six pieces in the first half of the step: they land
+                dma_w(next_step, wb ^ 1, 2 * u);                    // under the remaining MFMAs, before the barrier's vmcnt(0)
+                dma_w(next_step, wb ^ 1, 2 * u + 1);
+            }
             mfma16(fa[u & 1], fb[u & 1]);
             if ((u & 1) && write_next) write_w_tap(wb ^ 1, u >> 1);
         }
@@ -213,6 +248,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
 
     // prologue: activation image of K block 0, weights of step 0 (to LDS) and step 1 (in registers)
     load_x(0);
+    if (DMA) {
+#pragma unroll
+        for (int k = 0; k < WPASSES; ++k) dma_w(0, 0, k);
+    }
     load_w(0);
     write_x();
 #pragma unroll
@@ -223,9 +262,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
         const int cb = step / 3, r = step - cb * 3;
         const bool next_x = (r == 2) && (cb + 1 < kblocks);
         if (next_x) load_x(cb + 1);          // in flight under this step's 96 MFMAs
-        compute(step & 1, r, step + 1 < nsteps);
+        compute(step & 1, r, step + 1 < nsteps, step + 1);
         if (step + 2 < nsteps) load_w(step + 2);   // registers are free again: they were stored during this step
-        __syncthreads();
+        __syncthreads();                     // (DMA: the compiler drains vmcnt before the barrier, so the pieces have landed)
         if (next_x) {                        // every wave is done with the old image: swap it
             write_x();
             __syncthreads();
@@ -299,6 +338,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
 
 }  // namespace
 
+int g_patch_dma = 1;      // bd_conv_set_patch3x3 bit 3 clears it (register-staged weights everywhere)
+
 // called from conv_igemm.hip for 3x3 / stride 1 / pad 1 descriptors; mode 0 fwd (src = x, geometry in == out),
 // mode 1 dgrad (src = dY).  CK = reduction channels, CO = produced channels.
 int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias,
@@ -326,9 +367,13 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
     const size_t lds = X_BYTES + 2 * W_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_patch_kernel, dim3(grid), dim3(512), lds, stream, p);
+    if (g_patch_dma && p.CK % 64 == 0)
+        hipLaunchKernelGGL(conv3x3_patch_kernel<true>, dim3(grid), dim3(512), lds, stream, p);
+    else
+        hipLaunchKernelGGL(conv3x3_patch_kernel<false>, dim3(grid), dim3(512), lds, stream, p);
     return 0;
 }
