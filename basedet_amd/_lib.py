@@ -30,6 +30,11 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("row_scale", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
+                ("Cout", C.c_int32), ("RS", C.c_int32), ("Cin", C.c_int32), ("block_start", C.c_int32)]
+
+
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
 
@@ -44,6 +49,8 @@ SIGNATURES = {
     "bd_stem_conv7x7_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "bd_stem_weight_pack": (_I, [_P, _P, _P, _P]),
     "bd_weight_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "bd_weight_pack_blocks": (_I, [_I, _I, _I]),
+    "bd_weight_pack_multi": (_I, [_P, _I, _I, _P]),
     "bd_colsum_workspace_bytes": (_Z, [_I]),
     "bd_colsum_bf16": (_I, [_P, _I, _L, _L, _L, _I, _P, _I, _P, _Z, _P]),
     "bd_pad_normalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

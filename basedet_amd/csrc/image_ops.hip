@@ -253,6 +253,48 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
     }
 }
 
+// many convs in one launch (after every optimizer step): 32 x 32 (co, ci) tiles per tap, transposed through LDS so that both
+// packed copies are written with contiguous runs
+__global__ __launch_bounds__(256) void weight_pack_multi_kernel(const bd_pack_desc* __restrict__ descs, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                       // last descriptor with block_start <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_start <= b) lo = mid; else hi = mid - 1;
+    }
+    const bd_pack_desc d = descs[lo];
+    int t = b - d.block_start;
+    const int ci_tiles = (d.Cin + 31) / 32, co_tiles = (d.Cout + 31) / 32;
+    const int ci_t = t % ci_tiles; t /= ci_tiles;
+    const int co_t = t % co_tiles;
+    const int tap = t / co_tiles;
+    const float* w = d.w;
+    bf16_raw* wf = (bf16_raw*)d.w_fwd;
+    bf16_raw* wd = (bf16_raw*)d.w_dgrad;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co_t * 32 + ty + 8 * r, ci = ci_t * 32 + tx;
+        float v = 0.f;
+        if (co < d.Cout && ci < d.Cin) {
+            const long long i = ((long long)co * d.RS + tap) * d.Cin + ci;
+            v = w[i];
+            if (d.row_scale) v *= d.row_scale[co];
+            if (wf) wf[i] = f2bf(v);
+        }
+        tile[ty + 8 * r][tx] = v;
+    }
+    __syncthreads();
+    if (wd) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = ci_t * 32 + ty + 8 * r, co = co_t * 32 + tx;
+            if (co < d.Cout && ci < d.Cin) wd[((long long)ci * d.RS + tap) * d.Cout + co] = f2bf(tile[tx][ty + 8 * r]);
+        }
+    }
+}
+
 // column sums (bias gradients), atomics-free and reproducible:
 // stage 1: block b sums rows b, b+nblocks*rif, ... into partial[b][C] (16-byte loads, LDS reduce over row lanes);
 // stage 2 sums the partials in block order.
@@ -421,6 +463,15 @@ extern "C" int bd_weight_pack(const float* w, const float* row_scale, void* w_fw
     hipLaunchKernelGGL(weight_pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, row_scale,
                        (bf16_raw*)w_fwd, (bf16_raw*)w_dgrad, Cout, RS, Cin);
     BD_CHECK_LAUNCH("bd_weight_pack");
+    return BD_OK;
+}
+
+extern "C" int bd_weight_pack_blocks(int Cout, int RS, int Cin) { return RS * ((Cout + 31) / 32) * ((Cin + 31) / 32); }
+
+extern "C" int bd_weight_pack_multi(const bd_pack_desc* descs_dev, int n, int total_blocks, bd_stream_t stream) {
+    BD_REQUIRE(descs_dev && n > 0 && total_blocks > 0, "weight_pack_multi: bad arguments");
+    hipLaunchKernelGGL(weight_pack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    BD_CHECK_LAUNCH("bd_weight_pack_multi");
     return BD_OK;
 }
 

@@ -139,6 +139,7 @@ class FPNDetector:
         sc = g / np.sqrt(var + 1e-5)
         self.stem_scale = torch.from_numpy(sc.astype(np.float32)).to(dev)
         self.stem_shift = torch.from_numpy((b - mu * sc).astype(np.float32)).to(dev)
+        self._pack_table = None                 # row_scale tensors are re-created by bind()
         for c in list(self.convs.values()) + list(self.vparams.values()):
             c.bind(self.arena, params)
         self._bn_params = {k: np.asarray(v, np.float32).copy() for k, v in params.items() if (".bn" in k or "downsample.1" in k)}
@@ -157,9 +158,12 @@ class FPNDetector:
             c.pack()
 
     def repack_trainable(self):
-        for c in self.convs.values():
-            if c.trainable:
-                c.pack()
+        """All trainable convs in ONE launch (bd_weight_pack_multi); the table holds raw pointers into the arena and the packed
+        tensors, which never move after _build_layers."""
+        if getattr(self, "_pack_table", None) is None:
+            ent = [(c.w, c.row_scale, c.w_fwd, c.w_dgrad, c.cout, c.k * c.k, c.cin) for c in self.convs.values() if c.trainable]
+            self._pack_table = ops.build_pack_table(ent, self.device)
+        ops.weight_pack_multi(self._pack_table)
 
     # reference module protocol ------------------------------------------------------------------------
     def train(self, mode=True):

@@ -104,6 +104,30 @@ def weight_pack(w, row_scale, w_fwd, w_dgrad, Cout, RS, Cin):
     check(L().bd_weight_pack(ptr(w), ptr(row_scale), ptr(w_fwd), ptr(w_dgrad), Cout, RS, Cin, stream_ptr()), "bd_weight_pack")
 
 
+def build_pack_table(entries, device):
+    """entries: [(w, row_scale | None, w_fwd | None, w_dgrad | None, Cout, RS, Cin)] -> (device byte tensor of bd_pack_desc, n,
+    total blocks).  The tensors must stay alive (and in place) as long as the table is used."""
+    import ctypes as C
+    import numpy as np
+    from ._lib import PackDesc
+    arr = (PackDesc * len(entries))()
+    start = 0
+    for i, (w, rs, wf, wd, co, r, ci) in enumerate(entries):
+        arr[i].w = w.data_ptr()
+        arr[i].row_scale = rs.data_ptr() if rs is not None else None
+        arr[i].w_fwd = wf.data_ptr() if wf is not None else None
+        arr[i].w_dgrad = wd.data_ptr() if wd is not None else None
+        arr[i].Cout, arr[i].RS, arr[i].Cin, arr[i].block_start = co, r, ci, start
+        start += int(L().bd_weight_pack_blocks(co, r, ci))
+    raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+    return torch.from_numpy(raw).to(device), len(entries), start
+
+
+def weight_pack_multi(table):
+    t, n, blocks = table
+    check(L().bd_weight_pack_multi(ptr(t), n, blocks, stream_ptr()), "bd_weight_pack_multi")
+
+
 def colsum_workspace_bytes(Cn):
     return int(L().bd_colsum_workspace_bytes(Cn))
 

@@ -105,6 +105,19 @@ int bd_stem_weight_pack(const float* w /*[64][7][7][3] fp32*/, const float* row_
 int bd_weight_pack(const float* w, const float* row_scale, void* w_fwd, void* w_dgrad, int Cout, int RS,
                    int Cin, bd_stream_t stream);
 
+/* The same packing for many convolutions in one launch (the refresh after every optimizer step).  descs_dev: DEVICE array of
+ * n descriptors sorted by block_start, block_start = running sum of bd_weight_pack_blocks(Cout, RS, Cin);
+ * total_blocks = the final sum.  w_fwd / w_dgrad / row_scale may be NULL per descriptor. */
+typedef struct bd_pack_desc {
+    const float* w;
+    const float* row_scale;
+    void* w_fwd;
+    void* w_dgrad;
+    int32_t Cout, RS, Cin, block_start;
+} bd_pack_desc;
+int bd_weight_pack_blocks(int Cout, int RS, int Cin);
+int bd_weight_pack_multi(const bd_pack_desc* descs_dev, int n, int total_blocks, bd_stream_t stream);
+
 /* bias gradient: column sums over the pixel rows {n*pix_per_img + off + i : n < N, i < cnt} of a bf16
  * [.][C] activation gradient (one pyramid level, or the whole tensor with N=1, off=0) into fp32 out[C];
  * accumulate != 0 adds.  C % 8 == 0, C <= 2048; two-stage fixed-order reduction through ws (reproducible). */

@@ -227,3 +227,26 @@ def test_elementwise_pack_colsum_sgd():
     vref = 0.9 * vv + gg
     assert torch.allclose(vd.cpu(), vref, rtol=1e-6, atol=1e-7)
     assert torch.allclose(wd_.cpu(), wv - 0.01 * vref, rtol=1e-6, atol=1e-7)
+
+
+def test_weight_pack_multi_matches_single():
+    """bd_weight_pack_multi (one launch for all trainable convs) == bd_weight_pack per conv, bit for bit."""
+    from basedet_amd import ops
+    torch.manual_seed(0)
+    shapes = [(64, 9, 64), (256, 1, 1024), (40, 9, 256), (720, 9, 256), (16, 1, 256), (1024, 1, 72)]
+    ent, refs = [], []
+    for co, rs, ci in shapes:
+        w = torch.randn(co, rs, ci, device="cuda")
+        scale = torch.rand(co, device="cuda") + 0.5 if co % 3 == 1 else None
+        wf = torch.zeros((co, rs, ci), dtype=torch.bfloat16, device="cuda")
+        wd = torch.zeros((ci, rs, co), dtype=torch.bfloat16, device="cuda") if co != 16 else None
+        rf = torch.empty_like(wf)
+        rd = torch.empty((ci, rs, co), dtype=torch.bfloat16, device="cuda") if wd is not None else None
+        ops.weight_pack(w, scale, rf, rd, co, rs, ci)
+        ent.append((w, scale, wf, wd, co, rs, ci)); refs.append((rf, rd))
+    table = ops.build_pack_table(ent, torch.device("cuda"))
+    ops.weight_pack_multi(table)
+    for (w, scale, wf, wd, *_), (rf, rd) in zip(ent, refs):
+        assert torch.equal(wf, rf)
+        if wd is not None:
+            assert torch.equal(wd, rd)
