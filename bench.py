@@ -146,6 +146,9 @@ def main():
                     help="record per-conv HIP events on every n-th timed step (each event pair costs ~2.5 us of GPU "
                          "idle; sampling keeps the headline within 1 %% of an uninstrumented run)")
     ap.add_argument("--dump-convs", action="store_true", help="per-shape conv timing table on stderr")
+    ap.add_argument("--serial-wgrad", action="store_true",
+                    help="keep the weight-gradient kernels on the main stream for the whole run (what the instrumented steps do): "
+                         "use it under rocprofv3 so that per-kernel durations are not inflated by concurrent kernels")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,6 +216,8 @@ def main():
 
     last = None
     it = 0
+    if args.serial_wgrad:
+        model.async_wgrad = False
     for _ in range(args.warmup):
         sched.step(it); it += 1
         last = solver.minimize(model, batch)
@@ -225,6 +230,8 @@ def main():
             timer.enabled = (k % max(1, args.roofline_every) == 0)
             sampled += int(timer.enabled)
             model.async_wgrad = not timer.enabled     # instrumented steps run serialised: clean per-kernel durations
+        if args.serial_wgrad:
+            model.async_wgrad = False
         last = solver.minimize(model, batch)
     sync()
     elapsed = time.perf_counter() - t0
