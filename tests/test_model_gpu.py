@@ -389,3 +389,12 @@ def test_state_dict_roundtrip_and_load_weights(tmp_path):
     got = {k: float(v) for k, v in b(batch).items()}
     for k in ref:                     # loss sums are block-atomic fp32 adds: equal up to summation order
         assert abs(got[k] - ref[k]) <= 1e-5 * abs(ref[k]), (k, got[k], ref[k])
+
+
+def test_inference_without_detections_returns_empty():
+    """retinanet.py:185-186 / post_processing.py:59-61: nothing above TEST.CLS_THRESHOLD -> empty container."""
+    from basedet_amd.models import RetinaNet
+    cfg, params, batch = _setup("resnet18", 1, (128, 160), seed=5)        # prior-probability bias: every score ~ 0.01
+    model = RetinaNet(cfg, params=params).eval()
+    out = model({"data": batch["data"], "im_info": batch["im_info"]})
+    assert out["boxes"].numel() == 0 and out["box_scores"].numel() == 0 and out["box_labels"].numel() == 0

@@ -381,3 +381,46 @@ def test_rcnn_loss():
         l_box = (d.abs() if beta < 1e-5 else torch.where(d.abs() < beta, 0.5 * d * d / beta, d.abs() - 0.5 * beta)).sum() / nsamp
         (l_cls + l_box).backward()
         np.testing.assert_allclose(draw.float().cpu().numpy(), x.grad.float().numpy(), rtol=2 ** -7, atol=1e-7)
+
+
+def test_empty_and_degenerate_inputs():
+    """Edge cases: nothing above the score threshold, no valid NMS candidate, an image without proposals or ground truth."""
+    ops = _ops()
+    B, C, k = 2, 128, 64
+    scores = torch.full((B, C), -3.0, device="cuda")
+    idx = torch.empty((B, 1, k), dtype=torch.int32, device="cuda")
+    sc = torch.empty((B, 1, k), dtype=torch.float32, device="cuda")
+    cnt = torch.full((B, 1), -1, dtype=torch.int32, device="cuda")
+    ops.segment_topk(scores, B, C, 1, 1, 0, [0], [C], k, idx, sc, cnt, min_score=0.05)
+    assert cnt.cpu().tolist() == [[0], [0]] and bool((idx == -1).all())
+    boxes = torch.rand((B, C, 4), device="cuda")
+    neg = torch.full((B, C), float("-inf"), device="cuda")
+    keep = torch.full((B, 10), -1, dtype=torch.int32, device="cuda")
+    num = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    ws = torch.empty((ops.nms_batched_workspace_bytes(B, C),), dtype=torch.uint8, device="cuda")
+    ops.nms_batched(boxes, neg, None, 0.5, 10, keep, num, ws)
+    assert num.cpu().tolist() == [0, 0]
+    # RoI sampling: image 0 has neither proposals nor gts, image 1 has gts only
+    N, Gmax, post_k, S = 2, 4, 16, 8
+    rois = torch.zeros((N, post_k, 4), device="cuda")
+    num_rois = torch.zeros((N,), dtype=torch.int32, device="cuda")
+    gt = torch.zeros((N, Gmax, 5), device="cuda")
+    gt[1, 0] = torch.tensor([10., 10., 50., 60., 7.])
+    gt[1, 1] = torch.tensor([30., 20., 90., 80., 2.])
+    num_gt = torch.tensor([0, 2], dtype=torch.int32, device="cuda")
+    keys = torch.rand((N, post_k + Gmax), device="cuda")
+    o_rois = torch.empty((N, S, 4), device="cuda"); o_lab = torch.empty((N, S), dtype=torch.int32, device="cuda")
+    o_tgt = torch.empty((N, S, 4), device="cuda"); o_cnt = torch.empty((N,), dtype=torch.int32, device="cuda")
+    tot = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    ops.rcnn_sample_targets(rois, num_rois, gt, num_gt, keys, keys, S, 4, 0.5, 0.5, 0.0, [0, 0, 0, 0], [0.1, 0.1, 0.2, 0.2],
+                            o_rois, o_lab, o_tgt, o_cnt, tot)
+    assert o_cnt.cpu().tolist() == [0, 2] and int(tot.item()) == 2
+    assert o_lab.cpu().tolist()[0] == [-1] * S and o_lab.cpu().tolist()[1][:2] == [7, 2]
+    assert torch.equal(o_rois[1, :2], gt[1, :2, :4]) and float(o_tgt[1, :2].abs().max()) == 0.0
+    # the losses of an all-empty RoI batch are zero with zero gradients
+    R, K, ld = 8, 80, 408
+    raw = torch.randn((R, ld), device="cuda").to(torch.bfloat16)
+    loss = torch.zeros((2,), device="cuda"); draw = torch.ones((R, ld), dtype=torch.bfloat16, device="cuda")
+    ops.rcnn_loss_fwd_bwd(raw, ld, K, K + 1, torch.full((R,), -1, dtype=torch.int32, device="cuda"), torch.zeros((R, 4), device="cuda"), R,
+                          0.0, torch.zeros((1,), dtype=torch.int32, device="cuda"), loss, draw)
+    assert loss.cpu().tolist() == [0.0, 0.0] and not bool(draw.float().any())
