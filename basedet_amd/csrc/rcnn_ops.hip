@@ -724,35 +724,84 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// deterministic RoIAlign backward: per (image, level) RoI lists, then one workgroup per 8x8 pixel tile gathers the
-// contributions of every RoI sample whose bilinear footprint touches the tile.  One thread per channel owns a private
-// column of the LDS accumulator, so there are no atomics and the summation order is fixed (list order = slot order).
-// The result is written as bf16 straight into the feature-gradient pyramid (every level, zeros where no RoI lands).
+// deterministic RoIAlign backward: RoIs are binned into 4x8-pixel tiles of their pyramid level (count -> scan -> fill), then one
+// wave per (image, tile, 64-channel slice) gathers the contributions of the RoI samples whose bilinear footprint touches the
+// tile.  One lane per channel owns a private column of the LDS accumulator, so there are no float atomics and the summation
+// order is fixed (the tile's RoI list is sorted by slot).  The result is written as bf16 straight into the feature-gradient
+// pyramid (every level; zeros where no RoI lands).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void roi_level_lists_kernel(const float* __restrict__ rois, const int* __restrict__ labels, int S,
-                                                               RoiLevels lv, int* __restrict__ lists, int* __restrict__ counts) {
-    __shared__ int wcnt[16];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    for (int l = 0; l < lv.L; ++l) {
-        int base = 0;
-        for (int s0 = 0; s0 < S; s0 += 1024) {
-            const int slot = s0 + tid;
-            bool flag = false;
-            if (slot < S) {
-                const int r = n * S + slot;
-                if (!labels || labels[r] >= 0) flag = roi_level(ld_box(rois + r * 4ll), lv) == l;
-            }
-            int tot;
-            const int rank = block_rank_1024(flag, wcnt, tot);
-            if (flag) lists[((long long)n * lv.L + l) * S + base + rank] = slot;
-            base += tot;
-        }
-        if (tid == 0) counts[n * lv.L + l] = base;
-    }
+constexpr int RTY = 4, RTX = 8;          // pixel tile of one workgroup
+constexpr int ROI_LIST_MAX = 512;        // RoIs per tile the gather kernel can hold in LDS (= RoI slots per image)
+constexpr int ROI_BINS_MAX = 64;         // PH * PW <= 64
+constexpr int ROI_TILES_MAX = 96;        // tile-list entries reserved per RoI
+struct PyrTiles { int pix_off[BD_MAX_SEGS]; int H[BD_MAX_SEGS]; int W[BD_MAX_SEGS]; int tile_start[BD_MAX_SEGS + 1]; int tiles_x[BD_MAX_SEGS]; int tiles_y[BD_MAX_SEGS]; int L; };
+
+struct RoiFoot { int l, tx0, tx1, ty0, ty1; };
+// conservative tile range of the sample footprint of one RoI on its level (samples clamp into the map: clamp the range as well)
+__device__ __forceinline__ RoiFoot roi_footprint(const Box& b, const RoiLevels& lv, const PyrTiles& pt) {
+    RoiFoot f;
+    f.l = roi_level(b, lv);
+    const float sc = lv.scale[f.l];
+    const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
+    const float ew = b.x2 * sc - 0.5f, eh = b.y2 * sc - 0.5f;
+    float fx0 = fminf(sw, ew) - 1.f, fx1 = fmaxf(sw, ew) + 1.f, fy0 = fminf(sh_, eh) - 1.f, fy1 = fmaxf(sh_, eh) + 1.f;
+    const float W = (float)pt.W[f.l], H = (float)pt.H[f.l];
+    if (!(fx0 == fx0 && fx1 == fx1 && fy0 == fy0 && fy1 == fy1)) { fx0 = 0.f; fx1 = W; fy0 = 0.f; fy1 = H; }
+    fx0 = fminf(fmaxf(fx0, 0.f), W - 1.f); fx1 = fminf(fmaxf(fx1, 0.f), W - 1.f);
+    fy0 = fminf(fmaxf(fy0, 0.f), H - 1.f); fy1 = fminf(fmaxf(fy1, 0.f), H - 1.f);
+    f.tx0 = (int)fx0 / RTX; f.tx1 = (int)fx1 / RTX; f.ty0 = (int)fy0 / RTY; f.ty1 = (int)fy1 / RTY;
+    return f;
 }
 
-constexpr int RT = 8;     // tile side in pixels
-struct PyrTiles { int pix_off[BD_MAX_SEGS]; int H[BD_MAX_SEGS]; int W[BD_MAX_SEGS]; int tile_start[BD_MAX_SEGS + 1]; int tiles_x[BD_MAX_SEGS]; int L; };
+// pass 0: count (fill == 0) or fill (fill == 1) the per-tile RoI lists; one thread per RoI slot
+__global__ __launch_bounds__(256) void roi_tile_bin_kernel(const float* __restrict__ rois, const int* __restrict__ labels, int S, int total,
+                                                           RoiLevels lv, PyrTiles pt, int fill, int* __restrict__ tile_cnt,
+                                                           const int* __restrict__ tile_off, int* __restrict__ entries,
+                                                           int cap, int* __restrict__ overflow) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= total) return;
+    if (labels && labels[r] < 0) return;
+    const int n = r / S, slot = r - n * S;
+    const RoiFoot f = roi_footprint(ld_box(rois + r * 4ll), lv, pt);
+    const int tiles_per_img = pt.tile_start[pt.L];
+    for (int ty = f.ty0; ty <= f.ty1; ++ty)
+        for (int tx = f.tx0; tx <= f.tx1; ++tx) {
+            const int t = n * tiles_per_img + pt.tile_start[f.l] + ty * pt.tiles_x[f.l] + tx;
+            const int pos = atomicAdd(&tile_cnt[t], 1);
+            if (fill) {
+                const int o = tile_off[t] + pos;
+                if (o < cap) entries[o] = slot; else *overflow = 1;
+            }
+        }
+}
+
+// exclusive scan of the tile counts (single workgroup), zeroing the counters for the fill pass
+__global__ __launch_bounds__(1024) void roi_tile_scan_kernel(int* __restrict__ tile_cnt, int* __restrict__ tile_off, int ntiles) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < ntiles; i0 += 1024) {
+        const int i = i0 + tid;
+        const int v = i < ntiles ? tile_cnt[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < ntiles) { tile_off[i] = before + inc - v; tile_cnt[i] = 0; }
+        __syncthreads();
+        if (tid == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) tile_off[ntiles] = carry;
+}
 
 __device__ __forceinline__ void sample_range(float lo, float hi, float start, float step, int nsamp, int& j0, int& j1) {
     j0 = 0; j1 = nsamp - 1;
@@ -766,53 +815,72 @@ __device__ __forceinline__ void sample_range(float lo, float hi, float start, fl
     }
 }
 
-__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv,
-                                                                   PyrTiles pt, const float* __restrict__ rois, int S, int PH, int PW,
-                                                                   int SP, const int* __restrict__ lists,
-                                                                   const int* __restrict__ counts, bf16_raw* __restrict__ gfeat) {
-    __shared__ float acc[RT * RT * 256];
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(64) void roi_align_bwd_gather_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv,
+                                                                  PyrTiles pt, const float* __restrict__ rois, int S, int PH, int PW,
+                                                                  int SP, const int* __restrict__ tile_cnt,
+                                                                  const int* __restrict__ tile_off, const int* __restrict__ entries,
+                                                                  bf16_raw* __restrict__ gfeat) {
+    __shared__ float acc[RTY * RTX * 64];          //  8 KB: lane-private columns
+    __shared__ bf16_raw s_g[ROI_BINS_MAX * 64];    //  8 KB: pooled gradients of the current RoI, lane-private columns
+    __shared__ float s_par[64][4];                 // sw, sh, bw, bh of the current chunk of RoIs
+    __shared__ short s_slot[ROI_LIST_MAX];
+    __shared__ short s_sorted[ROI_LIST_MAX];
+    const int lane = threadIdx.x;
+    const int slices = (C + 63) / 64;
+    const int slice = blockIdx.x % slices;
+    const int tb = blockIdx.x / slices;            // global tile index: n * tiles_per_img + t
     const int tiles_per_img = pt.tile_start[pt.L];
-    const int n = blockIdx.x / tiles_per_img;
-    const int t = blockIdx.x - n * tiles_per_img;
+    const int n = tb / tiles_per_img;
+    const int t = tb - n * tiles_per_img;
     int la = 0;
     for (int q = 1; q < pt.L; ++q) if (t >= pt.tile_start[q]) la = q;
     const int tt = t - pt.tile_start[la];
-    const int ty0 = (tt / pt.tiles_x[la]) * RT, tx0 = (tt % pt.tiles_x[la]) * RT;
+    const int ty0 = (tt / pt.tiles_x[la]) * RTY, tx0 = (tt % pt.tiles_x[la]) * RTX;
     const int H = pt.H[la], W = pt.W[la];
     const int nb = PH * PW;
     const float inv = 1.f / (float)(SP * SP);
-    const int cnt = la < lv.L ? counts[n * lv.L + la] : 0;
-    const int* lst = lists + ((long long)n * lv.L + (la < lv.L ? la : 0)) * S;
+    int cnt = tile_cnt[tb];
+    if (cnt > ROI_LIST_MAX) cnt = ROI_LIST_MAX;
+    const int* ent = entries + tile_off[tb];
     const float sc = la < lv.L ? lv.scale[la] : 1.f;
-    for (int c0 = 0; c0 < C; c0 += 256) {
-        const int c = c0 + tid;
-        const bool cok = c < C;
+    const int c = slice * 64 + lane;
+    const bool cok = c < C;
 #pragma unroll
-        for (int p = 0; p < RT * RT; ++p) acc[p * 256 + tid] = 0.f;
-        for (int q = 0; q < cnt; ++q) {
-            const int slot = lst[q];
-            const long long r = (long long)n * S + slot;
+    for (int p = 0; p < RTY * RTX; ++p) acc[p * 64 + lane] = 0.f;
+
+    // the tile's RoI list sorted by slot (the fill order of the binning pass is not deterministic)
+    for (int q = lane; q < cnt; q += 64) s_slot[q] = (short)ent[q];
+    __syncthreads();
+    for (int q = lane; q < cnt; q += 64) {
+        const int v = s_slot[q];
+        int rank = 0;
+        for (int k = 0; k < cnt; ++k) rank += s_slot[k] < v;       // slots are distinct
+        s_sorted[rank] = (short)v;
+    }
+    __syncthreads();
+
+    for (int q0 = 0; q0 < cnt; q0 += 64) {
+        const int nq = min(64, cnt - q0);
+        if (lane < nq) {                                            // parameters of up to 64 RoIs, one per lane
+            const long long r = (long long)n * S + s_sorted[q0 + lane];
             const Box b = ld_box(rois + r * 4);
             const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
             const float rw = (b.x2 * sc - 0.5f) - sw, rh = (b.y2 * sc - 0.5f) - sh_;
-            // cheap cull first: the sample footprint [start - 1, start + extent + 1] against the tile (degenerate or reversed
-            // boxes have all samples inside [min, max] of the two ends)
-            const float fx0 = fminf(sw, sw + rw) - 1.f, fx1 = fmaxf(sw, sw + rw) + 1.f;
-            const float fy0 = fminf(sh_, sh_ + rh) - 1.f, fy1 = fmaxf(sh_, sh_ + rh) + 1.f;
-            if (fx1 < (float)tx0 || fx0 > (float)(tx0 + RT) || fy1 < (float)ty0 || fy0 > (float)(ty0 + RT)) {
-                // rows / columns clamped into the map (y <= 0 -> row 0, y >= H-1 -> row H-1) still lie within one pixel of the
-                // footprint unless the footprint is outside the map, where only the border tiles can be touched
-                const bool border = (ty0 == 0 && fy1 >= -1.f) || (ty0 + RT >= H && fy0 <= (float)H) || (tx0 == 0 && fx1 >= -1.f) ||
-                                    (tx0 + RT >= W && fx0 <= (float)W);
-                if (!border) continue;
-            }
-            const float bw = rw / (float)PW, bh = rh / (float)PH;
+            s_par[lane][0] = sw; s_par[lane][1] = sh_; s_par[lane][2] = rw / (float)PW; s_par[lane][3] = rh / (float)PH;
+        }
+        __syncthreads();
+        for (int q = 0; q < nq; ++q) {
+            const float sw = s_par[q][0], sh_ = s_par[q][1], bw = s_par[q][2], bh = s_par[q][3];
+            const long long r = (long long)n * S + s_sorted[q0 + q];
             int jy0, jy1, jx0, jx1;
-            sample_range((float)(ty0 - 1), (float)(ty0 + RT), sh_, bh / (float)SP, PH * SP, jy0, jy1);
-            sample_range((float)(tx0 - 1), (float)(tx0 + RT), sw, bw / (float)SP, PW * SP, jx0, jx1);
+            sample_range((float)(ty0 - 1), (float)(ty0 + RTY), sh_, bh / (float)SP, PH * SP, jy0, jy1);
+            sample_range((float)(tx0 - 1), (float)(tx0 + RTX), sw, bw / (float)SP, PW * SP, jx0, jx1);
             if (jy0 > jy1 || jx0 > jx1) continue;
-            const bf16_raw* go = gout + r * nb * C + c;
+            // pooled gradients of this lane's channel: independent loads (all in flight together) into the lane-private column
+            const bf16_raw* go = gout + r * nb * C + (cok ? c : 0);
+            const int ph0 = jy0 / SP, ph1 = jy1 / SP, pw0 = jx0 / SP, pw1 = jx1 / SP;
+            for (int ph = ph0; ph <= ph1; ++ph)
+                for (int pw = pw0; pw <= pw1; ++pw) s_g[(ph * PW + pw) * 64 + lane] = go[(long long)(ph * PW + pw) * C];
             for (int jy = jy0; jy <= jy1; ++jy) {
                 const int ph = jy / SP, iy = jy - ph * SP;
                 const float y = sh_ + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)SP;
@@ -822,22 +890,32 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const bf16_ra
                     const Bilinear bl = bilinear_setup(y, x, H, W);
                     if (!bl.ok) continue;
                     const int ya = bl.y0 - ty0, yb = bl.y1 - ty0, xa = bl.x0 - tx0, xb = bl.x1 - tx0;
-                    const bool ya_in = (unsigned)ya < RT, yb_in = (unsigned)yb < RT, xa_in = (unsigned)xa < RT, xb_in = (unsigned)xb < RT;
-                    if (!((ya_in || yb_in) && (xa_in || xb_in))) continue;
-                    const float g = cok ? bf2f(go[(long long)(ph * PW + pw) * C]) * inv : 0.f;
-                    if (ya_in && xa_in) acc[(ya * RT + xa) * 256 + tid] += bl.w00 * g;
-                    if (ya_in && xb_in) acc[(ya * RT + xb) * 256 + tid] += bl.w01 * g;
-                    if (yb_in && xa_in) acc[(yb * RT + xa) * 256 + tid] += bl.w10 * g;
-                    if (yb_in && xb_in) acc[(yb * RT + xb) * 256 + tid] += bl.w11 * g;
+                    const bool ya_in = (unsigned)ya < RTY, yb_in = (unsigned)yb < RTY, xa_in = (unsigned)xa < RTX, xb_in = (unsigned)xb < RTX;
+                    // a corner duplicated by the border clamp carries weight 0: skipping zero weights keeps the four targets distinct,
+                    // so the four read-modify-writes are independent (reads first, then the adds, then the writes)
+                    const bool u00 = ya_in && xa_in && bl.w00 != 0.f, u01 = ya_in && xb_in && bl.w01 != 0.f;
+                    const bool u10 = yb_in && xa_in && bl.w10 != 0.f, u11 = yb_in && xb_in && bl.w11 != 0.f;
+                    if (!(u00 || u01 || u10 || u11)) continue;
+                    const float g = bf2f(s_g[(ph * PW + pw) * 64 + lane]) * inv;
+                    float* p00 = acc + ((u00 ? ya * RTX + xa : 0) * 64 + lane);
+                    float* p01 = acc + ((u01 ? ya * RTX + xb : 0) * 64 + lane);
+                    float* p10 = acc + ((u10 ? yb * RTX + xa : 0) * 64 + lane);
+                    float* p11 = acc + ((u11 ? yb * RTX + xb : 0) * 64 + lane);
+                    const float v00 = *p00, v01 = *p01, v10 = *p10, v11 = *p11;
+                    if (u00) *p00 = v00 + bl.w00 * g;
+                    if (u01) *p01 = v01 + bl.w01 * g;
+                    if (u10) *p10 = v10 + bl.w10 * g;
+                    if (u11) *p11 = v11 + bl.w11 * g;
                 }
             }
         }
-        if (cok) {
-            bf16_raw* gp = gfeat + ((long long)n * ppi + pt.pix_off[la]) * C + c;
-            for (int p = 0; p < RT * RT; ++p) {
-                const int y = ty0 + p / RT, x = tx0 + p % RT;
-                if (y < H && x < W) gp[((long long)y * W + x) * C] = f2bf(acc[p * 256 + tid]);
-            }
+        __syncthreads();
+    }
+    if (cok) {
+        bf16_raw* gp = gfeat + ((long long)n * ppi + pt.pix_off[la]) * C + c;
+        for (int p = 0; p < RTY * RTX; ++p) {
+            const int y = ty0 + p / RTX, x = tx0 + p % RTX;
+            if (y < H && x < W) gp[((long long)y * W + x) * C] = f2bf(acc[p * 64 + lane]);
         }
     }
 }
@@ -1166,9 +1244,17 @@ extern "C" int bd_f32_to_bf16(const float* src, void* dst, int64_t n, bd_stream_
     return BD_OK;
 }
 
-extern "C" size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L, int rois_per_img) {
-    if (N <= 0 || L <= 0 || rois_per_img <= 0) return 256;
-    return align256((size_t)N * L * rois_per_img * 4) + align256((size_t)N * L * 4);
+static int roi_tiles_per_img(int L_all, const int32_t* H, const int32_t* W) {
+    int ts = 0;
+    for (int l = 0; l < L_all; ++l) ts += cdiv(W[l], RTX) * cdiv(H[l], RTY);
+    return ts;
+}
+
+extern "C" size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L_all, const int32_t* lvl_h_host, const int32_t* lvl_w_host,
+                                                        int rois_per_img) {
+    if (N <= 0 || L_all <= 0 || L_all > BD_MAX_SEGS || rois_per_img <= 0 || !lvl_h_host || !lvl_w_host) return 256;
+    const size_t ntiles = (size_t)N * roi_tiles_per_img(L_all, lvl_h_host, lvl_w_host);
+    return 2 * align256((ntiles + 1) * 4) + align256((size_t)N * rois_per_img * ROI_TILES_MAX * 4) + 256;
 }
 
 extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int C, int L, int L_all, const int32_t* lvl_pix_off_host,
@@ -1178,8 +1264,11 @@ extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int 
     BD_REQUIRE(gout && lvl_pix_off_host && lvl_h_host && lvl_w_host && strides_host && rois && gfeat && ws, "roi_align_bwd_bf16: null pointer");
     BD_REQUIRE(L > 0 && L <= L_all && L_all <= BD_MAX_SEGS && C > 0 && PH > 0 && PW > 0 && sample_points > 0 && rois_per_img > 0 && N > 0,
                "roi_align_bwd_bf16: bad sizes");
-    if (ws_bytes < bd_roi_align_bwd_bf16_workspace_bytes(N, L, rois_per_img)) {
-        bd_set_error("roi_align_bwd_bf16: workspace %zu < %zu bytes", ws_bytes, bd_roi_align_bwd_bf16_workspace_bytes(N, L, rois_per_img));
+    BD_REQUIRE(rois_per_img <= ROI_LIST_MAX, "roi_align_bwd_bf16: %d RoIs per image exceed %d", rois_per_img, ROI_LIST_MAX);
+    BD_REQUIRE(PH * PW <= ROI_BINS_MAX, "roi_align_bwd_bf16: %d bins exceed %d", PH * PW, ROI_BINS_MAX);
+    if (ws_bytes < bd_roi_align_bwd_bf16_workspace_bytes(N, L_all, lvl_h_host, lvl_w_host, rois_per_img)) {
+        bd_set_error("roi_align_bwd_bf16: workspace %zu < %zu bytes", ws_bytes,
+                     bd_roi_align_bwd_bf16_workspace_bytes(N, L_all, lvl_h_host, lvl_w_host, rois_per_img));
         return BD_EWORKSPACE;
     }
     RoiLevels lv{};
@@ -1189,17 +1278,30 @@ extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int 
     int ts = 0;
     for (int l = 0; l < L_all; ++l) {
         pt.pix_off[l] = lvl_pix_off_host[l]; pt.H[l] = lvl_h_host[l]; pt.W[l] = lvl_w_host[l];
-        pt.tiles_x[l] = cdiv(lvl_w_host[l], RT);
+        pt.tiles_x[l] = cdiv(lvl_w_host[l], RTX); pt.tiles_y[l] = cdiv(lvl_h_host[l], RTY);
         pt.tile_start[l] = ts;
-        ts += pt.tiles_x[l] * cdiv(lvl_h_host[l], RT);
+        ts += pt.tiles_x[l] * pt.tiles_y[l];
     }
     pt.tile_start[L_all] = ts;
-    int* lists = (int*)ws;
-    int* counts = (int*)((unsigned char*)ws + align256((size_t)N * L * rois_per_img * 4));
+    const int ntiles = N * ts;
+    unsigned char* wb = (unsigned char*)ws;
+    int* tile_cnt = (int*)wb;
+    int* tile_off = (int*)(wb + align256(((size_t)ntiles + 1) * 4));
+    int* entries = (int*)(wb + 2 * align256(((size_t)ntiles + 1) * 4));
+    const int cap = N * rois_per_img * ROI_TILES_MAX;
+    int* overflow = entries + cap;
+    const int total = N * rois_per_img;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(roi_level_lists_kernel, dim3(N), dim3(1024), 0, st, rois, labels, rois_per_img, lv, lists, counts);
-    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3(N * ts), dim3(256), 0, st, (const bf16_raw*)gout, (long long)pix_per_img, C, lv,
-                       pt, rois, rois_per_img, PH, PW, sample_points, lists, counts, (bf16_raw*)gfeat);
+    (void)hipMemsetAsync(tile_cnt, 0, ((size_t)ntiles + 1) * 4, st);
+    (void)hipMemsetAsync(overflow, 0, 4, st);
+    hipLaunchKernelGGL(roi_tile_bin_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, rois, labels, rois_per_img, total, lv, pt, 0, tile_cnt,
+                       (const int*)tile_off, entries, cap, overflow);
+    hipLaunchKernelGGL(roi_tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_cnt, tile_off, ntiles);
+    hipLaunchKernelGGL(roi_tile_bin_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, rois, labels, rois_per_img, total, lv, pt, 1, tile_cnt,
+                       (const int*)tile_off, entries, cap, overflow);
+    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3(ntiles * cdiv(C, 64)), dim3(64), 0, st, (const bf16_raw*)gout, (long long)pix_per_img,
+                       C, lv, pt, rois, rois_per_img, PH, PW, sample_points, (const int*)tile_cnt, (const int*)tile_off, (const int*)entries,
+                       (bf16_raw*)gfeat);
     BD_CHECK_LAUNCH("bd_roi_align_bwd_bf16");
     return BD_OK;
 }

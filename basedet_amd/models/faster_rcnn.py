@@ -138,7 +138,7 @@ class FasterRCNN(FPNDetector):
         pl.g_fc1 = torch.empty((R, 1024), **bf)
         pl.g_pooled = torch.empty((R, fin), **bf)
         pl.g_feat32 = torch.zeros((pyr.pixels, ch), **f32)
-        pl.roi_bwd_ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(N, self.rcnn_levels, S),), dtype=torch.uint8, device=dev)
+        pl.roi_bwd_ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(pyr, S),), dtype=torch.uint8, device=dev)
         pl.g_fc = ops.single(1, R, 1)
         pl.loss_buf = torch.zeros((4,), **f32)
 

@@ -317,8 +317,8 @@ def roi_align_bwd(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_im
                                pool[1], sample_points, ptr(gfeat), stream_ptr()), "bd_roi_align_bwd")
 
 
-def roi_align_bwd_bf16_workspace_bytes(N, nlev, rois_per_img):
-    return int(L().bd_roi_align_bwd_bf16_workspace_bytes(N, nlev, rois_per_img))
+def roi_align_bwd_bf16_workspace_bytes(geom: Geom, rois_per_img):
+    return int(L().bd_roi_align_bwd_bf16_workspace_bytes(geom.N, geom.nlev, i32arr(geom.H), i32arr(geom.W), rois_per_img))
 
 
 def roi_align_bwd_bf16(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_img, pool, sample_points, gfeat, ws):

@@ -342,11 +342,12 @@ int bd_roi_align_bwd(const void* gout, int64_t pix_per_img, int C, int L, const 
                      const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
                      int sample_points, float* gfeat, bd_stream_t stream);
 
-/* Deterministic backward of bd_roi_align_fwd for the training step: per (image, level) RoI lists + one workgroup per 8x8
- * pixel tile that gathers every sample touching it (no atomics, fixed summation order).  Writes the bf16 gradient of ALL
- * L_all pyramid levels of the pixel-major buffer (levels >= L and untouched pixels get zeros).  lvl_* arrays have L_all
- * entries, strides the first L. */
-size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L, int rois_per_img);
+/* Deterministic backward of bd_roi_align_fwd for the training step: the RoIs are binned into 4x8-pixel tiles of their level
+ * (count, scan, fill), then one wave per (image, tile, 64-channel slice) gathers every sample touching the tile -- no float
+ * atomics, fixed summation order.  Writes the bf16 gradient of ALL L_all pyramid levels of the pixel-major buffer (levels >= L
+ * and untouched pixels get zeros).  lvl_* arrays have L_all entries, strides the first L.  rois_per_img <= 512. */
+size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L_all, const int32_t* lvl_h_host, const int32_t* lvl_w_host,
+                                             int rois_per_img);
 int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int C, int L, int L_all, const int32_t* lvl_pix_off_host,
                           const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
                           const float* rois, const int32_t* labels, int N, int rois_per_img, int PH, int PW,

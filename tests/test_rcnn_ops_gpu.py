@@ -275,7 +275,7 @@ def test_roi_align_fwd_bwd():
     assert np.all(gg[:, o:] == 0)
     # deterministic gather variant: bf16 output over the whole pyramid, bitwise reproducible
     gbf = torch.full((N * ppi, C), 7.0, dtype=torch.bfloat16, device="cuda")
-    ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(N, nlev, rpi),), dtype=torch.uint8, device="cuda")
+    ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(geom, rpi),), dtype=torch.uint8, device="cuda")
     ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gbf, ws)
     g1 = gbf.float().cpu().numpy().reshape(N, ppi, C)
     o = 0
