@@ -38,6 +38,7 @@ struct C3Params {
     const bf16_raw* add;
     const bf16_raw* mask;
     bf16_raw* dst;
+    long long* dbg;          // optional timeline stamps of workgroup 0 (bd_conv3x3_set_debug)
     int CK, CO, mode, flags, N, nseg;
     int src_ppi, dst_ppi;
     int patches_per_img, total_patches, n_tiles;
@@ -46,6 +47,7 @@ struct C3Params {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+constexpr bool g_fence = true;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     // buffered: the ds_reads of sub-step u+1 are issued before the MFMAs of sub-step u, so LDS latency hides under the
     // MFMA pipe; after each tap the wave stores one tap of the NEXT step's weights (in registers since the end of the
     // previous step), so the LDS stores overlap the MFMAs as well.
-    bf16x8_t fa[2][4], fb[2][4];
+    bf16x8_t fa[3][4], fb[3][4];      // DMA variant: three sets, prefetch distance 2 (the compiler then waits with lgkmcnt(8))
     auto load_frags = [&](int wb, int r, int u, bf16x8_t (&a)[4], bf16x8_t (&b)[4]) {
         const int t = u >> 1, kk = u & 1;
         int dy = r, dx = t;
@@ -232,20 +234,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
+    auto mfma_rows = [&](const bf16x8_t (&a)[4], const bf16x8_t (&b)[4], int i0, int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
     auto compute = [&](int wb, int r, bool write_next, int next_step) {
+        if (DMA && write_next) {                                    // all six pieces at the start of the step: they land under the
+#pragma unroll
+            for (int k = 0; k < WPASSES; ++k) dma_w(next_step, wb ^ 1, k);      // MFMAs, long before the barrier's vmcnt(0)
+            if (g_fence) __builtin_amdgcn_sched_barrier(0);
+        }
         load_frags(wb, r, 0, fa[0], fb[0]);
+        if (DMA && g_fence) load_frags(wb, r, 1, fa[1], fb[1]);
 #pragma unroll
         for (int u = 0; u < 2 * TAPS_PER_STEP; ++u) {
-            if (u + 1 < 2 * TAPS_PER_STEP) load_frags(wb, r, u + 1, fa[(u + 1) & 1], fb[(u + 1) & 1]);
-            if (DMA && write_next && u < 3) {                       // all six pieces in the first half of the step: they land
-                dma_w(next_step, wb ^ 1, 2 * u);                    // under the remaining MFMAs, before the barrier's vmcnt(0)
-                dma_w(next_step, wb ^ 1, 2 * u + 1);
+            if (DMA && g_fence) {
+                // fragments two sub-steps ahead: the ds_reads of sub-step u+2 are issued behind the first MFMAs of sub-step u, and the
+                // wait in front of sub-step u+1 only covers reads that are a whole sub-step old
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_rows(fa[u % 3], fb[u % 3], 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 2 < 2 * TAPS_PER_STEP) load_frags(wb, r, u + 2, fa[(u + 2) % 3], fb[(u + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_rows(fa[u % 3], fb[u % 3], 1, 4);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                if (u + 1 < 2 * TAPS_PER_STEP) load_frags(wb, r, u + 1, fa[(u + 1) & 1], fb[(u + 1) & 1]);
+                mfma16(fa[u & 1], fb[u & 1]);
             }
-            mfma16(fa[u & 1], fb[u & 1]);
             if ((u & 1) && write_next) write_w_tap(wb ^ 1, u >> 1);
         }
     };
 
+#ifdef BD_PATCH_TIMELINE      // build with -DBD_PATCH_TIMELINE for scripts/patch_timeline.py (s_memtime stamps of one workgroup)
+    long long stamps[64];
+    int nst = 0;
+    const bool dbg_on = p.dbg != nullptr && blockIdx.x == 8 && lane == 0;
+#define STAMP() do { if (dbg_on && nst < 64) stamps[nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+    STAMP();
     // prologue: activation image of K block 0, weights of step 0 (to LDS) and step 1 (in registers)
     load_x(0);
     if (DMA) {
@@ -258,16 +290,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     for (int t = 0; t < TAPS_PER_STEP; ++t) write_w_tap(0, t);
     if (nsteps > 1) load_w(1);
     __syncthreads();
+    STAMP();
     for (int step = 0; step < nsteps; ++step) {
         const int cb = step / 3, r = step - cb * 3;
         const bool next_x = (r == 2) && (cb + 1 < kblocks);
         if (next_x) load_x(cb + 1);          // in flight under this step's 96 MFMAs
         compute(step & 1, r, step + 1 < nsteps, step + 1);
         if (step + 2 < nsteps) load_w(step + 2);   // registers are free again: they were stored during this step
+        STAMP();
         __syncthreads();                     // (DMA: the compiler drains vmcnt before the barrier, so the pieces have landed)
+        STAMP();
         if (next_x) {                        // every wave is done with the old image: swap it
             write_x();
             __syncthreads();
+            STAMP();
         }
     }
 
@@ -334,11 +370,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
             *reinterpret_cast<u32x4_t*>(p.dst + idx) = o;
         }
     }
+    STAMP();
+#ifdef BD_PATCH_TIMELINE
+    if (dbg_on) {
+        p.dbg[wave * 80] = nst;
+        for (int i = 0; i < nst; ++i) p.dbg[wave * 80 + 1 + i] = stamps[i];
+    }
+#endif
+#undef STAMP
 }
 
 }  // namespace
 
-int g_patch_dma = 1;      // bd_conv_set_patch3x3 bit 3 clears it (register-staged weights everywhere)
+int g_patch_dma = 1;
+static long long* g_patch_dbg = nullptr;
+extern "C" int bd_conv3x3_set_debug(long long* buf) { g_patch_dbg = buf; return 0; }      // bd_conv_set_patch3x3 bit 3 clears it (register-staged weights everywhere)
 
 // called from conv_igemm.hip for 3x3 / stride 1 / pad 1 descriptors; mode 0 fwd (src = x, geometry in == out),
 // mode 1 dgrad (src = dY).  CK = reduction channels, CO = produced channels.
@@ -347,6 +393,7 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
     C3Params p{};
     p.src = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias;
     p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)dst;
+    p.dbg = g_patch_dbg;
     p.CK = mode == 0 ? d->Cin : d->Cout;
     p.CO = mode == 0 ? d->Cout : d->Cin;
     p.mode = mode; p.flags = flags; p.N = d->N; p.nseg = d->nseg;
