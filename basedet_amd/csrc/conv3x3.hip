@@ -59,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xbuf = smem;                       // [X_BYTES]      (single buffer, swapped between K blocks)
     unsigned char* wbuf = smem + X_BYTES;             // [2][W_BYTES]
+    float* sbias = reinterpret_cast<float*>(smem + X_BYTES + 2 * W_BYTES);   // [128] epilogue vector of this channel tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 2, wp = wave & 3;
@@ -278,7 +279,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
 #define STAMP() do { } while (0)
 #endif
     STAMP();
-    // prologue: activation image of K block 0, weights of step 0 (to LDS) and step 1 (in registers)
+    // prologue: activation image of K block 0, weights of step 0 (to LDS) and step 1 (in registers); the epilogue vector goes to
+    // LDS now, so that its global-load latency is not exposed after the last MFMA
+    if (tid < TILE_CO) sbias[tid] = (p.bias && co0 + tid < p.CO) ? p.bias[co0 + tid] : 0.f;
     load_x(0);
     if (DMA) {
 #pragma unroll
@@ -317,13 +320,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     float bias[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) bias[k] = 0.f;
-    if (p.bias) {
+    {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (cbase + 32 * (q >> 1) + 4 * (q & 1) < p.CO) {
-                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 32 * (q >> 1) + 4 * (q & 1));
-                bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
-            }
+        for (int q = 0; q < 4; ++q) {
+            const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(sbias + wc * 64 + 8 * cg + 32 * (q >> 1) + 4 * (q & 1));
+            bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
+        }
     }
     int oy0 = py0[0], ox = px0[0] + frow, H = pH[0], W = pWd[0];
     long long dbase = pdst[0];
@@ -411,7 +413,7 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
     p.total_patches = ps * d->N;
     p.n_tiles = cdiv(p.CO, TILE_CO);
     const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
-    const size_t lds = X_BYTES + 2 * W_BYTES;
+    const size_t lds = X_BYTES + 2 * W_BYTES + TILE_CO * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
