@@ -155,9 +155,8 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_raw* __r
     }
 }
 
-// ab[(n*L + l)*32 + g] = (A, B) / count ; dgamma[c], dbeta[c] (+)= sums over every (n, l, chunk)
-__global__ void gn_bwd_final_kernel(const float* __restrict__ pg, const float* __restrict__ pc, GnLevels lv, int N, int C, int cpg,
-                                    float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+// ab[(n*L + l)*32 + g] = (A, B) / count
+__global__ void gn_bwd_final_kernel(const float* __restrict__ pg, GnLevels lv, int N, int cpg, float* __restrict__ ab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int ngl = N * lv.L * 32;
     if (i < ngl) {
@@ -169,13 +168,26 @@ __global__ void gn_bwd_final_kernel(const float* __restrict__ pg, const float* _
         }
         const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
         ab[i * 2] = A * inv; ab[i * 2 + 1] = B * inv;
-    } else if (i < ngl + C) {
-        const int c = i - ngl;
-        float dg = 0.f, db = 0.f;
-        const int slots = N * lv.L * GN_CHUNKS;
-        for (int s = 0; s < slots; ++s) { dg += pc[((long long)s * C + c) * 2]; db += pc[((long long)s * C + c) * 2 + 1]; }
-        dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-        dbeta[c] = accumulate ? dbeta[c] + db : db;
+    }
+}
+
+// dgamma[c], dbeta[c] (+)= sums over every (n, l, chunk) slot: a block owns 8 channels, 32 lanes walk the slots (each reads the
+// 64 contiguous bytes of its 8 channels), then a fixed-order LDS reduction -- reproducible, and no 1 280-long serial chains
+__global__ __launch_bounds__(256) void gn_bwd_final_c_kernel(const float* __restrict__ pc, int slots, int C, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[32][8][2];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    float dg = 0.f, db = 0.f;
+    if (c < C)
+        for (int s = sl; s < slots; s += 32) { dg += pc[((long long)s * C + c) * 2]; db += pc[((long long)s * C + c) * 2 + 1]; }
+    red[sl][cl][0] = dg; red[sl][cl][1] = db;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < 32; ++k) { a += red[k][cl][0]; b += red[k][cl][1]; }
+        dgamma[c] = accumulate ? dgamma[c] + a : a;
+        dbeta[c] = accumulate ? dbeta[c] + b : b;
     }
 }
 
@@ -332,8 +344,9 @@ extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const void* z, co
     float* ab = pc + (size_t)N * L * GN_CHUNKS * C * 2;
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(GN_CHUNKS, L, N), dim3(256), 0, st, (const bf16_raw*)dz, (const bf16_raw*)y,
                        (const bf16_raw*)z, stats, gamma, lv, (int)pix_per_img, C, relu, pg, pc);
-    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * L * 32 + C, 256)), dim3(256), 0, st, (const float*)pg, (const float*)pc, lv, N,
-                       C, C / 32, ab, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * L * 32, 256)), dim3(256), 0, st, (const float*)pg, lv, N, C / 32, ab);
+    hipLaunchKernelGGL(gn_bwd_final_c_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)pc, N * L * GN_CHUNKS, C, dgamma, dbeta,
+                       accumulate);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(egrid((long long)N * pix_per_img * 32)), dim3(256), 0, st, (const bf16_raw*)dz,
                        (const bf16_raw*)y, (const bf16_raw*)z, stats, (const float*)ab, gamma, lv, N, (int)pix_per_img, relu, (bf16_raw*)dy);
     BD_CHECK_LAUNCH("bd_groupnorm_bwd");
