@@ -684,7 +684,11 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const bf16_raw* __re
     }
 }
 
-// scatter of dL/d(pooled) into the fp32 feature-gradient pyramid; one thread per channel, wave-contiguous atomics
+// scatter of dL/d(pooled) into the fp32 feature-gradient pyramid; one thread per channel, wave-contiguous atomics.
+// All samples of a bin carry the same gradient g/S^2, so their bilinear weights are first merged per target pixel (a
+// workgroup-uniform 4x4 coefficient patch anchored at the top-left sample corner): one atomic per distinct pixel of the bin
+// (typically 9) instead of one per sample corner (16).  Bins whose samples spread over more than 4 rows / columns (very large
+// RoIs) take the direct path.
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv,
                                                             const float* __restrict__ rois, const int* __restrict__ labels,
                                                             int rois_per_img, int PH, int PW, int S,
@@ -705,6 +709,57 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
     const float inv = 1.f / (float)(S * S);
     for (int bin = 0; bin < nb; ++bin) {
         const int ph = bin / PW, pw = bin - ph * PW;
+        bool merged = S == 2;
+        float coef[4][4];
+        int Y0 = 0, X0 = 0;
+        if (merged) {
+            Bilinear sm[4];
+            int ymin = 1 << 30, xmin = 1 << 30, ymax = -1, xmax = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int iy = k >> 1, ix = k & 1;
+                const float y = sh_ + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)S;
+                const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)S;
+                sm[k] = bilinear_setup(y, x, H, W);
+                if (sm[k].ok) {
+                    ymin = min(ymin, sm[k].y0); xmin = min(xmin, sm[k].x0);
+                    ymax = max(ymax, sm[k].y1); xmax = max(xmax, sm[k].x1);
+                }
+            }
+            if (ymax < 0) continue;                                   // every sample is outside the map
+            merged = (ymax - ymin) < 4 && (xmax - xmin) < 4;
+            if (merged) {
+                Y0 = ymin; X0 = xmin;
+#pragma unroll
+                for (int py = 0; py < 4; ++py)
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        float cf = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (!sm[k].ok) continue;
+                            const int ya = sm[k].y0 - Y0, yb = sm[k].y1 - Y0, xa = sm[k].x0 - X0, xb = sm[k].x1 - X0;
+                            if (ya == py && xa == px) cf += sm[k].w00;
+                            if (ya == py && xb == px) cf += sm[k].w01;
+                            if (yb == py && xa == px) cf += sm[k].w10;
+                            if (yb == py && xb == px) cf += sm[k].w11;
+                        }
+                        coef[py][px] = cf;
+                    }
+            }
+        }
+        if (merged) {
+            for (int c = threadIdx.x; c < C; c += 256) {
+                const float g = bf2f(go[(long long)bin * C + c]) * inv;
+#pragma unroll
+                for (int py = 0; py < 4; ++py)
+#pragma unroll
+                    for (int px = 0; px < 4; ++px)
+                        if (coef[py][px] != 0.f)                      // workgroup-uniform
+                            unsafeAtomicAdd(gp + ((long long)(Y0 + py) * W + X0 + px) * C + c, coef[py][px] * g);
+            }
+            continue;
+        }
         for (int iy = 0; iy < S; ++iy) {
             const float y = sh_ + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)S;
             for (int ix = 0; ix < S; ++ix) {
