@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
-LIB = os.path.join(OUT_DIR, "libbasedet_hip.so")
+LIB = os.path.join(OUT_DIR, os.environ.get("BD_LIB_NAME", "libbasedet_hip.so"))      # BD_LIB_NAME: side-by-side experimental build
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -42,14 +42,14 @@ def _digest():
 
 def build(force=False, verbose=True):
     os.makedirs(OUT_DIR, exist_ok=True)
-    stamp = os.path.join(OUT_DIR, "build.stamp")
+    stamp = os.path.join(OUT_DIR, "build.stamp" if "BD_LIB_NAME" not in os.environ else os.environ["BD_LIB_NAME"] + ".stamp")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     objs = []
     procs = []
     for src, extra in SOURCES.items():
-        obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(OUT_DIR, os.environ.get("BD_LIB_NAME", "") + src.replace(".hip", ".o"))
         cmd = [HIPCC, *COMMON, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
