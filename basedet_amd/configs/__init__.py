@@ -136,3 +136,13 @@ class FasterRCNNConfig(ConfigDict):
             RCNN_BOX_REG=dict(MEAN=[0.0, 0.0, 0.0, 0.0], STD=[0.1, 0.1, 0.2, 0.2]),
             MATCHER=dict(THRESHOLDS=[0.3, 0.7], LABELS=[0, -1, 1], ALLOW_LOW_QUALITY=True),
         ), SOLVER=dict(BASIC_LR=0.02 / 16, WARM_ITERS=500, MAX_EPOCH=18, LR_DECAY_STAGES=[12, 16])))
+
+
+class ATSSConfig(FCOSConfig):
+    """basedet/configs/det_model/atss_cfg.py:5-26 (FCOS with the ATSS assignment; the size-of-interest / centre-sampling keys go)."""
+
+    def __init__(self):
+        super().__init__()
+        self.merge(dict(MODEL=dict(NAME="ATSS", ANCHOR=dict(SCALE=8, TOPK=9), LOSSES=dict(REG_LOSS_WEIGHT=2.0))))
+        del self.MODEL.HEAD["OBJECT_SIZES_OF_INTEREST"]
+        del self.MODEL.HEAD["CENTER_SAMPLING_RADIUS"]

@@ -226,6 +226,119 @@ __global__ __launch_bounds__(256) void fcos_assign_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// ATSS target assignment (models/det/atss.py:17-86)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int ATSS_TOPK_MAX = 16;
+
+// one workgroup per (gt, image): per level the TOPK points closest to the gt centre (ties: lower index), their IoUs with the
+// point-centred anchors, threshold = mean + std over all candidates, then an atomicMax per surviving candidate on
+// best[n][p] = (iou bits << 32) | ~g  (highest IoU wins, ties -> lowest gt index = argmax over the gt axis)
+__global__ __launch_bounds__(256) void atss_candidates_kernel(const float* __restrict__ points, FcosLevels lv, int topk, float half_scale,
+                                                              const float* __restrict__ gt_boxes, const int* __restrict__ num_gt,
+                                                              int Gmax, int P, unsigned long long* __restrict__ best) {
+    __shared__ unsigned long long red[4];
+    __shared__ int cand[BD_MAX_SEGS * ATSS_TOPK_MAX];
+    __shared__ float ciou[BD_MAX_SEGS * ATSS_TOPK_MAX];
+    __shared__ float s_thr;
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    if (g >= min(num_gt[n], Gmax)) return;
+    const Box gb = ld_gt(gt_boxes + ((long long)n * Gmax + g) * 5);
+    const float cx = (gb.x1 + gb.x2) / 2.f, cy = (gb.y1 + gb.y2) / 2.f;     // box_center (op_patch.py:101-112)
+    int ncand = 0;
+    for (int l = 0; l < lv.L; ++l) {
+        const int s0 = lv.start[l], cnt = lv.start[l + 1] - s0;
+        const int kk = min(topk, cnt);
+        unsigned long long last = 0ull;
+        bool have_last = false;
+        for (int k = 0; k < kk; ++k) {
+            unsigned long long mine = ~0ull;
+            for (int i = tid; i < cnt; i += 256) {
+                const float dx = cx - points[(s0 + i) * 2ll], dy = cy - points[(s0 + i) * 2ll + 1];
+                const float d = sqrtf(dx * dx + dy * dy);                        // atss.py:40-42
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)i;
+                if ((!have_last || key > last) && key < mine) mine = key;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long t = __shfl_xor(mine, o, 64);
+                mine = t < mine ? t : mine;
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = mine;
+            __syncthreads();
+            unsigned long long m = red[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) m = red[w] < m ? red[w] : m;
+            last = m; have_last = true;
+            if (tid == 0) cand[ncand + k] = s0 + (int)(m & 0xffffffffull);
+        }
+        ncand += kk;
+    }
+    __syncthreads();
+    if (tid < ncand) {
+        const int p = cand[tid];
+        int l = 0;
+        for (int q = 1; q < lv.L; ++q) if (p >= lv.start[q]) l = q;
+        const float hs = lv.radius[l] * half_scale;                               // stride * SCALE / 2 (atss.py:33-36)
+        const float px = points[p * 2ll], py = points[p * 2ll + 1];
+        const Box ab = Box{px - hs, py - hs, px + hs, py + hs};
+        ciou[tid] = box_iou_dev(gb, box_area(gb), ab, box_area(ab));
+    }
+    __syncthreads();
+    if (tid == 0) {                                                               // mean + std (population), index order
+        float sum = 0.f;
+        for (int i = 0; i < ncand; ++i) sum += ciou[i];
+        const float mean = sum / (float)ncand;
+        float var = 0.f;
+        for (int i = 0; i < ncand; ++i) { const float d = ciou[i] - mean; var += d * d; }
+        s_thr = mean + sqrtf(var / (float)ncand);
+    }
+    __syncthreads();
+    if (tid < ncand) {
+        const int p = cand[tid];
+        const float px = points[p * 2ll], py = points[p * 2ll + 1];
+        const bool inb = fminf(fminf(px - gb.x1, py - gb.y1), fminf(gb.x2 - px, gb.y2 - py)) > 0.f;     // atss.py:56-58
+        if (ciou[tid] >= s_thr && inb)
+            atomicMax(best + (long long)n * P + p, ((unsigned long long)__float_as_uint(ciou[tid]) << 32) | (0xffffffffu - (unsigned int)g));
+    }
+}
+
+__global__ __launch_bounds__(256) void atss_finalize_kernel(const float* __restrict__ points, int P, const float* __restrict__ gt_boxes,
+                                                            const int* __restrict__ num_gt, int Gmax,
+                                                            const unsigned long long* __restrict__ best, int* __restrict__ labels,
+                                                            float* __restrict__ offsets, float* __restrict__ ctrness,
+                                                            float* __restrict__ stats) {
+    const int n = blockIdx.y;
+    const int pidx = blockIdx.x * 256 + threadIdx.x;
+    const int G = min(num_gt[n], Gmax);
+    float fgf = 0.f, ctr_fg = 0.f;
+    if (pidx < P) {
+        const float px = points[pidx * 2ll], py = points[pidx * 2ll + 1];
+        const unsigned long long key = best[(long long)n * P + pidx];
+        int lab = 0;
+        f32x4_t off = {0.f, 0.f, 0.f, 0.f};
+        float ctr = 0.f;
+        if (G > 0) {
+            const int bi = key ? (int)(0xffffffffu - (unsigned int)(key & 0xffffffffull)) : 0;     // unmatched: argmax of all -1 = 0
+            const float* mg = gt_boxes + ((long long)n * Gmax + bi) * 5;
+            lab = key ? (int)mg[4] : 0;
+            off[0] = px - mg[0]; off[1] = py - mg[1]; off[2] = mg[2] - px; off[3] = mg[3] - py;
+            const float lr = fmaxf(fminf(off[0], off[2]) / fmaxf(off[0], off[2]), 0.f);
+            const float tb = fmaxf(fminf(off[1], off[3]) / fmaxf(off[1], off[3]), 0.f);
+            ctr = sqrtf(lr * tb);                                                 // atss.py:70-75
+        }
+        const long long o = (long long)n * P + pidx;
+        labels[o] = lab;
+        *reinterpret_cast<f32x4_t*>(offsets + o * 4) = off;
+        ctrness[o] = ctr;
+        if (lab > 0) { fgf = 1.f; ctr_fg = ctr; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { fgf += __shfl_xor(fgf, o, 64); ctr_fg += __shfl_xor(ctr_fg, o, 64); }
+    if ((threadIdx.x & 63) == 0 && fgf > 0.f) { atomicAdd(stats, fgf); atomicAdd(stats + 1, ctr_fg); }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // batched NMS (layers/common/post_processing.py:17-47)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int NMS_MAX = 16384;
@@ -422,6 +535,32 @@ extern "C" int bd_fcos_assign(const float* points, int P, const int32_t* lvl_sta
     hipLaunchKernelGGL(fcos_assign_kernel, dim3(cdiv(P, 256), N), dim3(256), 0, st, points, P, lv, radius > 0.f ? 1 : 0,
                        gt_boxes, num_gt, Gmax, labels, offsets, ctrness, stats);
     BD_CHECK_LAUNCH("bd_fcos_assign");
+    return BD_OK;
+}
+
+extern "C" size_t bd_atss_assign_workspace_bytes(int N, int P) { return (size_t)(N > 0 ? N : 0) * (size_t)(P > 0 ? P : 0) * 8 + 64; }
+
+extern "C" int bd_atss_assign(const float* points, int P, const int32_t* lvl_start, const int32_t* strides, int L, int topk,
+                              float anchor_scale, const float* gt_boxes, const int32_t* num_gt, int N, int Gmax, int32_t* labels,
+                              float* offsets, float* ctrness, float* stats, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(points && lvl_start && strides && gt_boxes && num_gt && labels && offsets && ctrness && stats && ws, "atss_assign: null pointer");
+    BD_REQUIRE(L >= 1 && L <= BD_MAX_SEGS && P > 0 && N > 0 && Gmax > 0 && topk >= 1 && topk <= ATSS_TOPK_MAX, "atss_assign: bad sizes");
+    if (ws_bytes < bd_atss_assign_workspace_bytes(N, P)) {
+        bd_set_error("atss_assign: workspace %zu < %zu bytes", ws_bytes, bd_atss_assign_workspace_bytes(N, P));
+        return BD_EWORKSPACE;
+    }
+    FcosLevels lv{};
+    lv.L = L;
+    for (int l = 0; l < L; ++l) { lv.start[l] = lvl_start[l]; lv.radius[l] = (float)strides[l]; }
+    lv.start[L] = lvl_start[L];
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(ws, 0, (size_t)N * P * 8, st);
+    (void)hipMemsetAsync(stats, 0, 2 * sizeof(float), st);
+    hipLaunchKernelGGL(atss_candidates_kernel, dim3(Gmax, N), dim3(256), 0, st, points, lv, topk, anchor_scale / 2.f, gt_boxes, num_gt, Gmax, P,
+                       (unsigned long long*)ws);
+    hipLaunchKernelGGL(atss_finalize_kernel, dim3(cdiv(P, 256), N), dim3(256), 0, st, points, P, gt_boxes, num_gt, Gmax,
+                       (const unsigned long long*)ws, labels, offsets, ctrness, stats);
+    BD_CHECK_LAUNCH("bd_atss_assign");
     return BD_OK;
 }
 

@@ -1,3 +1,3 @@
 from .retinanet import RetinaNet  # noqa: F401
-from .fcos import FCOS  # noqa: F401
+from .fcos import ATSS, FCOS  # noqa: F401
 from .faster_rcnn import FasterRCNN  # noqa: F401

@@ -121,8 +121,7 @@ class FCOS(FPNDetector):
         m = self.cfg.MODEL
         gt = pre["gt_boxes"]
         num_gt = pre["img_info"][:, 4].to(torch.int32).contiguous()
-        ops.fcos_assign(pl.points, pl.lvl_start, m.HEAD.OBJECT_SIZES_OF_INTEREST, self.strides, m.HEAD.CENTER_SAMPLING_RADIUS,
-                        gt, num_gt, pl.labels, pl.gt_offsets, pl.gt_ctr, pl.stats)
+        self._assign(pl, gt, num_gt)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(pl.stats, op=dist.ReduceOp.SUM)            # all_reduce(mode="mean") of num_fg and sum_ctr
             pl.stats.mul_(1.0 / dist.get_world_size())
@@ -136,6 +135,12 @@ class FCOS(FPNDetector):
         ops.bce_logits_fwd_bwd(pl.raw, pl.gt_ctr, pl.labels, rows, pl.stats[0:1], pl.loss_buf[2:3], pl.d_ctr, ld=8, off=4)
         cls_loss, reg_loss, ctr_loss = pl.loss_buf[0], pl.loss_buf[1], pl.loss_buf[2]
         return {"total_loss": cls_loss + reg_loss + ctr_loss, "cls_loss": cls_loss, "reg_loss": reg_loss, "ctr_loss": ctr_loss}
+
+    def _assign(self, pl, gt, num_gt):
+        """FCOS.get_ground_truth (fcos.py:222-293)."""
+        m = self.cfg.MODEL
+        ops.fcos_assign(pl.points, pl.lvl_start, m.HEAD.OBJECT_SIZES_OF_INTEREST, self.strides, m.HEAD.CENTER_SAMPLING_RADIUS,
+                        gt, num_gt, pl.labels, pl.gt_offsets, pl.gt_ctr, pl.stats)
 
     # ---- backward ----------------------------------------------------------------------------------------
     def head_backward(self, pl, ws, cws):
@@ -181,3 +186,16 @@ class FCOS(FPNDetector):
         ops.det_scores(pl.logits, rows, K, scores, ctr=pl.raw, ctr_ld=8, ctr_off=4)
         return self._detect(scores, [h * w for h, w in pl.sizes], K, 1, pre["img_info"], anchors=pl.points, offsets=pl.offsets,
                             off_ld=4, A=1)
+
+
+@registers.models.register()
+class ATSS(FCOS):
+    """ATSS (basedet/models/det/atss.py): the FCOS network and losses with the adaptive training-sample selection."""
+
+    def _assign(self, pl, gt, num_gt):
+        m = self.cfg.MODEL
+        N, P_total = pl.labels.shape
+        if getattr(pl, "atss_ws", None) is None:
+            pl.atss_ws = torch.empty((ops.atss_assign_workspace_bytes(N, P_total),), dtype=torch.uint8, device=self.device)
+        ops.atss_assign(pl.points, pl.lvl_start, self.strides, m.ANCHOR.TOPK, m.ANCHOR.SCALE, gt, num_gt, pl.labels, pl.gt_offsets,
+                        pl.gt_ctr, pl.stats, pl.atss_ws)

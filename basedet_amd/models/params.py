@@ -197,12 +197,13 @@ def oracle_arch(cfg):
                     rcnn_box_reg=(list(m.RCNN_BOX_REG.MEAN), list(m.RCNN_BOX_REG.STD)),
                     matcher=(list(m.MATCHER.THRESHOLDS), list(m.MATCHER.LABELS), m.MATCHER.ALLOW_LOW_QUALITY),
                     rpn_beta=m.LOSSES.RPN_SMOOTH_L1_BETA, rcnn_beta=m.LOSSES.RCNN_SMOOTH_L1_BETA)
-    if m.NAME == "FCOS":
-        return dict(backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
+    if m.NAME in ("FCOS", "ATSS"):
+        extra = dict(atss=dict(scale=m.ANCHOR.SCALE, topk=m.ANCHOR.TOPK), sizes_of_interest=None, center_sampling_radius=None) \
+            if m.NAME == "ATSS" else dict(sizes_of_interest=[list(s) for s in m.HEAD.OBJECT_SIZES_OF_INTEREST],
+                                          center_sampling_radius=m.HEAD.CENTER_SAMPLING_RADIUS)
+        return dict(extra, backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
                     num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),
                     strides=list(m.FPN.STRIDES), anchor_offset=m.ANCHOR.OFFSET,
-                    sizes_of_interest=[list(s) for s in m.HEAD.OBJECT_SIZES_OF_INTEREST],
-                    center_sampling_radius=m.HEAD.CENTER_SAMPLING_RADIUS,
                     focal_alpha=m.LOSSES.FOCAL_LOSS_ALPHA, focal_gamma=m.LOSSES.FOCAL_LOSS_GAMMA,
                     iou_loss_type=m.LOSSES.IOU_LOSS_TYPE, reg_loss_weight=m.LOSSES.REG_LOSS_WEIGHT)
     return dict(backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,

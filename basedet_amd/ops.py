@@ -235,6 +235,18 @@ def fcos_assign(points, lvl_start, soi, strides, radius, gt_boxes, num_gt, label
                              stream_ptr()), "bd_fcos_assign")
 
 
+def atss_assign_workspace_bytes(N, P):
+    return int(L().bd_atss_assign_workspace_bytes(N, P))
+
+
+def atss_assign(points, lvl_start, strides, topk, anchor_scale, gt_boxes, num_gt, labels, offsets, ctrness, stats, ws):
+    P = points.shape[0]
+    N, Gmax = gt_boxes.shape[0], gt_boxes.shape[1]
+    check(L().bd_atss_assign(ptr(points), P, i32arr(lvl_start), i32arr(strides), len(strides), int(topk), float(anchor_scale),
+                             ptr(gt_boxes), ptr(num_gt), N, Gmax, ptr(labels), ptr(offsets), ptr(ctrness), ptr(stats), ptr(ws),
+                             ws.numel() * ws.element_size(), stream_ptr()), "bd_atss_assign")
+
+
 def nms_workspace_bytes(n):
     return int(L().bd_nms_workspace_bytes(n))
 

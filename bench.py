@@ -29,6 +29,7 @@ TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): 
     "retinanet_r18_512x512": 277.2,
     "fcos_r50_800x1344": 1227.8,
     "retinanet_r101_800x1344": 1912.8,
+    "atss_r50_800x1344": 1227.8,          # the FCOS network; only the target assignment differs
     # Faster R-CNN R50-FPN (P2-P6): fwd 208.9 GMAC/img (backbone 87.6, FPN 60.9, RPN 53.1, box head 512 RoIs x 14.3 MMAC = 7.3);
     # stem + layer1 frozen, lateral2 needs no dgrad
     "faster_rcnn_r50_800x1344": 1177.2,
@@ -165,8 +166,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from basedet_amd import ops
-    from basedet_amd.configs import FasterRCNNConfig, FCOSConfig, RetinaNetConfig, retinanet_r18_config
-    from basedet_amd.models import FCOS, FasterRCNN, RetinaNet, params as P
+    from basedet_amd.configs import ATSSConfig, FasterRCNNConfig, FCOSConfig, RetinaNetConfig, retinanet_r18_config
+    from basedet_amd.models import ATSS, FCOS, FasterRCNN, RetinaNet, params as P
     from basedet_amd.solver import DetSolver, WarmupMultiStepLR, broadcast_parameters
     from basedet_amd.utils import DummyLoader
 
@@ -174,6 +175,8 @@ def main():
         cfg, size = RetinaNetConfig(), (800, 1344)
     elif args.workload == "fcos_r50_800x1344":
         cfg, size = FCOSConfig(), (800, 1344)
+    elif args.workload == "atss_r50_800x1344":
+        cfg, size = ATSSConfig(), (800, 1344)
     elif args.workload == "retinanet_r101_800x1344":
         cfg, size = RetinaNetConfig(), (800, 1344)
         cfg.MODEL.BACKBONE.NAME = "resnet101"
@@ -184,9 +187,9 @@ def main():
     cfg.MODEL.BATCHSIZE = args.batch
     # random-init weights of the named architecture; the last FrozenBN gamma of every residual branch is 0.2
     # (stand-in for ImageNet statistics: identity BN overflows a random ResNet-50; same FLOPs and bytes)
-    if cfg.MODEL.NAME == "FCOS":
+    if cfg.MODEL.NAME in ("FCOS", "ATSS"):
         params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.2)
-        model = FCOS(cfg, params=params)
+        model = (ATSS if cfg.MODEL.NAME == "ATSS" else FCOS)(cfg, params=params)
     elif cfg.MODEL.NAME == "FasterRCNN":
         params = P.init_faster_rcnn_params(cfg, seed=0, residual_gamma=0.2)
         model = FasterRCNN(cfg, params=params)

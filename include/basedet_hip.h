@@ -199,6 +199,15 @@ int bd_fcos_assign(const float* points, int P, const int32_t* lvl_start_host, co
                    const int32_t* num_gt, int N, int Gmax, int32_t* labels, float* offsets, float* ctrness,
                    float* stats, bd_stream_t stream);
 
+/* ATSS.get_ground_truth (models/det/atss.py:17-86): per gt and level the `topk` points closest to the gt centre (ties: lower
+ * index), IoU with the point-centred square anchors of side stride*anchor_scale, positives = candidates with IoU >= mean + std
+ * (population std, index-order fp32 sums) whose centre lies inside the gt; a point claimed by several gts goes to the highest
+ * IoU (ties: lowest gt index).  Outputs as bd_fcos_assign.  ws: bd_atss_assign_workspace_bytes. */
+size_t bd_atss_assign_workspace_bytes(int N, int P);
+int bd_atss_assign(const float* points, int P, const int32_t* lvl_start_host, const int32_t* strides_host, int L, int topk,
+                   float anchor_scale, const float* gt_boxes, const int32_t* num_gt, int N, int Gmax, int32_t* labels,
+                   float* offsets, float* ctrness, float* stats, void* ws, size_t ws_bytes, bd_stream_t stream);
+
 /* layers/common/post_processing.py:17-47 batched_nms (class-offset trick + greedy NMS, suppress iff IoU > thr).
  * boxes [n][4], scores [n], idxs [n] (may be NULL = plain NMS).  keep: int32[n] (descending score order),
  * num_keep: int32[1].  max_output <= 0 means unlimited.  ws from bd_nms_workspace_bytes(n). */

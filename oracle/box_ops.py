@@ -304,6 +304,72 @@ def fcos_ground_truth(points_list, strides, batched_gt_boxes, num_valid, sizes_o
 
 
 # --------------------------------------------------------------------------------------------
+# ATSS target assignment (models/det/atss.py:17-86)
+# --------------------------------------------------------------------------------------------
+def atss_ground_truth(points_list, strides, batched_gt_boxes, num_valid, anchor_scale=8, topk=9):
+    """Returns labels (N, P) int32, ltrb offsets (N, P, 4) f32, centerness (N, P) f32.
+    Unpinned choices: F.topk(distances, descending=False) ties -> lowest index; F.std = population standard deviation
+    (MegEngine: sqrt(mean((x - mean)^2))); mean / std are accumulated in float32 in candidate order (level-major, then rank);
+    argmax over the gt axis -> lowest gt index; points matched to nothing report gt 0 (argmax of an all -1 column)."""
+    all_pts = np.concatenate(points_list, axis=0).astype(F32)
+    P = all_pts.shape[0]
+    labs, offs, ctrs = [], [], []
+    for boxes_with_labels, n in zip(batched_gt_boxes, num_valid):
+        gtl = np.asarray(boxes_with_labels, F32)[: int(n)]
+        if gtl.shape[0] == 0:
+            labs.append(np.zeros(P, np.int32)); offs.append(np.zeros((P, 4), F32)); ctrs.append(np.zeros(P, F32))
+            continue
+        gt = gtl[:, :4]
+        G = gt.shape[0]
+        ctr = ((gt[:, :2] + gt[:, 2:4]) / F32(2)).astype(F32)
+        ious = np.full((G, P), F32(-1), F32)
+        base = 0
+        cand_idx, cand_iou = [], []
+        for stride, pts in zip(strides, points_list):
+            pts = np.asarray(pts, F32)
+            hs = F32(stride * anchor_scale / 2)
+            anchors = np.concatenate([pts - hs, pts + hs], axis=1).astype(F32)
+            iou_l = box_iou(gt, anchors)                                            # (G, P_l)
+            d = ctr[:, None, :] - pts[None, :, :]
+            dist = np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]).astype(F32)).astype(F32)
+            k = min(topk, pts.shape[0])
+            order = np.argsort(dist, axis=1, kind="stable")[:, :k]                  # ascending, ties -> lowest index
+            cand_idx.append(base + order)
+            cand_iou.append(np.take_along_axis(iou_l, order, axis=1))
+            base += pts.shape[0]
+        cand_idx = np.concatenate(cand_idx, axis=1)
+        cand_iou = np.concatenate(cand_iou, axis=1).astype(F32)
+        for g in range(G):
+            s = F32(0)
+            for v in cand_iou[g]:
+                s = F32(s + v)
+            mean = F32(s / F32(cand_iou.shape[1]))
+            var = F32(0)
+            for v in cand_iou[g]:
+                dv = F32(v - mean)
+                var = F32(var + F32(dv * dv))
+            thr = F32(mean + np.sqrt(F32(var / F32(cand_iou.shape[1]))).astype(F32))
+            fg = cand_iou[g] >= thr
+            pts_c = all_pts[cand_idx[g]]
+            ltrb = np.stack([pts_c[:, 0] - gt[g, 0], pts_c[:, 1] - gt[g, 1], gt[g, 2] - pts_c[:, 0], gt[g, 3] - pts_c[:, 1]], 1)
+            inb = ltrb.min(axis=1) > 0
+            keep = fg & inb
+            ious[g, cand_idx[g][keep]] = cand_iou[g][keep]
+        idx = ious.argmax(axis=0)
+        amax = ious[idx, np.arange(P)]
+        matched = gtl[idx]
+        lab = matched[:, 4].astype(np.int32)
+        lab[amax == F32(-1)] = 0
+        off = point_encode(all_pts, matched[:, :4])
+        lr = off[:, [0, 2]]
+        tb = off[:, [1, 3]]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c = np.sqrt(np.fmax(lr.min(1) / lr.max(1), F32(0)) * np.fmax(tb.min(1) / tb.max(1), F32(0))).astype(F32)
+        labs.append(lab); offs.append(off); ctrs.append(c)
+    return np.stack(labs), np.stack(offs), np.stack(ctrs)
+
+
+# --------------------------------------------------------------------------------------------
 # losses (layers/losses/*.py) -- elementwise values; float64 versions used for gradient checks
 # --------------------------------------------------------------------------------------------
 def _logsigmoid(x):

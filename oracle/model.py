@@ -281,8 +281,12 @@ class Oracle:
         ctrs = torch.cat([self._permute(x, 1) for x in ctrs], dim=1).reshape(-1)
         pts = box_ops.point_anchors(sizes, a["strides"], a["anchor_offset"], 1)
         num_valid = np.asarray(batch["im_info"])[:, 4].astype(np.int32)
-        labels, gt_off, gt_ctr = box_ops.fcos_ground_truth(pts, a["strides"], batch["gt_boxes"], num_valid, a["sizes_of_interest"],
-                                                           a["center_sampling_radius"])
+        if a.get("atss"):                       # ATSS(FCOS): only the target assignment differs (models/det/atss.py)
+            labels, gt_off, gt_ctr = box_ops.atss_ground_truth(pts, a["strides"], batch["gt_boxes"], num_valid, a["atss"]["scale"],
+                                                               a["atss"]["topk"])
+        else:
+            labels, gt_off, gt_ctr = box_ops.fcos_ground_truth(pts, a["strides"], batch["gt_boxes"], num_valid, a["sizes_of_interest"],
+                                                               a["center_sampling_radius"])
         labels_t = torch.from_numpy(labels.reshape(-1)).long()
         gt_off_t, gt_ctr_t = _t(gt_off.reshape(-1, 4)), _t(gt_ctr.reshape(-1))
         valid, fg = labels_t >= 0, labels_t > 0

@@ -255,3 +255,43 @@ def test_giou_and_bce_losses():
     assert abs(float(loss.item()) - ref) / ref < 1e-4
     refg = (1 / (1 + np.exp(-xf)) - t) * fg / fg.sum()
     assert np.allclose(dx.float().cpu().numpy(), refg, rtol=1e-2, atol=1e-9)
+
+
+def test_atss_assign_bit_exact():
+    """ATSS.get_ground_truth (models/det/atss.py:17-86): labels, ltrb offsets and centre-ness bit-exact against the oracle,
+    including a gt-free image, duplicated gts (ties between gts) and gts hanging over the image border."""
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    sizes = [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)]
+    strides = [8, 16, 32, 64, 128]
+    pts = ob.point_anchors(sizes, strides, 0.5, 1)
+    allp = np.concatenate(pts, 0)
+    P = allp.shape[0]
+    N, Gmax = 4, 8
+    gt = np.zeros((N, Gmax, 5), np.float32)
+    num = np.array([6, 0, 3, 8], np.int32)
+    for n in range(N):
+        for g in range(num[n]):
+            cx, cy = rng.uniform(0, 320), rng.uniform(0, 256)
+            w, h = rng.uniform(10, 200), rng.uniform(10, 200)
+            gt[n, g] = [cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, rng.integers(1, 81)]
+    gt[2, 2] = gt[2, 1]                                  # identical gts: the lower index must win
+    gt[3, 0, :4] = [-30, -20, 90, 70]                    # partly outside the image
+    lvl_start = [0]
+    for (h, w) in sizes:
+        lvl_start.append(lvl_start[-1] + h * w)
+    labels = torch.empty((N, P), dtype=torch.int32, device="cuda")
+    offs = torch.empty((N, P, 4), dtype=torch.float32, device="cuda")
+    ctr = torch.empty((N, P), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((2,), dtype=torch.float32, device="cuda")
+    ws = torch.empty((ops.atss_assign_workspace_bytes(N, P),), dtype=torch.uint8, device="cuda")
+    ops.atss_assign(_dev(allp), lvl_start, strides, 9, 8, _dev(gt), _dev(num), labels, offs, ctr, stats, ws)
+    rl, ro, rc = ob.atss_ground_truth(pts, strides, gt, num, 8, 9)
+    assert np.array_equal(labels.cpu().numpy(), rl)
+    assert np.array_equal(offs.cpu().numpy(), ro)
+    got_c = ctr.cpu().numpy()
+    fg = rl > 0
+    assert fg.sum() > 20 and np.array_equal(got_c[fg], rc[fg])
+    assert np.array_equal(np.nan_to_num(got_c), np.nan_to_num(rc))
+    st = stats.cpu().numpy()
+    assert st[0] == fg.sum() and abs(st[1] - rc[fg].sum()) <= 1e-4 * rc[fg].sum()
