@@ -437,3 +437,31 @@ def test_atss_training_step_matches_oracle():
         g = got[n].double().reshape(-1)
         rel = float((g - r).norm() / (r.norm() + 1e-30))
         assert rel < 2e-2, (n, rel)
+
+
+def test_ragged_batch_through_collator_matches_oracle():
+    """Images of different sizes -> DetectionPadCollator (pad to the batch maximum with 0) -> pre_process (pad to x32 with the
+    normalised value of 0, pre_processing.py:11-49) -> RetinaNet losses: same targets and losses as the oracle on the same dict."""
+    from basedet_amd.data import DetectionPadCollator
+    from basedet_amd.models import RetinaNet, params as P
+    from oracle.model import Oracle
+    cfg, params, _ = _setup("resnet18", 2, (128, 160))
+    rng = np.random.default_rng(9)
+    samples = []
+    for (h, w, nb) in ((100, 150, 3), (120, 130, 1)):
+        img = rng.uniform(0, 255, (3, h, w)).astype(np.float32)
+        x1 = rng.uniform(0, w * 0.5, nb); y1 = rng.uniform(0, h * 0.5, nb)
+        boxes = np.stack([x1, y1, x1 + rng.uniform(20, w * 0.45, nb), y1 + rng.uniform(20, h * 0.45, nb)], 1)
+        samples.append((img, boxes, rng.integers(1, 81, nb), (2 * h, 2 * w)))
+    batch = DetectionPadCollator().apply(samples)
+    assert batch["data"].shape == (2, 3, 120, 150) and batch["gt_boxes"].shape == (2, 3, 5)
+    model = RetinaNet(cfg, params=params)
+    names = P.trainable_names(params, cfg.MODEL.BACKBONE.FREEZE_AT)
+    ref, aux = Oracle(params, P.oracle_arch(cfg), trainable=names).retinanet_losses(batch)
+    out = model(batch)
+    pl = model._cur
+    assert (pl.Hp, pl.Wp) == (128, 160)
+    assert np.array_equal(pl.labels.cpu().numpy(), aux["labels"])
+    for k in ("cls_loss", "reg_loss", "total_loss"):
+        got, want = float(out[k]), float(ref[k].detach())
+        assert abs(got - want) / abs(want) < 2e-2, (k, got, want)
