@@ -16,6 +16,7 @@ SOURCES = {
     "image_ops.hip": [],
     "conv_igemm.hip": [],
     "conv3x3.hip": [],
+    "conv3x3_w4.hip": [],
     "conv1x1.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad3x3.hip": [],

@@ -19,7 +19,10 @@ constexpr int PH = 4, PW = 16;                 // output patch (4 rows of 16 px 
 constexpr int IH = PH + 2, IW = PW + 2;        // input patch
 constexpr int NPATCH = 4;                      // patches per workgroup
 constexpr int XROWS = NPATCH * IH * IW;        // 432 LDS rows
-constexpr int X_BYTES = XROWS * 128;           // 55296
+constexpr int X_PITCH = 144;                   // activation rows: 128 B of channels + 16 B pad -- 16 consecutive rows hit 16 distinct
+                                               // bank quads (conflict-free ds_read_b128 / ds_write_b128) and a tap shift becomes a
+                                               // compile-time byte offset: no swizzle arithmetic inside the MFMA loop
+constexpr int X_BYTES = XROWS * X_PITCH;       // 62208
 constexpr int TAPS_PER_STEP = 3;               // one filter row per barrier step
 constexpr int W_TAP_BYTES = 128 * 128;         // 16384: one tap's 128 x 64 weight tile
 constexpr int W_BYTES = TAPS_PER_STEP * W_TAP_BYTES;   // 49152
@@ -54,7 +57,7 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // DMA = true: the weight tiles go global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass); a
 // wave-instruction writes 1 KiB = 8 swizzled rows, the swizzle is applied on the per-lane SOURCE address.  Needs
 // CK % 64 == 0 (no zero-filled K tail) -- other shapes use the register-staged variant.
-template <bool DMA>
+template <bool DMA, int MODE>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xbuf = smem;                       // [X_BYTES]      (single buffer, swapped between K blocks)
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
             for (int q = 1; q < NPATCH; ++q)
                 if (pk == q) { qy = py0[q]; qx = px0[q]; H = pH[q]; W = pWd[q]; qs = psrc[q]; }
             const int y = qy - 1 + iy, x = qx - 1 + ix;
-            x_lds[k] = swz(row, x_chunk);
+            x_lds[k] = row * X_PITCH + x_chunk * 16;
             if (y >= 0 && x >= 0 && y < H && x < W) x_off[k] = (qs + (long long)y * W + x) * p.CK;
         }
     }
@@ -206,8 +209,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) a_off[i][kk] = swz(wc * 64 + i * 16 + frow, kk * 4 + fchunk);
-    // B rows: patch wp, output row j, column frow; input row = (j + dy)*IW + frow + dx
-    const int b_row0 = wp * (IH * IW) + frow;
+    // B rows: patch wp, output row j, column frow; input row = (j + dy)*IW + frow + dx: lane base + compile-time offsets
+    const unsigned char* b_base = xbuf + (wp * (IH * IW) + frow) * X_PITCH + fchunk * 16;
 
     // one barrier step = one filter row = 6 sub-steps (3 taps x 2 K halves) of 16 MFMAs.  Fragments are double
     // buffered: the ds_reads of sub-step u+1 are issued before the MFMAs of sub-step u, so LDS latency hides under the
@@ -217,16 +220,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
     auto load_frags = [&](int wb, int r, int u, bf16x8_t (&a)[4], bf16x8_t (&b)[4]) {
         const int t = u >> 1, kk = u & 1;
         int dy = r, dx = t;
-        if (p.mode == 1) { dy = 2 - dy; dx = 2 - dx; }     // dgrad: mirrored tap
+        if (MODE == 1) { dy = 2 - dy; dx = 2 - dx; }       // dgrad: mirrored tap
         const unsigned char* Wt = wbuf + wb * W_BYTES + t * W_TAP_BYTES;
-        const int shift = dy * IW + dx;
+        const unsigned char* Bt = b_base + dy * (IW * X_PITCH);
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(Wt + a_off[i][kk]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = b_row0 + j * IW + shift;
-            b[j] = *reinterpret_cast<const bf16x8_t*>(xbuf + swz(row, kk * 4 + fchunk));
-        }
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bt + (j * IW + dx) * X_PITCH + kk * 64);
     };
     auto mfma16 = [&](const bf16x8_t (&a)[4], const bf16x8_t (&b)[4]) {
 #pragma unroll
@@ -384,6 +384,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
 
 }  // namespace
 
+int g_patch_w4 = 0;       // bd_conv_set_patch3x3 bit 4: four-wave instance (conv3x3_w4.hip) for CK % 64 == 0
+int bd_conv3x3_patch4w_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
+                              const void* mask, void* dst, int flags, hipStream_t stream);
 int g_patch_dma = 1;
 static long long* g_patch_dbg = nullptr;
 extern "C" int bd_conv3x3_set_debug(long long* buf) { g_patch_dbg = buf; return 0; }      // bd_conv_set_patch3x3 bit 3 clears it (register-staged weights everywhere)
@@ -392,6 +395,9 @@ extern "C" int bd_conv3x3_set_debug(long long* buf) { g_patch_dbg = buf; return 
 // mode 1 dgrad (src = dY).  CK = reduction channels, CO = produced channels.
 int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias,
                             const void* add, const void* mask, void* dst, int flags, hipStream_t stream) {
+    if (g_patch_w4 && (mode == 0 ? d->Cin : d->Cout) % 64 == 0 &&
+        (long long)d->N * (mode == 0 ? d->in_pix_per_img : d->out_pix_per_img) * (mode == 0 ? d->Cin : d->Cout) < 0xffffffffll)
+        return bd_conv3x3_patch4w_launch(d, mode, src, w, bias, add, mask, dst, flags, stream);
     C3Params p{};
     p.src = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias;
     p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)dst;
@@ -416,13 +422,16 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
     const size_t lds = X_BYTES + 2 * W_BYTES + TILE_CO * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    if (g_patch_dma && p.CK % 64 == 0)
-        hipLaunchKernelGGL(conv3x3_patch_kernel<true>, dim3(grid), dim3(512), lds, stream, p);
-    else
-        hipLaunchKernelGGL(conv3x3_patch_kernel<false>, dim3(grid), dim3(512), lds, stream, p);
+    const bool dma = g_patch_dma && p.CK % 64 == 0;
+    if (dma && mode == 0) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 0>), dim3(grid), dim3(512), lds, stream, p);
+    else if (dma) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 1>), dim3(grid), dim3(512), lds, stream, p);
+    else if (mode == 0) hipLaunchKernelGGL((conv3x3_patch_kernel<false, 0>), dim3(grid), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 1>), dim3(grid), dim3(512), lds, stream, p);
     return 0;
 }
