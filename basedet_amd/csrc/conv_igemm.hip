@@ -38,7 +38,10 @@ struct Cfg {
     }
 };
 
-template <int BK>
+// PRE: the epilogue operands (residual / accumulated gradient `add`, ReLU `mask`) of a linear-destination tile are fetched at the
+// START of the kernel into registers, so that for the short-K 1x1 layers (HBM-bound, 2..8 K steps) their HBM latency overlaps the
+// operand loads and the MFMAs instead of forming a second serial round trip after the last MFMA.
+template <int BK, bool PRE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
     using C = Cfg<BK>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,6 +69,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
 
     const int chunk = tid % C::CHUNKS;
     const int row0 = tid / C::CHUNKS;
+
+    u32x4_t pre_add[PRE ? 8 : 1], pre_mask[PRE ? 8 : 1];
+    if (PRE) {
+        const int cb_ = co0 + wc * 64 + 8 * (lane >> 4);
+        const bool want_add = (p.flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER)) && p.add;
+        const bool want_mask = (p.flags & BD_EPI_MASK) && p.mask;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+                const bool ok = m < p.M && cb_ + 32 * half < p.CO;
+                const long long idx = (long long)m * p.CO + cb_ + 32 * half;
+                u32x4_t a = {0u, 0u, 0u, 0u}, k = {0u, 0u, 0u, 0u};
+                if (ok && want_add) a = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                if (ok && want_mask) k = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+                pre_add[j * 2 + half] = a; pre_mask[j * 2 + half] = k;
+            }
+    }
 
     // ---- per-row pixel decode (B operand rows handled by this thread) ----
     int b_py[C::PASSES], b_px[C::PASSES], b_hs[C::PASSES], b_ws[C::PASSES];
@@ -276,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];
             if (add_before) {
-                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                const u32x4_t av = PRE ? pre_add[j * 2 + half] : *reinterpret_cast<const u32x4_t*>(p.add + idx);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
             }
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
                 for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
             }
             if (do_mask) {
-                const u32x4_t mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+                const u32x4_t mv = PRE ? pre_mask[j * 2 + half] : *reinterpret_cast<const u32x4_t*>(p.mask + idx);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (!(bf_lo(mv[k]) > 0.f)) v[2 * k] = 0.f;
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
                 }
             }
             if (add_after) {
-                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                const u32x4_t av = PRE ? pre_add[j * 2 + half] : *reinterpret_cast<const u32x4_t*>(p.add + idx);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
             }
@@ -305,18 +327,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
     }
 }
 
+int g_igemm_prefetch_epi = 1;      // bd_conv_set_patch3x3 bit 5 clears it
+
 template <int BK>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
     using C = Cfg<BK>;
     const size_t lds = 4 * C::TILE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = p.m_tiles * p.n_tiles;
-    hipLaunchKernelGGL(conv_igemm_kernel<BK>, dim3(grid), dim3(256), lds, stream, p);
+    const bool epi_ops = ((p.flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER)) && p.add) || ((p.flags & BD_EPI_MASK) && p.mask);
+    const int ksteps = (p.CK + BK - 1) / BK * p.R * p.S;
+    if (g_igemm_prefetch_epi && p.linear_dst && epi_ops && ksteps <= 4)
+        hipLaunchKernelGGL((conv_igemm_kernel<BK, true>), dim3(grid), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BK, false>), dim3(grid), dim3(256), lds, stream, p);
     return 0;
 }
 
@@ -359,6 +390,7 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1; g_stream_1x1 = (enable >> 2) & 1;
     g_patch_dma = ((enable >> 3) & 1) ^ 1;
     g_patch_w4 = (enable >> 4) & 1;
+    g_igemm_prefetch_epi = ((enable >> 5) & 1) ^ 1;
     return BD_OK;
 }
 
