@@ -59,7 +59,6 @@ SIGNATURES = {
     "bd_upsample2x_add_fwd": (_I, [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _P]),
     "bd_upsample2x_add_bwd": (_I, [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "bd_relu_bf16": (_I, [_P, _P, _L, _P]),
-    "bd_scatter2x_epilogue": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P]),
     "bd_relu_bwd_bf16": (_I, [_P, _P, _P, _P, _L, _P]),
     "bd_add_bf16": (_I, [_P, _P, _P, _L, _P]),
     "bd_anchors_generate": (_I, [_I, _I, _I, _F, _P, _I, _P, _P]),

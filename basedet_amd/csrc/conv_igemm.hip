@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
     // XCD-aware bijective remap: consecutive tile ids stay on one XCD (shared weights / halo rows in its L2)
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
-    {
+    if (!(p.mode == 1 && p.stride > 1)) {
+        // (the stride-2 data-gradient enumerates its pixels parity-class-major: the classes differ in work -- for a 1x1 filter only
+        // one class has any -- so there the tiles stay round-robin over the XCDs; the contiguous remap put all the work on two)
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }

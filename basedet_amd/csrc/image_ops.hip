@@ -253,57 +253,6 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
     }
 }
 
-// dst[n, y, x, :] = epilogue(v), v = src[n, y/2, x/2, :] on the even pixels and 0 elsewhere: the data-gradient of a 1x1 / stride-2
-// convolution once the dense GEMM part has run on the small grid.  Same epilogue flags as the conv kernels.
-__global__ __launch_bounds__(256) void scatter2x_kernel(const bf16_raw* __restrict__ src, int Ho, int Wo, bf16_raw* __restrict__ dst,
-                                                        int Hi, int Wi, int C, int N, const bf16_raw* __restrict__ add,
-                                                        const bf16_raw* __restrict__ mask, int flags) {
-    const int cgs = C / 8;
-    const long long total = (long long)N * Hi * Wi * cgs;
-    const bool add_before = (flags & BD_EPI_ADD_BEFORE) && add, add_after = (flags & BD_EPI_ADD_AFTER) && add;
-    const bool do_mask = (flags & BD_EPI_MASK) && mask, do_relu = flags & BD_EPI_RELU;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cg = (int)(i % cgs);
-        long long p = i / cgs;
-        const int x = (int)(p % Wi); p /= Wi;
-        const int y = (int)(p % Hi);
-        const int n = (int)(p / Hi);
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (((x | y) & 1) == 0 && (y >> 1) < Ho && (x >> 1) < Wo) {
-            const u32x4_t sv = *reinterpret_cast<const u32x4_t*>(src + (((long long)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + cg * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[2 * q] = bf_lo(sv[q]); v[2 * q + 1] = bf_hi(sv[q]); }
-        }
-        const long long idx = i * 8;
-        if (add_before) {
-            const u32x4_t av = *reinterpret_cast<const u32x4_t*>(add + idx);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[2 * q] += bf_lo(av[q]); v[2 * q + 1] += bf_hi(av[q]); }
-        }
-        if (do_relu) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-        }
-        if (do_mask) {
-            const u32x4_t mv = *reinterpret_cast<const u32x4_t*>(mask + idx);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!(bf_lo(mv[q]) > 0.f)) v[2 * q] = 0.f;
-                if (!(bf_hi(mv[q]) > 0.f)) v[2 * q + 1] = 0.f;
-            }
-        }
-        if (add_after) {
-            const u32x4_t av = *reinterpret_cast<const u32x4_t*>(add + idx);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[2 * q] += bf_lo(av[q]); v[2 * q + 1] += bf_hi(av[q]); }
-        }
-        u32x4_t o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = pack_bf2(v[2 * q], v[2 * q + 1]);
-        *reinterpret_cast<u32x4_t*>(dst + idx) = o;
-    }
-}
-
 // many convs in one launch (after every optimizer step): 32 x 32 (co, ci) tiles per tap, transposed through LDS so that both
 // packed copies are written with contiguous runs
 __global__ __launch_bounds__(256) void weight_pack_multi_kernel(const bd_pack_desc* __restrict__ descs, int n) {
@@ -514,16 +463,6 @@ extern "C" int bd_weight_pack(const float* w, const float* row_scale, void* w_fw
     hipLaunchKernelGGL(weight_pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, row_scale,
                        (bf16_raw*)w_fwd, (bf16_raw*)w_dgrad, Cout, RS, Cin);
     BD_CHECK_LAUNCH("bd_weight_pack");
-    return BD_OK;
-}
-
-extern "C" int bd_scatter2x_epilogue(const void* src, int N, int Ho, int Wo, void* dst, int Hi, int Wi, int C, const void* add,
-                                     const void* mask, int flags, bd_stream_t stream) {
-    BD_REQUIRE(src && dst && N > 0 && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 8 == 0, "scatter2x_epilogue: bad arguments");
-    BD_REQUIRE((Hi - 1) / 2 + 1 == Ho && (Wi - 1) / 2 + 1 == Wo, "scatter2x_epilogue: %dx%d is not the stride-2 grid of %dx%d", Ho, Wo, Hi, Wi);
-    hipLaunchKernelGGL(scatter2x_kernel, dim3(grid_for((long long)N * Hi * Wi * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_raw*)src, Ho, Wo, (bf16_raw*)dst, Hi, Wi, C, N, (const bf16_raw*)add, (const bf16_raw*)mask, flags);
-    BD_CHECK_LAUNCH("bd_scatter2x_epilogue");
     return BD_OK;
 }
 

@@ -131,22 +131,6 @@ class ConvLayer:
             add = dx
         if mask is not None:
             flags |= ops.EPI_MASK
-        if self.k == 1 and self.stride == 2 and gin.nlev == 1 and gin.off[0] == 0 and gout.off[0] == 0 and \
-                gin.pix_per_img == gin.H[0] * gin.W[0] and gout.pix_per_img == gout.H[0] * gout.W[0]:
-            # 1x1 / stride 2 (downsample branches): dense GEMM on the small grid, then one streaming pass that places the result on
-            # the even pixels and applies the epilogue -- 2-3x faster than enumerating the four parity classes in the GEMM kernel
-            key = ("s2tmp", gout.pixels)
-            tmp = self._desc_cache.get(key)
-            if tmp is None:
-                tmp = torch.empty((gout.pixels, self.cin), dtype=torch.bfloat16, device=self.device)
-                self._desc_cache[key] = tmp
-            dkey = ("s2desc",) + tuple(gout.H) + tuple(gout.W) + (gout.N,)
-            d1 = self._desc_cache.get(dkey)
-            if d1 is None:
-                d1 = ops.conv_desc(gout, gout, self.cin, self.cout, 1, 1, 1, 0)
-                self._desc_cache[dkey] = d1
-            ops.conv2d_dgrad(d1, g, self.w_dgrad, tmp)
-            return ops.scatter2x_epilogue(tmp, gout, dx, gin, self.cin, add=add, mask=mask, flags=flags)
         return ops.conv2d_dgrad(self.desc(gin, gout), g, self.w_dgrad, dx, add=add, mask=mask, flags=flags)
 
     def wgrad(self, x, g, gin, gout, ws, colsum_ws=None):

@@ -177,11 +177,6 @@ def relu_bf16(x, y):
     return y
 
 
-def scatter2x_epilogue(src, gsrc: Geom, dst, gdst: Geom, Cn, add=None, mask=None, flags=0):
-    check(L().bd_scatter2x_epilogue(ptr(src), gsrc.N, gsrc.H[0], gsrc.W[0], ptr(dst), gdst.H[0], gdst.W[0], Cn, ptr(add), ptr(mask), flags,
-                                    stream_ptr()), "bd_scatter2x_epilogue")
-
-
 def relu_bwd_bf16(g, mask, y, add=None):
     check(L().bd_relu_bwd_bf16(ptr(g), ptr(mask), ptr(add), ptr(y), g.numel(), stream_ptr()), "bd_relu_bwd_bf16")
     return y

@@ -154,11 +154,6 @@ int bd_upsample2x_add_bwd(const void* dlat, int64_t lat_pix_per_img, int64_t lat
 
 /* elementwise helpers on bf16 buffers of n elements (n % 8 == 0) */
 int bd_relu_bf16(const void* x, void* y, int64_t n, bd_stream_t stream);
-/* Second half of the data-gradient of a 1x1 / stride-2 convolution (ResNet downsample branches): src [N][Ho][Wo][C] holds the
- * dense GEMM result on the small grid; dst [N][Hi][Wi][C] = epilogue(src on the even pixels, 0 elsewhere) with the conv kernels'
- * BD_EPI_* semantics (add / mask are dst-shaped). */
-int bd_scatter2x_epilogue(const void* src, int N, int Ho, int Wo, void* dst, int Hi, int Wi, int C, const void* add,
-                          const void* mask, int flags, bd_stream_t stream);
 /* y = (mask > 0 ? g : 0) [+ add] */
 int bd_relu_bwd_bf16(const void* g, const void* mask, const void* add, void* y, int64_t n, bd_stream_t stream);
 int bd_add_bf16(const void* a, const void* b, void* y, int64_t n, bd_stream_t stream);

@@ -251,28 +251,3 @@ def test_weight_pack_multi_matches_single():
         if wd is not None:
             assert torch.equal(wd, rd)
 
-
-def test_dgrad_1x1_stride2_two_step_matches_generic():
-    """ConvLayer.dgrad for 1x1 / stride 2 = dense GEMM on the small grid + bd_scatter2x_epilogue; must equal the generic
-    parity-class kernel (bd_conv2d_dgrad on the strided descriptor): bit for bit without an accumulated operand, within one bf16
-    ulp with one (the GEMM part is rounded to bf16 before the add instead of after it)."""
-    from basedet_amd import ops
-    from basedet_amd.models.engine import ConvLayer
-    torch.manual_seed(1)
-    N, H, W, cin, cout = 2, 13, 18, 64, 128
-    gin = ops.single(N, H, W); gout = gin.conv_out(1, 2, 0)
-    layer = ConvLayer("c", cin, cout, 1, 2, 0, torch.device("cuda"), trainable=False)
-    layer.w_dgrad = (torch.randn(cin, 1, cout, device="cuda") * 0.05).to(torch.bfloat16)
-    g = torch.randn(gout.pixels, cout, device="cuda").to(torch.bfloat16)
-    base = torch.randn(gin.pixels, cin, device="cuda").to(torch.bfloat16)
-    mask = torch.randn(gin.pixels, cin, device="cuda").to(torch.bfloat16)
-    d = ops.conv_desc(gin, gout, cin, cout, 1, 1, 2, 0)
-    for first, use_mask in ((True, False), (False, False), (False, True), (True, True)):
-        ref = base.clone(); got = base.clone()
-        flags = (0 if first else ops.EPI_ADD_BEFORE) | (ops.EPI_MASK if use_mask else 0)
-        ops.conv2d_dgrad(d, g, layer.w_dgrad, ref, add=None if first else ref, mask=mask if use_mask else None, flags=flags)
-        layer.dgrad(g, gin, gout, got, first=first, mask=mask if use_mask else None)
-        if first:
-            assert torch.equal(ref, got), (first, use_mask)
-        else:
-            torch.testing.assert_close(got.float(), ref.float(), rtol=2 ** -7, atol=2 ** -7)
