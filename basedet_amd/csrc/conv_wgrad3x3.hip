@@ -19,18 +19,31 @@
 namespace {
 
 constexpr int PATCH = 8;                 // output patch edge
-constexpr int XP = PATCH + 2;            // input patch edge
 constexpr int TILE_CI = 64, TILE_CO = 64;
 constexpr int X_PITCH = 160;             // 128 B data + 32 B pad  (40 dwords: 8 consecutive rows hit all 64 banks)
 constexpr int G_PITCH = 160;             // 128 B data + 32 B pad
-constexpr int X_BYTES = XP * XP * X_PITCH;
 constexpr int G_BYTES = PATCH * PATCH * G_PITCH;
-constexpr int BUF_BYTES = X_BYTES + G_BYTES;
-constexpr int X_CHUNKS = XP * XP * 8;    // 16-byte chunks in the X tile
-constexpr int X_PASSES = (X_CHUNKS + 255) / 256;   // 4
 constexpr int G_PASSES = 2;              // 64 rows x 8 chunks / 256 threads
 
-struct PSeg { int patch_start, H, W, pw, in_off, out_off; };
+// Input-patch image in LDS.  Stride 1: one (PATCH+2)^2 image, tap (r, s) = row offset r*XW + s.  Stride 2 (the first 3x3 of
+// layer2/3/4, P6/P7): the 17x17 input patch is stored PHASE-MAJOR -- four 9x9 images of the (row parity, column parity) classes --
+// so that the eight pixels a half-wave transposes are again eight CONSECUTIVE LDS rows; tap (r, s) selects the phase image
+// (r&1, s&1) and the row offset (r>>1)*XW + (s>>1).
+template <int STRIDE> struct XImg {
+    static constexpr int XW = STRIDE == 1 ? PATCH + 2 : PATCH + 1;        // rows per image line
+    static constexpr int IMG = XW * XW;                                    // rows per (phase) image
+    static constexpr int ROWS = STRIDE == 1 ? IMG : 4 * IMG;
+    static constexpr int X_BYTES = ROWS * X_PITCH;
+    static constexpr int BUF_BYTES = X_BYTES + G_BYTES;
+    static constexpr int X_CHUNKS = ROWS * 8;
+    static constexpr int X_PASSES = (X_CHUNKS + 255) / 256;
+    static constexpr int EXT = STRIDE == 1 ? PATCH + 2 : 2 * PATCH + 1;    // input patch edge in pixels
+    __host__ __device__ static constexpr int tap_row(int r, int s) {
+        return STRIDE == 1 ? r * XW + s : ((r & 1) * 2 + (s & 1)) * IMG + (r >> 1) * XW + (s >> 1);
+    }
+};
+
+struct PSeg { int patch_start, H, W, pw, in_off, out_off, Hi, Wi; };
 
 struct W3Params {
     const bf16_raw* x;
@@ -43,7 +56,10 @@ struct W3Params {
     PSeg seg[BD_MAX_SEGS];
 };
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p) {
+template <int STRIDE>
+__global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel(const W3Params p) {
+    using XI = XImg<STRIDE>;
+    constexpr int X_PASSES = XI::X_PASSES, X_CHUNKS = XI::X_CHUNKS, X_BYTES = XI::X_BYTES, BUF_BYTES = XI::BUF_BYTES, XW = XI::XW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -57,15 +73,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p)
     if (pend > p.total_patches) pend = p.total_patches;
 
     // per-thread staging slots
-    int x_iy[X_PASSES], x_ix[X_PASSES];      // position inside the 10x10 input patch, -1 = unused slot
+    int x_iy[X_PASSES], x_ix[X_PASSES];      // position inside the input patch (pixels), -1 = unused slot
     const int x_chunk = tid & 7;
     const bool x_cok = ci0 + x_chunk * 8 < p.Cin;
 #pragma unroll
     for (int k = 0; k < X_PASSES; ++k) {
         const int c = tid + 256 * k;
         const int row = c >> 3;
-        x_iy[k] = row < XP * XP ? row / XP : -1;
-        x_ix[k] = row - (row / XP) * XP;
+        if (STRIDE == 1) {
+            x_iy[k] = row < XI::ROWS ? row / XW : -1;
+            x_ix[k] = row - (row / XW) * XW;
+        } else {
+            const int ph = row / XI::IMG, rr = row - ph * XI::IMG;
+            const int a = rr / XW, b = rr - a * XW;
+            const int u = 2 * a + (ph >> 1), v = 2 * b + (ph & 1);
+            x_iy[k] = (row < XI::ROWS && u < XI::EXT && v < XI::EXT) ? u : -1;
+            x_ix[k] = v;
+        }
     }
     const int g_chunk = tid & 7;
     const bool g_cok = co0 + g_chunk * 8 < p.Cout;
@@ -88,9 +112,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p)
 #pragma unroll
         for (int k = 0; k < X_PASSES; ++k) {
             u32x4_t v = {0u, 0u, 0u, 0u};
-            const int y = y0 - 1 + x_iy[k], x = x0 - 1 + x_ix[k];
-            if (x_iy[k] >= 0 && x_cok && y >= 0 && x >= 0 && y < sg.H && x < sg.W)
-                v = *reinterpret_cast<const u32x4_t*>(p.x + (xbase + (long long)y * sg.W + x) * p.Cin + ci0 + x_chunk * 8);
+            const int y = STRIDE * y0 - 1 + x_iy[k], x = STRIDE * x0 - 1 + x_ix[k];
+            if (x_iy[k] >= 0 && x_cok && y >= 0 && x >= 0 && y < sg.Hi && x < sg.Wi)
+                v = *reinterpret_cast<const u32x4_t*>(p.x + (xbase + (long long)y * sg.Wi + x) * p.Cin + ci0 + x_chunk * 8);
             rx[k] = v;
         }
 #pragma unroll
@@ -129,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p)
     // lane-constant parts of the fragment addresses
     const int prow_hi = 2 * (g4 >> 1);            // patch row inside the 4-row sub-step
     const int pcol = 4 * (g4 & 1) + tr_q;         // patch column supplied by this lane
-    const int x_lane_off = (prow_hi * XP + pcol) * X_PITCH + (wave * 16 + 4 * tr_p) * 2;
+    const int x_lane_off = (prow_hi * XW + pcol) * X_PITCH + (wave * 16 + 4 * tr_p) * 2;
     const int g_lane_off = (prow_hi * PATCH + pcol) * G_PITCH + (4 * tr_p) * 2;
 
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -151,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int r = t / 3, s = t % 3;
-                const bf16x8_t a = tr_frag(Xt + ((4 * kk + r) * XP + s) * X_PITCH, XP * X_PITCH);
+                const bf16x8_t a = tr_frag(Xt + (4 * kk * XW + XI::tap_row(r, s)) * X_PITCH, XW * X_PITCH);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[t][j], 0, 0, 0);
@@ -218,17 +242,20 @@ int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, floa
     for (int s = 0; s < d->nseg; ++s) {
         PSeg& sg = p.seg[s];
         sg.patch_start = ps; sg.H = d->Ho[s]; sg.W = d->Wo[s]; sg.pw = cdiv(d->Wo[s], PATCH);
-        sg.in_off = d->in_off[s]; sg.out_off = d->out_off[s];
+        sg.in_off = d->in_off[s]; sg.out_off = d->out_off[s]; sg.Hi = d->Hi[s]; sg.Wi = d->Wi[s];
         ps += cdiv(d->Ho[s], PATCH) * sg.pw;
     }
-    const size_t lds = 2 * BUF_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * XImg<1>::BUF_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * XImg<2>::BUF_BYTES);
         attr_set = true;
     }
     const int grid = splits * p.ci_tiles * p.co_tiles;
-    hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3(grid), dim3(256), lds, stream, p);
+    if (d->stride == 1) hipLaunchKernelGGL(conv_wgrad3x3_kernel<1>, dim3(grid), dim3(256), 2 * XImg<1>::BUF_BYTES, stream, p);
+    else hipLaunchKernelGGL(conv_wgrad3x3_kernel<2>, dim3(grid), dim3(256), 2 * XImg<2>::BUF_BYTES, stream, p);
     *splits_out = splits;
     return 0;
 }

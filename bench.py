@@ -57,7 +57,8 @@ class ConvTimer:
             is1 = d.R == 1 and d.S == 1 and d.pad == 0
             if kind == "igemm":
                 return "conv3x3_patch_kernel" if is3 else "conv_igemm_kernel"
-            return "conv_wgrad3x3_kernel" if is3 else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")
+            is3w = d.R == 3 and d.S == 3 and d.pad == 1 and all((d.Hi[i] - 1) // d.stride + 1 == d.Ho[i] for i in range(d.nseg))
+            return "conv_wgrad3x3_kernel" if is3w else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")
 
         def wrap(fn, kind):
             def inner(d, *a, **k):
