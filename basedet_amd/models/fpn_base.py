@@ -11,6 +11,7 @@ by T > 0).  When T has several consumers, all but the last dgrad accumulate unma
 mask in its epilogue -- so ReLU backward, residual fan-in and FrozenBN never cost a separate pass over HBM.
 """
 import math
+from contextlib import nullcontext as _nullcontext
 
 import numpy as np
 import torch
@@ -393,6 +394,18 @@ class FPNDetector:
         # FPN (fpn_backbone.py:123-160): top-down from the coarsest level
         st = self.fpn_stages
         nl = len(st)
+        b5 = pl.blk[pl.res[st[-1]]]
+        side = self._wstream if (self.TOP_BLOCK == "p6p7" and self.async_wgrad and self._wstream is not None) else None
+        if self.TOP_BLOCK == "p6p7":
+            # LastLevelP6P7 (:198-204) only needs res5 and writes its own pyramid levels: its two small-grid convs (70 workgroups for
+            # P6 at 800x1344) run on the side stream, concurrently with the lateral / output convs below
+            g6, g7 = pl.pyr.level(nl), pl.pyr.level(nl + 1)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side) if side is not None else _nullcontext():
+                self.p6.forward(b5.out, b5.gout, g6, pl.P)
+                self._relu_level(pl.P, g6, pl.p6_relu)
+                self.p7.forward(pl.p6_relu, pl.g_p6r, g7, pl.P)
         prev, prev_geo = None, None
         for li in range(nl - 1, -1, -1):
             s = st[li]
@@ -402,12 +415,9 @@ class FPNDetector:
                 ops.upsample2x_add_fwd(prev, prev_geo, pl.lat[s], b.gout, self.fpn_ch)
             self.output[s].forward(pl.lat[s], b.gout, pl.pyr.level(li), pl.P)
             prev, prev_geo = pl.lat[s], b.gout
-        b5 = pl.blk[pl.res[st[-1]]]
         if self.TOP_BLOCK == "p6p7":
-            g6, g7 = pl.pyr.level(nl), pl.pyr.level(nl + 1)
-            self.p6.forward(b5.out, b5.gout, g6, pl.P)                             # LastLevelP6P7 (:198-204)
-            self._relu_level(pl.P, g6, pl.p6_relu)
-            self.p7.forward(pl.p6_relu, pl.g_p6r, g7, pl.P)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
         else:
             ops.subsample2x_fwd(pl.P, pl.pyr.level(nl - 1), pl.P, pl.pyr.level(nl), self.fpn_ch)   # FPNP6 (:172-183)
         self.head_forward(pl)
