@@ -74,6 +74,7 @@ class FPNDetector:
         # barrier bubbles of one kernel are filled by the other (set False to serialise, e.g. for per-kernel timing)
         self.async_wgrad = True
         self._wstream = torch.cuda.Stream() if (torch.cuda.is_available() and self.device.type == "cuda") else None
+        self._tstream = torch.cuda.Stream() if self._wstream is not None else None      # P6/P7 top-block dgrads
 
     # ------------------------------------------------------------------------------------------------
     # construction
@@ -500,10 +501,16 @@ class FPNDetector:
         if not pool_top:
             g6, g7 = pyr.level(nl), pyr.level(nl + 1)
             # P7 = conv(relu(P6)): d P6 = dgrad(g_P7) * (P6 > 0) + g_P6(head), written in place into g_P's P6 level
+            # The two dgrads are small grids that only touch the P6/P7 levels of g_P and res5's gradient, which the main stream
+            # does not read before the top lateral dgrad below: they run on their own stream next to the P3.. output-conv dgrads.
+            top = self._tstream if self.async_wgrad else None
             self._wgrad(self.p7, pl.p6_relu, pl.g_P, pl.g_p6r, g7, ws, cws)
-            self.p7.dgrad(pl.g_P, g6, g7, pl.g_P, mask=pl.P, add_after=pl.g_P)
-            self._wgrad(self.p6, b5.out, pl.g_P, b5.gout, g6, ws, cws)
-            self.p6.dgrad(pl.g_P, b5.gout, g6, b5.g_out, first=True)
+            if top is not None:
+                top.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(top) if top is not None else _nullcontext():
+                self.p7.dgrad(pl.g_P, g6, g7, pl.g_P, mask=pl.P, add_after=pl.g_P)
+                self._wgrad(self.p6, b5.out, pl.g_P, b5.gout, g6, ws, cws)
+                self.p6.dgrad(pl.g_P, b5.gout, g6, b5.g_out, first=True)
         else:
             ops.subsample2x_bwd_add(pl.g_P, pyr.level(nl), pl.g_P, pyr.level(nl - 1), self.fpn_ch)      # P6 = P5[::2, ::2]
         for li in range(nl):
@@ -521,6 +528,8 @@ class FPNDetector:
             if not self.blocks[pl.res[s]]["trainable"]:
                 continue                                   # res2 of a FREEZE_AT=2 backbone: nothing below needs the gradient
             if is_top:
+                if not pool_top and self._tstream is not None and self.async_wgrad:
+                    torch.cuda.current_stream().wait_stream(self._tstream)
                 self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=pool_top, mask=b.out)
             else:
                 self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=True)
