@@ -395,6 +395,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
 int g_patch_w4 = 0;       // bd_conv_set_patch3x3 bit 4: four-wave instance (conv3x3_w4.hip) for CK % 64 == 0
 int bd_conv3x3_patch4w_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                               const void* mask, void* dst, int flags, hipStream_t stream);
+int g_patch_pp = 1;       // bd_conv_set_patch3x3 bit 6 clears it: staggered 256-channel-tile instance (conv3x3_pp.hip) for CO > 128, CK % 64 == 0
+int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
+                         const void* mask, void* dst, int flags, hipStream_t stream);
 int g_patch_dma = 1;
 static long long* g_patch_dbg = nullptr;
 extern "C" int bd_conv3x3_set_debug(long long* buf) { g_patch_dbg = buf; return 0; }      // bd_conv_set_patch3x3 bit 3 clears it (register-staged weights everywhere)
@@ -406,6 +409,7 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
     if (g_patch_w4 && (mode == 0 ? d->Cin : d->Cout) % 64 == 0 &&
         (long long)d->N * (mode == 0 ? d->in_pix_per_img : d->out_pix_per_img) * (mode == 0 ? d->Cin : d->Cout) < 0xffffffffll)
         return bd_conv3x3_patch4w_launch(d, mode, src, w, bias, add, mask, dst, flags, stream);
+    if (g_patch_pp && bd_conv3x3_pp_launch(d, mode, src, w, bias, add, mask, dst, flags, stream) == 0) return 0;
     C3Params p{};
     p.src = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias;
     p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)dst;

@@ -388,10 +388,12 @@ int bd_conv1x1_stream_launch(const IgemmParams& p, hipStream_t stream);
 // bit 0: 3x3 patch kernel, bit 1: BK=32 tiles for 1x1 in the generic kernel, bit 2: persistent streaming 1x1 kernel
 extern int g_patch_dma;
 extern int g_patch_w4;
+extern int g_patch_pp;
 extern "C" int bd_conv_set_patch3x3(int enable) {
     g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1; g_stream_1x1 = (enable >> 2) & 1;
     g_patch_dma = ((enable >> 3) & 1) ^ 1;
     g_patch_w4 = (enable >> 4) & 1;
+    g_patch_pp = ((enable >> 6) & 1) ^ 1;
     g_igemm_prefetch_epi = ((enable >> 5) & 1) ^ 1;
     return BD_OK;
 }
