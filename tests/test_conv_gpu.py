@@ -28,15 +28,19 @@ CASES = [
     (1, 256, 40, 13, 21, 3, 1, 1),      # padded bbox_pred
     (3, 32, 64, 9, 11, 3, 1, 1),        # BK=32 path
     (1, 2048, 256, 25, 42, 3, 2, 1),    # P6 conv
+    (2, 256, 256, 22, 37, 3, 1, 1),     # staggered 256-channel patch kernel, forward and dgrad (ragged patches)
+    (1, 512, 192, 9, 40, 3, 1, 1),      # ... ragged channel tile (192 of 256), 8 K blocks; dgrad 192 -> 512 = two channel tiles
 ]
 
 
-@pytest.mark.parametrize("patch3x3", [1, 0])
+@pytest.mark.parametrize("patch3x3", [1, 0, 2])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops = _ops()
-    # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel
-    ops.L().bd_conv_set_patch3x3(7 if patch3x3 else 0)
+    # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel;
+    # (bit 7: the staggered 256-channel patch instance wherever the shape allows, whatever the grid size);
+    # 2: specialised kernels without the staggered instance (bit 6)
+    ops.L().bd_conv_set_patch3x3({0: 0, 1: 7 | 128, 2: 7 | 64}[patch3x3])
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -90,10 +94,13 @@ def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops.L().bd_conv_set_patch3x3(7)
 
 
-def test_conv_multilevel_head_layout():
-    """Five pyramid levels through one launch (RetinaNetHead weight sharing, retina_head.py:103-112)."""
+@pytest.mark.parametrize("chans", [(64, 72), (192, 256)])
+def test_conv_multilevel_head_layout(chans):
+    """Five pyramid levels through one launch (RetinaNetHead weight sharing, retina_head.py:103-112).  (192, 256): the staggered
+    256-channel patch instance on a multi-segment descriptor, forward and dgrad."""
     ops = _ops()
-    N, C, Cout = 2, 64, 72
+    ops.L().bd_conv_set_patch3x3(7 | 128)
+    N, (C, Cout) = 2, chans
     Hs, Ws = [12, 6, 3, 2, 1], [20, 10, 5, 3, 2]
     g = torch.Generator().manual_seed(7)
     geo = ops.Geom(N, Hs, Ws)
@@ -133,6 +140,7 @@ def test_conv_multilevel_head_layout():
         got = dxv[:, geo.off[i]: geo.off[i] + Hs[i] * Ws[i]].reshape(N, Hs[i], Ws[i], C).permute(0, 3, 1, 2)
         assert rel_l2(got, xr.grad) < TOL, f"dgrad level {i}"
     assert rel_l2(dw.cpu(), oihw_to_ohwi(ref_dw)) < 2e-3
+    ops.L().bd_conv_set_patch3x3(7)
 
 
 def test_stem_conv_and_pad_normalize():
