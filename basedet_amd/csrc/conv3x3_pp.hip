@@ -12,7 +12,7 @@
 //   * weights: ring of three 32 KB tap slots filled by LDS-DMA two taps ahead (counted vmcnt, raw s_barrier: the pieces stay
 //     in flight across barriers); activations: one padded image, re-staged through registers once per K block (the groups
 //     re-synchronise for that swap).
-// Used for Cout > 128 and Cin % 64 == 0 (heads, FPN outputs, res4/res5); everything else stays on conv3x3.hip.
+// Used for Cout > 128 and Cin % 8 == 0 (heads, FPN outputs, res4/res5) when its grid fills the chip; the rest stays on conv3x3.hip.
 #include "common.h"
 
 namespace {
@@ -133,8 +133,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     auto load_x = [&](int cb) {
         int so = cb * 128;
         asm volatile("" : "+s"(so));
+        // K tail (CK % 64 != 0, e.g. the 720-channel class-score gradient): chunks past CK read as zeros, so whatever finite weights
+        // the DMA picks up beyond a row's CK channels (the next tap's; zeros past the end of the buffer) contribute nothing
+        const bool dead = cb * 64 + (tid & 7) * 8 >= p.CK;
 #pragma unroll
-        for (int k = 0; k < XPASSES; ++k) rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, x_off[k], so, 0);
+        for (int k = 0; k < XPASSES; ++k) rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, dead ? X_NONE : x_off[k], so, 0);
     };
     auto write_x = [&]() {
 #pragma unroll
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i0 + i][j]) : "v"(fa[i]), "v"(fb[j]));
     };
 
-    const int kblocks = p.CK >> 6;
+    const int kblocks = (p.CK + 63) >> 6;
 
     // ---- prologue: activation image of K block 0, taps 0 and 1 ----
     if (tid < TILE_CO) sbias[tid] = (p.bias && co0 + tid < p.CO) ? p.bias[co0 + tid] : 0.f;
@@ -346,7 +349,7 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     p.CO = mode == 0 ? d->Cout : d->Cin;
     p.src_ppi = mode == 0 ? d->in_pix_per_img : d->out_pix_per_img;
     p.dst_ppi = mode == 0 ? d->out_pix_per_img : d->in_pix_per_img;
-    if (p.CK % 64 != 0 || p.CO <= 128 || p.CO % 8 != 0) return 1;
+    if (p.CK % 8 != 0 || p.CK < 64 || p.CO <= 128 || p.CO % 8 != 0) return 1;
     if ((long long)d->N * p.src_ppi * p.CK * 2 >= 0x7fffffffll || (long long)d->N * p.dst_ppi >= 0x7fffffffll ||
         (long long)p.CO * 9 * p.CK >= 0x7fffffffll) return 1;
     p.src = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias;

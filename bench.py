@@ -50,13 +50,21 @@ class ConvTimer:
             m = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
             return 2.0 * m * d.Cin * d.Cout * d.R * d.S
 
-        def kernel_of(d, kind):
-            """Which HIP kernel serves this descriptor (mirrors the dispatch in csrc/conv_igemm.hip / conv_wgrad.hip)."""
+        def kernel_of(d, kind, dgrad=False):
+            """Which HIP kernel serves this descriptor (mirrors the dispatch in csrc/conv_igemm.hip / conv3x3.hip /
+            conv3x3_pp.hip / conv_wgrad.hip with the default bd_conv_set_patch3x3 mask)."""
             same = all(d.Hi[i] == d.Ho[i] and d.Wi[i] == d.Wo[i] for i in range(d.nseg))
             is3 = d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and same
             is1 = d.R == 1 and d.S == 1 and d.pad == 0
             if kind == "igemm":
-                return "conv3x3_patch_kernel" if is3 else "conv_igemm_kernel"
+                if not is3:
+                    return "conv_igemm_kernel"
+                ck, co = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
+                cdiv = lambda a, b: (a + b - 1) // b
+                tiles = cdiv(d.N * sum(cdiv(d.Ho[i], 4) * cdiv(d.Wo[i], 16) for i in range(d.nseg)), 4)
+                pp = ck % 8 == 0 and ck >= 64 and co > 128 and co % 8 == 0 and \
+                    3 * cdiv(tiles * cdiv(co, 256), 256) < 2 * cdiv(tiles * cdiv(co, 128), 256)
+                return "conv3x3_pp_kernel" if pp else "conv3x3_patch_kernel"
             is3w = d.R == 3 and d.S == 3 and d.pad == 1 and all((d.Hi[i] - 1) // d.stride + 1 == d.Ho[i] for i in range(d.nseg))
             return "conv_wgrad3x3_kernel" if is3w else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")
 
@@ -68,7 +76,7 @@ class ConvTimer:
                 s.record()
                 r = fn(d, *a, **k)
                 e.record()
-                kern = kernel_of(d, kind)
+                kern = kernel_of(d, kind, fn.__name__ == "conv2d_dgrad")
                 self.records.setdefault(kern, []).append((s, e, flops(d)))
                 # lower bound of the HBM bytes: both activations once + weights (epilogue add / mask operands not counted)
                 mi = sum(d.Hi[i] * d.Wi[i] for i in range(d.nseg)) * d.N
@@ -151,6 +159,8 @@ def main():
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight-gradient kernels on the main stream for the whole run (what the instrumented steps do): "
                          "use it under rocprofv3 so that per-kernel durations are not inflated by concurrent kernels")
+    ap.add_argument("--conv-knob", type=int, default=None,
+                    help="ablation: bd_conv_set_patch3x3 bit mask (include/basedet_hip.h) applied before the run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,6 +232,9 @@ def main():
     it = 0
     if args.serial_wgrad:
         model.async_wgrad = False
+    if args.conv_knob is not None:
+        from basedet_amd import ops as _ops
+        _ops.L().bd_conv_set_patch3x3(args.conv_knob)
     for _ in range(args.warmup):
         sched.step(it); it += 1
         last = solver.minimize(model, batch)
