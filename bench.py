@@ -7,8 +7,10 @@ inputs are DummyLoader-shaped (basedet/utils/dummy.py:8-63) and already resident
 for N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RCCL over xGMI).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- the dominant kernel (MFMA implicit-GEMM conv, forward + dgrad launches): algorithmic FLOPs of those
-                  launches / their summed duration measured with HIP events on the launch stream during the timed steps
+  roofline     -- the kernel with the largest share of the step (per-kernel entries: roofline_others).  Each conv kernel is priced
+                  against the roof its launches sit under: "mfma" (algorithmic FLOPs / time vs 2.5 PFLOP/s) when their arithmetic
+                  intensity exceeds the machine balance, else "hbm" (algorithmic bytes -- every operand once -- / time vs 8 TB/s);
+                  durations are HIP events on the launch stream during the timed steps, `traffic` the PMC-measured HBM bytes
   cpu_baseline -- the CPU oracle's (oracle/model.py, torch-CPU fp32) training step on the host cores, bounded sample.
 """
 import argparse
@@ -24,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense")
+PEAK_HBM_GBS = 8000.0         # HBM3E, ~8 TB/s (same guide)
 TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): convs only, 1 MAC = 2 FLOP
     "retinanet_r50_800x1344": 1435.6,
     "retinanet_r18_512x512": 277.2,
@@ -58,7 +61,9 @@ class ConvTimer:
             is1 = d.R == 1 and d.S == 1 and d.pad == 0
             if kind == "igemm":
                 if not is3:
-                    return "conv_igemm_kernel"
+                    # generic kernel: BK = 32 instance for 1x1 filters (and Cin <= 32), BK = 64 for the strided 3x3 ones
+                    ck_ = d.Cout if dgrad else d.Cin
+                    return "conv_igemm_kernel<32>" if (d.R * d.S == 1 or ck_ <= 32) else "conv_igemm_kernel<64>"
                 ck, co = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
                 cdiv = lambda a, b: (a + b - 1) // b
                 tiles = cdiv(d.N * sum(cdiv(d.Ho[i], 4) * cdiv(d.Wo[i], 16) for i in range(d.nseg)), 4)
@@ -69,19 +74,28 @@ class ConvTimer:
             return "conv_wgrad3x3_kernel" if is3w else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")
 
         def wrap(fn, kind):
+            import inspect
+            names = list(inspect.signature(fn).parameters)
+
             def inner(d, *a, **k):
                 if not self.enabled:
                     return fn(d, *a, **k)
+                k = dict(zip(names[1:], a), **k)         # all operands by name (add= / mask= may come positionally)
+                a = ()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 r = fn(d, *a, **k)
                 e.record()
                 kern = kernel_of(d, kind, fn.__name__ == "conv2d_dgrad")
                 self.records.setdefault(kern, []).append((s, e, flops(d)))
-                # lower bound of the HBM bytes: both activations once + weights (epilogue add / mask operands not counted)
+                # algorithmic HBM bytes: every operand once -- both activations, the weights, and the epilogue's add / mask
+                # operands (residual, ReLU mask), which have the shape of the result
                 mi = sum(d.Hi[i] * d.Wi[i] for i in range(d.nseg)) * d.N
                 mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
                 nbytes = 2.0 * (mi * d.Cin + mo * d.Cout) + (4.0 if kind == "wgrad" else 2.0) * d.Cin * d.Cout * d.R * d.S
+                if kind == "igemm":
+                    res = 2.0 * (mi * d.Cin if fn.__name__ == "conv2d_dgrad" else mo * d.Cout)
+                    nbytes += res * ((k.get("add") is not None) + (k.get("mask") is not None))
                 self.meta.setdefault(kern, []).append((fn.__name__, d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
                 return r
             return inner
@@ -110,7 +124,8 @@ class ConvTimer:
             return None
         ms = sum(s.elapsed_time(e) for s, e, _ in rec)
         fl = sum(f for _, _, f in rec)
-        return dict(launches=len(rec), ms=ms, flops=fl)
+        nb = sum(m[8] for m in self.meta[kind])
+        return dict(launches=len(rec), ms=ms, flops=fl, bytes=nb)
 
 
 def cpu_baseline(cfg, params, seconds=20.0, batch=2, size=(800, 1344)):
@@ -289,10 +304,16 @@ def main():
                     pmc = json.load(f).get("kernels", {})
             for kern in timer.records:
                 sm = timer.summary(kern)
-                ach = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
-                entries.append({"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                tf = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
+                gbs = sm["bytes"] / (sm["ms"] * 1e-3) / 1e9
+                # which roof is lower for this kernel's mix of launches: arithmetic intensity against the machine balance
+                hbm_bound = sm["flops"] / sm["bytes"] < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+                ach, peak, unit = (gbs, PEAK_HBM_GBS, "GB/s") if hbm_bound else (tf, PEAK_BF16_TFLOPS, "TFLOP/s")
+                entries.append({"bound": "hbm" if hbm_bound else "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak,
+                                "unit": unit, "frac": round(ach / peak, 4),
                                 "traffic": pmc.get(kern, {}).get("hbm_bytes_per_launch"),
+                                "tflops": round(tf, 2), "algorithmic_gbs": round(gbs, 1),
+                                "algorithmic_bytes_per_launch": int(sm["bytes"] / sm["launches"]),
                                 "launches_per_step": sm["launches"] // sampled,
                                 "avg_launch_us": round(sm["ms"] * 1e3 / sm["launches"], 2),
                                 "ms_per_step": round(sm["ms"] / sampled, 3),

@@ -1,0 +1,48 @@
+"""Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into
+profiles/r01_pmc_traffic.json: HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests
+at 64 B -- MI355X_MICROARCH.md, HBM section).   python scripts/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def load(d, counter):
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    assert files, d
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"^void ", "", r["Kernel_Name"])
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        m = re.match(r"conv_igemm_kernel<(\d+)", name)      # the BK = 32 (1x1) and BK = 64 instances are reported separately
+        name = f"conv_igemm_kernel<{m.group(1)}>" if m else re.split(r"[<(]", name)[0].strip()
+        tot[name] += float(r["Counter_Value"])
+        cnt[name] += 1
+    return tot, cnt
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    f, fc = load(fetch_dir, "FETCH_SIZE")
+    w, wc = load(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0.0))):
+        n = fc[k]
+        fk, wk = f[k] / n, w.get(k, 0.0) / max(1, wc.get(k, 0))
+        kernels[k] = {"launches": n, "fetch_size_kb": round(fk, 1), "write_size_kb": round(wk, 1),
+                      "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    src = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 2 --warmup 1 "
+           "--no-cpu-baseline --no-roofline`, retinanet_r50_800x1344 batch 16; values in KB per launch (mean over all launches of "
+           "the kernel); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests at 64 B, "
+           "MI355X_MICROARCH.md section HBM); aggregated by scripts/pmc_traffic.py")
+    json.dump({"source": src, "kernels": kernels}, open(out, "w"), indent=1)
+    for k in list(kernels)[:8]:
+        print(k, kernels[k])
+
+
+if __name__ == "__main__":
+    main()
