@@ -6,3 +6,5 @@ What the training step consumes is the dict produced by ``DetectionPadCollator.a
 normalises on the device (bd_pad_normalize)."""
 from .collators import DetectionPadCollator, calculate_padding_shape  # noqa: F401
 from .samplers import AspectRatioGroupSampler, GroupedRandomSampler  # noqa: F401
+from .transforms import (Compose, RandomHorizontalFlip, ShortestEdgeResize, TestTimeCompose, ToMode,  # noqa: F401
+                         build_transform)

@@ -1,0 +1,134 @@
+"""Host-side pieces next to the inference / data path: the COCO box-AP restatement (hand-computable cases) and the
+augmentation transforms (configs/detection_cfg.py:42-53).  No GPU."""
+import numpy as np
+import pytest
+
+from basedet_amd.data import (Compose, RandomHorizontalFlip, ShortestEdgeResize, TestTimeCompose, ToMode, build_transform)
+from basedet_amd.evaluators import COCOEvaluator, bbox_eval
+
+
+def _gt(i, img, cat, box, crowd=0):
+    return {"id": i, "image_id": img, "category_id": cat, "bbox": list(box), "area": box[2] * box[3], "iscrowd": crowd}
+
+
+def _dt(img, cat, box, score):
+    return {"image_id": img, "category_id": cat, "bbox": list(box), "score": score}
+
+
+def test_perfect_detections_give_ap_one():
+    gts = [_gt(1, 1, 1, (10, 10, 50, 50)), _gt(2, 1, 2, (100, 100, 20, 20)), _gt(3, 2, 1, (0, 0, 200, 200))]
+    dts = [_dt(g["image_id"], g["category_id"], g["bbox"], 0.9) for g in gts]
+    st = bbox_eval(gts, dts)["stats"]
+    assert st[0] == pytest.approx(1.0) and st[1] == pytest.approx(1.0) and st[8] == pytest.approx(1.0)
+    assert st[3] == pytest.approx(1.0)      # small: the 20x20 box
+    assert st[4] == pytest.approx(1.0)      # medium: 50x50
+    assert st[5] == pytest.approx(1.0)      # large: 200x200
+
+
+def test_tp_fp_tp_curve():
+    # two ground truths; detections by score: TP, FP, TP  ->  precision envelope 1.0 up to recall 0.5, 2/3 up to recall 1.0
+    gts = [_gt(1, 1, 1, (0, 0, 40, 40)), _gt(2, 1, 1, (100, 100, 40, 40))]
+    dts = [_dt(1, 1, (0, 0, 40, 40), 0.9), _dt(1, 1, (300, 300, 40, 40), 0.8), _dt(1, 1, (100, 100, 40, 40), 0.7)]
+    r = bbox_eval(gts, dts)
+    expect = (51 * 1.0 + 50 * (2.0 / 3.0)) / 101
+    assert r["stats"][1] == pytest.approx(expect, abs=1e-9)       # AP50
+    assert r["stats"][0] == pytest.approx(expect, abs=1e-9)       # exact boxes: same at every IoU threshold
+    assert r["stats"][6] == pytest.approx(0.5)                     # AR@1: only the top detection counts
+    assert r["stats"][8] == pytest.approx(1.0)
+
+
+def test_iou_threshold_sweep():
+    # a detection with IoU 0.6 counts at thresholds 0.50, 0.55, 0.60 only -> AP = 3/10
+    gts = [_gt(1, 1, 1, (0, 0, 100, 100))]
+    dts = [_dt(1, 1, (0, 0, 100, 60), 0.9)]                        # IoU = 6000 / 10000
+    st = bbox_eval(gts, dts)["stats"]
+    assert st[1] == pytest.approx(1.0) and st[2] == pytest.approx(0.0) and st[0] == pytest.approx(0.3)
+
+
+def test_crowd_matches_are_ignored():
+    # the second detection lies inside a crowd region (IoU = inter / det area = 1): neither TP nor FP
+    gts = [_gt(1, 1, 1, (0, 0, 40, 40)), _gt(2, 1, 1, (100, 100, 200, 200), crowd=1)]
+    dts = [_dt(1, 1, (0, 0, 40, 40), 0.9), _dt(1, 1, (150, 150, 30, 30), 0.8), _dt(1, 1, (160, 160, 30, 30), 0.7)]
+    st = bbox_eval(gts, dts)["stats"]
+    assert st[0] == pytest.approx(1.0) and st[8] == pytest.approx(1.0)
+
+
+def test_missing_category_and_area_cells_are_minus_one():
+    gts = [_gt(1, 1, 1, (0, 0, 200, 200))]
+    st = bbox_eval(gts, [_dt(1, 1, (0, 0, 200, 200), 0.5)])["stats"]
+    assert st[3] == -1.0 and st[4] == -1.0 and st[5] == pytest.approx(1.0)
+    # ground truth but no detections at all: AP 0 (recall 0), not -1
+    none = bbox_eval(gts, [])["stats"]
+    assert none[0] == 0.0 and none[8] == 0.0
+
+
+def test_max_dets_truncation():
+    gts = [_gt(i, 1, 1, (20 * i, 0, 10, 10)) for i in range(12)]
+    dts = [_dt(1, 1, (20 * i, 0, 10, 10), 0.99 - 0.01 * i) for i in range(12)]
+    st = bbox_eval(gts, dts)["stats"]
+    assert st[6] == pytest.approx(1 / 12) and st[7] == pytest.approx(10 / 12) and st[8] == pytest.approx(1.0)
+
+
+def test_evaluator_format_roundtrip(tmp_path):
+    ev = COCOEvaluator()
+    rec = ev.postprocess({"boxes": np.array([[10, 20, 60, 100.0]]), "box_scores": np.array([0.75]), "box_labels": np.array([3])}, 7)
+    empty = ev.postprocess({"boxes": np.zeros((0, 4)), "box_scores": np.zeros(0), "box_labels": np.zeros(0)}, 8)
+    res = ev.format([rec, empty])
+    assert res == [{"image_id": 7, "bbox": [10.0, 20.0, 50.0, 80.0], "score": 0.75, "category_id": 4}]
+    path = ev.save_results([rec, empty], str(tmp_path / "predict_coco.json"))
+    ann = {"images": [{"id": 7}, {"id": 8}], "categories": [{"id": 4}],
+           "annotations": [_gt(1, 7, 4, (10, 20, 50, 80))]}
+    out = ev.evaluate(path, ann)
+    assert out["AP"] == pytest.approx(1.0) and out["AR100"] == pytest.approx(1.0)
+
+
+# ------------------------------------------------------------------------------------------------ transforms
+
+def test_shortest_edge_resize_shapes_and_boxes():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 255, size=(480, 640, 3), dtype=np.uint8)
+    t = ShortestEdgeResize(min_size=(800,), max_size=1333, sample_style="choice", rng=rng)
+    boxes = np.array([[64, 48, 320, 240]], dtype=np.float32)
+    t.order = ("image", "boxes", "boxes_category")
+    out, b, c = t.apply((img, boxes, np.array([5])))
+    assert out.shape == (800, 1067, 3) and out.dtype == np.uint8          # 640 * 800/480 = 1066.67 -> 1067
+    np.testing.assert_allclose(b, boxes * np.array([1067 / 640, 800 / 480, 1067 / 640, 800 / 480]), rtol=1e-6)
+    assert c[0] == 5
+    # long edge capped at max_size
+    t2 = ShortestEdgeResize(min_size=800, max_size=1333, sample_style="choice", rng=rng)
+    out2 = t2.apply(rng.integers(0, 255, size=(300, 900, 3), dtype=np.uint8))
+    assert out2.shape[:2] == (444, 1333)
+
+
+def test_resize_constant_and_gradient_images():
+    t = ShortestEdgeResize(min_size=64, max_size=1000, sample_style="choice")
+    const = np.full((32, 48, 3), 77, dtype=np.uint8)
+    assert (t.apply(const) == 77).all()
+    ramp = np.tile(np.arange(48, dtype=np.float32)[None, :, None], (32, 1, 1))
+    out = ShortestEdgeResize(min_size=64, max_size=1000, sample_style="choice").apply(ramp)
+    mid = out[10, 4:-4, 0]
+    np.testing.assert_allclose(np.diff(mid), 0.5, atol=1e-4)           # 2x upscale of a unit ramp: slope 0.5 away from the edges
+
+
+def test_flip_and_compose_order():
+    rng = np.random.default_rng(3)
+    img = np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3)
+    boxes = np.array([[1, 0, 3, 2]], dtype=np.float32)
+    pipe = Compose([RandomHorizontalFlip(prob=1.0, rng=rng), ToMode("CHW")])
+    o, b, c = pipe((img, boxes, np.array([1])))
+    assert o.shape == (3, 4, 6) and (o[:, :, 0] == img[:, 5].T).all()
+    np.testing.assert_array_equal(b, [[3, 0, 5, 2]])
+    o2, b2, _ = Compose([RandomHorizontalFlip(prob=0.0, rng=rng)])((img, boxes, np.array([1])))
+    assert (o2 == img).all() and (b2 == boxes).all()
+
+
+def test_test_time_compose_im_info():
+    pipe = build_transform(mode="test")
+    assert isinstance(pipe, TestTimeCompose)
+    img = np.zeros((500, 375, 3), dtype=np.uint8)
+    out, info = pipe(img)
+    assert out.shape == (1, 3, 1067, 800) and out.dtype == np.float32
+    np.testing.assert_array_equal(info, [[1067, 800, 500, 375]])
+    train = build_transform(mode="train", rng=np.random.default_rng(1))
+    o, b, c = train((img, np.array([[10, 10, 100, 100]], dtype=np.float32), np.array([2])))
+    assert o.shape[0] == 3 and min(o.shape[1:]) in (640, 672, 704, 736, 768, 800)
