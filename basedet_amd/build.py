@@ -26,6 +26,7 @@ SOURCES = {
     "boxops.hip": ["-ffp-contract=off"],
     "rcnn_ops.hip": ["-ffp-contract=off"],
     "postprocess.hip": ["-ffp-contract=off"],
+    "freeanchor.hip": ["-ffp-contract=off"],
     "losses.hip": [],
     "norm.hip": [],
 }

@@ -88,6 +88,21 @@ class RetinaNetConfig(ConfigDict):
         )))
 
 
+class FreeAnchorConfig(RetinaNetConfig):
+    """basedet/configs/det_model/freeanchor_cfg.py:5-33.  The reference writes the key FOCLA_LOSS_ALPHA (:10), so the value the
+    model reads, FOCAL_LOSS_ALPHA (free_anchor.py:132), keeps RetinaNet's 0.25; the stray key is carried as written."""
+
+    def __init__(self):
+        super().__init__()
+        self.merge(dict(MODEL=dict(
+            NAME="FreeAnchor",
+            LOSSES=dict(FOCLA_LOSS_ALPHA=0.5, FOCAL_LOSS_GAMMA=2, SMOOTH_L1_BETA=0.0, REG_LOSS_WEIGHT=0.75),
+            BOX_REG=dict(STD=[0.1, 0.1, 0.2, 0.2]),
+            HEAD=dict(CLS_PRIOR_PROB=0.02),
+            BUCKET=dict(BOX_IOU_THRESH=0.6, BUCKET_SIZE=50),
+        )))
+
+
 def retinanet_r18_config():
     """BASELINE.json configs[0]: RetinaNet-R18-FPN."""
     cfg = RetinaNetConfig()

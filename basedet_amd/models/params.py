@@ -206,7 +206,9 @@ def oracle_arch(cfg):
                     strides=list(m.FPN.STRIDES), anchor_offset=m.ANCHOR.OFFSET,
                     focal_alpha=m.LOSSES.FOCAL_LOSS_ALPHA, focal_gamma=m.LOSSES.FOCAL_LOSS_GAMMA,
                     iou_loss_type=m.LOSSES.IOU_LOSS_TYPE, reg_loss_weight=m.LOSSES.REG_LOSS_WEIGHT)
-    return dict(backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
+    extra = dict(freeanchor=dict(mean=list(m.BOX_REG.MEAN), std=list(m.BOX_REG.STD), iou_thresh=m.BUCKET.BOX_IOU_THRESH,
+                                 bucket=m.BUCKET.BUCKET_SIZE)) if m.NAME == "FreeAnchor" else {}
+    return dict(extra, backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
                 num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),
                 strides=list(m.FPN.STRIDES), anchor_scales=[list(s) for s in m.ANCHOR.SCALES],
                 anchor_ratios=[list(r) for r in m.ANCHOR.RATIOS], anchor_offset=m.ANCHOR.OFFSET,

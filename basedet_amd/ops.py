@@ -247,6 +247,22 @@ def atss_assign(points, lvl_start, strides, topk, anchor_scale, gt_boxes, num_gt
                              ws.numel() * ws.element_size(), stream_ptr()), "bd_atss_assign")
 
 
+def freeanchor_workspace_bytes(N, Gmax, bucket, A):
+    return int(L().bd_freeanchor_workspace_bytes(N, Gmax, bucket, A))
+
+
+def freeanchor_loss_fwd_bwd(logits, offsets, box_ld, anchors_per_pix, anchors, K, gt_boxes, num_gt, mean, std, iou_thresh, bucket,
+                            beta, reg_weight, alpha, gamma, loss_out, d_logits, d_offsets, ws):
+    """FreeAnchor bag losses + gradients (models/det/free_anchor.py:38-142); loss_out: fp32[2] = (pos_loss, neg_loss)."""
+    A = anchors.shape[0]
+    N, Gmax = gt_boxes.shape[0], gt_boxes.shape[1]
+    check(L().bd_freeanchor_loss_fwd_bwd(ptr(logits), ptr(offsets), int(box_ld), int(anchors_per_pix), ptr(anchors), A, int(K),
+                                         ptr(gt_boxes), ptr(num_gt), N, Gmax, f32arr(mean), f32arr(std), float(iou_thresh),
+                                         int(bucket), float(beta), float(reg_weight), float(alpha), float(gamma), ptr(loss_out),
+                                         ptr(d_logits), ptr(d_offsets), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()),
+          "bd_freeanchor_loss_fwd_bwd")
+
+
 def nms_workspace_bytes(n):
     return int(L().bd_nms_workspace_bytes(n))
 

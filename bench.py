@@ -33,6 +33,7 @@ TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): 
     "fcos_r50_800x1344": 1227.8,
     "retinanet_r101_800x1344": 1912.8,
     "atss_r50_800x1344": 1227.8,          # the FCOS network; only the target assignment differs
+    "freeanchor_r50_800x1344": 1435.6,    # the RetinaNet network; bag losses instead of matcher + focal / L1
     # Faster R-CNN R50-FPN (P2-P6): fwd 208.9 GMAC/img (backbone 87.6, FPN 60.9, RPN 53.1, box head 512 RoIs x 14.3 MMAC = 7.3);
     # stem + layer1 frozen, lateral2 needs no dgrad
     "faster_rcnn_r50_800x1344": 1177.2,
@@ -192,8 +193,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from basedet_amd import ops
-    from basedet_amd.configs import ATSSConfig, FasterRCNNConfig, FCOSConfig, RetinaNetConfig, retinanet_r18_config
-    from basedet_amd.models import ATSS, FCOS, FasterRCNN, RetinaNet, params as P
+    from basedet_amd.configs import (ATSSConfig, FasterRCNNConfig, FCOSConfig, FreeAnchorConfig, RetinaNetConfig,
+                                     retinanet_r18_config)
+    from basedet_amd.models import ATSS, FCOS, FasterRCNN, FreeAnchor, RetinaNet, params as P
     from basedet_amd.solver import DetSolver, WarmupMultiStepLR, broadcast_parameters
     from basedet_amd.utils import DummyLoader
 
@@ -203,6 +205,8 @@ def main():
         cfg, size = FCOSConfig(), (800, 1344)
     elif args.workload == "atss_r50_800x1344":
         cfg, size = ATSSConfig(), (800, 1344)
+    elif args.workload == "freeanchor_r50_800x1344":
+        cfg, size = FreeAnchorConfig(), (800, 1344)
     elif args.workload == "retinanet_r101_800x1344":
         cfg, size = RetinaNetConfig(), (800, 1344)
         cfg.MODEL.BACKBONE.NAME = "resnet101"
@@ -221,7 +225,7 @@ def main():
         model = FasterRCNN(cfg, params=params)
     else:
         params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
-        model = RetinaNet(cfg, params=params)
+        model = (FreeAnchor if cfg.MODEL.NAME == "FreeAnchor" else RetinaNet)(cfg, params=params)
     broadcast_parameters(model)
     solver = DetSolver.build(cfg, model)
     sched = WarmupMultiStepLR(solver.optimizer, cfg, world)     # LRSchedulerHook.before_iter (engine/hooks.py:218)

@@ -212,6 +212,20 @@ int bd_atss_assign(const float* points, int P, const int32_t* lvl_start_host, co
                    float anchor_scale, const float* gt_boxes, const int32_t* num_gt, int N, int Gmax, int32_t* labels,
                    float* offsets, float* ctrness, float* stats, void* ws, size_t ws_bytes, bd_stream_t stream);
 
+/* FreeAnchor.get_losses after the network forward (models/det/free_anchor.py:38-142): positive bag loss over the `bucket`
+ * anchors of largest IoU per gt (ties at the boundary: lowest anchor index) and negative loss over every (anchor, class) with the
+ * box probabilities of the decoded predictions (two gts of one class claiming an anchor: the later gt's value), both with their
+ * gradients.  logits bf16 [N*A][K]; offsets bf16 [N*A/anchors_per_pix][box_ld] (anchor a of a pixel at columns 4a..4a+3);
+ * anchors fp32 [A][4]; gt [N][Gmax][5] (class 1-based), num_gt int32 [N].  loss_out[0] = alpha * pos / max(1, sum num_gt),
+ * loss_out[1] = (1 - alpha) * neg / max(1, sum num_gt * bucket).  d_logits / d_offsets are overwritten (d_offsets zero outside
+ * the bags).  Deterministic: fixed-order reductions, bag gradients applied gt after gt.  ws: bd_freeanchor_workspace_bytes. */
+size_t bd_freeanchor_workspace_bytes(int N, int Gmax, int bucket, int A);
+int bd_freeanchor_loss_fwd_bwd(const void* logits, const void* offsets, int box_ld, int anchors_per_pix, const float* anchors,
+                               int A, int K, const float* gt_boxes, const int32_t* num_gt, int N, int Gmax, const float* mean4,
+                               const float* std4, float iou_thresh, int bucket, float beta, float reg_weight, float alpha,
+                               float gamma, float* loss_out, void* d_logits, void* d_offsets, void* ws, size_t ws_bytes,
+                               bd_stream_t stream);
+
 /* layers/common/post_processing.py:17-47 batched_nms (class-offset trick + greedy NMS, suppress iff IoU > thr).
  * boxes [n][4], scores [n], idxs [n] (may be NULL = plain NMS).  keep: int32[n] (descending score order),
  * num_keep: int32[1].  max_output <= 0 means unlimited.  ws from bd_nms_workspace_bytes(n). */

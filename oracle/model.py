@@ -230,6 +230,21 @@ class Oracle:
         return {"total_loss": total, "cls_loss": cls_loss, "reg_loss": reg_loss}, {
             "labels": labels, "gt_offsets": gt_off, "anchors": anchors, "logits": logits, "offsets": offsets, "num_fg": num_fg}
 
+    # ---- FreeAnchor.get_losses (models/det/free_anchor.py:20-142): RetinaNet's network, bag losses ------------
+    def freeanchor_losses(self, batch):
+        from . import freeanchor
+        a = self.arch
+        image = _t(box_ops.data_to_input(batch["data"], a["img_mean"], a["img_std"]))
+        logits, offsets, sizes, _ = self.retinanet_forward(image)
+        anchors = np.concatenate(box_ops.default_anchors(sizes, a["strides"], a["anchor_scales"], a["anchor_ratios"], a["anchor_offset"]), 0)
+        num_valid = np.asarray(batch["im_info"])[:, 4].astype(np.int32)
+        fa = a["freeanchor"]
+        pos, neg = freeanchor.bag_losses(logits, offsets, anchors, np.asarray(batch["gt_boxes"], np.float32), num_valid,
+                                         mean=fa["mean"], std=fa["std"], iou_thresh=fa["iou_thresh"], bucket=fa["bucket"],
+                                         beta=a.get("smooth_l1_beta", 0.0), reg_weight=a.get("reg_loss_weight", 1.0),
+                                         alpha=a.get("focal_alpha", 0.25), gamma=a.get("focal_gamma", 2.0))
+        return {"total_loss": pos + neg, "pos_loss": pos, "neg_loss": neg}, {"anchors": anchors, "logits": logits, "offsets": offsets}
+
     # ---- FCOS (layers/head/point_head.py:137-151, models/det/fcos.py:114-179) ---------------------------------
     def point_head(self, feats):
         """PointHead.forward: conv -> GroupNorm(32) -> ReLU towers (Sequential indices 3i / 3i+1), cls_score, and
