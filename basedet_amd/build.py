@@ -27,6 +27,7 @@ SOURCES = {
     "rcnn_ops.hip": ["-ffp-contract=off"],
     "postprocess.hip": ["-ffp-contract=off"],
     "freeanchor.hip": ["-ffp-contract=off"],
+    "ota.hip": ["-ffp-contract=off"],
     "losses.hip": [],
     "norm.hip": [],
 }

@@ -161,3 +161,11 @@ class ATSSConfig(FCOSConfig):
         self.merge(dict(MODEL=dict(NAME="ATSS", ANCHOR=dict(SCALE=8, TOPK=9), LOSSES=dict(REG_LOSS_WEIGHT=2.0))))
         del self.MODEL.HEAD["OBJECT_SIZES_OF_INTEREST"]
         del self.MODEL.HEAD["CENTER_SAMPLING_RADIUS"]
+
+
+class OTAConfig(FCOSConfig):
+    """basedet/configs/det_model/ota_cfg.py:6-14: FCOS with the OTAPointHead flags and the top-k ("simOTA") matcher."""
+
+    def __init__(self):
+        super().__init__()
+        self.merge(dict(MODEL=dict(NAME="OTA", MATCHING="topk", HEAD=dict(WITH_NORM=True, SHARE_PARAM=True, NORM_REG_TARGETS=True))))

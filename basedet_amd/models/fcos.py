@@ -199,3 +199,53 @@ class ATSS(FCOS):
             pl.atss_ws = torch.empty((ops.atss_assign_workspace_bytes(N, P_total),), dtype=torch.uint8, device=self.device)
         ops.atss_assign(pl.points, pl.lvl_start, self.strides, m.ANCHOR.TOPK, m.ANCHOR.SCALE, gt, num_gt, pl.labels, pl.gt_offsets,
                         pl.gt_ctr, pl.stats, pl.atss_ws)
+
+
+@registers.models.register()
+class OTA(FCOS):
+    """OTA (basedet/models/det/ota.py): the FCOS network -- OTAPointHead with NORM_REG_TARGETS is PointHead's forward, its
+    centre-ness branch read as the IoU prediction (point_head.py:154-212) -- with the prediction-aware dynamic top-k assignment
+    (bd_ota_assign) and emd_losses' weighting (:183-233): focal / num_fg, 2 x GIoU / num_fg, 0.5 x BCE(iou) / num_fg."""
+
+    def __init__(self, cfg, *a, **k):
+        matching = cfg.MODEL.get("MATCHING", "topk")
+        if matching != "topk":
+            raise NotImplementedError(f"OTA matching '{matching}': only the reference default 'topk' (OTATopkMatcher) is built on the HIP path")
+        hc = cfg.MODEL.HEAD
+        assert hc.get("NORM_REG_TARGETS", True) and hc.get("WITH_NORM", True) and hc.get("SHARE_PARAM", True), \
+            "OTA on the HIP path supports the reference's OTAConfig head flags (NORM_REG_TARGETS, WITH_NORM, SHARE_PARAM)"
+        super().__init__(cfg, *a, **k)
+
+    def _plan_head(self, pl):
+        super()._plan_head(pl)
+        pl.ota_ws = torch.empty((ops.ota_assign_workspace_bytes(pl.N, pl.points.shape[0]),), dtype=torch.uint8, device=self.device)
+
+    def _assign(self, pl, gt, num_gt):
+        m = self.cfg.MODEL
+        ops.ota_assign(pl.points, pl.lvl_start, self.strides, pl.logits, self.num_classes, pl.offsets, gt, num_gt,
+                       m.LOSSES.FOCAL_LOSS_ALPHA, m.LOSSES.FOCAL_LOSS_GAMMA, m.HEAD.get("COST_REG_WEIGHTS", 1.5), 2.5,
+                       m.HEAD.get("CANDIDATE_K", 10), pl.labels, pl.gt_offsets, pl.gt_ctr, pl.stats, pl.ota_ws)
+
+    def get_losses(self, inputs):
+        """OTA.get_losses (ota.py:62-74) + emd_losses (:183-233); pl.gt_ctr holds the IoU targets, pl.stats = (num_fg, 2 num_fg)."""
+        assert self.training
+        pre = self.pre_process(inputs)
+        pl = pre["plan"]
+        self._cur = pl
+        self.network_forward(pl)
+        m = self.cfg.MODEL
+        gt = pre["gt_boxes"]
+        num_gt = pre["img_info"][:, 4].to(torch.int32).contiguous()
+        self._assign(pl, gt, num_gt)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(pl.stats, op=dist.ReduceOp.SUM)            # all_reduce(num_foreground, mode="mean") (:200)
+            pl.stats.mul_(1.0 / dist.get_world_size())
+        pl.loss_buf.zero_()
+        rows = pl.N * pl.pyr.pix_per_img
+        assert m.LOSSES.IOU_LOSS_TYPE == "giou", "HIP OTA path implements the giou ltrb loss"
+        ops.focal_loss_fwd_bwd(pl.logits, pl.labels, rows, self.num_classes, m.LOSSES.FOCAL_LOSS_ALPHA, m.LOSSES.FOCAL_LOSS_GAMMA,
+                               pl.stats[0:1], 1.0, pl.loss_buf[0:1], pl.d_logits)
+        ops.giou_ltrb_fwd_bwd(pl.offsets, pl.gt_offsets, None, pl.labels, rows, pl.stats[0:1], 2.0, pl.loss_buf[1:2], pl.d_off)
+        ops.bce_logits_fwd_bwd(pl.raw, pl.gt_ctr, pl.labels, rows, pl.stats[1:2], pl.loss_buf[2:3], pl.d_ctr, ld=8, off=4)
+        loss_cls, loss_box, loss_iou = pl.loss_buf[0], pl.loss_buf[1], pl.loss_buf[2]
+        return {"total_loss": loss_cls + loss_box + loss_iou, "loss_cls": loss_cls, "loss_offsets": loss_box, "loss_ious": loss_iou}

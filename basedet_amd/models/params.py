@@ -197,10 +197,13 @@ def oracle_arch(cfg):
                     rcnn_box_reg=(list(m.RCNN_BOX_REG.MEAN), list(m.RCNN_BOX_REG.STD)),
                     matcher=(list(m.MATCHER.THRESHOLDS), list(m.MATCHER.LABELS), m.MATCHER.ALLOW_LOW_QUALITY),
                     rpn_beta=m.LOSSES.RPN_SMOOTH_L1_BETA, rcnn_beta=m.LOSSES.RCNN_SMOOTH_L1_BETA)
-    if m.NAME in ("FCOS", "ATSS"):
+    if m.NAME in ("FCOS", "ATSS", "OTA"):
         extra = dict(atss=dict(scale=m.ANCHOR.SCALE, topk=m.ANCHOR.TOPK), sizes_of_interest=None, center_sampling_radius=None) \
             if m.NAME == "ATSS" else dict(sizes_of_interest=[list(s) for s in m.HEAD.OBJECT_SIZES_OF_INTEREST],
                                           center_sampling_radius=m.HEAD.CENTER_SAMPLING_RADIUS)
+        if m.NAME == "OTA":
+            extra["ota"] = dict(reg_weight=m.HEAD.get("COST_REG_WEIGHTS", 1.5), candidate_k=m.HEAD.get("CANDIDATE_K", 10),
+                                center_radius=2.5)
         return dict(extra, backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
                     num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),
                     strides=list(m.FPN.STRIDES), anchor_offset=m.ANCHOR.OFFSET,

@@ -247,6 +247,21 @@ def atss_assign(points, lvl_start, strides, topk, anchor_scale, gt_boxes, num_gt
                              ws.numel() * ws.element_size(), stream_ptr()), "bd_atss_assign")
 
 
+def ota_assign_workspace_bytes(N, P):
+    return int(L().bd_ota_assign_workspace_bytes(N, P))
+
+
+def ota_assign(points, lvl_start, strides, logits, K, pred_ltrb, gt_boxes, num_gt, alpha, gamma, reg_weight, center_radius,
+               candidate_k, labels, targets, gt_ious, stats, ws):
+    """OTA.get_ground_truth, top-k matcher (models/det/ota.py:76-181)."""
+    P = points.shape[0]
+    N, Gmax = gt_boxes.shape[0], gt_boxes.shape[1]
+    check(L().bd_ota_assign(ptr(points), P, i32arr(lvl_start), i32arr(strides), len(strides), ptr(logits), int(K), ptr(pred_ltrb),
+                            ptr(gt_boxes), ptr(num_gt), N, Gmax, float(alpha), float(gamma), float(reg_weight), float(center_radius),
+                            int(candidate_k), ptr(labels), ptr(targets), ptr(gt_ious), ptr(stats), ptr(ws),
+                            ws.numel() * ws.element_size(), stream_ptr()), "bd_ota_assign")
+
+
 def freeanchor_workspace_bytes(N, Gmax, bucket, A):
     return int(L().bd_freeanchor_workspace_bytes(N, Gmax, bucket, A))
 

@@ -34,6 +34,7 @@ TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): 
     "retinanet_r101_800x1344": 1912.8,
     "atss_r50_800x1344": 1227.8,          # the FCOS network; only the target assignment differs
     "freeanchor_r50_800x1344": 1435.6,    # the RetinaNet network; bag losses instead of matcher + focal / L1
+    "ota_r50_800x1344": 1227.8,           # the FCOS network; prediction-aware dynamic top-k assignment
     # Faster R-CNN R50-FPN (P2-P6): fwd 208.9 GMAC/img (backbone 87.6, FPN 60.9, RPN 53.1, box head 512 RoIs x 14.3 MMAC = 7.3);
     # stem + layer1 frozen, lateral2 needs no dgrad
     "faster_rcnn_r50_800x1344": 1177.2,
@@ -193,9 +194,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from basedet_amd import ops
-    from basedet_amd.configs import (ATSSConfig, FasterRCNNConfig, FCOSConfig, FreeAnchorConfig, RetinaNetConfig,
+    from basedet_amd.configs import (ATSSConfig, FasterRCNNConfig, FCOSConfig, FreeAnchorConfig, OTAConfig, RetinaNetConfig,
                                      retinanet_r18_config)
-    from basedet_amd.models import ATSS, FCOS, FasterRCNN, FreeAnchor, RetinaNet, params as P
+    from basedet_amd.models import ATSS, FCOS, OTA, FasterRCNN, FreeAnchor, RetinaNet, params as P
     from basedet_amd.solver import DetSolver, WarmupMultiStepLR, broadcast_parameters
     from basedet_amd.utils import DummyLoader
 
@@ -207,6 +208,8 @@ def main():
         cfg, size = ATSSConfig(), (800, 1344)
     elif args.workload == "freeanchor_r50_800x1344":
         cfg, size = FreeAnchorConfig(), (800, 1344)
+    elif args.workload == "ota_r50_800x1344":
+        cfg, size = OTAConfig(), (800, 1344)
     elif args.workload == "retinanet_r101_800x1344":
         cfg, size = RetinaNetConfig(), (800, 1344)
         cfg.MODEL.BACKBONE.NAME = "resnet101"
@@ -217,9 +220,9 @@ def main():
     cfg.MODEL.BATCHSIZE = args.batch
     # random-init weights of the named architecture; the last FrozenBN gamma of every residual branch is 0.2
     # (stand-in for ImageNet statistics: identity BN overflows a random ResNet-50; same FLOPs and bytes)
-    if cfg.MODEL.NAME in ("FCOS", "ATSS"):
+    if cfg.MODEL.NAME in ("FCOS", "ATSS", "OTA"):
         params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.2)
-        model = (ATSS if cfg.MODEL.NAME == "ATSS" else FCOS)(cfg, params=params)
+        model = {"FCOS": FCOS, "ATSS": ATSS, "OTA": OTA}[cfg.MODEL.NAME](cfg, params=params)
     elif cfg.MODEL.NAME == "FasterRCNN":
         params = P.init_faster_rcnn_params(cfg, seed=0, residual_gamma=0.2)
         model = FasterRCNN(cfg, params=params)

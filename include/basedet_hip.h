@@ -212,6 +212,19 @@ int bd_atss_assign(const float* points, int P, const int32_t* lvl_start_host, co
                    float anchor_scale, const float* gt_boxes, const int32_t* num_gt, int N, int Gmax, int32_t* labels,
                    float* offsets, float* ctrness, float* stats, void* ws, size_t ws_bytes, bd_stream_t stream);
 
+/* OTA.get_ground_truth with the top-k matcher (models/det/ota.py:76-181, layers/common/matcher.py:123-161; cfg MATCHING =
+ * "topk", the reference default): per gt the dynamic number k = max(1, int(sum of the `candidate_k` largest IoUs with the predicted
+ * boxes)) of lowest-cost points, cost = focal classification cost + reg_weight * -log(IoU) + 1e6 outside the gt / its
+ * center_radius*stride centre box; a point taken by several gts goes to the gt of lowest cost.  logits bf16 [N*P][K], pred_ltrb
+ * bf16 [N*P][4] (the head's decoded l,t,r,b), points fp32 [P][2].  Outputs: labels int32 [N][P] (class, 0 = background), targets
+ * fp32 [N][P][4] (ltrb), gt_ious fp32 [N][P]; stats[0] = number of foreground points, stats[1] = 2 * stats[0] (the normaliser
+ * of the 0.5-weighted IoU-branch loss).  Ties: lowest point / gt index.  ws: bd_ota_assign_workspace_bytes. */
+size_t bd_ota_assign_workspace_bytes(int N, int P);
+int bd_ota_assign(const float* points, int P, const int32_t* lvl_start_host, const int32_t* strides_host, int L, const void* logits,
+                  int K, const void* pred_ltrb, const float* gt_boxes, const int32_t* num_gt, int N, int Gmax, float alpha,
+                  float gamma, float reg_weight, float center_radius, int candidate_k, int32_t* labels, float* targets,
+                  float* gt_ious, float* stats, void* ws, size_t ws_bytes, bd_stream_t stream);
+
 /* FreeAnchor.get_losses after the network forward (models/det/free_anchor.py:38-142): positive bag loss over the `bucket`
  * anchors of largest IoU per gt (ties at the boundary: lowest anchor index) and negative loss over every (anchor, class) with the
  * box probabilities of the decoded predictions (two gts of one class claiming an anchor: the later gt's value), both with their

@@ -304,6 +304,71 @@ def fcos_ground_truth(points_list, strides, batched_gt_boxes, num_valid, sizes_o
 
 
 # --------------------------------------------------------------------------------------------
+# OTA target assignment, top-k matcher (models/det/ota.py:76-181, layers/common/matcher.py:123-161)
+# --------------------------------------------------------------------------------------------
+def ota_ground_truth(points_list, strides, logits, pred_ltrb, batched_gt_boxes, num_valid, alpha=0.25, gamma=2.0,
+                     reg_weight=1.5, center_radius=2.5, candidate_k=10):
+    """logits (N, P, K), pred_ltrb (N, P, 4) float32 (detached predictions).  Returns labels (N, P) int32 (class, 0 = bg), ltrb
+    targets (N, P, 4), IoU targets (N, P), and the cost / IoU matrices per image (for tie analysis in the tests).
+    Unpinned orders fixed here: F.topk ties -> lowest point index, F.argmin ties -> lowest gt index."""
+    all_pts = np.concatenate(points_list, axis=0).astype(F32)
+    P = all_pts.shape[0]
+    eps = np.finfo(np.float32).eps
+    labs, tgts, ious_out, aux = [], [], [], []
+    for n, (boxes_with_labels, nv) in enumerate(zip(batched_gt_boxes, num_valid)):
+        gtl = np.asarray(boxes_with_labels, F32)[: int(nv)]
+        G = gtl.shape[0]
+        lab = np.zeros(P, np.int32); tgt = np.zeros((P, 4), F32); iou_t = np.zeros(P, F32)
+        if G == 0:
+            labs.append(lab); tgts.append(tgt); ious_out.append(iou_t); aux.append((np.zeros((0, P), F32), np.zeros((0, P), F32)))
+            continue
+        gt = gtl[:, :4]
+        deltas = point_encode(all_pts[None, :, :], gt[:, None, :])                     # (G, P, 4)
+        in_boxes = deltas.min(axis=-1) > F32(0.01)
+        ctr = ((gt[:, :2] + gt[:, 2:4]) / F32(2)).astype(F32)
+        in_ctr = []
+        for stride, pts in zip(strides, points_list):
+            r = F32(stride * center_radius)
+            cb = np.concatenate([np.maximum(ctr - r, gt[:, :2]), np.minimum(ctr + r, gt[:, 2:4])], axis=-1)
+            in_ctr.append(point_encode(np.asarray(pts, F32)[None], cb[:, None, :]).min(axis=-1) > 0)
+        in_boxes &= np.concatenate(in_ctr, axis=1)
+        x = np.asarray(logits[n], F32)                                                 # (P, K)
+        K = x.shape[1]
+        onehot = np.zeros((G, K), F32)
+        onehot[np.arange(G), gtl[:, 4].astype(np.int32) - 1] = 1
+        loss_cls = np.stack([sigmoid_focal_loss(x, np.broadcast_to(onehot[g][None], x.shape), alpha, gamma).sum(axis=-1)
+                             for g in range(G)]).astype(F32)                          # (G, P)
+        ious = ltrb_iou(np.broadcast_to(np.asarray(pred_ltrb[n], F32)[None], deltas.shape), deltas, "iou", eps).astype(F32)
+        loss_delta = (-np.log(np.maximum(ious, eps))).astype(F32)
+        cost = (loss_cls + F32(reg_weight) * loss_delta + F32(1e6) * (~in_boxes).astype(F32)).astype(F32)
+        # OTATopkMatcher
+        matching = np.zeros((G, P), np.int32)
+        kk = min(candidate_k, P)
+        topk = -np.sort(-ious, axis=1, kind="stable")[:, :kk]
+        dyn = []
+        for g in range(G):
+            s = F32(0)
+            for v in topk[g]:
+                s = F32(s + v)
+            dyn.append(max(1, int(s)))
+        for g in range(G):
+            idx = np.argsort(cost[g], kind="stable")[: dyn[g]]
+            matching[g, idx] = 1
+        multi = matching.sum(0) > 1
+        if multi.any():
+            am = cost[:, multi].argmin(axis=0)
+            matching[:, multi] = 0
+            matching[am, np.nonzero(multi)[0]] = 1
+        fg = matching.sum(0) > 0
+        mg = matching.argmax(axis=0)
+        lab[fg] = gtl[mg[fg], 4].astype(np.int32)
+        tgt[fg] = deltas[mg[fg], np.nonzero(fg)[0]]
+        iou_t[fg] = ious[mg[fg], np.nonzero(fg)[0]]
+        labs.append(lab); tgts.append(tgt); ious_out.append(iou_t); aux.append((cost, ious))
+    return np.stack(labs), np.stack(tgts), np.stack(ious_out), aux
+
+
+# --------------------------------------------------------------------------------------------
 # ATSS target assignment (models/det/atss.py:17-86)
 # --------------------------------------------------------------------------------------------
 def atss_ground_truth(points_list, strides, batched_gt_boxes, num_valid, anchor_scale=8, topk=9):

@@ -324,6 +324,49 @@ class Oracle:
             "labels": labels, "gt_offsets": gt_off, "gt_ctr": gt_ctr, "logits": logits, "offsets": offsets, "num_fg": num_fg,
             "sum_ctr": sum_ctr}
 
+    # ---- OTA (models/det/ota.py:62-233): the FCOS network (OTAPointHead with NORM_REG_TARGETS = PointHead's forward, the
+    # centre-ness branch renamed ious_pred, point_head.py:154-212), dynamic top-k assignment, emd_losses -------------------
+    def ota_losses(self, batch, forced=None):
+        a = self.arch
+        image = _t(box_ops.data_to_input(batch["data"], a["img_mean"], a["img_std"]))
+        feats = self.fpn(self.backbone(image))
+        logits, offsets, ious_pred = self.point_head(feats)
+        K = a["num_classes"]
+        sizes = [tuple(f.shape[-2:]) for f in feats]
+        N = logits[0].shape[0]
+        logits = torch.cat([self._permute(x, K) for x in logits], dim=1)
+        offsets = torch.cat([self._permute(x, 4) for x in offsets], dim=1)
+        ious_pred = torch.cat([self._permute(x, 1) for x in ious_pred], dim=1).reshape(-1)
+        pts = box_ops.point_anchors(sizes, a["strides"], a["anchor_offset"], 1)
+        num_valid = np.asarray(batch["im_info"])[:, 4].astype(np.int32)
+        o = a["ota"]
+        al, ga = a.get("focal_alpha", 0.25), a.get("focal_gamma", 2.0)
+        if forced is None:
+            labels, gt_off, gt_iou, aux = box_ops.ota_ground_truth(pts, a["strides"], logits.detach().numpy(), offsets.detach().numpy(),
+                                                                   batch["gt_boxes"], num_valid, al, ga, o["reg_weight"],
+                                                                   o["center_radius"], o["candidate_k"])
+        else:                   # targets taken from the device path (gradient checks on identical assignments)
+            labels, gt_off, gt_iou = forced
+            aux = None
+        logits, offsets = logits.reshape(-1, K), offsets.reshape(-1, 4)
+        labels_t = torch.from_numpy(np.asarray(labels).reshape(-1)).long()
+        gt_off_t, gt_iou_t = _t(np.asarray(gt_off).reshape(-1, 4)), _t(np.asarray(gt_iou).reshape(-1))
+        fg = labels_t > 0
+        num_fg = float(fg.sum())
+        tgt = torch.zeros_like(logits)
+        tgt[fg, labels_t[fg] - 1] = 1
+        p = torch.sigmoid(logits)
+        ce = -(tgt * TF.logsigmoid(logits) + (1 - tgt) * TF.logsigmoid(-logits))
+        fl = ce * (tgt * (1 - p) + (1 - tgt) * p) ** ga * (tgt * al + (1 - tgt) * (1 - al))
+        loss_cls = fl.sum() / max(1.0, num_fg)
+        giou = self._giou_ltrb(offsets[fg], gt_off_t[fg])
+        loss_box = (1 - giou).sum() / max(1.0, num_fg) * 2.0
+        xi, ti = ious_pred[fg], gt_iou_t[fg]
+        loss_iou = (-(ti * TF.logsigmoid(xi) + (1 - ti) * TF.logsigmoid(-xi))).sum() / max(1.0, num_fg) * 0.5
+        total = loss_cls + loss_box + loss_iou
+        return {"total_loss": total, "loss_cls": loss_cls, "loss_offsets": loss_box, "loss_ious": loss_iou}, {
+            "labels": labels, "gt_offsets": gt_off, "gt_ious": gt_iou, "num_fg": num_fg, "aux": aux, "logits": logits, "offsets": offsets}
+
     # ---- Faster R-CNN (models/det/faster_rcnn.py:64-97, rpn.py:70-132, layers/head/rcnn.py:52-83) ---------------
     def rpn_head(self, feats):
         """rpn.py:78-100: per level relu(rpn_conv) -> cls (A) / offsets (4A)."""
