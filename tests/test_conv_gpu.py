@@ -260,3 +260,34 @@ def test_weight_pack_multi_matches_single():
         if wd is not None:
             assert torch.equal(wd, rd)
 
+
+
+@pytest.mark.parametrize("shape", [(5, 96, 160, 128, 256), (2, 100, 168, 64, 720), (3, 50, 84, 192, 264)])
+def test_patch_instances_agree_bitwise(shape):
+    """Full-size grids (more workgroups than CUs, ragged channel tiles, K tails): the staggered 256-channel instance must give the
+    SAME bits as the 128-channel instance (same accumulation order), forward with residual + ReLU and dgrad with add + mask."""
+    ops = _ops()
+    N, H, W, Cin, Cout = shape
+    gin = ops.single(N, H, W)
+    d = ops.conv_desc(gin, gin, Cin, Cout, 3, 3, 1, 1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, 9, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    wt = (torch.randn(Cin, 9, Cout, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    res = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    gy = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    addx = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
+    outs = []
+    for knob in (7 | 64, 7 | 128):
+        ops.L().bd_conv_set_patch3x3(knob)
+        y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
+        dx = torch.full((gin.pixels, Cin), 3.0, device="cuda", dtype=torch.bfloat16)
+        ops.conv2d_fwd(d, x, w, b, y, add=res, flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE)
+        if Cin > 128:
+            ops.conv2d_dgrad(d, gy, wt, dx, add=addx, mask=addx, flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), dx.clone()))
+    ops.L().bd_conv_set_patch3x3(7)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
