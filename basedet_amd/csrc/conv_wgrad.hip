@@ -249,6 +249,9 @@ int g_wgrad_use_3x3 = 1;
 // 3x3 / pad 1 with stride 1 or 2: served by the nine-tap patch kernel (conv_wgrad3x3.hip)
 bool is_3x3s1(const bd_conv_desc* d) {
     if (!(d->R == 3 && d->S == 3 && (d->stride == 1 || d->stride == 2) && d->pad == 1)) return false;
+    // the patch kernel addresses both tensors with 32-bit byte offsets (range-checked buffer loads)
+    if ((long long)d->N * d->in_pix_per_img * d->Cin * 2 >= 0x7fffffffll || (long long)d->N * d->out_pix_per_img * d->Cout * 2 >= 0x7fffffffll)
+        return false;
     for (int s = 0; s < d->nseg; ++s)
         if ((d->Hi[s] - 1) / d->stride + 1 != d->Ho[s] || (d->Wi[s] - 1) / d->stride + 1 != d->Wo[s]) return false;
     return true;

@@ -51,6 +51,7 @@ struct W3Params {
     float* slab;
     int Cin, Cout, N, nseg;
     int in_ppi, out_ppi;
+    unsigned x_bytes, g_bytes;
     int patches_per_img, total_patches, patches_per_split;
     int ci_tiles, co_tiles;
     PSeg seg[BD_MAX_SEGS];
@@ -96,6 +97,16 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
 
     u32x4_t rx[X_PASSES], rg[G_PASSES];
 
+    // Range-checked buffer loads: a 32-bit per-thread byte offset, and X_NONE (past the end of the tensor: the host checks both
+    // tensors are < 2 GB) for halo / out-of-image / channel-tail positions, which then read as zeros -- no predicated loads, no
+    // 64-bit per-thread addresses, no zero-initialised staging registers.  The per-thread part of the offset depends on the pyramid
+    // level (row pitch) only and is recomputed when the patch sequence crosses into another level.
+    constexpr unsigned X_NONE = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.g), 0, p.g_bytes, 0x00020000);
+    int x_vec[X_PASSES], g_vec[G_PASSES];           // element offsets relative to the patch origin, for the current level
+    int cur_seg = -1;
+
     auto stage_load = [&](int pid) {
         const int n = pid / p.patches_per_img;
         const int rem = pid - n * p.patches_per_img;
@@ -104,27 +115,33 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
         for (int k = 1; k < BD_MAX_SEGS; ++k)
             if (k < p.nseg && rem >= p.seg[k].patch_start) s = k;
         const PSeg sg = p.seg[s];
+        if (s != cur_seg) {                           // workgroup-uniform
+            cur_seg = s;
+#pragma unroll
+            for (int k = 0; k < X_PASSES; ++k) x_vec[k] = (x_iy[k] * sg.Wi + x_ix[k]) * p.Cin + x_chunk * 8;
+#pragma unroll
+            for (int k = 0; k < G_PASSES; ++k) {
+                const int row = (tid >> 3) + 32 * k;
+                g_vec[k] = ((row >> 3) * sg.W + (row & 7)) * p.Cout + g_chunk * 8;
+            }
+        }
         const int local = rem - sg.patch_start;
         const int by = local / sg.pw, bx = local - by * sg.pw;
         const int y0 = by * PATCH, x0 = bx * PATCH;
-        const long long xbase = (long long)n * p.in_ppi + sg.in_off;
-        const long long gbase = (long long)n * p.out_ppi + sg.out_off;
+        const int ys = STRIDE * y0 - 1, xs = STRIDE * x0 - 1;
+        const int xorg = (n * p.in_ppi + sg.in_off + ys * sg.Wi + xs) * p.Cin + ci0;        // may be negative; valid sums are not
+        const int gorg = (n * p.out_ppi + sg.out_off + y0 * sg.W + x0) * p.Cout + co0;
 #pragma unroll
         for (int k = 0; k < X_PASSES; ++k) {
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            const int y = STRIDE * y0 - 1 + x_iy[k], x = STRIDE * x0 - 1 + x_ix[k];
-            if (x_iy[k] >= 0 && x_cok && y >= 0 && x >= 0 && y < sg.Hi && x < sg.Wi)
-                v = *reinterpret_cast<const u32x4_t*>(p.x + (xbase + (long long)y * sg.Wi + x) * p.Cin + ci0 + x_chunk * 8);
-            rx[k] = v;
+            const int y = ys + x_iy[k], x = xs + x_ix[k];
+            const bool ok = x_iy[k] >= 0 && x_cok && y >= 0 && x >= 0 && y < sg.Hi && x < sg.Wi;
+            rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(xorg + x_vec[k]) * 2u : X_NONE, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < G_PASSES; ++k) {
             const int row = (tid >> 3) + 32 * k;
-            const int y = y0 + (row >> 3), x = x0 + (row & 7);
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if (g_cok && y < sg.H && x < sg.W)
-                v = *reinterpret_cast<const u32x4_t*>(p.g + (gbase + (long long)y * sg.W + x) * p.Cout + co0 + g_chunk * 8);
-            rg[k] = v;
+            const bool ok = g_cok && y0 + (row >> 3) < sg.H && x0 + (row & 7) < sg.W;
+            rg[k] = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, ok ? (unsigned)(gorg + g_vec[k]) * 2u : X_NONE, 0, 0);
         }
     };
     auto stage_write = [&](int buf) {
@@ -234,6 +251,8 @@ int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, floa
     p.x = (const bf16_raw*)x; p.g = (const bf16_raw*)g; p.slab = slab;
     p.Cin = d->Cin; p.Cout = d->Cout; p.N = d->N; p.nseg = d->nseg;
     p.in_ppi = d->in_pix_per_img; p.out_ppi = d->out_pix_per_img;
+    p.x_bytes = (unsigned)((long long)d->N * d->in_pix_per_img * d->Cin * 2);
+    p.g_bytes = (unsigned)((long long)d->N * d->out_pix_per_img * d->Cout * 2);
     int total, ppi;
     const int splits = bd_wgrad3x3_splits(d, &total, &ppi);
     p.total_patches = total; p.patches_per_img = ppi; p.patches_per_split = cdiv(total, splits);
