@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
     auto compute = [&](int buf) {
         const unsigned char* Xt = smem + buf * BUF_BYTES + x_lane_off;
         const unsigned char* Gt = smem + buf * BUF_BYTES + X_BYTES + g_lane_off;
+        if (STRIDE == 1) __builtin_amdgcn_s_setprio(1);      // two workgroups per CU: the wave in its MFMA block wins the issue arbitration (+2 %)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t b[4];
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[t][j], 0, 0, 0);
             }
         }
+        if (STRIDE == 1) __builtin_amdgcn_s_setprio(0);
     };
 
     if (pbeg < pend) {
