@@ -12,7 +12,8 @@
 //   * weights: ring of three 32 KB tap slots filled by LDS-DMA two taps ahead (counted vmcnt, raw s_barrier: the pieces stay
 //     in flight across barriers); activations: one padded image, re-staged through registers once per K block (the groups
 //     re-synchronise for that swap).
-// Used for Cout > 128 and Cin % 8 == 0 (heads, FPN outputs, res4/res5) when its grid fills the chip; the rest stays on conv3x3.hip.
+// Used for Cout > 128 and Cin % 8 == 0 (heads incl. the 720- and 40-channel gradients, FPN outputs, res4/res5) when its grid fills the
+// chip; the rest stays on conv3x3.hip.
 #include "common.h"
 
 namespace {
@@ -349,7 +350,7 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     p.CO = mode == 0 ? d->Cout : d->Cin;
     p.src_ppi = mode == 0 ? d->in_pix_per_img : d->out_pix_per_img;
     p.dst_ppi = mode == 0 ? d->out_pix_per_img : d->in_pix_per_img;
-    if (p.CK % 8 != 0 || p.CK < 64 || p.CO <= 128 || p.CO % 8 != 0) return 1;
+    if (p.CK % 8 != 0 || p.CO <= 128 || p.CO % 8 != 0) return 1;
     if ((long long)d->N * p.src_ppi * p.CK * 2 >= 0x7fffffffll || (long long)d->N * p.dst_ppi >= 0x7fffffffll ||
         (long long)p.CO * 9 * p.CK >= 0x7fffffffll) return 1;
     p.src = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias;

@@ -69,7 +69,7 @@ class ConvTimer:
                 ck, co = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
                 cdiv = lambda a, b: (a + b - 1) // b
                 tiles = cdiv(d.N * sum(cdiv(d.Ho[i], 4) * cdiv(d.Wo[i], 16) for i in range(d.nseg)), 4)
-                pp = ck % 8 == 0 and ck >= 64 and co > 128 and co % 8 == 0 and \
+                pp = ck % 8 == 0 and co > 128 and co % 8 == 0 and \
                     3 * cdiv(tiles * cdiv(co, 256), 256) < 2 * cdiv(tiles * cdiv(co, 128), 256)
                 return "conv3x3_pp_kernel" if pp else "conv3x3_patch_kernel"
             is3w = d.R == 3 and d.S == 3 and d.pad == 1 and all((d.Hi[i] - 1) // d.stride + 1 == d.Ho[i] for i in range(d.nseg))
