@@ -280,7 +280,7 @@ Plan make_plan(const bd_conv_desc* d) {
 int bd_wgrad1x1_splits(const bd_conv_desc* d);
 int bd_wgrad1x1_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream);
 int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patches_per_img_out);
-int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream);
+int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, float* csum, int* splits_out, hipStream_t stream);
 
 // use_tr: 1 = transposing LDS reads (default), 0 = scalar-read reference path of the generic kernel.
 // bit 1 (value 2) additionally disables the nine-tap 3x3 kernel (forces the generic per-tap kernel).
@@ -306,8 +306,63 @@ extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
     return splits * d->Cout * d->R * d->S * d->Cin * sizeof(float);
 }
 
+namespace {
+// bias gradient from the per-split partial column sums the nine-tap kernel leaves behind: fixed-order sum over the splits
+__global__ __launch_bounds__(256) void csum_reduce_kernel(const float* __restrict__ part, int splits, int C, float* __restrict__ out,
+                                                          int accumulate) {
+    __shared__ float red[256];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;      // 32 columns x 8 interleaved split chains
+    float s = 0.f;
+    if (c < C)
+        for (int k = q; k < splits; k += 8) s += part[(long long)k * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j * 32 + threadIdx.x];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+}  // namespace
+
+extern "C" size_t bd_colsum_workspace_bytes(int C);
+extern "C" int bd_colsum_bf16(const void* g, int N, int64_t pix_per_img, int64_t off, int64_t cnt, int C, float* out, int accumulate,
+                              void* ws, size_t ws_bytes, bd_stream_t stream);
+static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw, float* dbias,
+                      int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
+
+extern "C" size_t bd_conv2d_wgrad_bias_workspace_bytes(const bd_conv_desc* d) {
+    const size_t w = bd_conv2d_wgrad_workspace_bytes(d);
+    if (!w) return 0;
+    size_t extra = bd_colsum_workspace_bytes(d->Cout);
+    if (is_3x3s1(d)) {
+        const size_t s3 = (size_t)bd_wgrad3x3_splits(d, nullptr, nullptr) * d->Cout * sizeof(float);
+        if (s3 > extra) extra = s3;
+    }
+    return align256(w) + extra;
+}
+
+extern "C" int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
+                                    float* dbias, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(dbias, "conv2d_wgrad_bias: null bias gradient");
+    BD_REQUIRE(d && d->Cout <= 2048, "conv2d_wgrad_bias: Cout must be <= 2048");
+    const size_t need = bd_conv2d_wgrad_bias_workspace_bytes(d);
+    if (ws_bytes < need) {
+        bd_set_error("conv2d_wgrad_bias: workspace %zu < required %zu bytes", ws_bytes, need);
+        return BD_EWORKSPACE;
+    }
+    return wgrad_impl(d, x, g, row_scale, dw, dbias, accumulate, ws, ws_bytes, stream);
+}
+
 extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale,
                                float* dw, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    return wgrad_impl(d, x, g, row_scale, dw, nullptr, accumulate, ws, ws_bytes, stream);
+}
+
+static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw, float* dbias,
+                      int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
     BD_REQUIRE(d && x && g && dw && ws, "conv2d_wgrad: null pointer");
     BD_REQUIRE(d->nseg >= 1 && d->nseg <= BD_MAX_SEGS, "conv2d_wgrad: nseg out of range");
     BD_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, "conv2d_wgrad: Cin=%d / Cout=%d must be multiples of 8", d->Cin, d->Cout);
@@ -318,13 +373,32 @@ extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void*
         bd_set_error("conv2d_wgrad: workspace %zu < required %zu bytes", ws_bytes, need);
         return BD_EWORKSPACE;
     }
+    // bias gradient (bd_conv2d_wgrad_bias): fused into the nine-tap kernel, which reads every row of g anyway; the other kernels are
+    // followed by the stand-alone column-sum pass, level by level.  Its scratch sits behind the weight slabs.
+    unsigned char* extra = (unsigned char*)ws + align256(need);
+    auto bias_fallback = [&]() -> int {
+        long long dense = 0;                      // levels packed back to back from offset 0: one pass over the whole tensor
+        bool packed = true;
+        for (int s = 0; s < d->nseg; ++s) { packed = packed && d->out_off[s] == dense; dense += (long long)d->Ho[s] * d->Wo[s]; }
+        if (packed && dense == d->out_pix_per_img)
+            return bd_colsum_bf16(g, 1, 0, 0, (int64_t)d->N * dense, d->Cout, dbias, accumulate, extra, bd_colsum_workspace_bytes(d->Cout), stream);
+        for (int s = 0; s < d->nseg; ++s) {
+            const int e = bd_colsum_bf16(g, d->N, d->out_pix_per_img, d->out_off[s], (int64_t)d->Ho[s] * d->Wo[s], d->Cout, dbias,
+                                         (s > 0 || accumulate) ? 1 : 0, extra, bd_colsum_workspace_bytes(d->Cout), stream);
+            if (e != BD_OK) return e;
+        }
+        return BD_OK;
+    };
     if (g_wgrad_use_3x3 && is_3x3s1(d)) {
         int splits3 = 1;
-        bd_wgrad3x3_launch(d, x, g, (float*)ws, &splits3, (hipStream_t)stream);
+        bd_wgrad3x3_launch(d, x, g, (float*)ws, dbias ? (float*)extra : nullptr, &splits3, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(3x3)");
         const long long n3 = (long long)d->Cout * 9 * d->Cin;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n3 / 4, 64)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)ws, splits3, n3, 9 * d->Cin, row_scale, dw, accumulate);
+        if (dbias)
+            hipLaunchKernelGGL(csum_reduce_kernel, dim3(cdiv(d->Cout, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)extra, splits3,
+                               d->Cout, dbias, accumulate);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
         return BD_OK;
     }
@@ -336,7 +410,7 @@ extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void*
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n1 / 4, 64)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)ws, splits1, n1, d->Cin, row_scale, dw, accumulate);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
-        return BD_OK;
+        return dbias ? bias_fallback() : BD_OK;
     }
     WgradParams p{};
     p.x = (const bf16_raw*)x; p.g = (const bf16_raw*)g; p.slab = (float*)ws;
@@ -374,5 +448,5 @@ extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void*
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
                        pl.splits, n, d->R * d->S * d->Cin, row_scale, dw, accumulate);
     BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
-    return BD_OK;
+    return dbias ? bias_fallback() : BD_OK;
 }

@@ -49,6 +49,7 @@ struct W3Params {
     const bf16_raw* x;
     const bf16_raw* g;
     float* slab;
+    float* csum;             // optional [splits][Cout] partial column sums of g (bias gradient), written by the ci_tile 0 workgroups
     int Cin, Cout, N, nseg;
     int in_ppi, out_ppi;
     unsigned x_bytes, g_bytes;
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
     const bool g_cok = co0 + g_chunk * 8 < p.Cout;
 
     u32x4_t rx[X_PASSES], rg[G_PASSES];
+    const bool do_cs = p.csum != nullptr && ci_tile == 0;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // column sums of this thread's 8 channels over the rows it stages
 
     // Range-checked buffer loads: a 32-bit per-thread byte offset, and X_NONE (past the end of the tensor: the host checks both
     // tensors are < 2 GB) for halo / out-of-image / channel-tail positions, which then read as zeros -- no predicated loads, no
@@ -157,6 +160,12 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
             const int row = (tid >> 3) + 32 * k;
             *reinterpret_cast<u32x4_t*>(Gt + row * G_PITCH + g_chunk * 16) = rg[k];
         }
+        if (do_cs) {            // bias gradient: every output pixel passes through exactly one patch (zeros where the patch overhangs)
+#pragma unroll
+            for (int k = 0; k < G_PASSES; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cs[2 * j] += bf_lo(rg[k][j]); cs[2 * j + 1] += bf_hi(rg[k][j]); }
+        }
     };
 
     f32x4_t acc[9][4];     // wave tile: 16 ci x 64 co per tap
@@ -217,6 +226,17 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
         cur ^= 1;
     }
 
+    if (do_cs) {            // 32 staging threads share a channel chunk: fixed-order sum through LDS (the loop's last barrier has passed)
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = cs[j];
+        __syncthreads();
+        if (tid < TILE_CO && co0 + tid < p.Cout) {
+            float s = 0.f;
+            for (int r = 0; r < 32; ++r) s += red[(r * 8 + (tid >> 3)) * 8 + (tid & 7)];
+            p.csum[(long long)split * p.Cout + co0 + tid] = s;
+        }
+    }
     float* slab = p.slab + (long long)split * p.Cout * 9 * p.Cin;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -248,9 +268,9 @@ int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patch
     return splits;
 }
 
-int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream) {
+int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, float* csum, int* splits_out, hipStream_t stream) {
     W3Params p{};
-    p.x = (const bf16_raw*)x; p.g = (const bf16_raw*)g; p.slab = slab;
+    p.x = (const bf16_raw*)x; p.g = (const bf16_raw*)g; p.slab = slab; p.csum = csum;
     p.Cin = d->Cin; p.Cout = d->Cout; p.N = d->N; p.nseg = d->nseg;
     p.in_ppi = d->in_pix_per_img; p.out_ppi = d->out_pix_per_img;
     p.x_bytes = (unsigned)((long long)d->N * d->in_pix_per_img * d->Cin * 2);

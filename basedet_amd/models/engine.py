@@ -135,16 +135,14 @@ class ConvLayer:
 
     def wgrad(self, x, g, gin, gout, ws, colsum_ws=None):
         d = self.desc(gin, gout)
-        ops.conv2d_wgrad(d, x, g, self.gw, ws, row_scale=self.row_scale)
-        if self.gb is not None:
-            if gout.nlev == 1:
-                ops.colsum_bf16(g, 0, self.cout, self.gb, colsum_ws, geom=gout)
-            else:   # all levels of a dense pyramid buffer
-                assert gout.pix_per_img == sum(h * w for h, w in zip(gout.H, gout.W))
-                ops.colsum_bf16(g, gout.pixels, self.cout, self.gb, colsum_ws)
+        if self.gb is not None:      # weight + bias gradient in one entry point (fused in the 3x3 patch kernel; colsum_ws is unused)
+            ops.conv2d_wgrad_bias(d, x, g, self.gw, self.gb, ws, row_scale=self.row_scale)
+        else:
+            ops.conv2d_wgrad(d, x, g, self.gw, ws, row_scale=self.row_scale)
 
     def wgrad_ws_bytes(self, gin, gout):
-        return ops.conv2d_wgrad_workspace_bytes(self.desc(gin, gout))
+        d = self.desc(gin, gout)
+        return ops.conv2d_wgrad_bias_workspace_bytes(d) if self.gb is not None else ops.conv2d_wgrad_workspace_bytes(d)
 
 
 class FusedPredConv(ConvLayer):

@@ -91,6 +91,17 @@ def conv2d_wgrad(d, x, g, dw, ws, row_scale=None, accumulate=False):
     return dw
 
 
+def conv2d_wgrad_bias_workspace_bytes(d):
+    return int(L().bd_conv2d_wgrad_bias_workspace_bytes(C.byref(d)))
+
+
+def conv2d_wgrad_bias(d, x, g, dw, dbias, ws, row_scale=None, accumulate=False):
+    """Weight and bias gradient in one call (the 3x3 patch kernel sums g's columns while staging them)."""
+    check(L().bd_conv2d_wgrad_bias(C.byref(d), ptr(x), ptr(g), ptr(row_scale), ptr(dw), ptr(dbias), int(accumulate), ptr(ws),
+                                   ws.numel() * ws.element_size(), stream_ptr()), "bd_conv2d_wgrad_bias")
+    return dw
+
+
 def stem_conv7x7_fwd(N, H, W, x_halo, w_stem, bias, y):
     check(L().bd_stem_conv7x7_fwd(N, H, W, ptr(x_halo), ptr(w_stem), ptr(bias), ptr(y), stream_ptr()), "bd_stem_conv7x7_fwd")
     return y

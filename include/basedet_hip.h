@@ -83,6 +83,13 @@ size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d);
 int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
                     int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
+/* bd_conv2d_wgrad plus the bias gradient dbias[Cout] = sum over all output pixels of g (the reference's autodiff of `conv + bias`).
+ * The nine-tap 3x3 kernel sums the columns of g while it stages them (no second pass over g); the other kernels are followed by
+ * bd_colsum_bf16 per pyramid level.  accumulate applies to dw and dbias alike.  Fixed-order reductions (reproducible). */
+size_t bd_conv2d_wgrad_bias_workspace_bytes(const bd_conv_desc* d);
+int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw, float* dbias,
+                         int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
+
 /* debug/measurement knob, bit mask (default 3): bit 0 = 3x3/stride-1 forward and dgrad use the patch kernel
  * (conv3x3.hip); bit 1 = BK=32 tiles for 1x1 convs in the generic kernel; bit 2 = persistent streaming 1x1 kernel
  * (conv1x1.hip).  0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip).

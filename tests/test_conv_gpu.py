@@ -291,3 +291,46 @@ def test_patch_instances_agree_bitwise(shape):
     ops.L().bd_conv_set_patch3x3(7)
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("case", [(2, 64, 72, 19, 27, 3, 1, 1), (2, 128, 64, 22, 30, 3, 2, 1), (3, 64, 136, 9, 14, 1, 1, 0)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_wgrad_bias_entry_point(case, accumulate):
+    """bd_conv2d_wgrad_bias: weight gradient + bias gradient (column sums of g) in one call -- fused into the nine-tap kernel for the
+    3x3 cases, followed by the column-sum pass for the 1x1 case; accumulate adds to both."""
+    ops = _ops()
+    N, Cin, Cout, H, W, R, stride, pad = case
+    gen = torch.Generator().manual_seed(77 + Cin + Cout)
+    x = bf16_round(torch.randn(N, Cin, H, W, generator=gen))
+    gin = ops.single(N, H, W)
+    gout = gin.conv_out(R, stride, pad)
+    Ho, Wo = gout.H[0], gout.W[0]
+    gy = bf16_round(torch.randn(N, Cout, Ho, Wo, generator=gen))
+    d = ops.conv_desc(gin, gout, Cin, Cout, R, R, stride, pad)
+    wr = torch.zeros(Cout, Cin, R, R, requires_grad=True)
+    br = torch.zeros(Cout, requires_grad=True)
+    TF.conv2d(x, wr, br, stride=stride, padding=pad).backward(gy)
+    ws = torch.empty((ops.conv2d_wgrad_bias_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
+    dw = torch.full((Cout, R, R, Cin), 0.5, dtype=torch.float32, device="cuda")
+    db = torch.full((Cout,), 0.25, dtype=torch.float32, device="cuda")
+    ops.conv2d_wgrad_bias(d, nchw_to_pm(x), nchw_to_pm(gy), dw, db, ws, accumulate=accumulate)
+    base_w, base_b = (0.5, 0.25) if accumulate else (0.0, 0.0)
+    assert rel_l2(dw.cpu() - base_w, oihw_to_ohwi(wr.grad)) < 2e-3
+    assert rel_l2(db.cpu() - base_b, br.grad) < 1e-4
+
+
+def test_wgrad_bias_multilevel():
+    """Five pyramid levels in one descriptor: the fused column sums cover every level's pixels exactly once (ragged patches)."""
+    ops = _ops()
+    N, C, Cout = 2, 64, 72
+    Hs, Ws = [12, 6, 3, 2, 1], [20, 10, 5, 3, 2]
+    gen = torch.Generator().manual_seed(11)
+    geo = ops.Geom(N, Hs, Ws)
+    d = ops.conv_desc(geo, geo, C, Cout, 3, 3, 1, 1)
+    xp = bf16_round(torch.randn(geo.pixels, C, generator=gen)).to(torch.bfloat16).cuda()
+    gy = bf16_round(torch.randn(geo.pixels, Cout, generator=gen))
+    ws = torch.empty((ops.conv2d_wgrad_bias_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
+    dw = torch.empty((Cout, 3, 3, C), dtype=torch.float32, device="cuda")
+    db = torch.empty((Cout,), dtype=torch.float32, device="cuda")
+    ops.conv2d_wgrad_bias(d, xp, gy.to(torch.bfloat16).cuda(), dw, db, ws)
+    assert rel_l2(db.cpu(), gy.sum(0)) < 1e-4
