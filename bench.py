@@ -49,7 +49,7 @@ class ConvTimer:
         self.records = {}
         self.enabled = False
         self.meta = {}
-        self._orig = (ops.conv2d_fwd, ops.conv2d_dgrad, ops.conv2d_wgrad)
+        self._orig = (ops.conv2d_fwd, ops.conv2d_dgrad, ops.conv2d_wgrad, ops.conv2d_wgrad_bias)
 
         def flops(d):
             m = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
@@ -105,6 +105,7 @@ class ConvTimer:
         ops.conv2d_fwd = wrap(ops.conv2d_fwd, "igemm")
         ops.conv2d_dgrad = wrap(ops.conv2d_dgrad, "igemm")
         ops.conv2d_wgrad = wrap(ops.conv2d_wgrad, "wgrad")
+        ops.conv2d_wgrad_bias = wrap(ops.conv2d_wgrad_bias, "wgrad")
 
     def dump(self, steps):
         agg = {}
