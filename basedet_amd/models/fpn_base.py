@@ -490,9 +490,9 @@ class FPNDetector:
         ws, cws = pl.wgrad_ws, pl.colsum_ws
         pyr = pl.pyr
         self.head_backward(pl, ws, cws)
+        side = (self._wstream,) if (self.async_wgrad and self._wstream is not None) else ()
         if on_bucket_ready:
-            self._join_wgrads()
-            on_bucket_ready("head")
+            on_bucket_ready("head", side)
         # ---- FPN
         st = self.fpn_stages
         nl = len(st)
@@ -534,8 +534,7 @@ class FPNDetector:
             else:
                 self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=True)
         if on_bucket_ready:
-            self._join_wgrads()
-            on_bucket_ready("fpn")
+            on_bucket_ready("fpn", side)
         # ---- backbone, last block first.  g_out of a block holds the masked gradient once all consumers are done:
         # res5: done above.  res3/res4 (and every inner block output): the next block's dgrads finish it.
         nb = len(self.blocks)
@@ -573,7 +572,6 @@ class FPNDetector:
                         ops.conv2d_dgrad(convs[0].desc(geos[0], geos[1]), g, convs[0].w_dgrad, gx, add=G, mask=xin,
                                          flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
             if on_bucket_ready and (bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]):
-                self._join_wgrads()
-                on_bucket_ready(f"layer{blk['layer']}")
+                on_bucket_ready(f"layer{blk['layer']}", side)
         self._join_wgrads()
 

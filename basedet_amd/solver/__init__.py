@@ -63,15 +63,19 @@ class GradBuckets:
             groups[k] = (min(lo, off), max(hi, (off + n + 63) // 64 * 64))
         return groups
 
-    def on_ready(self, phase):
+    def on_ready(self, phase, producers=()):
+        """All gradients of `phase` have been ENQUEUED on the current stream and on the `producers` streams (the weight-gradient
+        side stream): the communication stream waits for events on those streams -- the compute streams never wait for each other
+        or for the collective."""
         if not self.enabled or phase not in self.ranges:
             return
         lo, hi = self.ranges[phase]
         buf = self.model.arena.g[lo:hi]
         if self.comm_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
+            for st in (torch.cuda.current_stream(),) + tuple(s for s in producers if s is not None):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         else:
