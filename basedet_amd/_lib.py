@@ -72,6 +72,8 @@ SIGNATURES = {
     "bd_fcos_assign": (_I, [_P, _I, _P, _P, _P, _I, _F, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "bd_ota_assign_workspace_bytes": (_Z, [_I, _I]),
     "bd_ota_assign": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "bd_ota_sinkhorn_workspace_bytes": (_Z, [_I, _I, _I]),
+    "bd_ota_assign_sinkhorn": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "bd_freeanchor_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "bd_freeanchor_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _P, _P, _F, _I, _F, _F, _F, _F, _P, _P, _P, _P, _Z, _P]),
     "bd_atss_assign_workspace_bytes": (_Z, [_I, _I]),

@@ -56,7 +56,7 @@ __device__ __forceinline__ f32x4_t ld_pred(const bf16_raw* offsets, long long ro
 
 // cost and IoU of point p (row = n*P + p, level radius rad) against one gt
 __device__ __forceinline__ void ota_pair(const OtaIn& in, long long row, int p, float rad, const Box& gb, int cls, float& cost, float& iou,
-                                         f32x4_t& delta) {
+                                         f32x4_t& delta, bool* inside = nullptr) {
     const float px = in.points[2ll * p], py = in.points[2ll * p + 1];
     delta = (f32x4_t){px - gb.x1, py - gb.y1, gb.x2 - px, gb.y2 - py};                       // PointCoder.encode (boxcoder.py:132-133)
     const bool in_box = fminf(fminf(delta[0], delta[1]), fminf(delta[2], delta[3])) > 0.01f;   // ota.py:96
@@ -69,6 +69,7 @@ __device__ __forceinline__ void ota_pair(const OtaIn& in, long long row, int p, 
     const float xc = bf2f(in.logits[row * in.K + cls]);
     const float cls_cost = (in.sbg[row] - focal_value(xc, false, in.alpha, in.gamma)) + focal_value(xc, true, in.alpha, in.gamma);
     cost = (cls_cost + in.reg_w * loss_delta) + ((in_box && in_ctr) ? 0.f : 1e6f);            // ota.py:151
+    if (inside) *inside = in_box && in_ctr;
 }
 
 __global__ __launch_bounds__(256) void ota_prep_kernel(const bf16_raw* __restrict__ logits, long long rows, int K, float alpha,
@@ -192,7 +193,205 @@ __global__ __launch_bounds__(256) void ota_resolve_kernel(OtaIn in, OtaLevels lv
     if ((threadIdx.x & 63) == 0 && fg != 0.f) { atomicAdd(&stats[0], fg); atomicAdd(&stats[1], 2.f * fg); }   // integers: exact
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Sinkhorn matcher (layers/common/matcher.py:106-121, layers/blocks/sinkhorn_distance.py:22-50): cfg MATCHING = "sinkhorn"
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SK_MAX_ROWS = 512;         // gts + background row held in LDS vectors
+
+// one workgroup per (gt, image): the cost row (ota.py:151) into the workspace and the supply mu_g = max(1, int(sum of the 20 largest
+// IoUs, IoU counted only inside the gt / centre box)) (matcher.py:112-113, ota.py:155)
+__global__ __launch_bounds__(1024) void ota_sk_rows_kernel(OtaIn in, OtaLevels lv, const float* __restrict__ gt, const int* __restrict__ num_gt,
+                                                           int Gmax, int topq, float* __restrict__ cost, float* __restrict__ mu) {
+    __shared__ unsigned int hist[256];
+    __shared__ int sh[8];
+    __shared__ float s_top[OTA_MAX_K];
+    __shared__ int s_n;
+    const int tid = threadIdx.x, g = blockIdx.x, n = blockIdx.y;
+    const int P = in.P;
+    if (g >= num_gt[n]) return;
+    const float* gp = gt + ((long long)n * Gmax + g) * 5;
+    const Box gb = ld_gt(gp);
+    const int cls = (int)gp[4] - 1;
+    const long long row0 = (long long)n * P;
+    float* crow = cost + ((long long)n * (Gmax + 1) + g) * P;
+    auto level_radius = [&](int p) { int l = 0; for (int k = 1; k < lv.L; ++k) if (p >= lv.start[k]) l = k; return lv.radius[l]; };
+    auto masked_iou = [&](int p, float& c) -> float {
+        float u; f32x4_t d; bool inside;
+        ota_pair(in, row0 + p, p, level_radius(p), gb, cls, c, u, d, &inside);
+        return inside ? u : u * 0.f;
+    };
+    for (int p = tid; p < P; p += 1024) { float c; masked_iou(p, c); crow[p] = c; }
+    auto key_iou = [&](int i, bool& valid) -> unsigned int { valid = true; float c; return f32_asc_key(masked_iou(i, c)); };
+    const SelResult ri = radix_select_largest(P, topq, 4, key_iou, hist, sh);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i = tid; i < P; i += 1024) {
+        bool valid; const unsigned int kv = key_iou(i, valid);
+        if (ri.take_all || kv > ri.T) { const int q = atomicAdd(&s_n, 1); if (q < OTA_MAX_K) s_top[q] = f32_from_asc_key(kv); }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int m = s_n < OTA_MAX_K ? s_n : OTA_MAX_K;
+        if (!ri.take_all) for (int j = 0; j < ri.need_eq && m < OTA_MAX_K; ++j) s_top[m++] = f32_from_asc_key(ri.T);
+        for (int a = 1; a < m; ++a) {
+            const float v = s_top[a]; int b = a - 1;
+            while (b >= 0 && s_top[b] < v) { s_top[b + 1] = s_top[b]; --b; }
+            s_top[b + 1] = v;
+        }
+        float s = 0.f;
+        for (int a = 0; a < m; ++a) s += s_top[a];
+        const int k = (int)s;
+        mu[n * (Gmax + 1) + g] = (float)(k < 1 ? 1 : k);
+    }
+}
+
+// one workgroup per image: log-domain Sinkhorn iterations on the (G+1) x P cost (background row = S_bg, ota.py:154), then every point
+// goes to the row of largest rescaled plan entry pi_ij / max_j pi_ij (matcher.py:118-121; ties: lowest row)
+__global__ __launch_bounds__(1024) void ota_sinkhorn_kernel(OtaIn in, OtaLevels lv, const float* __restrict__ gt, const int* __restrict__ num_gt,
+                                                            int Gmax, float eps, int iters, float* __restrict__ cost,
+                                                            const float* __restrict__ mu_g, float* __restrict__ vbuf, int* __restrict__ labels,
+                                                            float* __restrict__ targets, float* __restrict__ gt_ious,
+                                                            float* __restrict__ stats) {
+    __shared__ float u[SK_MAX_ROWS], lmu[SK_MAX_ROWS], rmax[SK_MAX_ROWS];
+    __shared__ float s_mu_sum;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
+    const int P = in.P;
+    const int G = num_gt[n] < Gmax ? num_gt[n] : Gmax;
+    const long long row0 = (long long)n * P;
+    float fgc = 0.f;
+    if (G > 0) {
+        const int G1 = G + 1;
+        float* C = cost + (long long)n * (Gmax + 1) * P;
+        float* v = vbuf + row0;
+        for (int p = tid; p < P; p += 1024) { C[(long long)G * P + p] = in.sbg[row0 + p]; v[p] = 1.f; }      // background row, v = 1
+        if (tid == 0) {
+            float s = 0.f;
+            for (int i = 0; i < G; ++i) s += mu_g[n * (Gmax + 1) + i];
+            s_mu_sum = s;
+        }
+        __syncthreads();
+        if (tid < G1) {
+            const float m = tid < G ? mu_g[n * (Gmax + 1) + tid] : (float)P - s_mu_sum;      // matcher.py:114
+            lmu[tid] = logf(m + 1e-8f);
+            u[tid] = 1.f;
+        }
+        __syncthreads();
+        const float lnu = logf(1.f + 1e-8f);
+        const float inv = 1.f / eps;
+        for (int it = 0; it < iters; ++it) {
+            // v_j += eps (log nu_j - logsumexp_i M_ij),  M_ij = (-c_ij + u_i + v_j) / eps   (sinkhorn_distance.py:28-30)
+            for (int p = tid; p < P; p += 1024) {
+                const float vj = v[p];
+                float m = -INFINITY;
+                for (int i = 0; i < G1; ++i) m = fmaxf(m, (-C[(long long)i * P + p] + u[i] + vj) * inv);
+                float s = 0.f;
+                for (int i = 0; i < G1; ++i) s += expf((-C[(long long)i * P + p] + u[i] + vj) * inv - m);
+                v[p] = vj + eps * (lnu - (m + logf(s)));
+            }
+            __syncthreads();
+            // u_i += eps (log mu_i - logsumexp_j M_ij) with the new v (:31-33); rows spread over the 16 waves
+            for (int i = wave; i < G1; i += 16) {
+                const float ui = u[i];
+                float m = -INFINITY, s = 0.f;
+                for (int p = lane; p < P; p += 64) {
+                    const float x = (-C[(long long)i * P + p] + ui + v[p]) * inv;
+                    if (x > m) { s = s * expf(m - x) + 1.f; m = x; } else s += expf(x - m);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+                    const float mm = fmaxf(m, m2);
+                    s = (m == -INFINITY ? 0.f : s * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
+                    m = mm;
+                }
+                if (lane == 0) u[i] = ui + eps * (lmu[i] - (m + logf(s)));
+            }
+            __syncthreads();
+        }
+        // pi = exp(M); rescale each row by its maximum
+        for (int i = wave; i < G1; i += 16) {
+            float m = -INFINITY;
+            for (int p = lane; p < P; p += 64) m = fmaxf(m, expf((-C[(long long)i * P + p] + u[i] + v[p]) * inv));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if (lane == 0) rmax[i] = m;
+        }
+        __syncthreads();
+        for (int p = tid; p < P; p += 1024) {
+            float best = -INFINITY; int bi = 0;
+            for (int i = 0; i < G1; ++i) {
+                const float r = expf((-C[(long long)i * P + p] + u[i] + v[p]) * inv) / rmax[i];
+                if (r > best) { best = r; bi = i; }
+            }
+            int lab = 0; float iou_t = 0.f;
+            f32x4_t tgt = {0.f, 0.f, 0.f, 0.f};
+            if (bi != G) {
+                int l = 0;
+                for (int k = 1; k < lv.L; ++k) if (p >= lv.start[k]) l = k;
+                const float* gp = gt + ((long long)n * Gmax + bi) * 5;
+                float c; bool inside;
+                ota_pair(in, row0 + p, p, lv.radius[l], ld_gt(gp), (int)gp[4] - 1, c, iou_t, tgt, &inside);
+                if (!inside) iou_t = iou_t * 0.f;                              // ious * is_in_boxes (ota.py:155)
+                lab = (int)gp[4];
+                if (lab > 0) fgc += 1.f; else { iou_t = 0.f; tgt = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+            }
+            labels[row0 + p] = lab;
+            *reinterpret_cast<f32x4_t*>(targets + (row0 + p) * 4) = tgt;
+            gt_ious[row0 + p] = iou_t;
+        }
+    } else {
+        for (int p = tid; p < P; p += 1024) {
+            labels[row0 + p] = 0; gt_ious[row0 + p] = 0.f;
+            *reinterpret_cast<f32x4_t*>(targets + (row0 + p) * 4) = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    fgc = wave_sum(fgc);
+    if (lane == 0 && fgc != 0.f) { atomicAdd(&stats[0], fgc); atomicAdd(&stats[1], 2.f * fgc); }
+}
+
 }  // namespace
+
+extern "C" size_t bd_ota_sinkhorn_workspace_bytes(int N, int P, int Gmax) {
+    if (N <= 0 || P <= 0 || Gmax <= 0) return 256;
+    return (size_t)N * P * 8 + (size_t)N * (Gmax + 1) * P * 4 + (size_t)N * (Gmax + 1) * 4 + 1024;
+}
+
+extern "C" int bd_ota_assign_sinkhorn(const float* points, int P, const int32_t* lvl_start, const int32_t* strides, int L,
+                                      const void* logits, int K, const void* pred_ltrb, const float* gt_boxes, const int32_t* num_gt, int N,
+                                      int Gmax, float alpha, float gamma, float reg_weight, float center_radius, int topq, float eps,
+                                      int iters, int32_t* labels, float* targets, float* gt_ious, float* stats, void* ws, size_t ws_bytes,
+                                      bd_stream_t stream) {
+    BD_REQUIRE(points && lvl_start && strides && logits && pred_ltrb && gt_boxes && num_gt && labels && targets && gt_ious && stats && ws,
+               "ota_assign_sinkhorn: null pointer");
+    BD_REQUIRE(L >= 1 && L <= BD_MAX_SEGS && P > 0 && N > 0 && Gmax > 0 && K > 0 && K % 8 == 0, "ota_assign_sinkhorn: bad sizes");
+    BD_REQUIRE(Gmax + 1 <= SK_MAX_ROWS, "ota_assign_sinkhorn: %d gt slots exceed %d", Gmax, SK_MAX_ROWS - 1);
+    BD_REQUIRE(topq >= 1 && topq <= OTA_MAX_K && eps > 0.f && iters >= 1, "ota_assign_sinkhorn: bad matcher parameters");
+    if (ws_bytes < bd_ota_sinkhorn_workspace_bytes(N, P, Gmax)) {
+        bd_set_error("ota_assign_sinkhorn: workspace %zu < %zu bytes", ws_bytes, bd_ota_sinkhorn_workspace_bytes(N, P, Gmax));
+        return BD_EWORKSPACE;
+    }
+    OtaLevels lv{};
+    lv.L = L;
+    for (int l = 0; l < L; ++l) { lv.start[l] = lvl_start[l]; lv.radius[l] = (float)strides[l] * center_radius; }
+    lv.start[L] = lvl_start[L];
+    const long long rows = (long long)N * P;
+    unsigned char* wb = (unsigned char*)ws;
+    float* sbg = (float*)wb;
+    float* vbuf = (float*)(wb + rows * 4);
+    float* cost = (float*)(wb + rows * 8);
+    float* mu = (float*)(wb + rows * 8 + (size_t)N * (Gmax + 1) * P * 4);
+    OtaIn in{points, (const bf16_raw*)logits, (const bf16_raw*)pred_ltrb, sbg, P, K, alpha, gamma, reg_weight};
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(stats, 0, 2 * sizeof(float), st);
+    // the prep kernel also zeroes two int vectors of `rows` entries: point them at the v buffer and the first cost row
+    hipLaunchKernelGGL(ota_prep_kernel, dim3((unsigned)cdiv64(rows, 256)), dim3(256), 0, st, (const bf16_raw*)logits, rows, K, alpha, gamma,
+                       sbg, (int*)vbuf, (int*)vbuf);
+    hipLaunchKernelGGL(ota_sk_rows_kernel, dim3(Gmax, N), dim3(1024), 0, st, in, lv, gt_boxes, num_gt, Gmax, topq, cost, mu);
+    hipLaunchKernelGGL(ota_sinkhorn_kernel, dim3(N), dim3(1024), 0, st, in, lv, gt_boxes, num_gt, Gmax, eps, iters, cost, mu, vbuf, labels,
+                       targets, gt_ious, stats);
+    BD_CHECK_LAUNCH("bd_ota_assign_sinkhorn");
+    return BD_OK;
+}
 
 extern "C" size_t bd_ota_assign_workspace_bytes(int N, int P) {
     if (N <= 0 || P <= 0) return 256;

@@ -208,9 +208,8 @@ class OTA(FCOS):
     (bd_ota_assign) and emd_losses' weighting (:183-233): focal / num_fg, 2 x GIoU / num_fg, 0.5 x BCE(iou) / num_fg."""
 
     def __init__(self, cfg, *a, **k):
-        matching = cfg.MODEL.get("MATCHING", "topk")
-        if matching != "topk":
-            raise NotImplementedError(f"OTA matching '{matching}': only the reference default 'topk' (OTATopkMatcher) is built on the HIP path")
+        self.matching = cfg.MODEL.get("MATCHING", "topk")
+        assert self.matching in ("topk", "sinkhorn"), f"unsupported matching named {self.matching}"      # ota.py:21
         hc = cfg.MODEL.HEAD
         assert hc.get("NORM_REG_TARGETS", True) and hc.get("WITH_NORM", True) and hc.get("SHARE_PARAM", True), \
             "OTA on the HIP path supports the reference's OTAConfig head flags (NORM_REG_TARGETS, WITH_NORM, SHARE_PARAM)"
@@ -222,6 +221,14 @@ class OTA(FCOS):
 
     def _assign(self, pl, gt, num_gt):
         m = self.cfg.MODEL
+        if self.matching == "sinkhorn":              # SinkhornMatcher(eps=0.1, max_iter=50) (ota.py:43-44)
+            need = ops.ota_sinkhorn_workspace_bytes(pl.N, pl.points.shape[0], gt.shape[1])
+            if pl.ota_ws.numel() < need:
+                pl.ota_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+            ops.ota_assign_sinkhorn(pl.points, pl.lvl_start, self.strides, pl.logits, self.num_classes, pl.offsets, gt, num_gt,
+                                    m.LOSSES.FOCAL_LOSS_ALPHA, m.LOSSES.FOCAL_LOSS_GAMMA, m.HEAD.get("COST_REG_WEIGHTS", 1.5), 2.5,
+                                    pl.labels, pl.gt_offsets, pl.gt_ctr, pl.stats, pl.ota_ws)
+            return
         ops.ota_assign(pl.points, pl.lvl_start, self.strides, pl.logits, self.num_classes, pl.offsets, gt, num_gt,
                        m.LOSSES.FOCAL_LOSS_ALPHA, m.LOSSES.FOCAL_LOSS_GAMMA, m.HEAD.get("COST_REG_WEIGHTS", 1.5), 2.5,
                        m.HEAD.get("CANDIDATE_K", 10), pl.labels, pl.gt_offsets, pl.gt_ctr, pl.stats, pl.ota_ws)

@@ -203,7 +203,7 @@ def oracle_arch(cfg):
                                           center_sampling_radius=m.HEAD.CENTER_SAMPLING_RADIUS)
         if m.NAME == "OTA":
             extra["ota"] = dict(reg_weight=m.HEAD.get("COST_REG_WEIGHTS", 1.5), candidate_k=m.HEAD.get("CANDIDATE_K", 10),
-                                center_radius=2.5)
+                                center_radius=2.5, matching=m.get("MATCHING", "topk"))
         return dict(extra, backbone=m.BACKBONE.NAME, fpn_in=list(m.BACKBONE.OUT_FEATURES), num_convs=m.HEAD.NUM_CONVS,
                     num_classes=cfg.DATA.NUM_CLASSES, img_mean=list(m.BACKBONE.IMG_MEAN), img_std=list(m.BACKBONE.IMG_STD),
                     strides=list(m.FPN.STRIDES), anchor_offset=m.ANCHOR.OFFSET,

@@ -273,6 +273,21 @@ def ota_assign(points, lvl_start, strides, logits, K, pred_ltrb, gt_boxes, num_g
                             ws.numel() * ws.element_size(), stream_ptr()), "bd_ota_assign")
 
 
+def ota_sinkhorn_workspace_bytes(N, P, Gmax):
+    return int(L().bd_ota_sinkhorn_workspace_bytes(N, P, Gmax))
+
+
+def ota_assign_sinkhorn(points, lvl_start, strides, logits, K, pred_ltrb, gt_boxes, num_gt, alpha, gamma, reg_weight, center_radius,
+                        labels, targets, gt_ious, stats, ws, topq=20, eps=0.1, iters=50):
+    """OTA.get_ground_truth with the SinkhornMatcher (models/det/ota.py:153-157, layers/common/matcher.py:106-121)."""
+    P = points.shape[0]
+    N, Gmax = gt_boxes.shape[0], gt_boxes.shape[1]
+    check(L().bd_ota_assign_sinkhorn(ptr(points), P, i32arr(lvl_start), i32arr(strides), len(strides), ptr(logits), int(K), ptr(pred_ltrb),
+                                     ptr(gt_boxes), ptr(num_gt), N, Gmax, float(alpha), float(gamma), float(reg_weight),
+                                     float(center_radius), int(topq), float(eps), int(iters), ptr(labels), ptr(targets), ptr(gt_ious),
+                                     ptr(stats), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_ota_assign_sinkhorn")
+
+
 def freeanchor_workspace_bytes(N, Gmax, bucket, A):
     return int(L().bd_freeanchor_workspace_bytes(N, Gmax, bucket, A))
 

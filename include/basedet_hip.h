@@ -232,6 +232,18 @@ int bd_ota_assign(const float* points, int P, const int32_t* lvl_start_host, con
                   float gamma, float reg_weight, float center_radius, int candidate_k, int32_t* labels, float* targets,
                   float* gt_ious, float* stats, void* ws, size_t ws_bytes, bd_stream_t stream);
 
+/* The same assignment with the Sinkhorn matcher (cfg MATCHING = "sinkhorn"; layers/common/matcher.py:106-121,
+ * layers/blocks/sinkhorn_distance.py:22-50): supplies mu_g = max(1, int(sum of the `topq` = 20 largest in-box IoUs)), background
+ * supply P - sum mu, demands 1; `iters` = 50 log-domain Sinkhorn updates with regulariser eps = 0.1 on the (G+1) x P cost (last row:
+ * the background focal cost); each point goes to the row of largest plan entry after every row is rescaled by its maximum (ties:
+ * lowest row).  gt_ious are the IoUs masked by the in-box test (ota.py:155).  Gmax + 1 <= 512.  Outputs as bd_ota_assign. */
+size_t bd_ota_sinkhorn_workspace_bytes(int N, int P, int Gmax);
+int bd_ota_assign_sinkhorn(const float* points, int P, const int32_t* lvl_start_host, const int32_t* strides_host, int L,
+                           const void* logits, int K, const void* pred_ltrb, const float* gt_boxes, const int32_t* num_gt, int N,
+                           int Gmax, float alpha, float gamma, float reg_weight, float center_radius, int topq, float eps, int iters,
+                           int32_t* labels, float* targets, float* gt_ious, float* stats, void* ws, size_t ws_bytes,
+                           bd_stream_t stream);
+
 /* FreeAnchor.get_losses after the network forward (models/det/free_anchor.py:38-142): positive bag loss over the `bucket`
  * anchors of largest IoU per gt (ties at the boundary: lowest anchor index) and negative loss over every (anchor, class) with the
  * box probabilities of the decoded predictions (two gts of one class claiming an anchor: the later gt's value), both with their

@@ -306,8 +306,42 @@ def fcos_ground_truth(points_list, strides, batched_gt_boxes, num_valid, sizes_o
 # --------------------------------------------------------------------------------------------
 # OTA target assignment, top-k matcher (models/det/ota.py:76-181, layers/common/matcher.py:123-161)
 # --------------------------------------------------------------------------------------------
+def _logsumexp(x, axis):
+    m = x.max(axis=axis, keepdims=True)
+    return (m + np.log(np.exp(x - m).sum(axis=axis, keepdims=True, dtype=F32))).squeeze(axis).astype(F32)
+
+
+def sinkhorn_match(cost, ious, eps=0.1, max_iter=50, topq=20):
+    """SinkhornMatcher.__call__ + SinkhornDistance.forward (layers/common/matcher.py:106-121, layers/blocks/sinkhorn_distance.py:22-50)
+    in float32.  cost (G+1, P) with the background row last, ious (G, P).  Returns the matched row per point."""
+    cost = np.asarray(cost, F32)
+    P = cost.shape[1]
+    kk = min(topq, P)
+    topk = -np.sort(-np.asarray(ious, F32), axis=1, kind="stable")[:, :kk]
+    mu = []
+    for row in topk:
+        s = F32(0)
+        for v in row:
+            s = F32(s + v)
+        mu.append(F32(max(1, int(s))))
+    mu = np.asarray(mu + [F32(P) - np.asarray(mu, F32).sum(dtype=F32)], F32)
+    nu = np.ones(P, F32)
+    u, v = np.ones_like(mu), np.ones_like(nu)
+    e = F32(eps)
+
+    def M(u, v):
+        return ((-cost + u[:, None] + v[None, :]) / e).astype(F32)
+    for _ in range(max_iter):
+        v = (v + e * (np.log(nu + F32(1e-8)) - _logsumexp(M(u, v).T, -1))).astype(F32)
+        u = (u + e * (np.log(mu + F32(1e-8)) - _logsumexp(M(u, v), -1))).astype(F32)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        pi = np.exp(M(u, v)).astype(F32)
+        pi = pi / pi.max(axis=1, keepdims=True)
+    return pi.argmax(axis=0), pi
+
+
 def ota_ground_truth(points_list, strides, logits, pred_ltrb, batched_gt_boxes, num_valid, alpha=0.25, gamma=2.0,
-                     reg_weight=1.5, center_radius=2.5, candidate_k=10):
+                     reg_weight=1.5, center_radius=2.5, candidate_k=10, matching="topk"):
     """logits (N, P, K), pred_ltrb (N, P, 4) float32 (detached predictions).  Returns labels (N, P) int32 (class, 0 = bg), ltrb
     targets (N, P, 4), IoU targets (N, P), and the cost / IoU matrices per image (for tie analysis in the tests).
     Unpinned orders fixed here: F.topk ties -> lowest point index, F.argmin ties -> lowest gt index."""
@@ -341,8 +375,19 @@ def ota_ground_truth(points_list, strides, logits, pred_ltrb, batched_gt_boxes, 
         ious = ltrb_iou(np.broadcast_to(np.asarray(pred_ltrb[n], F32)[None], deltas.shape), deltas, "iou", eps).astype(F32)
         loss_delta = (-np.log(np.maximum(ious, eps))).astype(F32)
         cost = (loss_cls + F32(reg_weight) * loss_delta + F32(1e6) * (~in_boxes).astype(F32)).astype(F32)
+        if matching == "sinkhorn":                                                       # ota.py:153-157
+            loss_cls_bg = sigmoid_focal_loss(x, np.zeros_like(x), alpha, gamma).sum(axis=-1).astype(F32)
+            cost_bg = np.concatenate([cost, loss_cls_bg[None]], 0)
+            ious_m = (ious * in_boxes.astype(F32)).astype(F32)
+            mg, pi = sinkhorn_match(cost_bg, ious_m)
+            fg = mg != G
+            lab[fg] = gtl[mg[fg], 4].astype(np.int32)
+            tgt[fg] = deltas[mg[fg], np.nonzero(fg)[0]]
+            iou_t[fg] = ious_m[mg[fg], np.nonzero(fg)[0]]
+            labs.append(lab); tgts.append(tgt); ious_out.append(iou_t); aux.append((cost_bg, pi))
+            continue
         # OTATopkMatcher
-        matching = np.zeros((G, P), np.int32)
+        mm = np.zeros((G, P), np.int32)
         kk = min(candidate_k, P)
         topk = -np.sort(-ious, axis=1, kind="stable")[:, :kk]
         dyn = []
@@ -353,14 +398,14 @@ def ota_ground_truth(points_list, strides, logits, pred_ltrb, batched_gt_boxes, 
             dyn.append(max(1, int(s)))
         for g in range(G):
             idx = np.argsort(cost[g], kind="stable")[: dyn[g]]
-            matching[g, idx] = 1
-        multi = matching.sum(0) > 1
+            mm[g, idx] = 1
+        multi = mm.sum(0) > 1
         if multi.any():
             am = cost[:, multi].argmin(axis=0)
-            matching[:, multi] = 0
-            matching[am, np.nonzero(multi)[0]] = 1
-        fg = matching.sum(0) > 0
-        mg = matching.argmax(axis=0)
+            mm[:, multi] = 0
+            mm[am, np.nonzero(multi)[0]] = 1
+        fg = mm.sum(0) > 0
+        mg = mm.argmax(axis=0)
         lab[fg] = gtl[mg[fg], 4].astype(np.int32)
         tgt[fg] = deltas[mg[fg], np.nonzero(fg)[0]]
         iou_t[fg] = ious[mg[fg], np.nonzero(fg)[0]]

@@ -344,7 +344,7 @@ class Oracle:
         if forced is None:
             labels, gt_off, gt_iou, aux = box_ops.ota_ground_truth(pts, a["strides"], logits.detach().numpy(), offsets.detach().numpy(),
                                                                    batch["gt_boxes"], num_valid, al, ga, o["reg_weight"],
-                                                                   o["center_radius"], o["candidate_k"])
+                                                                   o["center_radius"], o["candidate_k"], o.get("matching", "topk"))
         else:                   # targets taken from the device path (gradient checks on identical assignments)
             labels, gt_off, gt_iou = forced
             aux = None

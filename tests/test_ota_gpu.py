@@ -128,3 +128,65 @@ def test_ota_training_step_matches_oracle():
         g = got[n].double().reshape(-1)
         rel = float((g - r).norm() / (r.norm() + 1e-30))
         assert rel < 2e-2, (n, rel)
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_ota_sinkhorn_assignment_matches_oracle(seed):
+    """MATCHING = "sinkhorn" (layers/common/matcher.py:106-121): 50 log-domain Sinkhorn updates in fp32 on both sides; the plans agree
+    to rounding, the assignment except where the two largest rescaled plan entries of a point are within 1e-3 of each other."""
+    from basedet_amd import ops
+    from oracle import box_ops
+    pts, allp, lvl_start, strides, gt, num, logits, pred = _problem(seed, gmax=5)
+    N, P, K = logits.shape
+    lg = torch.from_numpy(logits).to(torch.bfloat16)
+    pr = torch.from_numpy(pred).to(torch.bfloat16)
+    lab_o, tgt_o, iou_o, aux = box_ops.ota_ground_truth(pts, strides, lg.float().numpy(), pr.float().numpy(), gt, num, 0.25, 2.0, 1.5, 2.5,
+                                                        10, matching="sinkhorn")
+    dev = "cuda"
+    labels = torch.full((N, P), -7, dtype=torch.int32, device=dev)
+    targets = torch.full((N, P, 4), -7.0, dtype=torch.float32, device=dev)
+    ious = torch.full((N, P), -7.0, dtype=torch.float32, device=dev)
+    stats = torch.zeros(2, dtype=torch.float32, device=dev)
+    ws = torch.empty(ops.ota_sinkhorn_workspace_bytes(N, P, gt.shape[1]), dtype=torch.uint8, device=dev)
+    ops.ota_assign_sinkhorn(torch.from_numpy(allp).to(dev), lvl_start, strides, lg.reshape(N * P, K).to(dev), K, pr.reshape(N * P, 4).to(dev),
+                            torch.from_numpy(gt).to(dev), torch.from_numpy(num).to(dev), 0.25, 2.0, 1.5, 2.5, labels, targets, ious, stats, ws)
+    torch.cuda.synchronize()
+    lab, tgt, iou_t = labels.cpu().numpy(), targets.cpu().numpy(), ious.cpu().numpy()
+    nfg = int((lab_o > 0).sum())
+    assert nfg >= 5
+    diff = np.argwhere(lab != lab_o)
+    assert len(diff) <= max(1, nfg // 20), (len(diff), nfg)
+    for n, p in diff:
+        col = np.sort(aux[n][1][:, p])[::-1]
+        assert col[0] - col[1] < 1e-3 * max(col[0], 1e-30) or not np.isfinite(col[0]), (n, p, col[:3])
+    fg = (lab == lab_o) & (lab_o > 0)
+    np.testing.assert_array_equal(tgt[fg], tgt_o[fg])
+    np.testing.assert_allclose(iou_t[fg], iou_o[fg], rtol=2e-6, atol=1e-7)
+    st = stats.cpu().numpy()
+    assert st[0] == (lab > 0).sum() and st[1] == 2 * st[0]
+
+
+def test_ota_sinkhorn_model_step():
+    """OTA with MATCHING = "sinkhorn" end to end: finite losses of the expected structure and a backward pass."""
+    from basedet_amd.configs import OTAConfig
+    from basedet_amd.models import OTA, params as P
+    from basedet_amd.utils import DummyLoader
+    N, size = 2, (128, 160)
+    cfg = OTAConfig()
+    cfg.MODEL.MATCHING = "sinkhorn"
+    cfg.MODEL.BATCHSIZE = N
+    params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.25)
+    params["head.bbox_pred.bias"] = np.full_like(params["head.bbox_pred.bias"], 0.5)
+    batch = next(DummyLoader(N, size, seed=0))
+    batch["data"] = (batch["data"] * 255).astype(np.float32)
+    model = OTA(cfg, params=params)
+    out = model(batch)
+    vals = {k: float(v) for k, v in out.items()}
+    assert all(np.isfinite(v) for v in vals.values()) and vals["loss_cls"] > 0 and vals["loss_offsets"] > 0
+    assert abs(vals["total_loss"] - (vals["loss_cls"] + vals["loss_offsets"] + vals["loss_ious"])) < 1e-4 * vals["total_loss"]
+    nfg = float(model._cur.stats[0])
+    assert nfg >= 1 and nfg == float((model._cur.labels > 0).sum())
+    model.backward()
+    torch.cuda.synchronize()
+    g = model.reference_grads()
+    assert all(torch.isfinite(t).all() for t in g.values())
