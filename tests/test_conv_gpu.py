@@ -34,14 +34,14 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("patch3x3", [1, 0, 2])
+@pytest.mark.parametrize("patch3x3", [1, 0, 2, 3])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops = _ops()
     # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel;
     # (bit 7: the staggered 256-channel patch instance wherever the shape allows, whatever the grid size);
-    # 2: specialised kernels without the staggered instance (bit 6)
-    ops.L().bd_conv_set_patch3x3({0: 0, 1: 7 | 128, 2: 7 | 64}[patch3x3])
+    # 2: specialised kernels without the staggered instances (bit 6); 3: the staggered 128-channel instance everywhere (bits 6 + 8)
+    ops.L().bd_conv_set_patch3x3({0: 0, 1: 7 | 128, 2: 7 | 64, 3: 7 | 64 | 256}[patch3x3])
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -279,7 +279,7 @@ def test_patch_instances_agree_bitwise(shape):
     gy = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
     addx = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
     outs = []
-    for knob in (7 | 64, 7 | 128):
+    for knob in (7 | 64, 7 | 128, 7 | 64 | 256):
         ops.L().bd_conv_set_patch3x3(knob)
         y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
         dx = torch.full((gin.pixels, Cin), 3.0, device="cuda", dtype=torch.bfloat16)
@@ -289,8 +289,9 @@ def test_patch_instances_agree_bitwise(shape):
         torch.cuda.synchronize()
         outs.append((y.clone(), dx.clone()))
     ops.L().bd_conv_set_patch3x3(7)
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1], outs[1][1])
+    for k in (1, 2):          # both staggered instances against the plain 128-channel kernel
+        assert torch.equal(outs[0][0], outs[k][0])
+        assert torch.equal(outs[0][1], outs[k][1])
 
 
 @pytest.mark.parametrize("case", [(2, 64, 72, 19, 27, 3, 1, 1), (2, 128, 64, 22, 30, 3, 2, 1), (3, 64, 136, 9, 14, 1, 1, 0)])
