@@ -65,6 +65,12 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: the workgroups of one split (all ci x co tiles: they share the split's activation and gradient
+        // patches) get consecutive ids on ONE XCD, so each patch is fetched from HBM once per XCD instead of once per tile
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     const int tiles = p.ci_tiles * p.co_tiles;
     const int split = bid / tiles;
     bid -= split * tiles;
