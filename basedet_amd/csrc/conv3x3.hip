@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
 int g_patch_w4 = 0;       // bd_conv_set_patch3x3 bit 4: four-wave instance (conv3x3_w4.hip) for CK % 64 == 0
 int bd_conv3x3_patch4w_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                               const void* mask, void* dst, int flags, hipStream_t stream);
-int g_patch_pp = 1;       // bd_conv_set_patch3x3 bit 6 clears it: staggered 256-channel-tile instance (conv3x3_pp.hip) for CO > 128, CK % 8 == 0
+int g_patch_pp = 2;       // 2 = wherever the shape allows (default), 1 = only where the makespan estimate favours it (bit 7), 0 = never (bit 6): staggered 256-channel-tile instance (conv3x3_pp.hip) for CO > 128, CK % 8 == 0
 int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                          const void* mask, void* dst, int flags, hipStream_t stream);
 int g_patch_pp128 = 0;    // bd_conv_set_patch3x3 bit 8 sets it: staggered 128-channel-tile instance (conv3x3_pp128.hip) for everything else --

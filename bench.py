@@ -67,10 +67,7 @@ class ConvTimer:
                     ck_ = d.Cout if dgrad else d.Cin
                     return "conv_igemm_kernel<32>" if (d.R * d.S == 1 or ck_ <= 32) else "conv_igemm_kernel<64>"
                 ck, co = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
-                cdiv = lambda a, b: (a + b - 1) // b
-                tiles = cdiv(d.N * sum(cdiv(d.Ho[i], 4) * cdiv(d.Wo[i], 16) for i in range(d.nseg)), 4)
-                pp = ck % 8 == 0 and co > 128 and co % 8 == 0 and \
-                    3 * cdiv(tiles * cdiv(co, 256), 256) < 2 * cdiv(tiles * cdiv(co, 128), 256)
+                pp = ck % 8 == 0 and co > 128 and co % 8 == 0
                 return "conv3x3_pp_kernel" if pp else "conv3x3_patch_kernel"
             is3w = d.R == 3 and d.S == 3 and d.pad == 1 and all((d.Hi[i] - 1) // d.stride + 1 == d.Ho[i] for i in range(d.nseg))
             return "conv_wgrad3x3_kernel" if is3w else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")

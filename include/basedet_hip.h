@@ -95,8 +95,8 @@ int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const void* g, co
  * (conv1x1.hip).  0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip).
  * Ablation bits (set = feature OFF unless noted): bit 3 = register-staged instead of LDS-DMA weights in the patch kernel;
  * bit 4 = (set = ON) experimental four-wave patch instance; bit 5 = no early epilogue-operand prefetch in the generic kernel;
- * bit 6 = no staggered 256-channel patch instance (conv3x3_pp.hip; by default taken for Cout > 128, Cin % 8 == 0 when its
- * grid fills the chip better than the 128-channel instance's); bit 7 = (set = ON) take it wherever the shape allows;
+ * bit 6 = no staggered 256-channel patch instance (conv3x3_pp.hip; by default taken for every Cout > 128, Cin % 8 == 0 shape);
+ * bit 7 = take it only where its grid fills the chip better than the 128-channel instance's (makespan estimate);
  * bit 8 = (set = ON) staggered 128-channel patch instance (conv3x3_pp128.hip) for every other 3x3/stride-1 shape. */
 int bd_conv_set_patch3x3(int enable);
 

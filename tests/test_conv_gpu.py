@@ -39,9 +39,8 @@ CASES = [
 def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops = _ops()
     # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel;
-    # (bit 7: the staggered 256-channel patch instance wherever the shape allows, whatever the grid size);
     # 2: specialised kernels without the staggered instances (bit 6); 3: the staggered 128-channel instance everywhere (bits 6 + 8)
-    ops.L().bd_conv_set_patch3x3({0: 0, 1: 7 | 128, 2: 7 | 64, 3: 7 | 64 | 256}[patch3x3])
+    ops.L().bd_conv_set_patch3x3({0: 0, 1: 7, 2: 7 | 64, 3: 7 | 64 | 256}[patch3x3])
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -100,7 +99,7 @@ def test_conv_multilevel_head_layout(chans):
     """Five pyramid levels through one launch (RetinaNetHead weight sharing, retina_head.py:103-112).  (192, 256): the staggered
     256-channel patch instance on a multi-segment descriptor, forward and dgrad."""
     ops = _ops()
-    ops.L().bd_conv_set_patch3x3(7 | 128)
+    ops.L().bd_conv_set_patch3x3(7)
     N, (C, Cout) = 2, chans
     Hs, Ws = [12, 6, 3, 2, 1], [20, 10, 5, 3, 2]
     g = torch.Generator().manual_seed(7)
@@ -279,7 +278,7 @@ def test_patch_instances_agree_bitwise(shape):
     gy = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
     addx = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
     outs = []
-    for knob in (7 | 64, 7 | 128, 7 | 64 | 256):
+    for knob in (7 | 64, 7, 7 | 64 | 256):
         ops.L().bd_conv_set_patch3x3(knob)
         y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
         dx = torch.full((gin.pixels, Cin), 3.0, device="cuda", dtype=torch.bfloat16)
