@@ -398,8 +398,9 @@ int bd_conv3x3_patch4w_launch(const bd_conv_desc* d, int mode, const void* src, 
 int g_patch_pp = 2;       // 2 = wherever the shape allows (default), 1 = only where the makespan estimate favours it (bit 7), 0 = never (bit 6): staggered 256-channel-tile instance (conv3x3_pp.hip) for CO > 128, CK % 8 == 0
 int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                          const void* mask, void* dst, int flags, hipStream_t stream);
-int g_patch_pp128 = 0;    // bd_conv_set_patch3x3 bit 8 sets it: staggered 128-channel-tile instance (conv3x3_pp128.hip) for everything else --
-                          // 12-18 % faster per launch, but no faster in the whole step: opt-in
+int g_patch_pp128 = 0;    // staggered 128 / 64-channel-tile instances (conv3x3_pp128.hip): 0 = the 64-channel tile for Cout <= 64 (default: it
+                          // halves the matrix and LDS work of those layers), 1 = every remaining shape (bd_conv_set_patch3x3 bit 8: faster per
+                          // launch, not per step -- see DESIGN.md), -1 = never (bit 9)
 int bd_conv3x3_pp128_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                             const void* mask, void* dst, int flags, hipStream_t stream);
 int g_patch_dma = 1;
@@ -414,7 +415,7 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
         (long long)d->N * (mode == 0 ? d->in_pix_per_img : d->out_pix_per_img) * (mode == 0 ? d->Cin : d->Cout) < 0xffffffffll)
         return bd_conv3x3_patch4w_launch(d, mode, src, w, bias, add, mask, dst, flags, stream);
     if (g_patch_pp && bd_conv3x3_pp_launch(d, mode, src, w, bias, add, mask, dst, flags, stream) == 0) return 0;
-    if (g_patch_pp128 && bd_conv3x3_pp128_launch(d, mode, src, w, bias, add, mask, dst, flags, stream) == 0) return 0;
+    if (g_patch_pp128 >= 0 && bd_conv3x3_pp128_launch(d, mode, src, w, bias, add, mask, dst, flags, stream) == 0) return 0;
     C3Params p{};
     p.src = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias;
     p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)dst;

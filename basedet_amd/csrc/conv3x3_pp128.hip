@@ -17,11 +17,15 @@ constexpr int XROWS = NPATCH * IH * IW;        // 432
 constexpr int X_PITCH = 144;
 constexpr int X_BYTES = XROWS * X_PITCH;       // 62208
 constexpr int XPASSES = 7;                     // 432 rows x 8 chunks / 512 threads
-constexpr int TILE_CO = 128;
-constexpr int W_SLOT = TILE_CO * 128;          // 16384: one tap's 128 x 64 weight tile
 constexpr int NSLOT = 4;
-constexpr int W_BYTES = NSLOT * W_SLOT;        // 65536
-constexpr int LDS_BYTES = W_BYTES + X_BYTES + TILE_CO * 4;   // 128256
+// TCO = channel tile: 128 (wave tile 64 x 64) or 64 (wave tile 32 x 64, for the <= 64-channel layers: no wasted matrix work)
+template <int TCO> struct Tile {
+    static constexpr int W_SLOT = TCO * 128;               // one tap's TCO x 64 weight tile: 16384 / 8192
+    static constexpr int W_BYTES = NSLOT * W_SLOT;
+    static constexpr int LDS_BYTES = W_BYTES + X_BYTES + TCO * 4;
+    static constexpr int MREP = TCO / 32;                  // 16-row MFMA tiles per wave: 4 / 2
+    static constexpr int NPIECE = TCO / 64;                // 1 KiB DMA pieces per wave and tap: 2 / 1
+};
 constexpr int MAX_SEG = BD_MAX_SEGS;
 
 struct PSeg { int patch_start, H, W, pw, src_off, dst_off; };
@@ -51,8 +55,10 @@ __device__ __forceinline__ int xpos(int chunk) { return (chunk >> 2) * 64 + ((((
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-template <int MODE>
+template <int MODE, int TCO>
 __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) {
+    constexpr int TILE_CO = TCO, W_SLOT = Tile<TCO>::W_SLOT, W_BYTES = Tile<TCO>::W_BYTES, MREP = Tile<TCO>::MREP, NPIECE = Tile<TCO>::NPIECE;
+    constexpr int HALF = TCO / 2;                          // channels per wave group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wbuf = smem;                                   // [4][W_SLOT]
     unsigned char* xbuf = smem + W_BYTES;                         // [X_BYTES]
@@ -144,14 +150,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) 
     // 8 pc .. 8 pc + 7; lane -> row lane >> 3, position lane & 7 (source chunk = position ^ (row & 7): the swizzle sits on the
     // SOURCE address).  LDS row lrow holds channel co(lrow): the permutation that gives every lane 8 consecutive channels in the
     // epilogue (as conv_igemm.hip).
-    unsigned dma_src[2];       // byte offsets
+    unsigned dma_src[2];            // byte offsets (fixed size: a template-dependent size here keeps clang from emitting the host stub)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NPIECE; ++k) {
         const int pc = wave + 8 * k;
         const int lrow = 8 * pc + (lane >> 3);
         const int chunk = (lane & 7) ^ (lane >> 3);
         const int rho = lrow & 15;
-        int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
+        int co = TCO == 128 ? co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3)
+                            : co0 + (lrow & 32) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
         if (co >= p.CO) co = p.CO - 1;                 // rows past CO are never stored: any finite data will do
         dma_src[k] = (unsigned)(co * 9 * p.CK + chunk * 8) * 2u;
     }
@@ -159,15 +166,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.w), 0, (unsigned)(p.CO * 9 * p.CK) * 2u, 0x00020000);
     // piece k of the tap with index `tap` (0..8) of K block `cb`; gtap = its running index over the whole tile (ring slot gtap & 3)
     auto dma_piece = [&](int tap, int cb, int gtap, int k) {
+        if (k >= NPIECE) return;               // the 64-channel tile has one piece per wave and tap
         unsigned char* l = wbuf + (gtap & 3) * W_SLOT + (wave + 8 * k) * 1024;
         int so = (tap * p.CK + cb * 64) * 2;
         asm volatile("" : "+s"(so));          // keep the tap offset in the scalar operand
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)l, 16, dma_src[k], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)l, 16, dma_src[k < NPIECE ? k : 0], so, 0, 0);
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[MREP][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MREP; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -175,15 +183,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) 
     const int frow = lane & 15, fchunk = lane >> 4;
     const unsigned char* a_base[2];          // K half kk: row wm*64 + frow of slot 0; + slot * W_SLOT (run time) + i * 2048
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) a_base[kk] = wbuf + swz(wm * 64 + frow, kk * 4 + fchunk);
+    for (int kk = 0; kk < 2; ++kk) a_base[kk] = wbuf + swz(wm * HALF + frow, kk * 4 + fchunk);
     const unsigned char* b_base = xbuf + (wp * (IH * IW) + colperm(frow)) * X_PITCH + xpos(fchunk);
 
     // one tap = two phases (K halves): A rows 0-63 of this wave's channel half + the B fragments of all four patch rows
-    bf16x8_t fa[4], fb[4];
+    bf16x8_t fa[MREP], fb[4];
     auto load_a = [&](int kk, int gtap) {
         const unsigned char* base = a_base[kk] + (gtap & 3) * W_SLOT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(base + i * 2048);
+        for (int i = 0; i < MREP; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(base + i * 2048);
     };
     auto load_b = [&](int kk, int t) {
         int dy = t / 3, dx = t - 3 * (t / 3);
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) 
     auto mfma_tile = [&]() {
         constexpr int i0 = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MREP; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 // tied accumulator (D = C) in inline asm: under this register pressure the allocator otherwise rotates the 32
@@ -239,8 +247,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) 
                     // retire tap t+1 (pieces of phases (t-2, 1) and (t-1, 0)); the two pieces of tap t+2 stay in flight -- and, in
                     // phase (7, 1), the seven activation loads of phase (6, 1)
                     if (last_kb && t >= 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (t == 7) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (NPIECE == 2) {
+                        if (t == 7) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    } else {                       // one piece per tap: one newer piece (tap t+2), plus the seven activation loads at t = 7
+                        if (t == 7) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    }
                     if (t == 6 && !last_kb) load_x(cb + 1);        // consumed by the swap after tap 8
                     PP_FENCE();
                     // first piece of tap t+3 (its slot's previous tenant, tap t-1, was last read in phase (t-1, 1))
@@ -277,18 +290,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) 
     const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
     const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
     const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
-    const int cbase = co0 + wm * 64 + 8 * cg;           // + 32 h
+    const int cbase = co0 + wm * HALF + 8 * cg;         // + 32 h
     int oy0 = py0[0], ox = px0[0] + colperm(frow), H = pH[0], W = pWd[0], dbase = pdst[0];
 #pragma unroll
     for (int q = 1; q < NPATCH; ++q)
         if (wp == q) { oy0 = py0[q]; ox = px0[q] + colperm(frow); H = pH[q]; W = pWd[q]; dbase = pdst[q]; }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < MREP / 2; ++h) {
         if (cbase + 32 * h >= p.CO) continue;
         float bias[8];
         {
-            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 64 + 8 * cg + 32 * h);
-            const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 64 + 8 * cg + 32 * h + 4);
+            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sbias + wm * HALF + 8 * cg + 32 * h);
+            const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sbias + wm * HALF + 8 * cg + 32 * h + 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { bias[k] = b0[k]; bias[4 + k] = b1[k]; }
         }
@@ -333,6 +346,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) 
 }  // namespace
 
 // 0 = launched, 1 = shape not handled here (caller falls back to conv3x3.hip)
+extern int g_patch_pp128;     // 0 = the 64-channel tile for Cout <= 64 only (default), 1 = every shape, -1 = never
 int bd_conv3x3_pp128_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                             const void* mask, void* dst, int flags, hipStream_t stream) {
     PParams p{};
@@ -357,15 +371,24 @@ int bd_conv3x3_pp128_launch(const bd_conv_desc* d, int mode, const void* src, co
     }
     p.patches_per_img = ps;
     p.total_patches = ps * d->N;
-    p.n_tiles = cdiv(p.CO, TILE_CO);
+    const bool small = p.CO <= 64;            // 64-channel tile: no matrix work on absent channels (res2 3x3, bbox_pred)
+    if (g_patch_pp128 < 0 || (g_patch_pp128 == 0 && !small)) return 1;
+    p.n_tiles = cdiv(p.CO, small ? 64 : 128);
     const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<128>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<128>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<64>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<64>::LDS_BYTES);
         attr_set = true;
     }
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_pp128_kernel<0>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((conv3x3_pp128_kernel<1>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
+    if (small) {
+        if (mode == 0) hipLaunchKernelGGL((conv3x3_pp128_kernel<0, 64>), dim3(grid), dim3(512), Tile<64>::LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv3x3_pp128_kernel<1, 64>), dim3(grid), dim3(512), Tile<64>::LDS_BYTES, stream, p);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((conv3x3_pp128_kernel<0, 128>), dim3(grid), dim3(512), Tile<128>::LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv3x3_pp128_kernel<1, 128>), dim3(grid), dim3(512), Tile<128>::LDS_BYTES, stream, p);
+    }
     return 0;
 }

@@ -395,7 +395,7 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_patch_dma = ((enable >> 3) & 1) ^ 1;
     g_patch_w4 = (enable >> 4) & 1;
     g_patch_pp = ((enable >> 6) & 1) ? 0 : (((enable >> 7) & 1) ? 1 : 2);
-    g_patch_pp128 = (enable >> 8) & 1;
+    g_patch_pp128 = ((enable >> 9) & 1) ? -1 : ((enable >> 8) & 1);
     g_igemm_prefetch_epi = ((enable >> 5) & 1) ^ 1;
     return BD_OK;
 }

@@ -19,7 +19,7 @@ def check(N, H, W, Cin, Cout, mode, flags=0):
     b = torch.randn(co, device="cuda") if mode == "fwd" else None
     add = torch.randn(gin.pixels, co, device="cuda").to(torch.bfloat16)
     outs = []
-    for knob in (7 | 64, 7 | 64 | 256):
+    for knob in (7 | 64 | 512, 7 | 64 | 256):
         ops.L().bd_conv_set_patch3x3(knob)
         y = torch.full((gin.pixels, co), 7.0, device="cuda", dtype=torch.bfloat16)
         if mode == "fwd":
@@ -42,7 +42,7 @@ for (N, H, W, Cin, Cout) in ((2, 13, 21, 256, 256), (2, 25, 42, 512, 512), (1, 2
     bad += check(N, H, W, Cin, Cout, "dgrad", ops.EPI_ADD_BEFORE | ops.EPI_MASK) > 0.05
 print("MISMATCHES", bad, flush=True)
 for rep in range(2):
-    for knob in (3 | 64, 3 | 64 | 256, 3):
+    for knob in (3 | 64 | 512, 3 | 64 | 256, 3):
         ops.L().bd_conv_set_patch3x3(knob)
         print("knob", knob, flush=True)
         for mode in ("fwd", "dgrad"):

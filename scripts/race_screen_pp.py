@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(_here))
 import torch
 from basedet_amd import ops
 
-shapes = [(16, 100, 168, 256, 256), (4, 100, 168, 64, 720), (16, 50, 84, 256, 256), (16, 25, 42, 512, 512), (3, 37, 53, 200, 264), (16, 100, 168, 720, 256),
+shapes = [(16, 200, 336, 64, 64), (16, 100, 168, 256, 40), (16, 100, 168, 256, 256), (4, 100, 168, 64, 720), (16, 50, 84, 256, 256), (16, 25, 42, 512, 512), (3, 37, 53, 200, 264), (16, 100, 168, 720, 256),
           (2, 13, 21, 256, 256), (16, 100, 168, 40, 256)]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
@@ -18,7 +18,7 @@ for (N, H, W, Cin, Cout) in shapes:
     x = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(Cout, 9, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
     b = torch.randn(Cout, device="cuda", generator=g)
-    ops.L().bd_conv_set_patch3x3(3 | 64)
+    ops.L().bd_conv_set_patch3x3(3 | 64 | 512)
     ref = torch.empty((gin.pixels, Cout), device="cuda", dtype=torch.bfloat16)
     ops.conv2d_fwd(d, x, w, b, ref, flags=ops.EPI_RELU)
     ops.L().bd_conv_set_patch3x3(3)

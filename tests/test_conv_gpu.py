@@ -39,8 +39,8 @@ CASES = [
 def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops = _ops()
     # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel;
-    # 2: specialised kernels without the staggered instances (bit 6); 3: the staggered 128-channel instance everywhere (bits 6 + 8)
-    ops.L().bd_conv_set_patch3x3({0: 0, 1: 7, 2: 7 | 64, 3: 7 | 64 | 256}[patch3x3])
+    # 2: specialised kernels without any staggered instance (bits 6 + 9); 3: the staggered 128 / 64-channel instances everywhere (bits 6 + 8)
+    ops.L().bd_conv_set_patch3x3({0: 0, 1: 7, 2: 7 | 64 | 512, 3: 7 | 64 | 256}[patch3x3])
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -261,7 +261,8 @@ def test_weight_pack_multi_matches_single():
 
 
 
-@pytest.mark.parametrize("shape", [(5, 96, 160, 128, 256), (2, 100, 168, 64, 720), (3, 50, 84, 192, 264), (2, 40, 56, 136, 40)])
+@pytest.mark.parametrize("shape", [(5, 96, 160, 128, 256), (2, 100, 168, 64, 720), (3, 50, 84, 192, 264), (2, 40, 56, 136, 40), (4, 120, 200, 64, 64),
+                                   (2, 64, 96, 200, 56)])
 def test_patch_instances_agree_bitwise(shape):
     """Full-size grids (more workgroups than CUs, ragged channel tiles, K tails): the staggered 256-channel instance must give the
     SAME bits as the 128-channel instance (same accumulation order), forward with residual + ReLU and dgrad with add + mask."""
@@ -278,7 +279,7 @@ def test_patch_instances_agree_bitwise(shape):
     gy = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
     addx = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
     outs = []
-    for knob in (7 | 64, 7, 7 | 64 | 256):
+    for knob in (7 | 64 | 512, 7, 7 | 64 | 256):
         ops.L().bd_conv_set_patch3x3(knob)
         y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
         dx = torch.full((gin.pixels, Cin), 3.0, device="cuda", dtype=torch.bfloat16)
