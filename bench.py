@@ -68,7 +68,10 @@ class ConvTimer:
                     return "conv_igemm_kernel<32>" if (d.R * d.S == 1 or ck_ <= 32) else "conv_igemm_kernel<64>"
                 ck, co = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
                 pp = ck % 8 == 0 and co > 128 and co % 8 == 0
-                return "conv3x3_pp_kernel" if pp else "conv3x3_patch_kernel"
+                if pp:
+                    return "conv3x3_pp_kernel"
+                # Cout <= 64: the 64-channel tile of conv3x3_pp128.hip; the rest: conv3x3.hip
+                return "conv3x3_pp128_kernel" if (ck % 8 == 0 and co % 8 == 0 and co <= 64) else "conv3x3_patch_kernel"
             is3w = d.R == 3 and d.S == 3 and d.pad == 1 and all((d.Hi[i] - 1) // d.stride + 1 == d.Ho[i] for i in range(d.nseg))
             return "conv_wgrad3x3_kernel" if is3w else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")
 
