@@ -1,0 +1,102 @@
+"""Size-independent properties at BASELINE.json's full sizes (RetinaNet-R50, 800x1344: 22 400 locations / 201 600 anchors per
+image), where the CPU oracle is too slow to be the checker:
+  * linearity of the conv kernels in bf16-exact scalings (x -> 2x must give bitwise 2y / 2 dW),
+  * bitwise reproducibility of the gradients of a whole training step (fixed-order reductions on the default path; only the
+    reported scalar losses are accumulated with float atomics),
+  * anchor-grid invariants, NMS idempotence."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+
+
+def test_head_conv_linearity_full_size():
+    from basedet_amd import ops
+    N, C = 4, 256
+    geo = ops.Geom(N, [h for h, _ in SIZES], [w for _, w in SIZES])
+    d = ops.conv_desc(geo, geo, C, C, 3, 3, 1, 1)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(geo.pixels, C, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(C, 9, C, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
+    gy = torch.randn(geo.pixels, C, device="cuda", generator=g).to(torch.bfloat16)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    ops.conv2d_fwd(d, x, w, None, y1)
+    ops.conv2d_fwd(d, (x.float() * 2).to(torch.bfloat16), w, None, y2)
+    assert torch.equal((y1.float() * 2).to(torch.bfloat16), y2)
+    ops.conv2d_dgrad(d, gy, w, y1)
+    ops.conv2d_dgrad(d, (gy.float() * 2).to(torch.bfloat16), w, y2)
+    assert torch.equal((y1.float() * 2).to(torch.bfloat16), y2)
+    ws = torch.empty(ops.conv2d_wgrad_bias_workspace_bytes(d) // 4 + 4, device="cuda")
+    dw1 = torch.empty(C, 3, 3, C, device="cuda"); dw2 = torch.empty_like(dw1)
+    db1 = torch.empty(C, device="cuda"); db2 = torch.empty_like(db1)
+    ops.conv2d_wgrad_bias(d, x, gy, dw1, db1, ws)
+    ops.conv2d_wgrad_bias(d, x, (gy.float() * 2).to(torch.bfloat16), dw2, db2, ws)
+    assert torch.equal(dw1 * 2, dw2) and torch.equal(db1 * 2, db2)
+    # the bias gradient is the plain column sum of dY (every pixel of every level exactly once)
+    ref = gy.float().sum(0)
+    assert float((db1 - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+def test_training_step_is_bitwise_reproducible_full_size():
+    from basedet_amd.configs import RetinaNetConfig
+    from basedet_amd.models import RetinaNet, params as P
+    from basedet_amd.utils import DummyLoader
+    cfg = RetinaNetConfig()
+    cfg.MODEL.BATCHSIZE = 2
+    params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
+    b = next(DummyLoader(2, (800, 1344), seed=0))
+    batch = {"data": torch.from_numpy(b["data"].astype(np.float32)).cuda(), "gt_boxes": torch.from_numpy(b["gt_boxes"]).cuda(),
+             "im_info": torch.from_numpy(b["im_info"]).cuda()}
+    outs = []
+    for _ in range(2):
+        model = RetinaNet(cfg, params=params)
+        loss = model(batch)
+        model.backward()
+        torch.cuda.synchronize()
+        pl = model._cur
+        assert pl.A_total == 201600 and int(pl.num_fg) > 0
+        outs.append((float(loss["total_loss"]), model.arena.g.clone(), pl.labels.clone()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * abs(outs[0][0])       # the scalar loss is summed with float atomics; nothing reads it back
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][1], outs[1][1])          # every gradient of the arena, bit for bit
+
+
+def test_anchor_grid_invariants_full_size():
+    from basedet_amd import ops
+    from oracle import box_ops
+    scales = [[x, x * 2 ** (1.0 / 3), x * 2 ** (2.0 / 3)] for x in [32, 64, 128, 256, 512]]
+    strides = [8, 16, 32, 64, 128]
+    total = 0
+    for (h, w), s, sc in zip(SIZES, strides, scales):
+        base = torch.tensor(box_ops.generate_base_anchors(sc, [0.5, 1, 2]), dtype=torch.float32, device="cuda")
+        out = torch.empty((h * w * 9, 4), dtype=torch.float32, device="cuda")
+        ops.anchors_generate(h, w, s, 0.5, base, out)
+        a = out.cpu().numpy().reshape(h, w, 9, 4)
+        cx, cy = (a[..., 0] + a[..., 2]) / 2, (a[..., 1] + a[..., 3]) / 2
+        # centres: (j + 0.5) * stride, (i + 0.5) * stride, the same for the 9 anchors of a location; row-major order
+        np.testing.assert_allclose(cx[:, :, 0], np.broadcast_to((np.arange(w) + 0.5) * s, (h, w)), rtol=0, atol=1e-3)
+        np.testing.assert_allclose(cy[:, :, 0], np.broadcast_to(((np.arange(h) + 0.5) * s)[:, None], (h, w)), rtol=0, atol=1e-3)
+        assert np.abs(cx - cx[:, :, :1]).max() < 1e-3 and np.abs(cy - cy[:, :, :1]).max() < 1e-3
+        # the anchor shapes do not depend on the location
+        wh = np.stack([a[..., 2] - a[..., 0], a[..., 3] - a[..., 1]], -1)
+        assert np.abs(wh - wh[:1, :1]).max() < 1e-3
+        total += h * w * 9
+    assert total == 201600
+
+
+def test_nms_idempotent_full_size():
+    from basedet_amd import ops
+    rng = np.random.default_rng(0)
+    n = 5000                                               # 5 levels x top-1000 candidates (retinanet.py:188-192)
+    xy = rng.uniform(0, 1200, (n, 2)); wh = rng.uniform(8, 300, (n, 2))
+    boxes = torch.from_numpy(np.concatenate([xy, xy + wh], 1).astype(np.float32)).cuda()
+    scores = torch.from_numpy(rng.uniform(0.05, 1, n).astype(np.float32)).cuda()
+    idxs = torch.from_numpy(rng.integers(0, 80, n).astype(np.int32)).cuda()
+    keep = ops.batched_nms(boxes, scores, idxs, 0.5).long()
+    s1 = scores[keep]
+    assert keep.numel() > 100 and torch.all(s1[:-1] >= s1[1:])                   # descending scores
+    keep2 = ops.batched_nms(boxes[keep].contiguous(), scores[keep].contiguous(), idxs[keep].contiguous(), 0.5).long()
+    assert torch.equal(keep2, torch.arange(keep.numel(), device="cuda"))        # survivors survive, in the same order
