@@ -97,30 +97,52 @@ __global__ __launch_bounds__(1024) void fa_gt_kernel(const bf16_raw* __restrict_
         thresh2[slot] = fminf(fmaxf(m, iou_thresh + 1e-7f), 1.f);
     }
 
-    // (b) the bag: `bucket` largest IoU(gt, anchor), ascending anchor index
+    // (b) the bag: `bucket` largest IoU(gt, anchor), ascending anchor index.  Nearly every anchor has IoU exactly 0 with a given gt:
+    // counted into the radix histograms they would all hit one LDS bin (same-address atomics serialise), so the selection first runs
+    // over the positive IoUs only and falls back to all anchors in the rare case that fewer than `bucket` overlap the gt at all.
+    bool pos_only = true;
     auto key = [&](int i, bool& valid) -> unsigned int {
-        valid = true;
         const Box ab = ld_box(anchors + 4ll * i);
-        return f32_asc_key(box_iou_dev(gb, garea, ab, box_area(ab)));
+        const float u = box_iou_dev(gb, garea, ab, box_area(ab));
+        valid = !pos_only || u > 0.f;
+        return f32_asc_key(u);
     };
-    const SelResult r = radix_select_largest(A, bucket, 4, key, hist, sh);
-    int base = 0, eq_base = 0;
-    for (int c0 = 0; c0 < A; c0 += 1024) {
-        const int i = c0 + tid;
-        bool valid = false;
-        unsigned int kv = 0;
-        if (i < A) kv = key(i, valid);
-        int tot;
-        bool take = valid && (r.take_all || kv > r.T);
-        if (!r.take_all) {
+    SelResult r = radix_select_largest(A, bucket, 4, key, hist, sh);
+    if (r.take_all && r.n_valid < bucket && r.n_valid < A) {          // workgroup-uniform
+        pos_only = false;
+        r = radix_select_largest(A, bucket, 4, key, hist, sh);
+    }
+    // members above the threshold: unordered collection; members equal to it: the first need_eq in index order
+    if (tid == 0) sh[4] = 0;
+    __syncthreads();
+    for (int i = tid; i < A; i += 1024) {
+        bool valid; const unsigned int kv = key(i, valid);
+        if (valid && (r.take_all || kv > r.T)) { const int q = atomicAdd(&sh[4], 1); if (q < FA_MAX_BUCKET) s_idx[q] = i; }
+    }
+    __syncthreads();
+    int base = sh[4];
+    if (!r.take_all && r.need_eq > 0) {
+        int eq_base = 0;
+        for (int c0 = 0; c0 < A && eq_base < r.need_eq; c0 += 1024) {       // eq_base is workgroup-uniform
+            const int i = c0 + tid;
+            bool valid = false; unsigned int kv = 0;
+            if (i < A) kv = key(i, valid);
+            int tot;
             const bool eq = valid && kv == r.T;
             const int my = eq_base + block_rank_1024(eq, wcnt, tot);
+            if (eq && my < r.need_eq && base + my < FA_MAX_BUCKET) s_idx[base + my] = i;
             eq_base += tot;
-            take = take || (eq && my < r.need_eq);
         }
-        const int pos = base + block_rank_1024(take, wcnt, tot);
-        if (take && pos < FA_MAX_BUCKET) s_idx[pos] = i;
-        base += tot;
+        base += r.need_eq;
+    }
+    __syncthreads();
+    if (tid == 0) {             // ascending anchor index: a fixed summation order for the bag (the atomic collection order is not)
+        const int mm = base < FA_MAX_BUCKET ? base : FA_MAX_BUCKET;
+        for (int x = 1; x < mm; ++x) {
+            const int v = s_idx[x]; int y = x - 1;
+            while (y >= 0 && s_idx[y] > v) { s_idx[y + 1] = s_idx[y]; --y; }
+            s_idx[y + 1] = v;
+        }
     }
     __syncthreads();
     const int m = base < bucket ? base : bucket;          // fewer than `bucket` anchors exist only in toy cases
@@ -214,17 +236,37 @@ __global__ __launch_bounds__(256) void fa_neg_kernel(const bf16_raw* __restrict_
     float acc = 0.f;
     const int nel = (A - a0 < FA_NEG_ANCH ? A - a0 : FA_NEG_ANCH) * K;
     const long long e0 = ((long long)n * A + a0) * K;
-    for (int i = tid; i < nel; i += 256) {
-        const float s = sigmoidf_(bf2f(logits[e0 + i]));
-        const float keep = 1.f - __uint_as_float((unsigned int)(bp[i] & 0xffffffffull));
+    auto elem = [&](float x, float bpv, float& g) -> float {
+        const float s = sigmoidf_(x);
+        const float keep = 1.f - bpv;
         const float q = s * keep;
         const float om = 1.f - q;
         const float nl = -safelogf_(om);
         const float qg = gamma == 2.f ? q * q : (q > 0.f ? expf(gamma * logf(q)) : 0.f);
         const float qg1 = gamma == 2.f ? q : (q > 0.f ? expf((gamma - 1.f) * logf(q)) : 0.f);
-        acc += qg * nl;
         const float dq = gamma * qg1 * nl + (om > FLT_MIN ? qg / om : 0.f);
-        d_logits[e0 + i] = f2bf(scale * dq * s * (1.f - s) * keep);
+        g = scale * dq * s * (1.f - s) * keep;
+        return qg * nl;
+    };
+    if (K % 8 == 0) {           // 16-byte logit / gradient accesses (e0 is a multiple of 8)
+        for (int i = tid; i < nel / 8; i += 256) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(logits + e0 + 8ll * i);
+            u32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float g0, g1;
+                acc += elem(bf_lo(v[j]), __uint_as_float((unsigned int)(bp[8 * i + 2 * j] & 0xffffffffull)), g0);
+                acc += elem(bf_hi(v[j]), __uint_as_float((unsigned int)(bp[8 * i + 2 * j + 1] & 0xffffffffull)), g1);
+                o[j] = pack_bf2(g0, g1);
+            }
+            *reinterpret_cast<u32x4_t*>(d_logits + e0 + 8ll * i) = o;
+        }
+    } else {
+        for (int i = tid; i < nel; i += 256) {
+            float g;
+            acc += elem(bf2f(logits[e0 + i]), __uint_as_float((unsigned int)(bp[i] & 0xffffffffull)), g);
+            d_logits[e0 + i] = f2bf(g);
+        }
     }
     acc = wave_sum(acc);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
