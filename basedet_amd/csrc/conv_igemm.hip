@@ -375,6 +375,11 @@ bool is_3x3s1(const bd_conv_desc* d) {
 }
 int g_use_patch3x3 = 1;
 int g_bk32_for_1x1 = 1;
+// Stride-2 3x3 layers stay on the generic kernel, and there the tiles are short (the data gradient visits 1 / 2 / 2 / 4 taps per
+// parity class) and bound by the latency of their few K steps: BK=32 tiles (32 KB of LDS instead of 80 KB: four workgroups per CU
+// instead of two) run them 10-35 % faster as long as the grid still fills the chip (P6's 70-tile forward keeps BK=64).
+// bd_conv_set_patch3x3 bit 10 clears it.
+int g_bk32_s2 = 1;
 int g_stream_1x1 = 0;   // persistent 1x1 kernel (conv1x1.hip): correct, but 3 one-tile WGs/CU measured faster
 
 }  // namespace
@@ -396,6 +401,7 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_patch_w4 = (enable >> 4) & 1;
     g_patch_pp = ((enable >> 6) & 1) ? 0 : (((enable >> 7) & 1) ? 1 : 2);
     g_patch_pp128 = ((enable >> 9) & 1) ? -1 : ((enable >> 8) & 1);
+    g_bk32_s2 = ((enable >> 10) & 1) ^ 1;
     g_igemm_prefetch_epi = ((enable >> 5) & 1) ^ 1;
     return BD_OK;
 }
@@ -436,7 +442,8 @@ extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w
     p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
-    else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1)) launch_igemm<64>(p, (hipStream_t)stream);
+    else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
+        launch_igemm<64>(p, (hipStream_t)stream);
     else launch_igemm<32>(p, (hipStream_t)stream);
     BD_CHECK_LAUNCH("bd_conv2d_fwd");
     return BD_OK;
@@ -486,7 +493,8 @@ extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void*
     p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
-    else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1)) launch_igemm<64>(p, (hipStream_t)stream);
+    else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
+        launch_igemm<64>(p, (hipStream_t)stream);
     else launch_igemm<32>(p, (hipStream_t)stream);
     BD_CHECK_LAUNCH("bd_conv2d_dgrad");
     return BD_OK;

@@ -18,26 +18,32 @@
 
 namespace {
 
-constexpr int PATCH = 8;                 // output patch edge
+constexpr int PATCH = 8;                 // output patch: 8 x 8 pixels (stride 1), 4 rows x 8 pixels (stride 2)
 constexpr int TILE_CI = 64, TILE_CO = 64;
 constexpr int X_PITCH = 160;             // 128 B data + 32 B pad  (40 dwords: 8 consecutive rows hit all 64 banks)
 constexpr int G_PITCH = 160;             // 128 B data + 32 B pad
-constexpr int G_BYTES = PATCH * PATCH * G_PITCH;
-constexpr int G_PASSES = 2;              // 64 rows x 8 chunks / 256 threads
 
 // Input-patch image in LDS.  Stride 1: one (PATCH+2)^2 image, tap (r, s) = row offset r*XW + s.  Stride 2 (the first 3x3 of
-// layer2/3/4, P6/P7): the 17x17 input patch is stored PHASE-MAJOR -- four 9x9 images of the (row parity, column parity) classes --
-// so that the eight pixels a half-wave transposes are again eight CONSECUTIVE LDS rows; tap (r, s) selects the phase image
-// (r&1, s&1) and the row offset (r>>1)*XW + (s>>1).
+// layer2/3/4, P6/P7): the input patch is stored PHASE-MAJOR -- four images of the (row parity, column parity) classes -- so that
+// the eight pixels a half-wave transposes are again eight CONSECUTIVE LDS rows; tap (r, s) selects the phase image (r&1, s&1) and
+// the row offset (r>>1)*XW + (s>>1).  The stride-2 patch is 4 output rows x 8 (one 32-pixel K step, 9 x 17 input pixels): the 8 x 8
+// patch's 17 x 17 input image would be 62 KB double-buffered twice = one four-wave workgroup per CU and nothing to overlap its
+// staging with (that variant ran at 300-390 TFLOP/s); 2 x 34 KB keeps two workgroups per CU.
 template <int STRIDE> struct XImg {
-    static constexpr int XW = STRIDE == 1 ? PATCH + 2 : PATCH + 1;        // rows per image line
-    static constexpr int IMG = XW * XW;                                    // rows per (phase) image
+    static constexpr int PH = STRIDE == 1 ? PATCH : PATCH / 2, PW = PATCH;  // output patch rows / columns
+    static constexpr int KSUB = PH / 4;                                    // 32-pixel MFMA K sub-steps per patch
+    static constexpr int XW = STRIDE == 1 ? PW + 2 : PW + 1;               // rows per image line
+    static constexpr int XH = STRIDE == 1 ? PH + 2 : PH + 1;               // lines per (phase) image
+    static constexpr int IMG = XW * XH;                                    // rows per (phase) image
     static constexpr int ROWS = STRIDE == 1 ? IMG : 4 * IMG;
     static constexpr int X_BYTES = ROWS * X_PITCH;
+    static constexpr int G_BYTES = PH * PW * G_PITCH;
+    static constexpr int G_PASSES = PH * PW * 8 / 256;                     // 2 / 1
     static constexpr int BUF_BYTES = X_BYTES + G_BYTES;
     static constexpr int X_CHUNKS = ROWS * 8;
     static constexpr int X_PASSES = (X_CHUNKS + 255) / 256;
-    static constexpr int EXT = STRIDE == 1 ? PATCH + 2 : 2 * PATCH + 1;    // input patch edge in pixels
+    static constexpr int EXT_H = STRIDE == 1 ? PH + 2 : 2 * PH + 1;        // input patch extent in pixels
+    static constexpr int EXT_W = STRIDE == 1 ? PW + 2 : 2 * PW + 1;
     __host__ __device__ static constexpr int tap_row(int r, int s) {
         return STRIDE == 1 ? r * XW + s : ((r & 1) * 2 + (s & 1)) * IMG + (r >> 1) * XW + (s >> 1);
     }
@@ -59,9 +65,10 @@ struct W3Params {
 };
 
 template <int STRIDE>
-__global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel(const W3Params p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p) {
     using XI = XImg<STRIDE>;
     constexpr int X_PASSES = XI::X_PASSES, X_CHUNKS = XI::X_CHUNKS, X_BYTES = XI::X_BYTES, BUF_BYTES = XI::BUF_BYTES, XW = XI::XW;
+    constexpr int G_PASSES = XI::G_PASSES, PH = XI::PH, PW = XI::PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
             const int ph = row / XI::IMG, rr = row - ph * XI::IMG;
             const int a = rr / XW, b = rr - a * XW;
             const int u = 2 * a + (ph >> 1), v = 2 * b + (ph & 1);
-            x_iy[k] = (row < XI::ROWS && u < XI::EXT && v < XI::EXT) ? u : -1;
+            x_iy[k] = (row < XI::ROWS && u < XI::EXT_H && v < XI::EXT_W) ? u : -1;
             x_ix[k] = v;
         }
     }
@@ -113,7 +120,9 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
     constexpr unsigned X_NONE = 0x80000000u;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.g), 0, p.g_bytes, 0x00020000);
-    int x_vec[X_PASSES], g_vec[G_PASSES];           // element offsets relative to the patch origin, for the current level
+    // element offsets relative to the patch origin, for the current level (the stride-2 instance has six activation passes and no
+    // registers to spare at two waves per SIMD: it recomputes x_vec per patch)
+    int x_vec[STRIDE == 1 ? X_PASSES : 1], g_vec[G_PASSES];
     int cur_seg = -1;
 
     auto stage_load = [&](int pid) {
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
         if (s != cur_seg) {                           // workgroup-uniform
             cur_seg = s;
 #pragma unroll
-            for (int k = 0; k < X_PASSES; ++k) x_vec[k] = (x_iy[k] * sg.Wi + x_ix[k]) * p.Cin + x_chunk * 8;
+            for (int k = 0; k < (STRIDE == 1 ? X_PASSES : 0); ++k) x_vec[k] = (x_iy[k] * sg.Wi + x_ix[k]) * p.Cin + x_chunk * 8;
 #pragma unroll
             for (int k = 0; k < G_PASSES; ++k) {
                 const int row = (tid >> 3) + 32 * k;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
         }
         const int local = rem - sg.patch_start;
         const int by = local / sg.pw, bx = local - by * sg.pw;
-        const int y0 = by * PATCH, x0 = bx * PATCH;
+        const int y0 = by * PH, x0 = bx * PW;
         const int ys = STRIDE * y0 - 1, xs = STRIDE * x0 - 1;
         const int xorg = (n * p.in_ppi + sg.in_off + ys * sg.Wi + xs) * p.Cin + ci0;        // may be negative; valid sums are not
         const int gorg = (n * p.out_ppi + sg.out_off + y0 * sg.W + x0) * p.Cout + co0;
@@ -144,7 +153,8 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
         for (int k = 0; k < X_PASSES; ++k) {
             const int y = ys + x_iy[k], x = xs + x_ix[k];
             const bool ok = x_iy[k] >= 0 && x_cok && y >= 0 && x >= 0 && y < sg.Hi && x < sg.Wi;
-            rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(xorg + x_vec[k]) * 2u : X_NONE, 0, 0);
+            const int xv = STRIDE == 1 ? x_vec[k] : (x_iy[k] * sg.Wi + x_ix[k]) * p.Cin + x_chunk * 8;
+            rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(xorg + xv) * 2u : X_NONE, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < G_PASSES; ++k) {
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
     const int prow_hi = 2 * (g4 >> 1);            // patch row inside the 4-row sub-step
     const int pcol = 4 * (g4 & 1) + tr_q;         // patch column supplied by this lane
     const int x_lane_off = (prow_hi * XW + pcol) * X_PITCH + (wave * 16 + 4 * tr_p) * 2;
-    const int g_lane_off = (prow_hi * PATCH + pcol) * G_PITCH + (4 * tr_p) * 2;
+    const int g_lane_off = (prow_hi * PW + pcol) * G_PITCH + (4 * tr_p) * 2;
 
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     auto tr_frag = [&](const unsigned char* a0, int row_pitch_bytes) -> bf16x8_t {
@@ -199,12 +209,12 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
     auto compute = [&](int buf) {
         const unsigned char* Xt = smem + buf * BUF_BYTES + x_lane_off;
         const unsigned char* Gt = smem + buf * BUF_BYTES + X_BYTES + g_lane_off;
-        if (STRIDE == 1) __builtin_amdgcn_s_setprio(1);      // two workgroups per CU: the wave in its MFMA block wins the issue arbitration (+2 %)
+        __builtin_amdgcn_s_setprio(1);      // two workgroups per CU: the wave in its MFMA block wins the issue arbitration (+2 %)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < XI::KSUB; ++kk) {
             bf16x8_t b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = tr_frag(Gt + (4 * kk * PATCH) * G_PITCH + j * 32, PATCH * G_PITCH);
+            for (int j = 0; j < 4; ++j) b[j] = tr_frag(Gt + (4 * kk * PW) * G_PITCH + j * 32, PW * G_PITCH);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int r = t / 3, s = t % 3;
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[t][j], 0, 0, 0);
             }
         }
-        if (STRIDE == 1) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
     };
 
     if (pbeg < pend) {
@@ -261,7 +271,8 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv_wgrad3x3_kernel
 // plan shared with conv_wgrad.hip
 int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patches_per_img_out) {
     int ppi = 0;
-    for (int s = 0; s < d->nseg; ++s) ppi += cdiv(d->Ho[s], PATCH) * cdiv(d->Wo[s], PATCH);
+    const int ph = d->stride == 1 ? XImg<1>::PH : XImg<2>::PH;
+    for (int s = 0; s < d->nseg; ++s) ppi += cdiv(d->Ho[s], ph) * cdiv(d->Wo[s], PATCH);
     const int total = ppi * d->N;
     const int tiles = cdiv(d->Cin, TILE_CI) * cdiv(d->Cout, TILE_CO);
     int splits = 512 / tiles;
@@ -286,11 +297,12 @@ int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, floa
     p.total_patches = total; p.patches_per_img = ppi; p.patches_per_split = cdiv(total, splits);
     p.ci_tiles = cdiv(d->Cin, TILE_CI); p.co_tiles = cdiv(d->Cout, TILE_CO);
     int ps = 0;
+    const int ph = d->stride == 1 ? XImg<1>::PH : XImg<2>::PH;
     for (int s = 0; s < d->nseg; ++s) {
         PSeg& sg = p.seg[s];
         sg.patch_start = ps; sg.H = d->Ho[s]; sg.W = d->Wo[s]; sg.pw = cdiv(d->Wo[s], PATCH);
         sg.in_off = d->in_off[s]; sg.out_off = d->out_off[s]; sg.Hi = d->Hi[s]; sg.Wi = d->Wi[s];
-        ps += cdiv(d->Ho[s], PATCH) * sg.pw;
+        ps += cdiv(d->Ho[s], ph) * sg.pw;
     }
     static bool attr_set = false;
     if (!attr_set) {

@@ -63,9 +63,12 @@ class ConvTimer:
             is1 = d.R == 1 and d.S == 1 and d.pad == 0
             if kind == "igemm":
                 if not is3:
-                    # generic kernel: BK = 32 instance for 1x1 filters (and Cin <= 32), BK = 64 for the strided 3x3 ones
-                    ck_ = d.Cout if dgrad else d.Cin
-                    return "conv_igemm_kernel<32>" if (d.R * d.S == 1 or ck_ <= 32) else "conv_igemm_kernel<64>"
+                    # generic kernel: BK = 32 instance for 1x1 filters (and Cin <= 32) and for stride-2 launches of >= 512 tiles,
+                    # BK = 64 for the rest
+                    ck_, co_ = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
+                    pix = d.N * (d.in_pix_per_img if dgrad else d.out_pix_per_img)
+                    big = d.stride == 2 and -(-pix // 128) * -(-co_ // 128) >= 512
+                    return "conv_igemm_kernel<32>" if (d.R * d.S == 1 or ck_ <= 32 or big) else "conv_igemm_kernel<64>"
                 ck, co = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
                 pp = ck % 8 == 0 and co > 128 and co % 8 == 0
                 if pp:

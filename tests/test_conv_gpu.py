@@ -31,6 +31,7 @@ CASES = [
     (2, 256, 256, 22, 37, 3, 1, 1),     # staggered 256-channel patch kernel, forward and dgrad (ragged patches)
     (1, 512, 192, 9, 40, 3, 1, 1),      # ... ragged channel tile (192 of 256), 8 K blocks; dgrad 192 -> 512 = two channel tiles
     (1, 200, 136, 11, 19, 3, 1, 1),     # ... K tails: forward Cin = 200 (3 x 64 + 8), dgrad K = 136
+    (2, 64, 192, 27, 31, 3, 2, 1),      # stride 2 on odd input sizes (14 x 16 outputs: ragged 4 x 8 weight-gradient patches), three channel tiles
 ]
 
 
