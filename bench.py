@@ -66,7 +66,7 @@ class ConvTimer:
                     # generic kernel: BK = 32 instance for 1x1 filters (and Cin <= 32) and for stride-2 launches of >= 512 tiles,
                     # BK = 64 for the rest
                     ck_, co_ = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
-                    pix = d.N * (d.in_pix_per_img if dgrad else d.out_pix_per_img)
+                    pix = d.N * sum((d.Hi[i] * d.Wi[i]) if dgrad else (d.Ho[i] * d.Wo[i]) for i in range(d.nseg))
                     big = d.stride == 2 and -(-pix // 128) * -(-co_ // 128) >= 512
                     return "conv_igemm_kernel<32>" if (d.R * d.S == 1 or ck_ <= 32 or big) else "conv_igemm_kernel<64>"
                 ck, co = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
