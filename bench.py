@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# HIP binds a stream to one of GPU_MAX_HW_QUEUES (default 4) hardware queues at its first use, sharing queues beyond that.  With
+# the process group up, RCCL's and c10d's streams come first and the weight-gradient side stream ended up on the MAIN stream's
+# queue: the two ran back to back (rocprofv3 kernel trace, Queue_Id column; scripts/queue_map.py).  Eight queues keep them apart.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -164,6 +169,28 @@ def cpu_baseline(cfg, params, seconds=20.0, batch=2, size=(800, 1344)):
                        f"{len(t_all)} timed iteration(s) after 1 warm-up, {mean:.2f} s/iter")
 
 
+def _stdout_to_stderr():
+    """RCCL prints a version banner on the C stdout when the first communicator comes up (and it surfaces whenever that buffer is
+    flushed -- after the JSON line, at exit): everything but the result line goes to stderr."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return saved
+
+
+def _print_result(saved_fd, line):
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)         # C stdio buffers (the banner) leave through the redirected descriptor
+    except OSError:
+        pass
+    os.dup2(saved_fd, 1)
+    print(line, flush=True)
+    os.dup2(2, 1)
+    os.close(saved_fd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +217,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the basedet_amd path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    saved_stdout = _stdout_to_stderr()
     import torch.distributed as dist
     if world > 1 or os.environ.get("BD_FORCE_ALLREDUCE") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -335,7 +363,7 @@ def main():
             out["roofline_others"] = entries[1:]
         if world == 1 and not args.no_cpu_baseline and args.workload == "retinanet_r50_800x1344":
             out["cpu_baseline"] = cpu_baseline(cfg, params)
-        print(json.dumps(out), flush=True)
+        _print_result(saved_stdout, json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
