@@ -41,7 +41,11 @@ struct Cfg {
 // PRE: the epilogue operands (residual / accumulated gradient `add`, ReLU `mask`) of a linear-destination tile are fetched at the
 // START of the kernel into registers, so that for the short-K 1x1 layers (HBM-bound, 2..8 K steps) their HBM latency overlaps the
 // operand loads and the MFMAs instead of forming a second serial round trip after the last MFMA.
-template <int BK, bool PRE>
+// BUF: operands staged with range-checked buffer loads -- a 32-bit per-thread byte offset per staged row, recomputed only when the
+// filter tap changes, plus a scalar K-block offset; rows outside the image / past the tile read as zeros through an offset beyond
+// the buffer.  The 64-bit pointer arithmetic and the predicated loads of the general path are ~110 VALU instructions per K step and
+// wave against 16 MFMAs: they, not the matrix pipe or the memory system, bounded the K >= 256 layers (tensors >= 2 GB keep that path).
+template <int BK, bool PRE, bool BUF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
     using C = Cfg<BK>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -151,7 +155,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
     int cur_tap = -1, cur_kb = kblocks;   // forces a tap advance on first call
     int tap_r = 0, tap_s = 0;
 
+    constexpr unsigned X_NONE = 0x80000000u;          // >= num_records of either buffer: the load returns zeros
+    unsigned a_voff[BUF ? C::PASSES : 1], b_voff[BUF ? C::PASSES : 1];
+    __amdgpu_buffer_rsrc_t x_rsrc, w_rsrc;
+    if (BUF) {
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.src), 0, p.src_bytes, 0x00020000);
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.w), 0, p.w_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < C::PASSES; ++i) {
+            const int lrow = row0 + i * C::ROWS_PER_PASS;
+            const int rho = lrow & 15;
+            const int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
+            a_voff[i] = co < p.CO ? (unsigned)(co * RS * p.CK + chunk * 8) * 2u : X_NONE;
+        }
+    }
+
     auto stage_load = [&]() {
+        if (BUF) {
+            if (cur_kb == kblocks) {          // next filter tap (workgroup-uniform): the source pixel of every staged row moves
+                cur_kb = 0;
+                cur_tap = __ffs(rem_mask) - 1;
+                rem_mask &= rem_mask - 1;
+                tap_r = cur_tap / p.S;
+                tap_s = cur_tap - tap_r * p.S;
+#pragma unroll
+                for (int i = 0; i < C::PASSES; ++i) {
+                    int sy, sx;
+                    bool ok = b_base[i] >= 0;
+                    if (p.mode == 0) {
+                        sy = b_py[i] + tap_r; sx = b_px[i] + tap_s;
+                        ok = ok && sy >= 0 && sx >= 0 && sy < b_hs[i] && sx < b_ws[i];
+                    } else {
+                        const int ty = b_py[i] - tap_r, tx = b_px[i] - tap_s;
+                        ok = ok && ty >= 0 && tx >= 0;
+                        if (p.stride == 2) { ok = ok && (((ty | tx) & 1) == 0); sy = ty >> 1; sx = tx >> 1; }
+                        else { sy = ty; sx = tx; }
+                        ok = ok && sy < b_hs[i] && sx < b_ws[i];
+                    }
+                    b_voff[i] = ok ? (unsigned)(((int)b_base[i] + sy * b_ws[i] + sx) * p.CK + chunk * 8) * 2u : X_NONE;
+                }
+            }
+            int so_a = (cur_tap * p.CK + cur_kb * BK) * 2, so_b = cur_kb * BK * 2;
+            asm volatile("" : "+s"(so_a), "+s"(so_b));           // keep the K-block offsets in the scalar operand
+            const bool dead = cur_kb * BK + chunk * 8 >= p.CK;    // channel tail (CK % 8 == 0): zero-fill
+#pragma unroll
+            for (int i = 0; i < C::PASSES; ++i) {
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, dead ? X_NONE : a_voff[i], so_a, 0);
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, dead ? X_NONE : b_voff[i], so_b, 0);
+            }
+            ++cur_kb;
+            return;
+        }
         if (cur_kb == kblocks) {
             cur_kb = 0;
             cur_tap = __ffs(rem_mask) - 1;
@@ -330,6 +384,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
 }
 
 int g_igemm_prefetch_epi = 1;      // bd_conv_set_patch3x3 bit 5 clears it
+int g_igemm_buf = 1;               // bd_conv_set_patch3x3 bit 11 clears it: 64-bit pointer staging instead of buffer loads
 
 template <int BK>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
@@ -337,19 +392,25 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
     const size_t lds = 4 * C::TILE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = p.m_tiles * p.n_tiles;
     const bool epi_ops = ((p.flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER)) && p.add) || ((p.flags & BD_EPI_MASK) && p.mask);
     const int ksteps = (p.CK + BK - 1) / BK * p.R * p.S;
-    if (g_igemm_prefetch_epi && p.linear_dst && epi_ops && ksteps <= 4)
-        hipLaunchKernelGGL((conv_igemm_kernel<BK, true>), dim3(grid), dim3(256), lds, stream, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<BK, false>), dim3(grid), dim3(256), lds, stream, p);
+    const bool pre = g_igemm_prefetch_epi && p.linear_dst && epi_ops && ksteps <= 4;
+    const bool buf = g_igemm_buf && p.src_bytes != 0 && p.w_bytes != 0;
+    if (pre && buf) hipLaunchKernelGGL((conv_igemm_kernel<BK, true, true>), dim3(grid), dim3(256), lds, stream, p);
+    else if (pre) hipLaunchKernelGGL((conv_igemm_kernel<BK, true, false>), dim3(grid), dim3(256), lds, stream, p);
+    else if (buf) hipLaunchKernelGGL((conv_igemm_kernel<BK, false, true>), dim3(grid), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BK, false, false>), dim3(grid), dim3(256), lds, stream, p);
     return 0;
 }
 
@@ -365,6 +426,13 @@ int check_desc(const bd_conv_desc* d) {
                    "conv: level %d output size inconsistent with input/stride/pad", s);
     }
     return 0;
+}
+
+// buffer-load staging needs 32-bit byte offsets: both operands < 2 GB (else the kernel keeps its 64-bit pointer path)
+void set_buffer_sizes(IgemmParams& p, int N) {
+    const long long sb = (long long)N * p.src_pix_per_img * p.CK * 2, wb = (long long)p.CO * p.R * p.S * p.CK * 2;
+    p.src_bytes = (sb > 0 && sb < 0x7fffffffll) ? (unsigned)sb : 0u;
+    p.w_bytes = (wb > 0 && wb < 0x7fffffffll) ? (unsigned)wb : 0u;
 }
 
 bool is_3x3s1(const bd_conv_desc* d) {
@@ -403,6 +471,7 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_patch_pp128 = ((enable >> 9) & 1) ? -1 : ((enable >> 8) & 1);
     g_bk32_s2 = ((enable >> 10) & 1) ^ 1;
     g_igemm_prefetch_epi = ((enable >> 5) & 1) ^ 1;
+    g_igemm_buf = ((enable >> 11) & 1) ^ 1;
     return BD_OK;
 }
 
@@ -440,6 +509,7 @@ extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w
                     d->in_pix_per_img == d->Hi[0] * d->Wi[0]) ? 1 : 0;
     p.M = (int)m;
     p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
+    set_buffer_sizes(p, d->N);
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
     else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
@@ -491,6 +561,7 @@ extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void*
                     d->out_pix_per_img == d->Ho[0] * d->Wo[0]) ? 1 : 0;
     p.M = (int)m;
     p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
+    set_buffer_sizes(p, d->N);
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
     else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))

@@ -70,6 +70,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p)
         goff = ((long long)n * p.out_ppi + sg.out_off + oy * sg.Wo + ox) * p.Cout;
         xoff = ((long long)n * p.in_ppi + sg.in_off + (long long)(oy * p.stride) * sg.Wi + ox * p.stride) * p.Cin;
     };
+    // Strided / offset single-level layers (the stride-2 shortcut convolutions): the two float divisions of decode() per staged row
+    // cost more VALU cycles than the step has MFMA cycles (4 rows x ~50 instructions x 4 cycles against 32 MFMAs x 16).  The steps
+    // of a workgroup are consecutive, so each staged row keeps its (image, row, column) and advances it by BKP pixels per call.
+    // (only in the 256 x 256 instance, which serves them: the 128 x 512 one has no registers to spare)
+    const bool inc = TCI == 256 && TCO == 256 && !p.linear && p.nseg == 1;
+    const WSeg1 sg0 = p.seg[0];
+    const int n_img = p.M / (sg0.per_img > 0 ? sg0.per_img : 1);
+    int ix_n[XPASS], ix_y[XPASS], ix_x[XPASS], ig_n[GPASS], ig_y[GPASS], ig_x[GPASS];
+    if (inc) {
+#pragma unroll
+        for (int k = 0; k < XPASS; ++k) {
+            int rem;
+            fast_divmod1(step_begin * BKP + (tid + 512 * k) / XCH, sg0.per_img, sg0.inv_per_img, ix_n[k], rem);
+            fast_divmod1(rem, sg0.Wo, sg0.inv_wo, ix_y[k], ix_x[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < GPASS; ++k) {
+            int rem;
+            fast_divmod1(step_begin * BKP + (tid + 512 * k) / GCH, sg0.per_img, sg0.inv_per_img, ig_n[k], rem);
+            fast_divmod1(rem, sg0.Wo, sg0.inv_wo, ig_y[k], ig_x[k]);
+        }
+    }
+    auto advance = [&](int& n, int& y, int& x) {
+        x += BKP;
+        while (x >= sg0.Wo) { x -= sg0.Wo; ++y; }
+        while (y >= sg0.Ho) { y -= sg0.Ho; ++n; }
+    };
     auto stage_load = [&](int step, u32x4_t (&rx)[XPASS], u32x4_t (&rg)[GPASS]) {
         // x: chunk id c = tid + 512*k -> row c / XCH, chunk c % XCH ; g likewise
 #pragma unroll
@@ -77,7 +104,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p)
             const int c = tid + 512 * k;
             const int row = c / XCH, ch = c - row * XCH;
             long long xo, go;
-            decode(step * BKP + row, xo, go);
+            if (inc) {
+                xo = ix_n[k] < n_img ? (long long)(ix_n[k] * p.in_ppi + sg0.in_off + ix_y[k] * p.stride * sg0.Wi + ix_x[k] * p.stride) * p.Cin : -1;
+                advance(ix_n[k], ix_y[k], ix_x[k]);
+            } else {
+                decode(step * BKP + row, xo, go);
+            }
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (xo >= 0 && ci0 + ch * 8 < p.Cin) v = *reinterpret_cast<const u32x4_t*>(p.x + xo + ci0 + ch * 8);
             rx[k] = v;
@@ -87,7 +119,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p)
             const int c = tid + 512 * k;
             const int row = c / GCH, ch = c - row * GCH;
             long long xo, go;
-            decode(step * BKP + row, xo, go);
+            if (inc) {
+                go = ig_n[k] < n_img ? (long long)(ig_n[k] * p.out_ppi + sg0.out_off + ig_y[k] * sg0.Wo + ig_x[k]) * p.Cout : -1;
+                advance(ig_n[k], ig_y[k], ig_x[k]);
+            } else {
+                decode(step * BKP + row, xo, go);
+            }
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (go >= 0 && co0 + ch * 8 < p.Cout) v = *reinterpret_cast<const u32x4_t*>(p.g + go + co0 + ch * 8);
             rg[k] = v;

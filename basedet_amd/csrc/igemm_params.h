@@ -37,6 +37,7 @@ struct IgemmParams {
     int m_tiles, n_tiles;
     int linear_dst;   // 1: destination pixel index == GEMM column m (single dense level, unit step)
     int linear_src;   // 1: additionally 1x1 / stride 1 with the same source geometry: source pixel index == m
+    unsigned src_bytes, w_bytes;   // sizes of the source tensor and the packed weights when both are < 2 GB (buffer-load staging), else 0
     SubSeg sub[MAX_SUB];
 };
 

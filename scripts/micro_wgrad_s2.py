@@ -8,3 +8,5 @@ from micro_conv import bench
 for rep in range(2):
     for (h, w, cin, cout) in ((200, 336, 128, 128), (100, 168, 256, 256), (50, 84, 512, 512), (25, 42, 2048, 256), (13, 21, 256, 256)):
         bench(16, h, w, cin, cout, mode="wgrad", stride=2)
+    for (h, w, cin, cout) in ((200, 336, 256, 512), (100, 168, 512, 1024), (50, 84, 1024, 2048)):
+        bench(16, h, w, cin, cout, R=1, pad=0, mode="wgrad", stride=2)
