@@ -405,7 +405,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
     const int grid = p.m_tiles * p.n_tiles;
     const bool epi_ops = ((p.flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER)) && p.add) || ((p.flags & BD_EPI_MASK) && p.mask);
     const int ksteps = (p.CK + BK - 1) / BK * p.R * p.S;
-    const bool pre = g_igemm_prefetch_epi && p.linear_dst && epi_ops && ksteps <= 4;
+    const bool pre = g_igemm_prefetch_epi && p.linear_dst && epi_ops && ksteps <= 4;     // (<= 8 / 16 / 64 measured: no difference)
     const bool buf = g_igemm_buf && p.src_bytes != 0 && p.w_bytes != 0;
     if (pre && buf) hipLaunchKernelGGL((conv_igemm_kernel<BK, true, true>), dim3(grid), dim3(256), lds, stream, p);
     else if (pre) hipLaunchKernelGGL((conv_igemm_kernel<BK, true, false>), dim3(grid), dim3(256), lds, stream, p);
