@@ -6,6 +6,7 @@
 // 65 536 outputs -- 256 ci x 256 co, or 128 ci x 512 co when Cin <= 128 -- i.e. 128 FLOP per staged byte and half the
 // operand traffic.  8 waves, each 128 ci x 64 co (128 fp32 accumulators per lane); operands staged [pixel][channel]
 // and transposed on the way to the MFMA by ds_read_b64_tr_b16 (conv_wgrad.hip); split over pixels into fp32 slabs.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -20,6 +21,7 @@ struct W1Params {
     float* slab;
     int Cin, Cout, stride, M, nseg;
     int linear;      // 1: single dense level, stride 1 -> source/destination pixel index == GEMM row (no decode)
+    unsigned x_bytes, g_bytes;   // tensor sizes when both are < 2 GB (buffer-load staging), else 0
     int in_ppi, out_ppi;
     int ci_tiles, co_tiles, steps_per_split, total_steps;
     WSeg1 seg[MAX_SEG];
@@ -32,7 +34,10 @@ __device__ __forceinline__ void fast_divmod1(int n, int d, float inv, int& q, in
     else if (r >= d) { ++q; r -= d; }
 }
 
-template <int TCI, int TCO, int BKP>
+// BUF: operands staged with range-checked buffer loads (32-bit per-thread byte offsets, an offset past the buffer reads zeros).  On a
+// dense stride-1 level the per-thread offset is a CONSTANT and the K step is a scalar offset: no per-load address arithmetic and no
+// predication branches (the pointer path spent 50-125 VALU instructions and ~20 branches per 32 MFMAs).
+template <int TCI, int TCO, int BKP, bool BUF>
 __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p) {
     constexpr int XP = TCI * 2 + 32, GP = TCO * 2 + 32;        // row pitches (== 8 dwords mod 64)
     constexpr int X_BYTES = BKP * XP, G_BYTES = BKP * GP;
@@ -97,8 +102,36 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p)
         while (x >= sg0.Wo) { x -= sg0.Wo; ++y; }
         while (y >= sg0.Ho) { y -= sg0.Ho; ++n; }
     };
+    constexpr unsigned X_NONE = 0x80000000u;
+    __amdgpu_buffer_rsrc_t x_rsrc, g_rsrc;
+    unsigned xv[BUF ? XPASS : 1], gv[BUF ? GPASS : 1];      // dense level: constant byte offset of this thread's chunk in K step 0
+    if (BUF) {
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
+        g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.g), 0, p.g_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < XPASS; ++k) {
+            const int c = tid + 512 * k, row = c / XCH, ch = c - row * XCH;
+            xv[k] = ci0 + ch * 8 < p.Cin ? (unsigned)(row * p.Cin + ci0 + ch * 8) * 2u : X_NONE;
+        }
+#pragma unroll
+        for (int k = 0; k < GPASS; ++k) {
+            const int c = tid + 512 * k, row = c / GCH, ch = c - row * GCH;
+            gv[k] = co0 + ch * 8 < p.Cout ? (unsigned)(row * p.Cout + co0 + ch * 8) * 2u : X_NONE;
+        }
+    }
     auto stage_load = [&](int step, u32x4_t (&rx)[XPASS], u32x4_t (&rg)[GPASS]) {
         // x: chunk id c = tid + 512*k -> row c / XCH, chunk c % XCH ; g likewise
+        if (BUF && p.linear) {
+            int sx = step * BKP * p.Cin * 2, sg = step * BKP * p.Cout * 2;
+            asm volatile("" : "+s"(sx), "+s"(sg));                 // the K step travels in the scalar offset
+#pragma unroll
+            for (int k = 0; k < XPASS; ++k)
+                rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, step * BKP + (tid + 512 * k) / XCH < p.M ? xv[k] : X_NONE, sx, 0);
+#pragma unroll
+            for (int k = 0; k < GPASS; ++k)
+                rg[k] = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, step * BKP + (tid + 512 * k) / GCH < p.M ? gv[k] : X_NONE, sg, 0);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < XPASS; ++k) {
             const int c = tid + 512 * k;
@@ -111,7 +144,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p)
                 decode(step * BKP + row, xo, go);
             }
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if (xo >= 0 && ci0 + ch * 8 < p.Cin) v = *reinterpret_cast<const u32x4_t*>(p.x + xo + ci0 + ch * 8);
+            if (BUF) v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (xo >= 0 && ci0 + ch * 8 < p.Cin) ? (unsigned)(xo + ci0 + ch * 8) * 2u : X_NONE, 0, 0);
+            else if (xo >= 0 && ci0 + ch * 8 < p.Cin) v = *reinterpret_cast<const u32x4_t*>(p.x + xo + ci0 + ch * 8);
             rx[k] = v;
         }
 #pragma unroll
@@ -126,7 +160,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p)
                 decode(step * BKP + row, xo, go);
             }
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if (go >= 0 && co0 + ch * 8 < p.Cout) v = *reinterpret_cast<const u32x4_t*>(p.g + go + co0 + ch * 8);
+            if (BUF) v = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (go >= 0 && co0 + ch * 8 < p.Cout) ? (unsigned)(go + co0 + ch * 8) * 2u : X_NONE, 0, 0);
+            else if (go >= 0 && co0 + ch * 8 < p.Cout) v = *reinterpret_cast<const u32x4_t*>(p.g + go + co0 + ch * 8);
             rg[k] = v;
         }
     };
@@ -215,19 +250,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p)
     }
 }
 
-template <int TCI, int TCO, int BKP>
+template <int TCI, int TCO, int BKP, bool BUF>
 void launch_w1(const W1Params& p, int grid, hipStream_t stream) {
     constexpr size_t lds = 2 * (size_t)BKP * ((TCI * 2 + 32) + (TCO * 2 + 32));
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1x1_kernel<TCI, TCO, BKP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1x1_kernel<TCI, TCO, BKP, BUF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad1x1_kernel<TCI, TCO, BKP>), dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((conv_wgrad1x1_kernel<TCI, TCO, BKP, BUF>), dim3(grid), dim3(512), lds, stream, p);
 }
 
+int g_w1_buf = 1;         // 0 (BD_W1_PTR=1 in the environment): 64-bit pointer staging, for A/B runs
 int g_w1_allow_512 = 0;   // the 512 x 128 tile measured 2.7x slower than its 128 x 512 mirror image (kept for study)
 // (tile_ci, tile_co, pixels per K step): 128 x 512 needs the shorter step to fit LDS (2 x 32 x 1344 B = 84 KB)
 void tile_shape(const bd_conv_desc* d, int& tci, int& tco, int& bkp) {
@@ -276,9 +312,13 @@ int bd_wgrad1x1_launch(const bd_conv_desc* d, const void* x, const void* g, floa
     p.steps_per_split = cdiv(p.total_steps, splits);
     p.ci_tiles = cdiv(d->Cin, tci); p.co_tiles = cdiv(d->Cout, tco);
     const int grid = splits * p.ci_tiles * p.co_tiles;
-    if (tci == 128) launch_w1<128, 512, 32>(p, grid, stream);
-    else if (tci == 512) launch_w1<512, 128, 32>(p, grid, stream);
-    else launch_w1<256, 256, 32>(p, grid, stream);
+    const long long xb = (long long)d->N * d->in_pix_per_img * d->Cin * 2, gb = (long long)d->N * d->out_pix_per_img * d->Cout * 2;
+    static const bool env_ptr = getenv("BD_W1_PTR") != nullptr;
+    const bool buf = g_w1_buf && !env_ptr && xb < 0x7fffffffll && gb < 0x7fffffffll;
+    p.x_bytes = buf ? (unsigned)xb : 0u; p.g_bytes = buf ? (unsigned)gb : 0u;
+    if (tci == 128) { if (buf) launch_w1<128, 512, 32, true>(p, grid, stream); else launch_w1<128, 512, 32, false>(p, grid, stream); }
+    else if (tci == 512) launch_w1<512, 128, 32, false>(p, grid, stream);
+    else { if (buf) launch_w1<256, 256, 32, true>(p, grid, stream); else launch_w1<256, 256, 32, false>(p, grid, stream); }
     *splits_out = splits;
     return 0;
 }
