@@ -18,29 +18,36 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_raw* __restri
                                                         int N, int H, int W) {
     __shared__ __attribute__((aligned(16))) unsigned char wl[64 * W_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // weights: 64 rows x 28 chunks of 16 B
+    // weights: 64 rows x 28 chunks of 16 B.  LDS row (t*16 + rho) holds output channel 32*(t>>1) + 8*(rho>>2) + 4*(t&1) + (rho&3)
+    // (the permutation of conv_igemm.hip): after the MFMAs lane group q owns channels 8q..8q+7 of each 32-channel half, so the
+    // epilogue stores 16 bytes per lane = 64 contiguous bytes per pixel and instruction instead of 8 / 32
     for (int c = tid; c < 64 * 28; c += 256) {
         const int row = c / 28, ch = c - row * 28;
+        const int rho = row & 15, t = row >> 4;
+        const int co = 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
         *reinterpret_cast<u32x4_t*>(wl + row * W_PITCH + ch * 16) =
-            *reinterpret_cast<const u32x4_t*>(w + row * 224 + ch * 8);
+            *reinterpret_cast<const u32x4_t*>(w + co * 224 + ch * 8);
     }
     __syncthreads();
 
     const int Ho = H / 2, Wo = W / 2;
     const int Hb = H + 6, Wb = W + 8;
-    const long long M = (long long)N * Ho * Wo;
-    const long long ngroups = (M + 63) / 64;
+    const int M = N * Ho * Wo;                    // < 2^31 (checked on the host): 32-bit index arithmetic
+    const int ngroups = (M + 63) / 64;
     const int pix = lane & 15, q = lane >> 4;
+    float bias_r[16];                              // this lane's 16 channels: 8q..8q+7 and 32+8q..32+8q+7
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bias_r[k] = bias[32 * (k >> 3) + 8 * q + (k & 7)];
 
-    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long long)gridDim.x * 4) {
-        const long long mbase = grp * 64;
+    for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+        const int mbase = grp * 64;
         const bf16_raw* src[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            long long m = mbase + j * 16 + pix;
+            int m = mbase + j * 16 + pix;
             if (m >= M) m = M - 1;   // clamp loads, stores are masked
-            const int n = (int)(m / (Ho * Wo));
-            const int rem = (int)(m - (long long)n * Ho * Wo);
+            const int n = m / (Ho * Wo);
+            const int rem = m - n * Ho * Wo;
             const int oy = rem / Wo, ox = rem - oy * Wo;
             src[j] = x + (((long long)n * Hb + 2 * oy) * Wb + 2 * ox + 2 * q) * 4;
         }
@@ -65,16 +72,18 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_raw* __restri
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long long m = mbase + j * 16 + pix;
+            const int m = mbase + j * 16 + pix;
             if (m >= M) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = i * 16 + q * 4;
-                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + co);
-                u32x2_t o;
-                o[0] = pack_bf2(fmaxf(acc[i][j][0] + bv[0], 0.f), fmaxf(acc[i][j][1] + bv[1], 0.f));
-                o[1] = pack_bf2(fmaxf(acc[i][j][2] + bv[2], 0.f), fmaxf(acc[i][j][3] + bv[3], 0.f));
-                *reinterpret_cast<u32x2_t*>(y + m * 64 + co) = o;
+            for (int half = 0; half < 2; ++half) {
+                u32x4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e0 = 2 * k, e1 = 2 * k + 1;       // element e of the 8: tile 2*half + (e>>2), register e&3
+                    o[k] = pack_bf2(fmaxf(acc[2 * half + (e0 >> 2)][j][e0 & 3] + bias_r[8 * half + e0], 0.f),
+                                    fmaxf(acc[2 * half + (e1 >> 2)][j][e1 & 3] + bias_r[8 * half + e1], 0.f));
+                }
+                *reinterpret_cast<u32x4_t*>(y + (long long)m * 64 + 32 * half + 8 * q) = o;
             }
         }
     }
@@ -100,6 +109,7 @@ extern "C" int bd_stem_conv7x7_fwd(int N, int H, int W, const void* x_halo, cons
     BD_REQUIRE(x_halo && w_stem && bias && y, "stem_conv7x7_fwd: null pointer");
     BD_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_conv7x7_fwd: H=%d W=%d must be even", H, W);
     const long long M = (long long)N * (H / 2) * (W / 2);
+    BD_REQUIRE(M < 0x7fffffffll, "stem_conv7x7_fwd: too many output pixels");
     long long groups = (M + 255) / 256;
     const int grid = (int)(groups < 2048 ? groups : 2048);
     hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x_halo,
