@@ -23,6 +23,7 @@ import time
 # the process group up, RCCL's and c10d's streams come first and the weight-gradient side stream ended up on the MAIN stream's
 # queue: the two ran back to back (rocprofv3 kernel trace, Queue_Id column; scripts/queue_map.py).  Eight queues keep them apart.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
 
 import numpy as np
 import torch
