@@ -36,6 +36,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
     int l_co0 = 0;
     long long b_src[PASSES];     // source pixel element offset (pixel * CK) or -1
     int a_co[PASSES];
+    // range-checked buffer loads (the host takes this kernel only when both operands are < 2 GB): 32-bit byte offsets per staged row,
+    // recomputed once per tile; the K step travels in the scalar offset; rows outside the problem read zeros
+    constexpr unsigned X_NONE = 0x80000000u;
+    unsigned a_voff[PASSES], b_voff[PASSES];
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.w), 0, p.w_bytes, 0x00020000);
     u32x4_t ra[DEPTH][PASSES], rb[DEPTH][PASSES];
     int ls = 0;
 
@@ -67,18 +73,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
                 ok = ok && sy < ss.Hsrc && sx < ss.Wsrc;
                 if (ok) b_src[i] = ((long long)n * p.src_pix_per_img + ss.src_off + (long long)sy * ss.Wsrc + sx) * p.CK;
             }
+            a_voff[i] = a_co[i] < p.CO ? (unsigned)(a_co[i] * p.CK + chunk * 8) * 2u : X_NONE;
+            b_voff[i] = b_src[i] >= 0 ? (unsigned)((int)b_src[i] + chunk * 8) * 2u : X_NONE;
         }
     };
     auto issue_load = [&](u32x4_t (&xa)[PASSES], u32x4_t (&xb)[PASSES]) {
         if (l_kb == kblocks) { l_kb = 0; l_tile += G; decode_rows(); }
-        const int c0 = l_kb * BK + chunk * 8;
-        const bool cvalid = c0 + 8 <= p.CK;
+        const bool dead = l_kb * BK + chunk * 8 >= p.CK;      // channel tail (CK % 8 == 0): zero-fill
+        int so = l_kb * BK * 2;
+        asm volatile("" : "+s"(so));
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-            u32x4_t va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
-            if (cvalid && a_co[i] < p.CO) va = *reinterpret_cast<const u32x4_t*>(p.w + (long long)a_co[i] * p.CK + c0);
-            if (cvalid && b_src[i] >= 0) vb = *reinterpret_cast<const u32x4_t*>(p.src + b_src[i] + c0);
-            xa[i] = va; xb[i] = vb;
+            xa[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, dead ? X_NONE : a_voff[i], so, 0);
+            xb[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, dead ? X_NONE : b_voff[i], so, 0);
         }
         ++l_kb; ++ls;
     };

@@ -511,7 +511,7 @@ extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w
     p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
     set_buffer_sizes(p, d->N);
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
-    if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
+    if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0 && p.src_bytes && p.w_bytes) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
     else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
         launch_igemm<64>(p, (hipStream_t)stream);
     else launch_igemm<32>(p, (hipStream_t)stream);
@@ -563,7 +563,7 @@ extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void*
     p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
     set_buffer_sizes(p, d->N);
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
-    if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
+    if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0 && p.src_bytes && p.w_bytes) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
     else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
         launch_igemm<64>(p, (hipStream_t)stream);
     else launch_igemm<32>(p, (hipStream_t)stream);
