@@ -599,10 +599,21 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const bf16_raw* __re
 // workgroup-uniform 4x4 coefficient patch anchored at the top-left sample corner): one atomic per distinct pixel of the bin
 // (typically 9) instead of one per sample corner (16).  Bins whose samples spread over more than 4 rows / columns (very large
 // RoIs) take the direct path.
+// PK: the target is the bf16 gradient pyramid itself and two channels travel per atomic (global_atomic_pk_add_bf16): half the
+// atomic operations -- the kernel runs at the chip's atomic rate -- and no fp32 staging buffer / conversion pass.  The sums are then
+// rounded to bf16 at every add (a feature-map element receives ~2.5 contributions on average).  The thread block splits into
+// 256 / (C/2) groups that take alternate bins.
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+__device__ __forceinline__ void pk_atomic_add(bf16_raw* p, float a, float b) {
+    const unsigned v = pack_bf2(a, b);
+    __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) s16x2_t*)p, __builtin_bit_cast(s16x2_t, v));
+}
+
+template <bool PK>
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv,
                                                             const float* __restrict__ rois, const int* __restrict__ labels,
                                                             int rois_per_img, int PH, int PW, int S,
-                                                            float* __restrict__ gfeat) {
+                                                            void* __restrict__ gfeat_) {
     const int r = blockIdx.x;
     if (labels && labels[r] < 0) return;
     const int n = r / rois_per_img;
@@ -614,10 +625,18 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
     const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
     const float rw = (b.x2 * sc - 0.5f) - sw, rh = (b.y2 * sc - 0.5f) - sh_;
     const float bw = rw / (float)PW, bh = rh / (float)PH;
-    float* gp = gfeat + ((long long)n * ppi + lv.pix_off[l]) * C;
+    float* gp = reinterpret_cast<float*>(gfeat_) + ((long long)n * ppi + lv.pix_off[l]) * C;
+    bf16_raw* gpb = reinterpret_cast<bf16_raw*>(gfeat_) + ((long long)n * ppi + lv.pix_off[l]) * C;
     const bf16_raw* go = gout + (long long)r * nb * C;
     const float inv = 1.f / (float)(S * S);
-    for (int bin = 0; bin < nb; ++bin) {
+    // PK: thread -> (bin group, channel pair); the groups interleave over the bins
+    const int pairs = C >> 1;
+    const int groups = PK ? (pairs >= 256 ? 1 : 256 / pairs) : 1;
+    const int grp = PK ? (int)threadIdx.x / (pairs >= 256 ? 256 : pairs) : 0;
+    const int t0 = PK ? (int)threadIdx.x - grp * (pairs >= 256 ? 256 : pairs) : (int)threadIdx.x;
+    const int tstep = PK ? (pairs >= 256 ? 256 : pairs) : 256;
+    if (PK && grp >= groups) return;
+    for (int bin = grp; bin < nb; bin += groups) {
         const int ph = bin / PW, pw = bin - ph * PW;
         bool merged = S == 2;
         float coef[4][4];
@@ -659,6 +678,19 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
             }
         }
         if (merged) {
+            if (PK) {
+                for (int c2 = t0; c2 < pairs; c2 += tstep) {
+                    const unsigned gv = *reinterpret_cast<const unsigned*>(go + (long long)bin * C + 2 * c2);
+                    const float g0 = bf_lo(gv) * inv, g1 = bf_hi(gv) * inv;
+#pragma unroll
+                    for (int py = 0; py < 4; ++py)
+#pragma unroll
+                        for (int px = 0; px < 4; ++px)
+                            if (coef[py][px] != 0.f)                  // uniform over the bin group
+                                pk_atomic_add(gpb + ((long long)(Y0 + py) * W + X0 + px) * C + 2 * c2, coef[py][px] * g0, coef[py][px] * g1);
+                }
+                continue;
+            }
             for (int c = threadIdx.x; c < C; c += 256) {
                 const float g = bf2f(go[(long long)bin * C + c]) * inv;
 #pragma unroll
@@ -676,6 +708,17 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
                 const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)S;
                 const Bilinear bl = bilinear_setup(y, x, H, W);
                 if (!bl.ok) continue;
+                if (PK) {
+                    for (int c2 = t0; c2 < pairs; c2 += tstep) {
+                        const unsigned gv = *reinterpret_cast<const unsigned*>(go + (long long)bin * C + 2 * c2);
+                        const float g0 = bf_lo(gv) * inv, g1 = bf_hi(gv) * inv;
+                        pk_atomic_add(gpb + ((long long)bl.y0 * W + bl.x0) * C + 2 * c2, bl.w00 * g0, bl.w00 * g1);
+                        pk_atomic_add(gpb + ((long long)bl.y0 * W + bl.x1) * C + 2 * c2, bl.w01 * g0, bl.w01 * g1);
+                        pk_atomic_add(gpb + ((long long)bl.y1 * W + bl.x0) * C + 2 * c2, bl.w10 * g0, bl.w10 * g1);
+                        pk_atomic_add(gpb + ((long long)bl.y1 * W + bl.x1) * C + 2 * c2, bl.w11 * g0, bl.w11 * g1);
+                    }
+                    continue;
+                }
                 for (int c = threadIdx.x; c < C; c += 256) {
                     const float g = bf2f(go[(long long)bin * C + c]) * inv;
                     unsafeAtomicAdd(gp + ((long long)bl.y0 * W + bl.x0) * C + c, bl.w00 * g);
@@ -1165,9 +1208,25 @@ extern "C" int bd_roi_align_bwd(const void* gout, int64_t pix_per_img, int C, in
     if (R == 0) return BD_OK;
     RoiLevels lv{};
     BD_REQUIRE(fill_roi_levels(lv, L, lvl_pix_off_host, lvl_h_host, lvl_w_host, strides_host) == 0, "roi_align_bwd: strides must be powers of two");
-    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
-                       C, lv, rois, labels, rois_per_img, PH, PW, sample_points, gfeat);
+    hipLaunchKernelGGL(roi_align_bwd_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
+                       C, lv, rois, labels, rois_per_img, PH, PW, sample_points, (void*)gfeat);
     BD_CHECK_LAUNCH("bd_roi_align_bwd");
+    return BD_OK;
+}
+
+extern "C" int bd_roi_align_bwd_pk(const void* gout, int64_t pix_per_img, int C, int L, const int32_t* lvl_pix_off_host,
+                                   const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
+                                   const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
+                                   int sample_points, void* gfeat_bf16, bd_stream_t stream) {
+    BD_REQUIRE(gout && lvl_pix_off_host && lvl_h_host && lvl_w_host && strides_host && rois && gfeat_bf16, "roi_align_bwd_pk: null pointer");
+    BD_REQUIRE(L > 0 && L <= BD_MAX_SEGS && C > 0 && C % 2 == 0 && PH > 0 && PW > 0 && sample_points > 0 && rois_per_img > 0,
+               "roi_align_bwd_pk: bad sizes (C must be even)");
+    if (R == 0) return BD_OK;
+    RoiLevels lv{};
+    BD_REQUIRE(fill_roi_levels(lv, L, lvl_pix_off_host, lvl_h_host, lvl_w_host, strides_host) == 0, "roi_align_bwd_pk: strides must be powers of two");
+    hipLaunchKernelGGL(roi_align_bwd_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
+                       C, lv, rois, labels, rois_per_img, PH, PW, sample_points, gfeat_bf16);
+    BD_CHECK_LAUNCH("bd_roi_align_bwd_pk");
     return BD_OK;
 }
 

@@ -74,6 +74,7 @@ class FasterRCNN(FPNDetector):
         self.pre_k = {True: m.RPN.TRAIN_PREV_NMS_TOPK, False: m.RPN.TEST_PREV_NMS_TOPK}
         self.post_k = {True: m.RPN.TRAIN_POST_NMS_TOPK, False: m.RPN.TEST_POST_NMS_TOPK}
         self.deterministic_roi_bwd = False
+        self.roi_bwd_pk = True              # packed-bf16 atomics straight into the bf16 gradient pyramid (half the atomics of the fp32 scatter)
         self._gen = torch.Generator(device=dev) if self.device.type == "cuda" else None
         if self._gen is not None:
             self._gen.manual_seed(0)
@@ -229,6 +230,10 @@ class FasterRCNN(FPNDetector):
         if self.deterministic_roi_bwd:      # gather kernel: fixed summation order, ~2x slower than the atomic scatter
             ops.roi_align_bwd_bf16(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4),
                                    pl.s_labels.view(-1), S, self.pool, 2, pl.g_P, pl.roi_bwd_ws)
+        elif self.roi_bwd_pk:
+            pl.g_P.zero_()
+            ops.roi_align_bwd_pk(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
+                                 self.pool, 2, pl.g_P)
         else:
             pl.g_feat32.zero_()
             ops.roi_align_bwd(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,

@@ -406,6 +406,13 @@ int bd_roi_align_bwd(const void* gout, int64_t pix_per_img, int C, int L, const 
                      const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
                      int sample_points, float* gfeat, bd_stream_t stream);
 
+/* bd_roi_align_bwd with two channels per atomic (global_atomic_pk_add_bf16) straight into the ZEROED bf16 gradient pyramid: half the
+ * atomic operations of the fp32 scatter, no fp32 staging buffer and no conversion pass; every add rounds to bf16.  C even. */
+int bd_roi_align_bwd_pk(const void* gout, int64_t pix_per_img, int C, int L, const int32_t* lvl_pix_off_host,
+                        const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
+                        const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
+                        int sample_points, void* gfeat_bf16, bd_stream_t stream);
+
 /* Deterministic backward of bd_roi_align_fwd for the training step: the RoIs are binned into 4x8-pixel tiles of their level
  * (count, scan, fill), then one wave per (image, tile, 64-channel slice) gathers every sample touching the tile -- no float
  * atomics, fixed summation order.  Writes the bf16 gradient of ALL L_all pyramid levels of the pixel-major buffer (levels >= L
