@@ -179,8 +179,15 @@ class FasterRCNN(FPNDetector):
         info = pre["img_info"]
         num_gt = info[:, 4].to(torch.int32).contiguous()
         Gmax = gt.shape[1]
-        # ---- RPN: proposals (detached), targets, losses
-        self._proposals(pl, info)
+        # ---- RPN: proposals (detached), targets, losses.  The proposal chain (decode, per-level top-k, batched NMS: ~2 ms of
+        # kernels with 16 workgroups each) runs on a side stream under the anchor assignment, anchor sampling and RPN losses
+        side = self._tstream if (self.async_wgrad and self._tstream is not None) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._proposals(pl, info)
+        else:
+            self._proposals(pl, info)
         thr = m.MATCHER.THRESHOLDS
         ws = pl.wgrad_ws[: N * Gmax]
         ops.rpn_assign_encode(pl.anchors, gt, num_gt, thr[0], thr[1], m.MATCHER.ALLOW_LOW_QUALITY, m.RPN_BOX_REG.MEAN,
@@ -192,6 +199,8 @@ class FasterRCNN(FPNDetector):
         ops.rpn_loss_fwd_bwd(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.rpn_labels, pl.rpn_offsets, pl.pyr.pixels,
                              m.LOSSES.RPN_SMOOTH_L1_BETA, pl.rpn_num_valid, pl.loss_buf[0:2], pl.d_rpn_raw)
         # ---- RCNN: sampling, RoIAlign, box head, losses
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         S = m.RCNN.NUM_ROIS
         key_ld = pl.rois.shape[1] + Gmax
         ops.rcnn_sample_targets(pl.rois, pl.num_rois, gt, num_gt, self._keys(inputs, "rcnn_fg", (N, key_ld)),
