@@ -198,6 +198,12 @@ class FasterRCNN(FPNDetector):
         pl.loss_buf.zero_()
         ops.rpn_loss_fwd_bwd(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.rpn_labels, pl.rpn_offsets, pl.pyr.pixels,
                              m.LOSSES.RPN_SMOOTH_L1_BETA, pl.rpn_num_valid, pl.loss_buf[0:2], pl.d_rpn_raw)
+        pl.rpn_bwd_done = False
+        if side is not None and self.roi_bwd_pk and not self.deterministic_roi_bwd:
+            # the RPN head's backward needs nothing from the proposal chain: it runs now, under it, and leaves the FIRST contribution
+            # to dL/dP; the RoIAlign backward adds its packed atomics on top later (head_backward)
+            self._rpn_head_backward(pl, pl.wgrad_ws, pl.colsum_ws, first=True)
+            pl.rpn_bwd_done = True
         # ---- RCNN: sampling, RoIAlign, box head, losses
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -240,7 +246,8 @@ class FasterRCNN(FPNDetector):
             ops.roi_align_bwd_bf16(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4),
                                    pl.s_labels.view(-1), S, self.pool, 2, pl.g_P, pl.roi_bwd_ws)
         elif self.roi_bwd_pk:
-            pl.g_P.zero_()
+            if not pl.rpn_bwd_done:
+                pl.g_P.zero_()
             ops.roi_align_bwd_pk(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
                                  self.pool, 2, pl.g_P)
         else:
@@ -248,11 +255,16 @@ class FasterRCNN(FPNDetector):
             ops.roi_align_bwd(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
                               self.pool, 2, pl.g_feat32)
             ops.f32_to_bf16(pl.g_feat32, pl.g_P)
-        # RPN head
+        # RPN head (unless get_losses already ran it under the proposal chain)
+        if not pl.rpn_bwd_done:
+            self._rpn_head_backward(pl, ws, cws, first=False)
+
+    def _rpn_head_backward(self, pl, ws, cws, first):
+        pyr = pl.pyr
         self._wgrad(self.rpn_pred, pl.rpn_t, pl.d_rpn_raw, pyr, pyr, ws, cws)
         self.rpn_pred.dgrad(pl.d_rpn_raw, pyr, pyr, pl.g_rpn_t, mask=pl.rpn_t)
         self._wgrad(self.rpn_conv, pl.P, pl.g_rpn_t, pyr, pyr, ws, cws)
-        self.rpn_conv.dgrad(pl.g_rpn_t, pyr, pyr, pl.g_P, first=False)
+        self.rpn_conv.dgrad(pl.g_rpn_t, pyr, pyr, pl.g_P, first=first)
 
     def _debug_head(self, pl, out, lvl):
         A = self.num_anchors
