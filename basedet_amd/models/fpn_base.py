@@ -547,6 +547,10 @@ class FPNDetector:
             xin = pl.blk[bi - 1].out if bi > 0 else pl.pool_out
             prev_tr = bi > 0 and self.blocks[bi - 1]["trainable"]
             G = b.g_out
+            # the shortcut convolution's weight gradient needs only the block's input and output gradient: first in the side
+            # stream's queue, not last (after the final block nothing is left on the main stream to hide it)
+            if blk["ds"] is not None:
+                self._wgrad(blk["ds"], xin, G, b.gin, b.gout, ws)
             # main branch, last conv backwards
             g = G
             for ci in range(len(convs) - 1, 0, -1):
@@ -554,8 +558,6 @@ class FPNDetector:
                 convs[ci].dgrad(g, geos[ci], geos[ci + 1], b.g_mids[ci - 1], mask=b.mids[ci - 1])
                 g = b.g_mids[ci - 1]
             self._wgrad(convs[0], xin, g, geos[0], geos[1], ws)
-            if blk["ds"] is not None:
-                self._wgrad(blk["ds"], xin, G, b.gin, b.gout, ws)
             if prev_tr:
                 gx = pl.blk[bi - 1].g_out
                 # has the input already received a contribution (FPN lateral of res3/res4)?
