@@ -38,14 +38,15 @@ torch.cuda.synchronize()
 assert np.isfinite(float(out["total_loss"]))
 w = model.arena.w.cpu().numpy()
 sys.stderr.write("DIGEST " + hashlib.sha256(w.tobytes()).hexdigest() + " " + repr(float(np.abs(w).sum())) + "\n")
+sys.stderr.flush()
 if dist.is_initialized():
-    dist.destroy_process_group()
+    os._exit(0)          # no process-group teardown: its watchdog threads can hold a finished process for minutes
 """
 
 
 def _run(force, port):
     env = dict(os.environ, BD_FORCE_ALLREDUCE="1" if force else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", _SCRIPT, ROOT, str(port)], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", _SCRIPT, ROOT, str(port)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stderr.splitlines() if l.startswith("DIGEST ")]
     assert line, r.stderr[-2000:]
