@@ -131,6 +131,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
     const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
     const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
 
+    // epilogue operands of the tile being computed, requested when its first K step starts (linear destinations only)
+    u32x4_t pre_add[8], pre_mask[8];
+    const bool pre_ok = p.linear_dst && (((add_before || add_after)) || do_mask);
+    auto prefetch_epi = [&](int tile) {
+        const int tile_m = tile / p.n_tiles;
+        const int co0 = (tile - tile_m * p.n_tiles) * TILE_C;
+        const int cb_ = co0 + wc * 64 + 8 * cg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int m = tile_m * TILE_P + wp * 64 + j * 16 + (lane & 15);
+                const bool ok = m < p.M && cb_ + 32 * half < p.CO;
+                const long long idx = (long long)m * p.CO + cb_ + 32 * half;
+                u32x4_t a = {0u, 0u, 0u, 0u}, k = {0u, 0u, 0u, 0u};
+                if (ok && (add_before || add_after)) a = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                if (ok && do_mask) k = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+                pre_add[j * 2 + half] = a; pre_mask[j * 2 + half] = k;
+            }
+    };
+
     auto epilogue = [&](int tile) {
         const int tile_m = tile / p.n_tiles;
         const int co0 = (tile - tile_m * p.n_tiles) * TILE_C;
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];
                 if (add_before) {
-                    const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                    const u32x4_t av = pre_ok ? pre_add[j * 2 + half] : *reinterpret_cast<const u32x4_t*>(p.add + idx);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
                 }
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
                     for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
                 }
                 if (do_mask) {
-                    const u32x4_t mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+                    const u32x4_t mv = pre_ok ? pre_mask[j * 2 + half] : *reinterpret_cast<const u32x4_t*>(p.mask + idx);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (!(bf_lo(mv[k]) > 0.f)) v[2 * k] = 0.f;
@@ -186,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
                     }
                 }
                 if (add_after) {
-                    const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                    const u32x4_t av = pre_ok ? pre_add[j * 2 + half] : *reinterpret_cast<const u32x4_t*>(p.add + idx);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
                 }
@@ -212,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParam
                 write_lds(step & 1, ra[u], rb[u]);
                 __syncthreads();
                 if (ls < total_steps) issue_load(ra[u], rb[u]);
+                if (pre_ok && c_kb == 0) prefetch_epi(c_tile);
                 compute(step & 1);
                 if (++c_kb == kblocks) {
                     epilogue(c_tile);
