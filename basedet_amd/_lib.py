@@ -113,6 +113,24 @@ SIGNATURES = {
     "bd_det_candidates": (_I, [_I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bd_det_finalize": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "bd_sgd_momentum_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _P]),
+    "bd_sigmoid_focal_loss_elem": (_I, [_P, _P, _L, _F, _F, _P, _P, _P, _P]),
+    "bd_bce_elem": (_I, [_P, _P, _L, _I, _P, _P, _P, _P]),
+    "bd_smooth_l1_elem": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "bd_iou_loss_ltrb": (_I, [_P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
+    "bd_iou_to_loss": (_I, [_P, _L, _I, _F, _P, _P]),
+    "bd_matcher_matrix": (_I, [_P, _I, _L, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "bd_assign_roi_levels": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "bd_roi_pool_max_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P, _P]),
+    "bd_comm_unique_id": (_I, [_P]),
+    "bd_comm_init": (_I, [C.POINTER(C.c_void_p), _P, _I, _I, _I]),
+    "bd_comm_rank": (_I, [_P]),
+    "bd_comm_world": (_I, [_P]),
+    "bd_comm_stream": (_P, [_P]),
+    "bd_comm_bcast": (_I, [_P, _P, _Z, _I, _I, _P]),
+    "bd_comm_allreduce": (_I, [_P, _P, _Z, _I, _I, _P]),
+    "bd_comm_allreduce_async": (_I, [_P, _P, _Z, _I, _I, C.POINTER(C.c_void_p), _I]),
+    "bd_comm_wait": (_I, [_P, _P]),
+    "bd_comm_destroy": (_I, [_P]),
     "bd_wgrad_set_transpose_read": (_I, [_I]),
     "bd_conv_set_patch3x3": (_I, [_I]),
 }

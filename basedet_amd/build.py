@@ -16,10 +16,8 @@ SOURCES = {
     "image_ops.hip": [],
     "conv_igemm.hip": [],
     "conv3x3.hip": [],
-    "conv3x3_w4.hip": [],
     "conv3x3_pp.hip": [],
     "conv3x3_pp128.hip": [],
-    "conv1x1.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad3x3.hip": [],
     "conv_wgrad1x1.hip": [],
@@ -31,6 +29,8 @@ SOURCES = {
     "ota.hip": ["-ffp-contract=off"],
     "losses.hip": [],
     "norm.hip": [],
+    "comm.hip": [],
+    "layer_ops.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
 

@@ -51,29 +51,88 @@ class ConfigDict(dict):
         return self
 
 
+class DetectionConfig(ConfigDict):
+    """configs/detection_cfg.py:23-106: the sections every model config shares, plus the builder methods the training entry
+    (tools/det_train.py:111) calls.  `DetectionConfig(cfg=None, **kwargs)`: later values win, as in the reference."""
+
+    def __init__(self, cfg=None, **kwargs):
+        super().__init__()
+        self.MODEL = dict(
+            NAME="", BATCHSIZE=2, WEIGHTS=None,
+            BACKBONE=dict(NAME="resnet50", IMG_MEAN=[103.530, 116.280, 123.675], IMG_STD=[57.375, 57.12, 58.395],
+                          NORM="FrozenBN", FREEZE_AT=2),                                   # extra_cfg.py:46-57
+        )
+        self.DATA = dict(BUILDER_NAME="DataloaderBuilder", NUM_CLASSES=80, NUM_WORKERS=2, ENABLE_INFINITE_SAMPLER=True,
+                         TRAIN=dict(name="coco_2017_train", remove_images_without_annotations=True,
+                                    order=("image", "boxes", "boxes_category", "info")),
+                         TEST=dict(name="coco_2017_val", remove_images_without_annotations=False, order=("image", "info")))
+        self.SOLVER = dict(BUILDER_NAME="DetSolver", OPTIMIZER_NAME="SGD", LR_SCHEDULER_NAME="MultiStepLR",
+                           BASIC_LR=0.01 / 16.0, WEIGHT_DECAY=1e-4, EXTRA_OPT_ARGS=dict(momentum=0.9),
+                           REDUCE_MODE="MEAN", EPOCHWISE_STEP=False, WARM_ITERS=500, NUM_IMAGE_PER_EPOCH=80000,
+                           MAX_EPOCH=18, LR_DECAY_STAGES=[12, 16], LR_DECAY_RATE=0.1,
+                           EXTRA_LR_ARGS=dict())                                           # extra_cfg.py:60-78
+        self.TRAINER = dict(NAME="DetTrainer", RESUME=False, AMP=dict(ENABLE=False, DYNAMIC_SCALE=False),
+                            EMA=dict(ENABLE=False, ALPHA=5e-4, MOMENTUM=None, UPDATE_PERIOD=1, BURNIN_ITER=2000),
+                            GRAD_CLIP=dict(ENABLE=False, TYPE="value", ARGS=dict(lower=-1, upper=1)))
+        self.HOOKS = dict(BUILDER_NAME="SimpleHookList")
+        self.TEST = dict(EVALUATOR_NAME="COCOEvaluator", IOU_THRESHOLD=0.5, CLS_THRESHOLD=0.05, MAX_BOXES_PER_IMAGE=100,
+                         IMG_MIN_SIZE=800, IMG_MAX_SIZE=1333, VIS_THRESHOLD=0.3, EVAL_EPOCH_INTERVAL=None)
+        self.AUG = dict(TRAIN_VALUE=(
+            ("MGE_ShortestEdgeResize", dict(min_size=(640, 672, 704, 736, 768, 800), max_size=1333, sample_style="choice")),
+            ("MGE_RandomHorizontalFlip", dict(prob=0.5)),
+            ("MGE_ToMode", dict(mode="CHW"))),
+            TRAIN_WRAPPER=(("MGE_Compose", dict(order=("image", "boxes", "boxes_category"))),))
+        self.GLOBAL = dict(OUTPUT_DIR="logs", CKPT_SAVE_DIR="/data/Outputs/model_logs/basedet_playground", LOG_INTERVAL=20,
+                           TENSORBOARD=dict(ENABLE=False))                                 # extra_cfg.py:35-44
+        if cfg:
+            self.merge(cfg)
+        if kwargs:
+            self.merge(kwargs)
+
+    def _override(self, cfg, kwargs):
+        if cfg:
+            self.merge(cfg)
+        if kwargs:
+            self.merge(kwargs)
+
+    # builders (detection_cfg.py:55-106) ------------------------------------------------------------------
+    def build_model(self):
+        from ..utils.registry import registers
+        from .. import models  # noqa: F401  (fills the registry)
+        return registers.models.get(self.MODEL.NAME)(self)
+
+    def build_solver(self, model):
+        from ..utils.registry import registers
+        from .. import solver  # noqa: F401
+        return registers.solvers.get(self.SOLVER.BUILDER_NAME).build(self, model)
+
+    def build_dataloader(self):
+        """The reference builds a COCO reader here (registers.dataloader, data/build.py) -- out of the hot-path scope.  The
+        synthetic loader of the reference's own benchmark harness (utils/dummy.py, tools/benchmark.py:173) stands in."""
+        from ..utils import DummyLoader
+        from .. import comm
+        return DummyLoader(self.MODEL.BATCHSIZE, tuple(self.DATA.get("DUMMY_SIZE", (800, 1344))), seed=comm.rank())
+
+    def build_trainer(self):
+        """detection_cfg.py:67-106: model (+ weights), parameter broadcast, dataloader, solver -> trainer."""
+        from ..engine import DetTrainer
+        from ..solver import broadcast_parameters
+        model = self.build_model()
+        if self.MODEL.WEIGHTS:
+            model.load_weights(self.MODEL.WEIGHTS)
+        broadcast_parameters(model)
+        return DetTrainer(self, model, self.build_dataloader(), self.build_solver(model))
+
+
 def _base():
-    cfg = ConfigDict()
-    cfg.MODEL = dict(
-        NAME="", BATCHSIZE=2, WEIGHTS=None,
-        BACKBONE=dict(NAME="resnet50", IMG_MEAN=[103.530, 116.280, 123.675], IMG_STD=[57.375, 57.12, 58.395],
-                      NORM="FrozenBN", FREEZE_AT=2),                                   # extra_cfg.py:46-57
-    )
-    cfg.DATA = dict(NUM_CLASSES=80)
-    cfg.SOLVER = dict(BUILDER_NAME="DetSolver", OPTIMIZER_NAME="SGD", LR_SCHEDULER_NAME="MultiStepLR",
-                      BASIC_LR=0.01 / 16.0, WEIGHT_DECAY=1e-4, EXTRA_OPT_ARGS=dict(momentum=0.9),
-                      REDUCE_MODE="MEAN", EPOCHWISE_STEP=False, WARM_ITERS=500, NUM_IMAGE_PER_EPOCH=80000,
-                      MAX_EPOCH=18, LR_DECAY_STAGES=[12, 16], LR_DECAY_RATE=0.1)       # extra_cfg.py:60-78
-    cfg.TRAINER = dict(NAME="DetTrainer", RESUME=False, AMP=dict(ENABLE=False, DYNAMIC_SCALE=False),
-                       GRAD_CLIP=dict(ENABLE=False))
-    cfg.TEST = dict(IOU_THRESHOLD=0.5, CLS_THRESHOLD=0.05, MAX_BOXES_PER_IMAGE=100)
-    return cfg
+    return DetectionConfig()
 
 
-class RetinaNetConfig(ConfigDict):
+class RetinaNetConfig(DetectionConfig):
     """basedet/configs/det_model/retinanet_cfg.py:5-56."""
 
-    def __init__(self):
-        super().__init__(_base())
+    def __init__(self, cfg=None, **kwargs):
+        super().__init__()
         self.merge(dict(MODEL=dict(
             NAME="RetinaNet",
             BACKBONE=dict(OUT_FEATURES=["res3", "res4", "res5"], OUT_FEATURE_CHANNELS=[512, 1024, 2048]),
@@ -86,13 +145,14 @@ class RetinaNetConfig(ConfigDict):
             MATCHER=dict(THRESHOLDS=[0.4, 0.5], LABELS=[0, -1, 1], ALLOW_LOW_QUALITY=True),
             HEAD=dict(NUM_CONVS=4, CLS_PRIOR_PROB=0.01),
         )))
+        self._override(cfg, kwargs)
 
 
 class FreeAnchorConfig(RetinaNetConfig):
     """basedet/configs/det_model/freeanchor_cfg.py:5-33.  The reference writes the key FOCLA_LOSS_ALPHA (:10), so the value the
     model reads, FOCAL_LOSS_ALPHA (free_anchor.py:132), keeps RetinaNet's 0.25; the stray key is carried as written."""
 
-    def __init__(self):
+    def __init__(self, cfg=None, **kwargs):
         super().__init__()
         self.merge(dict(MODEL=dict(
             NAME="FreeAnchor",
@@ -101,6 +161,7 @@ class FreeAnchorConfig(RetinaNetConfig):
             HEAD=dict(CLS_PRIOR_PROB=0.02),
             BUCKET=dict(BOX_IOU_THRESH=0.6, BUCKET_SIZE=50),
         )))
+        self._override(cfg, kwargs)
 
 
 def retinanet_r18_config():
@@ -111,11 +172,11 @@ def retinanet_r18_config():
     return cfg
 
 
-class FCOSConfig(ConfigDict):
+class FCOSConfig(DetectionConfig):
     """basedet/configs/det_model/fcos_cfg.py:7-56."""
 
-    def __init__(self):
-        super().__init__(_base())
+    def __init__(self, cfg=None, **kwargs):
+        super().__init__()
         self.merge(dict(MODEL=dict(
             NAME="FCOS",
             ANCHOR=dict(NUM_ANCHORS=1, OFFSET=0.5),
@@ -128,13 +189,14 @@ class FCOSConfig(ConfigDict):
                       OBJECT_SIZES_OF_INTEREST=[[-1, 64], [64, 128], [128, 256], [256, 512], [512, float("inf")]],
                       CENTER_SAMPLING_RADIUS=1.5),
         ), TEST=dict(IOU_THRESHOLD=0.6)))
+        self._override(cfg, kwargs)
 
 
-class FasterRCNNConfig(ConfigDict):
+class FasterRCNNConfig(DetectionConfig):
     """basedet/configs/det_model/faster_rcnn_cfg.py:5-78."""
 
-    def __init__(self):
-        super().__init__(_base())
+    def __init__(self, cfg=None, **kwargs):
+        super().__init__()
         self.merge(dict(MODEL=dict(
             NAME="FasterRCNN",
             BACKBONE=dict(OUT_FEATURES=["res2", "res3", "res4", "res5"], OUT_FEATURE_CHANNELS=[256, 512, 1024, 2048]),
@@ -151,21 +213,24 @@ class FasterRCNNConfig(ConfigDict):
             RCNN_BOX_REG=dict(MEAN=[0.0, 0.0, 0.0, 0.0], STD=[0.1, 0.1, 0.2, 0.2]),
             MATCHER=dict(THRESHOLDS=[0.3, 0.7], LABELS=[0, -1, 1], ALLOW_LOW_QUALITY=True),
         ), SOLVER=dict(BASIC_LR=0.02 / 16, WARM_ITERS=500, MAX_EPOCH=18, LR_DECAY_STAGES=[12, 16])))
+        self._override(cfg, kwargs)
 
 
 class ATSSConfig(FCOSConfig):
     """basedet/configs/det_model/atss_cfg.py:5-26 (FCOS with the ATSS assignment; the size-of-interest / centre-sampling keys go)."""
 
-    def __init__(self):
+    def __init__(self, cfg=None, **kwargs):
         super().__init__()
         self.merge(dict(MODEL=dict(NAME="ATSS", ANCHOR=dict(SCALE=8, TOPK=9), LOSSES=dict(REG_LOSS_WEIGHT=2.0))))
         del self.MODEL.HEAD["OBJECT_SIZES_OF_INTEREST"]
         del self.MODEL.HEAD["CENTER_SAMPLING_RADIUS"]
+        self._override(cfg, kwargs)
 
 
 class OTAConfig(FCOSConfig):
     """basedet/configs/det_model/ota_cfg.py:6-14: FCOS with the OTAPointHead flags and the top-k ("simOTA") matcher."""
 
-    def __init__(self):
+    def __init__(self, cfg=None, **kwargs):
         super().__init__()
         self.merge(dict(MODEL=dict(NAME="OTA", MATCHING="topk", HEAD=dict(WITH_NORM=True, SHARE_PARAM=True, NORM_REG_TARGETS=True))))
+        self._override(cfg, kwargs)

@@ -392,9 +392,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
 
 }  // namespace
 
-int g_patch_w4 = 0;       // bd_conv_set_patch3x3 bit 4: four-wave instance (conv3x3_w4.hip) for CK % 64 == 0
-int bd_conv3x3_patch4w_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
-                              const void* mask, void* dst, int flags, hipStream_t stream);
 int g_patch_pp = 2;       // 2 = wherever the shape allows (default), 1 = only where the makespan estimate favours it (bit 7), 0 = never (bit 6): staggered 256-channel-tile instance (conv3x3_pp.hip) for CO > 128, CK % 8 == 0
 int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                          const void* mask, void* dst, int flags, hipStream_t stream);
@@ -411,9 +408,6 @@ extern "C" int bd_conv3x3_set_debug(long long* buf) { g_patch_dbg = buf; return 
 // mode 1 dgrad (src = dY).  CK = reduction channels, CO = produced channels.
 int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias,
                             const void* add, const void* mask, void* dst, int flags, hipStream_t stream) {
-    if (g_patch_w4 && (mode == 0 ? d->Cin : d->Cout) % 64 == 0 &&
-        (long long)d->N * (mode == 0 ? d->in_pix_per_img : d->out_pix_per_img) * (mode == 0 ? d->Cin : d->Cout) < 0xffffffffll)
-        return bd_conv3x3_patch4w_launch(d, mode, src, w, bias, add, mask, dst, flags, stream);
     if (g_patch_pp && bd_conv3x3_pp_launch(d, mode, src, w, bias, add, mask, dst, flags, stream) == 0) return 0;
     if (g_patch_pp128 >= 0 && bd_conv3x3_pp128_launch(d, mode, src, w, bias, add, mask, dst, flags, stream) == 0) return 0;
     C3Params p{};

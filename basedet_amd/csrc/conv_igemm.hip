@@ -448,25 +448,19 @@ int g_bk32_for_1x1 = 1;
 // instead of two) run them 10-35 % faster as long as the grid still fills the chip (P6's 70-tile forward keeps BK=64).
 // bd_conv_set_patch3x3 bit 10 clears it.
 int g_bk32_s2 = 1;
-int g_stream_1x1 = 0;   // persistent 1x1 kernel (conv1x1.hip): correct, but 3 one-tile WGs/CU measured faster
 
 }  // namespace
 
 int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias,
                             const void* add, const void* mask, void* dst, int flags, hipStream_t stream);
 
-// debug/measurement knob: 0 forces the generic per-tap kernel for 3x3 stride-1 convolutions
-int bd_conv1x1_stream_launch(const IgemmParams& p, hipStream_t stream);
-
-// bit 0: 3x3 patch kernel, bit 1: BK=32 tiles for 1x1 in the generic kernel, bit 2: persistent streaming 1x1 kernel
+// debug/measurement knob: bit 0 clear forces the generic per-tap kernel for 3x3 stride-1 convolutions; bit 1: BK=32 tiles for 1x1
 extern int g_patch_dma;
-extern int g_patch_w4;
 extern int g_patch_pp;
 extern int g_patch_pp128;
 extern "C" int bd_conv_set_patch3x3(int enable) {
-    g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1; g_stream_1x1 = (enable >> 2) & 1;
+    g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1;
     g_patch_dma = ((enable >> 3) & 1) ^ 1;
-    g_patch_w4 = (enable >> 4) & 1;
     g_patch_pp = ((enable >> 6) & 1) ? 0 : (((enable >> 7) & 1) ? 1 : 2);
     g_patch_pp128 = ((enable >> 9) & 1) ? -1 : ((enable >> 8) & 1);
     g_bk32_s2 = ((enable >> 10) & 1) ^ 1;
@@ -511,8 +505,7 @@ extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w
     p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
     set_buffer_sizes(p, d->N);
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
-    if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0 && p.src_bytes && p.w_bytes) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
-    else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
+    if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
         launch_igemm<64>(p, (hipStream_t)stream);
     else launch_igemm<32>(p, (hipStream_t)stream);
     BD_CHECK_LAUNCH("bd_conv2d_fwd");
@@ -563,8 +556,7 @@ extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void*
     p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
     set_buffer_sizes(p, d->N);
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
-    if (g_stream_1x1 && p.R * p.S == 1 && p.pad == 0 && p.src_bytes && p.w_bytes) bd_conv1x1_stream_launch(p, (hipStream_t)stream);
-    else if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
+    if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
         launch_igemm<64>(p, (hipStream_t)stream);
     else launch_igemm<32>(p, (hipStream_t)stream);
     BD_CHECK_LAUNCH("bd_conv2d_dgrad");

@@ -1,4 +1,4 @@
-// Shared parameter block of the implicit-GEMM convolution kernels (conv_igemm.hip, conv1x1.hip).
+// Shared parameter block of the implicit-GEMM convolution kernels (conv_igemm.hip).
 #pragma once
 #include "common.h"
 

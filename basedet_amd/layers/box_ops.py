@@ -83,19 +83,36 @@ class AnchorPointGenerator:
 
 
 class Matcher:
-    """layers/common/matcher.py:19-51 for the two-threshold configuration used by RetinaNet / RPN
-    (labels [0, -1, 1]).  Takes boxes instead of a materialised IoU matrix: ``match(gt_boxes, anchors)``."""
+    """layers/common/matcher.py:19-51.  `matcher(matrix)` with a (G, A) similarity matrix -> (match_indices, labels), any number of
+    thresholds / labels (bd_matcher_matrix).  `match(gt_boxes, anchors)` is the fused form the training step uses: IoU, matching
+    and labelling without materialising the matrix (bd_retina_assign_encode; two thresholds, labels [0, -1, 1])."""
 
     def __init__(self, thresholds, labels, allow_low_quality_matches=False):
         assert len(thresholds) + 1 == len(labels), "thresholds and labels are not matched"
         assert all(low <= high for (low, high) in zip(thresholds[:-1], thresholds[1:]))
-        assert list(labels) == [0, -1, 1] and len(thresholds) == 2, "HIP Matcher supports labels [0, -1, 1]"
-        self.thresholds = list(thresholds)
-        self.labels = labels
+        thresholds = list(thresholds)                     # the reference mutates the caller's list in place (matcher.py:24-25)
+        self.inner_thresholds = thresholds
+        self.thresholds = [-float("inf")] + thresholds + [float("inf")]
+        self.labels = list(labels)
         self.allow_low_quality_matches = allow_low_quality_matches
+
+    def __call__(self, matrix):
+        assert len(matrix.shape) == 2
+        m = matrix.float().contiguous()
+        G, A = m.shape
+        dev = m.device
+        idx = torch.empty((A,), dtype=torch.int32, device=dev)
+        labels = torch.empty((A,), dtype=torch.int32, device=dev)
+        ws = torch.empty((max(G, 1),), dtype=torch.float32, device=dev)
+        from .._lib import check, f32arr, i32arr, ptr, stream_ptr
+        check(ops.L().bd_matcher_matrix(ptr(m), G, A, f32arr(self.inner_thresholds), i32arr(self.labels), len(self.inner_thresholds),
+                                        int(self.allow_low_quality_matches), ptr(idx), ptr(labels), ptr(ws), stream_ptr()),
+              "bd_matcher_matrix")
+        return idx, labels
 
     def match(self, gt_boxes_with_labels, anchors):
         """gt (G,5) with class in column 4 -> (match_indices, labels) with labels in {-1, 0, class}."""
+        assert list(self.labels) == [0, -1, 1] and len(self.inner_thresholds) == 2, "the fused matcher supports labels [0, -1, 1]"
         dev = anchors.device
         gt = gt_boxes_with_labels.reshape(1, -1, 5).contiguous().float()
         G = gt.shape[1]
@@ -108,7 +125,7 @@ class Matcher:
         ng = torch.tensor([G], dtype=torch.int32, device=dev)
         if G == 0:
             gt = torch.zeros((1, 1, 5), dtype=torch.float32, device=dev)
-        ops.retina_assign_encode(anchors, gt, ng, self.thresholds[0], self.thresholds[1], self.allow_low_quality_matches,
+        ops.retina_assign_encode(anchors, gt, ng, self.inner_thresholds[0], self.inner_thresholds[1], self.allow_low_quality_matches,
                                  (0, 0, 0, 0), (1, 1, 1, 1), labels, idx, offs, nfg, ws)
         return idx[0], labels[0]
 

@@ -6,8 +6,8 @@ Data-parallel detail (fcos.py:143-144): ``num_fg`` and ``sum_ctr`` are all-reduc
 are normalised -- one 2-float RCCL all-reduce in the forward pass.
 """
 import torch
-import torch.distributed as dist
 
+from .. import comm as _comm
 from .. import ops
 from ..utils.registry import registers
 from . import params as P
@@ -122,9 +122,9 @@ class FCOS(FPNDetector):
         gt = pre["gt_boxes"]
         num_gt = pre["img_info"][:, 4].to(torch.int32).contiguous()
         self._assign(pl, gt, num_gt)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(pl.stats, op=dist.ReduceOp.SUM)            # all_reduce(mode="mean") of num_fg and sum_ctr
-            pl.stats.mul_(1.0 / dist.get_world_size())
+        c = _comm.get_comm()
+        if c is not None and c.world > 1:
+            c.allreduce(pl.stats, "avg")                               # all_reduce(mode="mean") of num_fg and sum_ctr (fcos.py:143-144)
         pl.loss_buf.zero_()
         rows = pl.N * pl.pyr.pix_per_img
         assert m.LOSSES.IOU_LOSS_TYPE == "giou", "HIP FCOS path implements the giou ltrb loss"
@@ -244,9 +244,9 @@ class OTA(FCOS):
         gt = pre["gt_boxes"]
         num_gt = pre["img_info"][:, 4].to(torch.int32).contiguous()
         self._assign(pl, gt, num_gt)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(pl.stats, op=dist.ReduceOp.SUM)            # all_reduce(num_foreground, mode="mean") (:200)
-            pl.stats.mul_(1.0 / dist.get_world_size())
+        c = _comm.get_comm()
+        if c is not None and c.world > 1:
+            c.allreduce(pl.stats, "avg")                               # all_reduce(num_foreground, mode="mean") (ota.py:200)
         pl.loss_buf.zero_()
         rows = pl.N * pl.pyr.pix_per_img
         assert m.LOSSES.IOU_LOSS_TYPE == "giou", "HIP OTA path implements the giou ltrb loss"

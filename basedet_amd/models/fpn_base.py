@@ -352,7 +352,9 @@ class FPNDetector:
         """RetinaNet.pre_process (retinanet.py:90-107): H2D copy + pad to x32 + normalise (fused kernel)."""
         image = inputs["data"] if isinstance(inputs, dict) else inputs
         if not torch.is_tensor(image):
-            image = torch.as_tensor(np.asarray(image), dtype=torch.float32)
+            image = torch.as_tensor(np.asarray(image))
+        if not image.is_cuda:
+            image = self._host_to_device(image)
         image = image.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
         N, _, H, W = image.shape
         Hp, Wp = _round_up(H, 32), _round_up(W, 32)
@@ -361,13 +363,33 @@ class FPNDetector:
         out = {"plan": pl}
         if isinstance(inputs, dict) and "gt_boxes" in inputs:
             gt = torch.as_tensor(np.asarray(inputs["gt_boxes"]), dtype=torch.float32) if not torch.is_tensor(inputs["gt_boxes"]) else inputs["gt_boxes"]
-            out["gt_boxes"] = gt.to(self.device, dtype=torch.float32).contiguous()
+            gt = gt.to(self.device, dtype=torch.float32)
+            if gt.shape[1] == 0:
+                # a batch without a single annotation (the pad collator then yields (N, 0, 5)): one all-zero padding row keeps the
+                # assignment kernels' Gmax > 0 contract; num_gt (im_info[:, 4]) is 0, so every anchor / point is background
+                gt = torch.zeros((gt.shape[0], 1, 5), dtype=torch.float32, device=self.device)
+            out["gt_boxes"] = gt.contiguous()
         if isinstance(inputs, dict) and "im_info" in inputs:
             info = torch.as_tensor(np.asarray(inputs["im_info"]), dtype=torch.float32) if not torch.is_tensor(inputs["im_info"]) else inputs["im_info"]
         else:
             info = torch.tensor([[Hp, Wp, H, W, 0]] * N, dtype=torch.float32)
         out["img_info"] = info.to(self.device, dtype=torch.float32).contiguous()
         return out
+
+    def _host_to_device(self, image):
+        """data_to_input's `Tensor(image)` (layers/common/pre_processing.py:13): a host batch of any float dtype (the loaders yield
+        float64 / uint8-valued float32) becomes fp32 in a pinned staging buffer -- the conversion is torch's multi-threaded host copy
+        -- and goes to HBM with one asynchronous DMA on the current stream.  The staging buffer is reused: the next call first waits
+        for the previous transfer's event."""
+        st = getattr(self, "_stage", None)
+        if st is None or st[0].shape != image.shape:
+            st = self._stage = [torch.empty(image.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event()]
+        else:
+            st[1].synchronize()
+        st[0].copy_(image)
+        dev = st[0].to(self.device, non_blocking=True)
+        st[1].record()
+        return dev
 
     def _block_forward(self, blk, b, x):
         convs = blk["convs"]

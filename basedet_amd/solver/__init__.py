@@ -2,11 +2,12 @@
 
 lr = BASIC_LR * BATCHSIZE * world_size for MEAN reduction (:99-106); SGD(momentum, weight_decay) over the
 trainable parameter arena in ONE fused launch; gradients are all-reduced (mean) over RCCL in arena buckets that
-follow the backward order (head -> FPN -> layer4 -> ... -> layer2) on a side stream, overlapped with backward.
+follow the backward order (head -> FPN -> layer4 -> ... -> layer2) on the communicator's stream, overlapped with backward.
+The collectives are the bd_comm_* entry points of the C ABI (basedet_amd/comm.py); no c10d process group is involved.
 """
 import torch
-import torch.distributed as dist
 
+from .. import comm as _comm
 from .. import ops
 from ..utils.registry import registers
 
@@ -37,14 +38,14 @@ class GradBuckets:
     """Asynchronous bucketed all-reduce of the gradient arena (replaces dist.make_allreduce_cb,
     solver/default_solver.py:121).  Buckets = contiguous arena ranges closed in backward order."""
 
-    def __init__(self, model, mode="MEAN"):
+    def __init__(self, model, mode="MEAN", comm=None):
         self.model = model
         self.mode = mode
-        import os
-        force = os.environ.get("BD_FORCE_ALLREDUCE") == "1"       # exercise the RCCL path on a single GPU (tests)
-        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
-        self.world = dist.get_world_size() if self.enabled else 1
-        self.comm_stream = torch.cuda.Stream() if (self.enabled and torch.cuda.is_available()) else None
+        self.comm = comm if comm is not None else _comm.get_comm()
+        # a communicator of one rank (BD_FORCE_ALLREDUCE=1 in bench / tests) still sends every bucket through RCCL: the identity
+        # reduction exercises the stream plumbing on a single GPU
+        self.enabled = self.comm is not None
+        self.world = self.comm.world if self.enabled else 1
         self.ranges = self._ranges()
 
     def _ranges(self):
@@ -64,31 +65,22 @@ class GradBuckets:
 
     def on_ready(self, phase, producers=()):
         """All gradients of `phase` have been ENQUEUED on the current stream and on the `producers` streams (the weight-gradient
-        side stream): the communication stream waits for events on those streams -- the compute streams never wait for each other
-        or for the collective.
-
-        The collective is issued with async_op=False INSIDE the communication-stream context: for the NCCL/RCCL backend that does
-        not block the host, it orders the communication stream behind the collective (Work.wait() is a stream wait), and `wait()`
-        then joins that one stream.  Keeping the Work objects and waiting on them from the main stream at the end of the step
-        (async_op=True) measured 2.3 ms per step slower on the same box (470 vs 508 img/s with the RCCL path forced on one GPU,
-        even for 64-byte buffers: a per-call cost of pending work, not of the data)."""
+        side stream).  bd_comm_allreduce_async records an event on each of them, makes the communication stream wait for those
+        events and enqueues the collective there -- the compute streams never wait for each other or for the collective, and the
+        host does not block."""
         if not self.enabled or phase not in self.ranges:
             return
         lo, hi = self.ranges[phase]
         buf = self.model.arena.g[lo:hi]
-        if self.comm_stream is not None:
-            for st in (torch.cuda.current_stream(),) + tuple(s for s in producers if s is not None):
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=False)
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=False)      # CPU / gloo: completes before returning
+        prod = []
+        if buf.is_cuda:
+            prod = [torch.cuda.current_stream()] + [s for s in producers if s is not None]
+        self.comm.allreduce_async(buf, prod, "sum")
 
     def wait(self):
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        """The current stream (the SGD launch comes next) waits for every bucket; returns the gradient scale of the reduce mode."""
+        if self.enabled:
+            self.comm.wait()
         return 1.0 / self.world if (self.enabled and self.mode == "MEAN") else 1.0
 
 
@@ -112,8 +104,12 @@ class Solver:
 
 class WarmupMultiStepLR:
     """LRSchedulerHook.build_lr_scheduler (engine/hooks.py:222-248): MultiStepLR with iteration-wise milestones
-    (epochs * iters_per_epoch) wrapped in basecore's WarmUpScheduler (un-vendored; restated as a linear ramp
-    lr * (it + 1) / WARM_ITERS over the first WARM_ITERS iterations)."""
+    (epochs * iters_per_epoch) wrapped in basecore's WarmUpScheduler(scheduler, warmup_length=WARM_ITERS).
+
+    basecore is not vendored, so the SHAPE of its warm-up ramp is an assumption of this build (parity unpinned):
+    by default a linear ramp lr * (it + 1) / WARM_ITERS that reaches the base rate at the last warm-up iteration.  Two config keys
+    select the other common forms should basecore's differ: SOLVER.WARMUP_START_FACTOR = f ramps lr * (f + (1 - f) * it / WARM_ITERS)
+    (detectron-style, starts at f * lr); SOLVER.WARMUP_MODE = "constant" holds lr * f for the whole warm-up."""
 
     def __init__(self, optimizer, cfg, world_size=1):
         s = cfg.SOLVER
@@ -123,11 +119,19 @@ class WarmupMultiStepLR:
         self.milestones = [int(e) * iters_per_epoch for e in s.LR_DECAY_STAGES]
         self.gamma = s.LR_DECAY_RATE
         self.warm_iters = s.get("WARM_ITERS", 0)
+        self.warm_mode = s.get("WARMUP_MODE", "linear")
+        self.warm_start = s.get("WARMUP_START_FACTOR", None)
+        assert self.warm_mode in ("linear", "constant")
 
     def lr_at(self, it):
         lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if it >= m)
         if it < self.warm_iters:
-            lr *= (it + 1) / self.warm_iters
+            if self.warm_mode == "constant":
+                lr *= self.warm_start if self.warm_start is not None else 1.0 / self.warm_iters
+            elif self.warm_start is not None:
+                lr *= self.warm_start + (1.0 - self.warm_start) * it / self.warm_iters
+            else:
+                lr *= (it + 1) / self.warm_iters
         return lr
 
     def step(self, it):
@@ -141,7 +145,7 @@ class DetSolver:
         solver_cfg = cfg.SOLVER
         mode = solver_cfg.get("REDUCE_MODE", "MEAN")
         assert mode in ["MEAN", "SUM"]
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        world = _comm.world_size()
         lr = solver_cfg.BASIC_LR * cfg.MODEL.BATCHSIZE
         wd = solver_cfg.WEIGHT_DECAY
         if mode == "MEAN":
@@ -155,6 +159,7 @@ class DetSolver:
 
 def broadcast_parameters(model, src=0):
     """configs/detection_cfg.py:80-82 (dist.bcast_list_ of params and buffers) as one flat broadcast."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(model.arena.w, src=src)
+    c = _comm.get_comm()
+    if c is not None and c.world > 1:
+        c.bcast(model.arena.w, root=src)
         model.repack_trainable()

@@ -23,6 +23,22 @@ class Boxes(torch.Tensor):
     def _raw(self):
         return self.as_subclass(torch.Tensor).float().contiguous()
 
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        # results of tensor ops are plain tensors; only (N, 4) indexing results come back as Boxes (boxes.py:214-219)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+    def __getitem__(self, idx):
+        """structures/boxes.py:214-219: a (N, 4) result stays a Boxes, anything else is a plain tensor."""
+        out = self.as_subclass(torch.Tensor)[idx]
+        if out.ndim == 2 and out.shape[1] == 4:
+            out = Boxes(out)
+        return out
+
+    def numpy(self):
+        return self.as_subclass(torch.Tensor).detach().cpu().numpy()
+
     @property
     def centers(self):
         r = self._raw()
@@ -55,24 +71,65 @@ class Boxes(torch.Tensor):
         return ops.box_pairwise(self._raw(), torch.as_tensor(boxes).as_subclass(torch.Tensor).float().contiguous(), 3)
 
     def scale(self, scale_ratios, inplace=True):
+        """structures/boxes.py:190-212: scale_ratios = (height, width) factors, or one number for both."""
+        if torch.is_tensor(scale_ratios):
+            scale_ratios = scale_ratios.tolist()
         if isinstance(scale_ratios, (int, float)):
             scale_ratios = (scale_ratios, scale_ratios)
+        assert len(scale_ratios) == 2
         rh, rw = scale_ratios
-        t = self if inplace else self.clone()
-        r = t.as_subclass(torch.Tensor)
+        r = self.as_subclass(torch.Tensor)
+        if not inplace:
+            r = r.clone()
         r[:, 0::2] *= rw
         r[:, 1::2] *= rh
-        return t
+        return self if inplace else Boxes(r)
 
     def clip(self, sizes, inplace=True):
+        """structures/boxes.py:150-177: sizes = (height, width) of the image region."""
+        if torch.is_tensor(sizes):
+            sizes = sizes.tolist()
         if isinstance(sizes, (int, float)):
             sizes = (sizes, sizes)
+        assert len(sizes) == 2
         h, w = sizes
-        t = self if inplace else self.clone()
-        r = t.as_subclass(torch.Tensor)
+        r = self.as_subclass(torch.Tensor)
+        if not inplace:
+            r = r.clone()
         r[:, 0::2] = r[:, 0::2].clamp(0, w)
         r[:, 1::2] = r[:, 1::2].clamp(0, h)
-        return t
+        return self if inplace else Boxes(r)
+
+    def filter_by_size(self, sizes=0):
+        """structures/boxes.py:132-148: boolean keep mask of the boxes larger than `sizes`.  The reference binds `h, w = self.width,
+        self.height` (sic) and then tests `w > sizes[0]`, `h > sizes[1]`: sizes[0] is compared with the box HEIGHT and sizes[1] with
+        its WIDTH, i.e. sizes = (height, width) as documented; kept."""
+        if torch.is_tensor(sizes):
+            sizes = sizes.tolist()
+        if isinstance(sizes, (int, float)):
+            sizes = (sizes, sizes)
+        assert len(sizes) == 2
+        return (self.height > sizes[0]) & (self.width > sizes[1])
+
+    def cat(self, boxes, inplace=True):
+        """structures/boxes.py:179-188: concatenated boxes.  The reference's in-place branch assigns a longer tensor into `self[:]`,
+        which cannot succeed; both branches return the concatenation here."""
+        return Boxes(torch.cat([self.as_subclass(torch.Tensor), torch.as_tensor(boxes).as_subclass(torch.Tensor)], 0))
+
+
+def box_iou(boxes1, boxes2):
+    """structures/op_patch.py:81-97."""
+    return Boxes(torch.as_tensor(boxes1).as_subclass(torch.Tensor)).iou(boxes2)
+
+
+def box_ioa(boxes1, boxes2):
+    """structures/op_patch.py:211-227."""
+    return Boxes(torch.as_tensor(boxes1).as_subclass(torch.Tensor)).ioa(boxes2)
+
+
+def box_center(boxes):
+    """structures/op_patch.py:101-130."""
+    return Boxes(torch.as_tensor(boxes).as_subclass(torch.Tensor)).centers
 
 
 class BoxCoder:

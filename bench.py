@@ -1,37 +1,44 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec, training RetinaNet-R50-FPN on synthetic 1333x800 (padded 800x1344) images.
 
-Protocol = the reference's own harness (basedet/tools/benchmark.py:125-140): device sync, K full training steps
-(pre-process, forward, target assignment, losses, backward, gradient all-reduce, SGD + weight repack), device sync;
-inputs are DummyLoader-shaped (basedet/utils/dummy.py:8-63) and already resident in HBM.  One process per GPU;
-for N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RCCL over xGMI).
+One "step" = one full training step (pre-process, forward, target assignment, losses, backward, gradient all-reduce, SGD + weight
+repack) over one DummyLoader-shaped batch (basedet/utils/dummy.py:8-63).  The headline `value` times K steps between two device
+syncs (+ barrier for N > 1) with the batch ALREADY RESIDENT IN HBM (the fp32 NCHW -> bf16 NHWC conversion is inside the step).
+`reference_protocol` times the same step the way the reference's own harness does (basedet/tools/benchmark.py:125-140): the
+float64 host batch goes to the device inside the timed step and the device is synchronised before and after EVERY step; it is a
+second, PCIe-inclusive figure -- never `value`.
+
+One process per GPU.  `python bench.py --gpus N` starts the N rank processes itself (fresh children, before the parent touches the
+GPU; like the reference's harness, tools/benchmark.py:269); under `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N` the launcher's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are used as they are.  Collectives = bd_comm_* (RCCL over xGMI).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- the kernel with the largest share of the step (per-kernel entries: roofline_others).  Each conv kernel is priced
-                  against the roof its launches sit under: "mfma" (algorithmic FLOPs / time vs 2.5 PFLOP/s) when their arithmetic
-                  intensity exceeds the machine balance, else "hbm" (algorithmic bytes -- every operand once -- / time vs 8 TB/s);
-                  durations are HIP events on the launch stream during the timed steps, `traffic` the PMC-measured HBM bytes
+  roofline     -- the kernel with the largest share of the step (per-kernel entries: roofline_others).  Each kernel is priced against
+                  the roof its launches sit under: "mfma" (algorithmic FLOPs / time vs 2.5 PFLOP/s) when their arithmetic intensity
+                  exceeds the machine balance, else "hbm" (algorithmic bytes -- every operand once -- / time vs 8 TB/s); durations
+                  are HIP events on the launch stream during the timed steps, `traffic` the PMC-measured HBM bytes per launch
+                  (profiles/r02_pmc_traffic.json; refused -- null -- when it was collected on a different build of the kernels)
   cpu_baseline -- the CPU oracle's (oracle/model.py, torch-CPU fp32) training step on the host cores, bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 # HIP binds a stream to one of GPU_MAX_HW_QUEUES (default 4) hardware queues at its first use, sharing queues beyond that.  With
-# the process group up, RCCL's and c10d's streams come first and the weight-gradient side stream ended up on the MAIN stream's
-# queue: the two ran back to back (rocprofv3 kernel trace, Queue_Id column; scripts/queue_map.py).  Eight queues keep them apart.
+# RCCL's streams up the weight-gradient side stream ended up on the MAIN stream's queue: the two ran back to back (rocprofv3 kernel
+# trace, Queue_Id column; scripts/queue_map.py).  Eight queues keep them apart.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense")
+PEAK_FP8_TFLOPS = 5000.0      # dense fp8 (same table)
 PEAK_HBM_GBS = 8000.0         # HBM3E, ~8 TB/s (same guide)
 TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): convs only, 1 MAC = 2 FLOP
     "retinanet_r50_800x1344": 1435.6,
@@ -46,16 +53,19 @@ TRAIN_GFLOP_PER_IMG = {       # BASELINE.md section 3 / SURVEY.md section 8(d): 
     "faster_rcnn_r50_800x1344": 1177.2,
 }
 
+torch = None        # imported by the worker only: the launching parent never touches torch or the GPU
+np = None
 
-class ConvTimer:
-    """HIP-event timing + algorithmic FLOP accounting of every conv launch (fwd / dgrad / wgrad)."""
+
+class KernelTimer:
+    """HIP-event timing + algorithmic FLOP / byte accounting of the conv launches (fwd / dgrad / wgrad) and of the HBM-bound
+    elementwise kernels SURVEY section 8(d) names (focal loss, SGD, stem, max-pool, pad + normalise)."""
 
     def __init__(self, ops):
         self.ops = ops
         self.records = {}
         self.enabled = False
         self.meta = {}
-        self._orig = (ops.conv2d_fwd, ops.conv2d_dgrad, ops.conv2d_wgrad, ops.conv2d_wgrad_bias)
 
         def flops(d):
             m = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
@@ -116,6 +126,42 @@ class ConvTimer:
         ops.conv2d_wgrad = wrap(ops.conv2d_wgrad, "wgrad")
         ops.conv2d_wgrad_bias = wrap(ops.conv2d_wgrad_bias, "wgrad")
 
+        # ---- HBM-bound elementwise kernels: algorithmic bytes per launch from the call's own arguments
+        def wrap_stream(name, kern, nbytes_of):
+            fn = getattr(ops, name, None)
+            if fn is None:
+                return
+            import inspect
+            names = list(inspect.signature(fn).parameters)
+
+            def inner(*a, **k):
+                if not self.enabled:
+                    return fn(*a, **k)
+                kw = dict(zip(names, a), **k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = fn(*a, **k)
+                e.record()
+                self.records.setdefault(kern, []).append((s, e, 0.0))
+                self.meta.setdefault(kern, []).append((name, 0, 0, 0, 0, 0, 0, 0, float(nbytes_of(kw))))
+                return r
+            setattr(ops, name, inner)
+
+        # focal: 2 B logit read + 2 B gradient write per logit, 4 B label per row
+        wrap_stream("focal_loss_fwd_bwd", "focal_kernel", lambda k: k["rows"] * k["K"] * 4.0 + k["rows"] * 4.0)
+        # SGD: read w, v, g; write w, v (fp32)
+        wrap_stream("sgd_momentum_step", "sgd_kernel", lambda k: k["w"].numel() * 20.0)
+        # stem: bf16 [N][H+6][W+8][4] in, bf16 [N][H/2][W/2][64] out
+        wrap_stream("stem_conv7x7_fwd", "stem_conv_kernel",
+                    lambda k: k["N"] * ((k["H"] + 6) * (k["W"] + 8) * 8.0 + (k["H"] // 2) * (k["W"] // 2) * 128.0))
+        wrap_stream("stem_pool_fwd", "stem_pool_kernel",
+                    lambda k: k["N"] * ((k["H"] + 6) * (k["W"] + 8) * 8.0 + ((k["H"] // 2 - 1) // 2 + 1) * ((k["W"] // 2 - 1) // 2 + 1) * 128.0))
+        wrap_stream("maxpool3x3s2_fwd", "maxpool3x3s2_kernel",
+                    lambda k: k["N"] * k["Cn"] * 2.0 * (k["H"] * k["W"] + ((k["H"] - 1) // 2 + 1) * ((k["W"] - 1) // 2 + 1)))
+        # pad + normalise: fp32 NCHW in (3 channels), bf16 [N][Hp+6][Wp+8][4] out
+        wrap_stream("pad_normalize", "pad_normalize_kernel",
+                    lambda k: k["x"].numel() * 4.0 + k["x"].shape[0] * (k["Hp"] + 6) * (k["Wp"] + 8) * 8.0)
+
     def dump(self, steps):
         agg = {}
         for kind, rec in self.records.items():
@@ -124,7 +170,7 @@ class ConvTimer:
                 a = agg.setdefault(k, [0, 0.0, 0.0, 0.0])
                 a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f; a[3] += m[8]
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-        print("# per-shape conv time per step (ms), TFLOP/s", file=sys.stderr)
+        print("# per-shape kernel time per step (ms), TFLOP/s", file=sys.stderr)
         for k, (n, ms, fl, nb) in rows:
             print(f"# {k[0]:22s} {k[1]:14s} Cin={k[2]:5d} Cout={k[3]:5d} R={k[4]} s={k[5]} nseg={k[6]} HxW={k[7]}x{k[8]} "
                   f"launches/step={n // steps:3d} ms/step={ms / steps:7.3f} TF/s={fl / (ms * 1e-3) / 1e12:7.1f} "
@@ -140,8 +186,40 @@ class ConvTimer:
         return dict(launches=len(rec), ms=ms, flops=fl, bytes=nb)
 
 
-def cpu_baseline(cfg, params, seconds=20.0, batch=2, size=(800, 1344)):
-    """Oracle training step (fwd + bwd + SGD) on the host cores, bounded sample of the same workload."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_oracle_step(orc, b, lr, wd, min_iters, seconds):
+    """One warm-up iteration, then >= min_iters timed iterations (more while the budget lasts, at most 6)."""
+    state, t_all = {}, []
+    t_start = time.time()
+    it = 0
+    while True:
+        t0 = time.time()
+        losses, _ = orc.retinanet_losses(b)
+        g = orc.grads(losses["total_loss"])
+        orc.sgd_step(g, state, lr, 0.9, wd)
+        dt = time.time() - t0
+        it += 1
+        if it > 1:
+            t_all.append(dt)
+        if len(t_all) >= min_iters and (time.time() - t_start > seconds or len(t_all) >= 6):
+            break
+    return t_all
+
+
+def cpu_baseline(cfg, params, seconds=25.0, batch=2, size=(800, 1344)):
+    """Oracle training step (fwd + bwd + SGD) on the host cores: a bounded sample of the headline workload (batch 2 at full
+    resolution, >= 3 timed iterations -- SURVEY 8d) plus BASELINE config C1 (RetinaNet-R18, 2 x 512x512) in full."""
+    from basedet_amd.configs import retinanet_r18_config
     from basedet_amd.models import params as P
     from basedet_amd.utils import DummyLoader
     from oracle.model import Oracle
@@ -149,25 +227,21 @@ def cpu_baseline(cfg, params, seconds=20.0, batch=2, size=(800, 1344)):
     orc = Oracle(params, P.oracle_arch(cfg), trainable=names)
     b = next(DummyLoader(batch, size, seed=0))
     b["data"] = b["data"].astype(np.float32)
-    state = {}
-    lr = cfg.SOLVER.BASIC_LR * batch
-    t_all, iters = [], 0
-    t_start = time.time()
-    while True:
-        t0 = time.time()
-        losses, _ = orc.retinanet_losses(b)
-        g = orc.grads(losses["total_loss"])
-        orc.sgd_step(g, state, lr, 0.9, cfg.SOLVER.WEIGHT_DECAY)
-        dt = time.time() - t0
-        iters += 1
-        if iters > 1:
-            t_all.append(dt)          # first iteration = warm-up
-        if (time.time() - t_start > seconds and t_all) or iters >= 4:
-            break
+    t_all = _time_oracle_step(orc, b, cfg.SOLVER.BASIC_LR * batch, cfg.SOLVER.WEIGHT_DECAY, 3, seconds)
     mean = float(np.mean(t_all))
-    return dict(value=batch / mean, unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle/model.py torch-CPU fp32 RetinaNet-R50 step, batch {batch} x {size[0]}x{size[1]}, "
-                       f"{len(t_all)} timed iteration(s) after 1 warm-up, {mean:.2f} s/iter")
+    out = dict(value=round(batch / mean, 4), unit="images/sec", cores=torch.get_num_threads(), kind="port", cpu=_cpu_model(),
+               sample=f"oracle/model.py torch-CPU fp32 RetinaNet-R50 step, batch {batch} x {size[0]}x{size[1]}, "
+                      f"{len(t_all)} timed iterations after 1 warm-up, {mean:.2f} s/iter (min {min(t_all):.2f}, max {max(t_all):.2f})")
+    # C1: the reference's own CPU-runnable plumbing configuration
+    c1 = retinanet_r18_config()
+    p1 = P.init_retinanet_params(c1, seed=0)
+    o1 = Oracle(p1, P.oracle_arch(c1), trainable=P.trainable_names(p1, c1.MODEL.BACKBONE.FREEZE_AT))
+    b1 = next(DummyLoader(2, (512, 512), seed=0))
+    b1["data"] = b1["data"].astype(np.float32)
+    t1 = _time_oracle_step(o1, b1, c1.SOLVER.BASIC_LR * 2, c1.SOLVER.WEIGHT_DECAY, 3, 5.0)
+    out["c1_retinanet_r18_2x512x512"] = dict(value=round(2 / float(np.mean(t1)), 3), unit="images/sec",
+                                             sample=f"{len(t1)} timed iterations after 1 warm-up, {float(np.mean(t1)):.3f} s/iter")
+    return out
 
 
 def _stdout_to_stderr():
@@ -192,20 +266,74 @@ def _print_result(saved_fd, line):
     os.close(saved_fd)
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """The parent of a `python bench.py --gpus N` run: N fresh rank processes (one per GPU), started before this process has
+    imported torch or made any HIP call; relays rank 0's result line; non-zero exit if any rank fails.  The children are ended by
+    their exact PIDs if one of them dies."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    line = None
+    import threading
+
+    def _read():
+        nonlocal line
+        for ln in procs[0].stdout:
+            if ln.strip().startswith("{"):
+                line = ln.strip()
+
+    t = threading.Thread(target=_read, daemon=True)
+    t.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is not None:
+                alive.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    for o in alive:          # one rank failed: the others would wait in a collective forever
+                        procs[o].kill()
+        time.sleep(0.2)
+    t.join(5)
+    if line:
+        print(line, flush=True)
+    if rc == 0 and not line:
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--steps", type=int, default=100)      # the reference harness: 100 iterations ...
+    ap.add_argument("--warmup", type=int, default=20)     # ... of which 20 warm up (tools/benchmark.py:57-58)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 16; 32 for the fp8 R101 workload)")
     ap.add_argument("--workload", default="retinanet_r50_800x1344", choices=sorted(TRAIN_GFLOP_PER_IMG))
+    ap.add_argument("--fp8", action="store_true",
+                    help="fp8 (e4m3) weights for the forward / data-gradient convolutions (BASELINE config 5: retinanet_r101_800x1344)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--ref-protocol-steps", type=int, default=10,
+                    help="steps of the reference-protocol leg (host float64 batch in, device sync around every step); 0 = skip")
     ap.add_argument("--roofline-every", type=int, default=10,
-                    help="record per-conv HIP events on every n-th timed step (an event pair opens a ~10 us gap in the queue and the "
-                         "instrumented step keeps the weight gradients on the main stream: ~2.7 ms per instrumented step; with the "
-                         "default 10 steps one step is sampled and the headline stays within ~1 %% of an uninstrumented run)")
-    ap.add_argument("--dump-convs", action="store_true", help="per-shape conv timing table on stderr")
+                    help="record per-kernel HIP events on every n-th timed step (an event pair opens a ~10 us gap in the queue and the "
+                         "instrumented step keeps the weight gradients on the main stream: ~2.7 ms per instrumented step; the headline "
+                         "stays within ~1 %% of an uninstrumented run)")
+    ap.add_argument("--dump-convs", action="store_true", help="per-shape kernel timing table on stderr")
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight-gradient kernels on the main stream for the whole run (what the instrumented steps do): "
                          "use it under rocprofv3 so that per-kernel durations are not inflated by concurrent kernels")
@@ -213,20 +341,27 @@ def main():
                     help="ablation: bd_conv_set_patch3x3 bit mask (include/basedet_hip.h) applied before the run")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)          # does not return
+    worker(args)
+
+
+def worker(args):
+    global torch, np
+    import numpy as _np
+    import torch as _torch
+    torch, np = _torch, _np
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the basedet_amd path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     saved_stdout = _stdout_to_stderr()
-    import torch.distributed as dist
-    if world > 1 or os.environ.get("BD_FORCE_ALLREDUCE") == "1":
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
+    from basedet_amd import comm as bdcomm
     from basedet_amd import ops
     from basedet_amd.configs import (ATSSConfig, FasterRCNNConfig, FCOSConfig, FreeAnchorConfig, OTAConfig, RetinaNetConfig,
                                      retinanet_r18_config)
@@ -234,6 +369,14 @@ def main():
     from basedet_amd.solver import DetSolver, WarmupMultiStepLR, broadcast_parameters
     from basedet_amd.utils import DummyLoader
 
+    comm = None
+    if world > 1 or os.environ.get("BD_FORCE_ALLREDUCE") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        comm = bdcomm.set_comm(bdcomm.Comm.from_env())       # bd_comm_init: ncclCommInitRank over the env:// store
+
+    if args.batch is None:
+        args.batch = 32 if args.fp8 else 16
     if args.workload == "retinanet_r50_800x1344":
         cfg, size = RetinaNetConfig(), (800, 1344)
     elif args.workload == "fcos_r50_800x1344":
@@ -252,6 +395,8 @@ def main():
     else:
         cfg, size = retinanet_r18_config(), (512, 512)
     cfg.MODEL.BATCHSIZE = args.batch
+    if args.fp8:
+        cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
     # random-init weights of the named architecture; the last FrozenBN gamma of every residual branch is 0.2
     # (stand-in for ImageNet statistics: identity BN overflows a random ResNet-50; same FLOPs and bytes)
     if cfg.MODEL.NAME in ("FCOS", "ATSS", "OTA"):
@@ -268,33 +413,32 @@ def main():
     sched = WarmupMultiStepLR(solver.optimizer, cfg, world)     # LRSchedulerHook.before_iter (engine/hooks.py:218)
 
     loader = DummyLoader(args.batch, size, seed=rank)
-    b = next(loader)
+    host_batch = next(loader)                                   # data float64 on the host, as the reference's loader yields it
     batch = {
-        "data": torch.from_numpy(b["data"].astype(np.float32)).cuda(),      # resident in HBM before the timed region
-        "gt_boxes": torch.from_numpy(b["gt_boxes"]).cuda(),
-        "im_info": torch.from_numpy(b["im_info"]).cuda(),
+        "data": torch.from_numpy(host_batch["data"].astype(np.float32)).cuda(),      # resident in HBM before the timed region
+        "gt_boxes": torch.from_numpy(host_batch["gt_boxes"]).cuda(),
+        "im_info": torch.from_numpy(host_batch["im_info"]).cuda(),
     }
     if os.environ.get("BD_PATCH3X3"):
         ops.L().bd_conv_set_patch3x3(int(os.environ["BD_PATCH3X3"]))
-    timer = None if args.no_roofline else ConvTimer(ops)
+    timer = None if args.no_roofline else KernelTimer(ops)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None and world > 1:
+            comm.barrier()
 
     last = None
     it = 0
     if args.serial_wgrad:
         model.async_wgrad = False
     if args.conv_knob is not None:
-        from basedet_amd import ops as _ops
-        _ops.L().bd_conv_set_patch3x3(args.conv_knob)
+        ops.L().bd_conv_set_patch3x3(args.conv_knob)
     for _ in range(args.warmup):
         sched.step(it); it += 1
         last = solver.minimize(model, batch)
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]       # step boundaries on the main stream (p50 / p95)
     t0 = time.perf_counter()
     sampled = 0
     for k in range(args.steps):
@@ -305,30 +449,66 @@ def main():
             model.async_wgrad = not timer.enabled     # instrumented steps run serialised: clean per-kernel durations
         if args.serial_wgrad:
             model.async_wgrad = False
+        marks[k].record()
         last = solver.minimize(model, batch)
+    marks[args.steps].record()
     sync()
     elapsed = time.perf_counter() - t0
     if timer:
         timer.enabled = False
-    if world > 1:
+        model.async_wgrad = not args.serial_wgrad
+    if comm is not None and world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm.allreduce(t, "max")
         elapsed = float(t.item())
     loss = float(last["total_loss"])
     assert np.isfinite(loss), "training diverged"
+    step_ms = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)])
+
+    # ---- the reference harness's own protocol (tools/benchmark.py:125-133): host batch in, full device sync around every step
+    ref_proto = None
+    if args.ref_protocol_steps > 0:
+        hb = {"data": host_batch["data"], "gt_boxes": host_batch["gt_boxes"], "im_info": host_batch["im_info"]}
+        ts = []
+        for k in range(args.ref_protocol_steps + 2):
+            sched.step(it); it += 1
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            solver.minimize(model, hb)
+            torch.cuda.synchronize()
+            if k >= 2:
+                ts.append((time.perf_counter() - a) * 1e3)
+        if comm is not None and world > 1:
+            t = torch.tensor([float(np.mean(ts))], dtype=torch.float64, device="cuda")
+            comm.allreduce(t, "max")
+            mean_ms = float(t.item())
+        else:
+            mean_ms = float(np.mean(ts))
+        ref_proto = {"images_per_sec": round(args.batch * world / (mean_ms * 1e-3), 2), "ms_per_step_mean": round(mean_ms, 3),
+                     "ms_p50": round(float(np.percentile(ts, 50)), 3), "ms_p95": round(float(np.percentile(ts, 95)), 3),
+                     "steps": len(ts),
+                     "protocol": "basedet/tools/benchmark.py:125-133: float64 host batch -> fp32 -> H2D inside the step "
+                                 "(pinned staging buffer), torch.cuda.synchronize() before and after every step; 2 untimed steps first"}
 
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / elapsed
+        name = args.workload + ("_fp8w" if args.fp8 else "")
         out = {
-            "metric": "images/sec training RetinaNet-R50-FPN 1333x800" if args.workload == "retinanet_r50_800x1344" else "images/sec training " + args.workload,
+            "metric": "images/sec training RetinaNet-R50-FPN 1333x800" if name == "retinanet_r50_800x1344" else "images/sec training " + name,
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.workload} train step (fwd+bwd+allreduce+SGD), DummyLoader boxes, random-init weights",
+            "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 activations / fp8-e4m3 weights (fwd + dgrad), fp32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": f"{name} train step (fwd+bwd+allreduce+SGD), DummyLoader boxes, random-init weights, "
+                                   "inputs resident in HBM",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "final_loss": round(loss, 4)},
+            "step_ms_p50": round(float(np.percentile(step_ms, 50)), 3), "step_ms_p95": round(float(np.percentile(step_ms, 95)), 3),
+            "step_ms_note": "device time between step boundaries on rank 0's main stream (HIP events), instrumented steps included",
         }
+        if ref_proto:
+            out["reference_protocol"] = ref_proto
         gf = TRAIN_GFLOP_PER_IMG[args.workload]
         out["config"]["train_gflop_per_img"] = gf
         out["config"]["whole_step_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
@@ -336,13 +516,18 @@ def main():
             timer.dump(sampled)
         if timer:
             entries = []
-            # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the bench):
-            # valid for the workload / batch they were collected on, null otherwise
-            pmc = {}
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if args.workload == "retinanet_r50_800x1344" and args.batch == 16 and os.path.exists(pmc_path):
+            # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the bench): valid for the
+            # workload / batch AND the kernel build they were collected on (source digest recorded by scripts/pmc_traffic.py)
+            pmc, pmc_note = {}, None
+            pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if name == "retinanet_r50_800x1344" and args.batch == 16 and os.path.exists(pmc_path):
+                from basedet_amd import build as _b
                 with open(pmc_path) as f:
-                    pmc = json.load(f).get("kernels", {})
+                    rec = json.load(f)
+                if rec.get("build_digest") == _b._digest():
+                    pmc = rec.get("kernels", {})
+                else:
+                    pmc_note = "profiles/r02_pmc_traffic.json was collected on a different build of csrc/: traffic refused (null)"
             for kern in timer.records:
                 sm = timer.summary(kern)
                 tf = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
@@ -363,14 +548,14 @@ def main():
             entries.sort(key=lambda e: -e["ms_per_step"])
             out["roofline"] = entries[0]                 # the dominant kernel of the step
             out["roofline_others"] = entries[1:]
-        if world == 1 and not args.no_cpu_baseline and args.workload == "retinanet_r50_800x1344":
+            if pmc_note:
+                out["roofline_traffic_note"] = pmc_note
+        if world == 1 and not args.no_cpu_baseline and name == "retinanet_r50_800x1344":
             out["cpu_baseline"] = cpu_baseline(cfg, params)
         _print_result(saved_stdout, json.dumps(out))
-    if dist.is_initialized():
-        dist.barrier()
-        torch.cuda.synchronize()
-        # every rank is past its last collective: leave without the process-group teardown (c10d's watchdog / heartbeat threads can
-        # hold a finished process for minutes -- one GPU test run here took 10 min instead of 1 with all tests passing)
+    if comm is not None:
+        comm.barrier()
+        # every rank is past its last collective: leave without tearing the communicator down
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(0)
 

@@ -91,10 +91,10 @@ int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const void* g, co
                          int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
 /* debug/measurement knob, bit mask (default 3): bit 0 = 3x3/stride-1 forward and dgrad use the patch kernel
- * (conv3x3.hip); bit 1 = BK=32 tiles for 1x1 convs in the generic kernel; bit 2 = persistent streaming 1x1 kernel
- * (conv1x1.hip).  0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip).
+ * (conv3x3.hip); bit 1 = BK=32 tiles for 1x1 convs in the generic kernel; bit 2 = unused.
+ * 0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip).
  * Ablation bits (set = feature OFF unless noted): bit 3 = register-staged instead of LDS-DMA weights in the patch kernel;
- * bit 4 = (set = ON) experimental four-wave patch instance; bit 5 = no early epilogue-operand prefetch in the generic kernel;
+ * bit 4 = unused; bit 5 = no early epilogue-operand prefetch in the generic kernel;
  * bit 6 = no staggered 256-channel patch instance (conv3x3_pp.hip; by default taken for every Cout > 128, Cin % 8 == 0 shape);
  * bit 7 = take it only where its grid fills the chip better than the 128-channel instance's (makespan estimate);
  * bit 8 = (set = ON) staggered 128-channel patch instance (conv3x3_pp128.hip) for every other 3x3/stride-1 shape (its 64-channel
@@ -476,6 +476,76 @@ int bd_det_finalize(const float* boxes, const float* scores, const int32_t* labe
  * ------------------------------------------------------------------------------------------------------- */
 int bd_sgd_momentum_step(float* w, float* v, const float* g, int64_t n, float lr, float momentum, float wd,
                          float grad_scale, bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Operator surface of basedet.layers / basedet.structures as stand-alone fp32 entry points (callers written against the
+ * reference's Python signatures; the training step uses the fused label-driven kernels above).  Every *_elem function
+ * writes loss (value per element, may be NULL) and/or the gradient w.r.t. the prediction times gout (NULL = ones).
+ * ------------------------------------------------------------------------------------------------------- */
+/* sigmoid_focal_loss(logits, targets, alpha=-1, gamma=0) (layers/losses/sigmoid_focal_loss.py:9-36). */
+int bd_sigmoid_focal_loss_elem(const float* logits, const float* targets, int64_t n, float alpha, float gamma, const float* gout,
+                               float* loss, float* dlogits, bd_stream_t stream);
+/* binary_cross_entropy(pred, label, with_logits=True) (layers/losses/cross_entropy.py:7-29). */
+int bd_bce_elem(const float* pred, const float* label, int64_t n, int with_logits, const float* gout, float* loss, float* dpred,
+                bd_stream_t stream);
+/* smooth_l1_loss(pred, target, beta=1.0) (layers/losses/smooth_l1_loss.py:7-34); beta < 1e-5 = L1. */
+int bd_smooth_l1_elem(const float* pred, const float* target, int64_t n, float beta, const float* gout, float* loss, float* dpred,
+                      bd_stream_t stream);
+/* iou_loss(pred, target, box_mode="ltrb", loss_type, eps) (layers/losses/iou_loss.py:9-56,59-105), row-wise on [n][4] distances.
+ * loss_type: 0 "iou" (-log clip(iou, eps)), 1 "linear_iou", 2 "giou", 3 "square_iou".  ious gets iou (giou for type 2). */
+int bd_iou_loss_ltrb(const float* pred, const float* target, int64_t n, int loss_type, float eps, const float* gout, float* loss,
+                     float* ious, float* dpred, bd_stream_t stream);
+/* the loss map of iou_loss applied to an already computed iou / giou array (its xyxy branch works on the PAIRWISE matrix of
+ * Boxes.iou / Boxes.giou, iou_loss.py:83-91: bd_box_pairwise mode 0 / 3, then this). */
+int bd_iou_to_loss(const float* ious, int64_t n, int loss_type, float eps, float* loss, bd_stream_t stream);
+/* Matcher.__call__(matrix) (layers/common/matcher.py:31-51): matrix fp32 [G][A]; per column max / argmax (first maximum), label of
+ * the band [thr[k-1], thr[k]) the maximum falls in (thresholds padded with -inf / +inf as the reference does), and with
+ * allow_low_quality label 1 for every column that equals some row's maximum.  ws_rowmax: G floats. */
+int bd_matcher_matrix(const float* matrix, int G, int64_t A, const float* thresholds_host, const int32_t* labels_host, int n_thresholds,
+                      int allow_low_quality, int32_t* match_idx, int32_t* labels, float* ws_rowmax, bd_stream_t stream);
+/* assign_rois (layers/common/roi_pool.py:12-25): level index (0-based from min_level) of rois [R][ld], ld 4 (xyxy) or 5 (index + xyxy). */
+int bd_assign_roi_levels(const float* rois, int ld, int R, int min_level, int max_level, int32_t* levels, bd_stream_t stream);
+/* roi_pool(pooler_type="roi_pool") = F.nn.roi_pooling(mode="max") (roi_pool.py:65): Caffe ROIPooling on one fp32 NCHW level.
+ * rois5 [R][5] = (batch index, x1, y1, x2, y2); out fp32 [R][C][PH][PW]. */
+int bd_roi_pool_max_fwd(const float* feat_nchw, int N, int C, int H, int W, const float* rois5, int R, float scale, int PH, int PW,
+                        float* out, bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Data-parallel collectives (RCCL over xGMI; one communicator per process / GPU).  Replaces
+ *   dist.bcast_list_(model.parameters() / buffers())      configs/detection_cfg.py:80-82      -> bd_comm_bcast
+ *   dist.make_allreduce_cb(reduce_mode) on GradManager     solver/default_solver.py:58-63,121  -> bd_comm_allreduce_async + bd_comm_wait
+ *   all_reduce_mean(num_fg), all_reduce_mean(sum_ctr)      models/det/fcos.py:143-144          -> bd_comm_allreduce (caller's stream)
+ * RCCL is resolved with dlopen at the first bd_comm_* call (an already mapped copy, else $BD_RCCL_LIB, else
+ * /opt/rocm/lib/librccl.so.1).  Rendezvous of the 128-byte id (rank 0 -> all) is the caller's business (a TCP store, MPI, a file).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct bd_comm* bd_comm_t;
+#define BD_COMM_ID_BYTES 128
+#define BD_COMM_F32 0
+#define BD_COMM_BF16 1
+#define BD_COMM_I32 2
+#define BD_COMM_F64 3
+#define BD_COMM_SUM 0
+#define BD_COMM_MAX 1
+#define BD_COMM_AVG 2   /* sum / world (ncclAvg) */
+
+/* rank 0: fill id128_host (HOST memory, BD_COMM_ID_BYTES) with a fresh ncclUniqueId. */
+int bd_comm_unique_id(void* id128_host);
+/* collective over all ranks: ncclCommInitRank on `device`; creates the communicator's own high-priority communication stream. */
+int bd_comm_init(bd_comm_t* comm, const void* id128_host, int rank, int world, int device);
+int bd_comm_rank(bd_comm_t comm);
+int bd_comm_world(bd_comm_t comm);
+bd_stream_t bd_comm_stream(bd_comm_t comm);
+/* in-place broadcast of `count` elements from `root`, ordered on `stream`. */
+int bd_comm_bcast(bd_comm_t comm, void* buf, size_t count, int dtype, int root, bd_stream_t stream);
+/* in-place all-reduce ordered on the CALLER's stream (small forward-side exchanges). */
+int bd_comm_allreduce(bd_comm_t comm, void* buf, size_t count, int dtype, int op, bd_stream_t stream);
+/* in-place all-reduce on the communication stream, after everything enqueued so far on the `producers` streams
+ * (n_producers <= 8; host array of hipStream_t).  Returns at once; the compute streams are not touched. */
+int bd_comm_allreduce_async(bd_comm_t comm, void* buf, size_t count, int dtype, int op, const bd_stream_t* producers_host,
+                            int n_producers);
+/* `consumer` waits (stream-side) for every collective enqueued so far on the communication stream. */
+int bd_comm_wait(bd_comm_t comm, bd_stream_t consumer);
+int bd_comm_destroy(bd_comm_t comm);
 
 #ifdef __cplusplus
 }

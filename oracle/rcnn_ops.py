@@ -4,12 +4,17 @@ This file is NOT part of the product path.  Only ``tests/``, ``__graft_entry__.s
 ``cpu_baseline`` leg of ``bench.py`` may import it.  Every function cites the reference file:line it restates
 (paths relative to the reference repo ``basedet/``).
 
-PARITY UNPINNED: the reference holds no test or golden vector for RPN / RCNN / roi_pool / sample_labels, and it
-cannot be imported here (megengine / basecore are absent).  Two pieces live inside MegEngine itself (an un-vendored
-dependency, ``megengine>=1.8`` in the reference's requirements) and are restated from their published algorithms:
+PARITY: RoIAlign and max RoI pooling are PINNED by the reference's own known-answer tests (tests/layers/test_roi_pool.py:32-61: the
+two 4x4 matrices on the 5x5 arange map; :64-75: invariance under a 2x bilinear upsampling at stride 1/2), carried as data in
+tests/golden/reference_kat.npz and asserted on this file by tests/test_oracle_rcnn_cpu.py (and on the HIP kernels by
+tests/test_rcnn_ops_gpu.py / tests/test_layers_gpu.py).  PARITY UNPINNED for the rest (RPN / RCNN target sampling, proposal
+selection, the losses): the reference holds no vector for them and cannot be imported here (megengine / basecore are absent).
+Two pieces live inside MegEngine itself (an un-vendored dependency, ``megengine>=1.8`` in the reference's requirements) and are
+restated from their published algorithms:
   * ``F.nn.roi_align(mode="average", sample_points=2, aligned=True)`` -- the Detectron / caffe2 RoIAlign the MegEngine
     kernel is derived from (bilinear_interpolate with the [-1, size] validity window, continuous coordinates shifted
-    by -0.5 when aligned, no minimum RoI size when aligned);
+    by -0.5 when aligned, no minimum RoI size when aligned); ``F.nn.roi_pooling(mode="max")`` -- Caffe's ROIPooling (rounded
+    corners, inclusive extent, floor / ceil bin edges);
   * ``F.topk`` -- k > 0 smallest / k < 0 largest, so ``sample_labels`` (sampling.py:27) with its negative k marks the
     entries with the LARGEST random keys as ignored.
 Documented choices where the reference is silent or random:
@@ -204,6 +209,26 @@ def roi_align(feats, rois, batch_idx, strides, PH=7, PW=7, S=2):
                 y0, y1, x0, x1, w00, w01, w10, w11 = p
                 acc += w00 * f[y0, x0] + w01 * f[y0, x1] + w10 * f[y1, x0] + w11 * f[y1, x1]
             out[r, b] = acc * F32(1.0 / (S * S))
+    return out
+
+
+def roi_pool_max(feat, rois5, scale, PH, PW):
+    """roi_pool(..., "roi_pool") = F.nn.roi_pooling(mode="max") (roi_pool.py:65) on one level: Caffe ROIPooling.
+    feat (N, C, H, W), rois5 (R, 5) = (batch index, x1, y1, x2, y2) -> (R, C, PH, PW); an empty bin gives 0."""
+    feat = np.asarray(feat, F32)
+    _, C, H, W = feat.shape
+    out = np.zeros((len(rois5), C, PH, PW), F32)
+    for r, roi in enumerate(np.asarray(rois5, F32)):
+        n = int(roi[0])
+        x1, y1, x2, y2 = [int(np.floor(F32(v) * F32(scale) + F32(0.5))) for v in roi[1:]]      # C roundf for non-negative inputs
+        rw, rh = max(x2 - x1 + 1, 1), max(y2 - y1 + 1, 1)
+        bh, bw = F32(rh) / F32(PH), F32(rw) / F32(PW)
+        for ph in range(PH):
+            hs = min(max(int(np.floor(F32(ph) * bh)) + y1, 0), H); he = min(max(int(np.ceil(F32(ph + 1) * bh)) + y1, 0), H)
+            for pw in range(PW):
+                ws = min(max(int(np.floor(F32(pw) * bw)) + x1, 0), W); we = min(max(int(np.ceil(F32(pw + 1) * bw)) + x1, 0), W)
+                if he > hs and we > ws:
+                    out[r, :, ph, pw] = feat[n, :, hs:he, ws:we].max(axis=(1, 2))
     return out
 
 

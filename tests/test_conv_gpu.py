@@ -41,7 +41,7 @@ def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops = _ops()
     # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel;
     # 2: specialised kernels without any staggered instance (bits 6 + 9); 3: the staggered 128 / 64-channel instances everywhere (bits 6 + 8)
-    ops.L().bd_conv_set_patch3x3({0: 0, 1: 7, 2: 7 | 64 | 512, 3: 7 | 64 | 256}[patch3x3])
+    ops.L().bd_conv_set_patch3x3({0: 0, 1: 3, 2: 3 | 64 | 512, 3: 3 | 64 | 256}[patch3x3])
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -92,7 +92,7 @@ def test_conv_fwd_dgrad_wgrad(case, patch3x3):
         ops.conv2d_wgrad(d, xp, nchw_to_pm(gy), dw, ws, row_scale=scale.cuda(), accumulate=True)
         assert rel_l2(dw.cpu(), ref_dw * (1 + scale.view(-1, 1, 1, 1))) < 2e-3
     ops.L().bd_wgrad_set_transpose_read(1)
-    ops.L().bd_conv_set_patch3x3(7)
+    ops.L().bd_conv_set_patch3x3(3)
 
 
 @pytest.mark.parametrize("chans", [(64, 72), (192, 256)])
@@ -100,7 +100,7 @@ def test_conv_multilevel_head_layout(chans):
     """Five pyramid levels through one launch (RetinaNetHead weight sharing, retina_head.py:103-112).  (192, 256): the staggered
     256-channel patch instance on a multi-segment descriptor, forward and dgrad."""
     ops = _ops()
-    ops.L().bd_conv_set_patch3x3(7)
+    ops.L().bd_conv_set_patch3x3(3)
     N, (C, Cout) = 2, chans
     Hs, Ws = [12, 6, 3, 2, 1], [20, 10, 5, 3, 2]
     g = torch.Generator().manual_seed(7)
@@ -141,7 +141,7 @@ def test_conv_multilevel_head_layout(chans):
         got = dxv[:, geo.off[i]: geo.off[i] + Hs[i] * Ws[i]].reshape(N, Hs[i], Ws[i], C).permute(0, 3, 1, 2)
         assert rel_l2(got, xr.grad) < TOL, f"dgrad level {i}"
     assert rel_l2(dw.cpu(), oihw_to_ohwi(ref_dw)) < 2e-3
-    ops.L().bd_conv_set_patch3x3(7)
+    ops.L().bd_conv_set_patch3x3(3)
 
 
 def test_stem_conv_and_pad_normalize():
@@ -280,7 +280,7 @@ def test_patch_instances_agree_bitwise(shape):
     gy = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
     addx = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
     outs = []
-    for knob in (7 | 64 | 512, 7, 7 | 64 | 256):
+    for knob in (3 | 64 | 512, 3, 3 | 64 | 256):
         ops.L().bd_conv_set_patch3x3(knob)
         y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
         dx = torch.full((gin.pixels, Cin), 3.0, device="cuda", dtype=torch.bfloat16)
@@ -289,7 +289,7 @@ def test_patch_instances_agree_bitwise(shape):
             ops.conv2d_dgrad(d, gy, wt, dx, add=addx, mask=addx, flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
         torch.cuda.synchronize()
         outs.append((y.clone(), dx.clone()))
-    ops.L().bd_conv_set_patch3x3(7)
+    ops.L().bd_conv_set_patch3x3(3)
     for k in (1, 2):          # both staggered instances against the plain 128-channel kernel
         assert torch.equal(outs[0][0], outs[k][0])
         assert torch.equal(outs[0][1], outs[k][1])

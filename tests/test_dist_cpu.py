@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world-size-2 gloo run of the solver's bucketed gradient all-reduce (GradBuckets), the
 world-size LR scaling of DetSolver.build (solver/default_solver.py:99-106) and the flat parameter broadcast
-(configs/detection_cfg.py:80-82).  No kernels are launched: the arenas are plain CPU tensors."""
+(configs/detection_cfg.py:80-82).  No kernels are launched: the arenas are plain CPU tensors and the transport is
+comm.GlooComm (the GPU path's transport is the bd_comm_* C ABI over RCCL: tests/test_dist_gpu.py)."""
 import os
 import socket
 
@@ -39,8 +40,10 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basedet_amd import comm
     from basedet_amd.configs import RetinaNetConfig
     from basedet_amd.solver import DetSolver, GradBuckets, broadcast_parameters
+    comm.set_comm(comm.GlooComm())       # CPU stand-in with the interface of the bd_comm_* wrapper
     model = _FakeModel()
     cfg = RetinaNetConfig()
     cfg.MODEL.BATCHSIZE = 16
@@ -98,3 +101,9 @@ def test_lr_schedule_restates_reference_hook():
     assert s.milestones == [12 * ipe, 16 * ipe]
     assert np.isclose(s.lr_at(0), 0.01 / 500) and np.isclose(s.lr_at(499), 0.01) and np.isclose(s.lr_at(5000), 0.01)
     assert np.isclose(s.lr_at(12 * ipe), 0.001) and np.isclose(s.lr_at(16 * ipe + 3), 0.0001)
+    # the warm-up shape is configurable (basecore's WarmUpScheduler is not vendored: the default ramp is an assumption)
+    cfg.SOLVER.WARMUP_START_FACTOR = 0.001
+    s2 = WarmupMultiStepLR(opt, cfg, world_size=1)
+    assert np.isclose(s2.lr_at(0), 0.01 * 0.001) and np.isclose(s2.lr_at(250), 0.01 * (0.001 + 0.999 * 0.5)) and np.isclose(s2.lr_at(500), 0.01)
+    cfg.SOLVER.WARMUP_MODE = "constant"
+    assert np.isclose(WarmupMultiStepLR(opt, cfg, world_size=1).lr_at(499), 0.01 * 0.001)

@@ -1,0 +1,77 @@
+"""Drop-in check of the `basedet` import alias (CPU; no kernels run).
+
+1. In the build container only (skipped where /root/reference is absent, e.g. on the GPU box): the reference's own
+   playground/examples/retinanet/res50_coco_800size_1x/config.py is imported BY PATH against the alias -- `from basedet.configs import
+   RetinaNetConfig` resolves to this repo -- and its `Cfg()` instantiates; the names the training entry resolves from it
+   (registers.models / registers.solvers / registers.trainers, tools/det_train.py:111, configs/detection_cfg.py:55-63) exist.
+   `megfile` (a path-joining helper the config imports; not installed here) is stood in by os.path.join for the duration of the test.
+2. Everywhere: the alias exposes the operator surface under the reference's module paths and names."""
+import importlib.util
+import os
+import sys
+import types
+
+import pytest
+
+REF_CFG = "/root/reference/playground/examples/retinanet/res50_coco_800size_1x/config.py"
+
+
+def _load_by_path(path):
+    spec = importlib.util.spec_from_file_location("playground_cfg_under_test", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("rel", ["retinanet/res50_coco_800size_1x", "fcos", "faster_rcnn/res50_coco_800size_1x", "atss", "freeanchor", "ota"])
+def test_reference_playground_config_loads_against_the_alias(rel, monkeypatch):
+    path = os.path.join("/root/reference/playground/examples", rel, "config.py")
+    if not os.path.exists(path):
+        pytest.skip(path + " absent")
+    import basedet  # noqa: F401  (the alias package at the repo root)
+    if "megfile" not in sys.modules:
+        stub = types.ModuleType("megfile")
+        stub.smart_path_join = lambda *a: os.path.join(*a)
+        monkeypatch.setitem(sys.modules, "megfile", stub)
+    cfg = _load_by_path(path).Cfg()
+    from basedet.configs import DetectionConfig
+    from basedet.utils import registers
+    import basedet.models, basedet.solver, basedet.engine  # noqa: F401,E401
+    assert isinstance(cfg, DetectionConfig)
+    assert cfg.GLOBAL.OUTPUT_DIR.endswith(os.path.join("examples", rel))
+    model_cls = registers.models.get(cfg.MODEL.NAME)
+    solver_builder = registers.solvers.get(cfg.SOLVER.BUILDER_NAME)
+    trainer_cls = registers.trainers.get(cfg.TRAINER.NAME)
+    assert callable(model_cls) and hasattr(solver_builder, "build") and hasattr(trainer_cls, "train")
+    assert hasattr(cfg, "build_model") and hasattr(cfg, "build_solver") and hasattr(cfg, "build_trainer")
+    # the values the hot path reads are the reference's (configs/det_model/*.py, configs/extra_cfg.py)
+    assert cfg.SOLVER.REDUCE_MODE == "MEAN" and cfg.MODEL.BACKBONE.FREEZE_AT == 2 and cfg.DATA.NUM_CLASSES == 80
+
+
+def test_alias_exposes_the_operator_surface():
+    import basedet
+    from basedet import layers, structures
+    import basedet_amd
+    assert basedet.layers is basedet_amd.layers and sys.modules["basedet.configs"] is basedet_amd.configs
+    for name in ("sigmoid_focal_loss", "smooth_l1_loss", "iou_loss", "binary_cross_entropy", "weighted_cross_entropy", "box_iou",
+                 "roi_pool", "assign_rois", "sample_labels", "Matcher", "batched_nms", "post_processing", "data_to_input",
+                 "get_padded_tensor", "permute_to_N_Any_K", "DefaultAnchorGenerator", "AnchorPointGenerator", "FPN", "RetinaNetHead",
+                 "PointHead", "resnet50", "build_backbone"):
+        assert callable(getattr(layers, name)), name
+    for name in ("Boxes", "BoxCoder", "PointCoder", "Container", "box_iou", "box_ioa", "box_center"):
+        assert hasattr(structures, name), name
+    for m in ("filter_by_size", "cat", "scale", "clip", "iou", "ioa", "giou", "intersection", "__getitem__"):
+        assert hasattr(structures.Boxes, m), m
+    from basedet.tools.det_train import main, default_parser  # noqa: F401  (the basedet_train entry)
+
+
+def test_matcher_keeps_the_reference_constructor_contract():
+    from basedet.layers import Matcher
+    thr = [0.4, 0.5]
+    m = Matcher(thr, [0, -1, 1], allow_low_quality_matches=True)
+    assert m.thresholds == [-float("inf"), 0.4, 0.5, float("inf")] and m.labels == [0, -1, 1]
+    with pytest.raises(AssertionError):
+        Matcher([0.5, 0.4], [0, -1, 1])
+    with pytest.raises(AssertionError):
+        Matcher([0.5], [0, -1, 1])

@@ -1,7 +1,11 @@
-"""CPU checks of the Faster R-CNN oracle (oracle/rcnn_ops.py).  The reference holds no vectors for these operators
-(parity unpinned), so the restatement is pinned by the properties its published definitions imply: RoIAlign reproduces
-constant and affine feature maps at the bin centres, its backward is the exact adjoint, the FPN level rule maps the
-canonical 224-pixel box to level 4, and the samplers keep exactly the requested number of smallest-key entries."""
+"""CPU checks of the Faster R-CNN oracle (oracle/rcnn_ops.py).  RoIAlign is PINNED by the reference's own known-answer test
+(tests/layers/test_roi_pool.py:32-45: the 4x4 matrix; :64-75: invariance under a 2x bilinear upsampling with stride 1/2), re-typed
+as data in tests/golden/reference_kat.npz.  The other operators have no reference vector (parity unpinned) and are pinned by the
+properties their published definitions imply: RoIAlign reproduces constant and affine feature maps at the bin centres, its backward
+is the exact adjoint, the FPN level rule maps the canonical 224-pixel box to level 4, and the samplers keep exactly the requested
+number of smallest-key entries."""
+import os
+
 import numpy as np
 
 from oracle import box_ops as ob
@@ -17,6 +21,41 @@ def test_assign_roi_levels_known_values():
     lv = orc.assign_roi_levels(rois, STRIDES)
     # floor(4 + log2(s / 224)) clamped to [2, 5], minus 2
     assert lv.tolist() == [2, 1, 1, 0, 3, 3, 0, 0]
+
+
+def _kat():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kat.npz"))
+
+
+def test_roi_align_reference_known_answer():
+    """tests/layers/test_roi_pool.py:32-45: 5x5 arange feature, roi [0, 1, 1, 3, 3], strides [1], pool 4 -> the 4x4 matrix."""
+    k = _kat()
+    feat = k["roi_feat"].transpose(0, 2, 3, 1)                 # (1, 5, 5, 1) channel-last
+    rois = k["roi_rois"]
+    out = orc.roi_align([feat], rois[:, 1:], rois[:, 0].astype(int), [1], 4, 4, 2)
+    assert np.allclose(out.reshape(4, 4), k["roi_align_4x4"])
+    assert np.array_equal(out.reshape(4, 4).astype(np.float64), k["roi_align_4x4"])       # every value is exact in fp32
+
+
+def test_roi_pool_max_reference_known_answer():
+    """tests/layers/test_roi_pool.py:47-61."""
+    k = _kat()
+    out = orc.roi_pool_max(k["roi_feat"], k["roi_rois"], 1.0, 4, 4)
+    assert np.array_equal(out[0, 0].astype(np.float64), k["roi_pool_4x4"])
+
+
+def test_roi_align_reference_scale_invariance():
+    """tests/layers/test_roi_pool.py:64-75: the same RoI on the 2x bilinearly upsampled map with strides [1/2] gives the same
+    output (F.vision.interpolate defaults: bilinear, align_corners=False)."""
+    import torch
+    import torch.nn.functional as TF
+    k = _kat()
+    feat = k["roi_feat"]
+    rois = k["roi_rois"]
+    f2 = TF.interpolate(torch.from_numpy(feat), scale_factor=2, mode="bilinear", align_corners=False).numpy()
+    out1 = orc.roi_align([feat.transpose(0, 2, 3, 1)], rois[:, 1:], [0], [1], 4, 4, 2)
+    out2 = orc.roi_align([f2.transpose(0, 2, 3, 1)], rois[:, 1:], [0], [0.5], 4, 4, 2)
+    assert np.allclose(out2, out1)
 
 
 def test_roi_align_constant_and_affine_maps():

@@ -230,6 +230,88 @@ def test_rcnn_sample_targets():
         assert int(tot.item()) == total
 
 
+def test_roi_align_reference_known_answer(golden_dir):
+    """The reference's own RoIAlign vectors on bd_roi_align_fwd (tests/layers/test_roi_pool.py:32-45: the 4x4 matrix on the 5x5
+    arange map; :64-75: the same RoI on the 2x bilinearly upsampled map at half the stride gives the same output).  One level,
+    PH = PW = 4, the single channel replicated over 8 (16-byte channel groups).  Every value is exact in bf16."""
+    import os
+    import torch.nn.functional as TF
+    ops = _ops()
+    k = np.load(os.path.join(golden_dir, "reference_kat.npz"))
+    C = 8
+
+    def run(feat_nchw, stride, rois):
+        _, _, h, w = feat_nchw.shape
+        f = np.repeat(feat_nchw.transpose(0, 2, 3, 1), C, axis=3).reshape(h * w, C)
+        geom = _geom(1, [(h, w)])
+        out = torch.empty((1, 16, C), dtype=torch.bfloat16, device="cuda")
+        ops.roi_align_fwd(_bf16(f).cuda(), geom, 1, [stride], C, _dev(rois), _dev(np.ones(1, np.int32)), 1, (4, 4), 2, out)
+        o = out.float().cpu().numpy()
+        assert np.all(o == o[..., :1]), "replicated channels differ"
+        return o[0, :, 0].reshape(4, 4)
+
+    feat, rois = k["roi_feat"], k["roi_rois"][:, 1:].copy()
+    got = run(feat, 1, rois)
+    assert np.array_equal(got.astype(np.float64), k["roi_align_4x4"]), got
+    # scale invariance: integer strides only in the ABI, so the pair (stride 1, stride 1/2) becomes (stride 2, stride 1) with the
+    # RoI given in 2x image coordinates
+    f2 = TF.interpolate(torch.from_numpy(feat), scale_factor=2, mode="bilinear", align_corners=False).numpy()
+    assert np.array_equal(run(feat, 2, rois * 2), got)
+    assert np.array_equal(run(f2, 1, rois * 2), got)
+
+
+def test_roi_align_bwd_pk_full_size():
+    """The training default of Faster R-CNN's RoIAlign backward at BASELINE config C4's sizes: 256 channels, 512 RoIs per image,
+    P2..P5 of an 800x1344 input (2 images), packed-bf16 atomics (a) into a zeroed pyramid and (b) on top of a pre-loaded gradient
+    (the RPN head's dL/dP is already there in the model, models/faster_rcnn.py) -- against the float64 adjoint of the oracle.
+    Also the fp32 scatter variant at the same sizes."""
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    N, C, rpi = 2, 256, 512
+    sizes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    nlev = 4
+    geom = _geom(N, sizes)
+    ppi = geom.pix_per_img
+    rois = np.concatenate([_rand_boxes(rng, rpi, 1344, 800, 8, 700) for _ in range(N)], 0)
+    labels = np.ones(N * rpi, np.int32)
+    labels[rng.integers(0, N * rpi, 40)] = -1                      # empty sample slots
+    bidx = np.repeat(np.arange(N), rpi)
+    gout = _bf16(rng.normal(0, 1, (N * rpi, 49, C)).astype(np.float32))
+    g_in = gout.float().numpy().copy()
+    g_in[labels < 0] = 0
+    shapes = [(N, h, w, C) for h, w in sizes[:nlev]]
+    refg = orc.roi_align_backward(g_in, shapes, rois, bidx, STRIDES[:nlev], 7, 7, 2)
+    assert len(set(orc.assign_roi_levels(rois, STRIDES[:nlev]).tolist())) == 4
+    # fp32 scatter
+    gfeat = torch.zeros((N * ppi, C), dtype=torch.float32, device="cuda")
+    ops.roi_align_bwd(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gfeat)
+    gg = gfeat.cpu().numpy().reshape(N, ppi, C)
+    o = 0
+    for l, (h, w) in enumerate(sizes[:nlev]):
+        np.testing.assert_allclose(gg[:, o:o + h * w].reshape(N, h, w, C), refg[l], rtol=2e-4, atol=2e-4)
+        o += h * w
+    # packed bf16, zeroed pyramid
+    gpk = torch.zeros((N * ppi, C), dtype=torch.bfloat16, device="cuda")
+    ops.roi_align_bwd_pk(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gpk)
+    gk = gpk.float().cpu().numpy().reshape(N, ppi, C)
+    # ... and on top of an existing gradient of comparable size
+    base = _bf16(rng.normal(0, 0.5, (N * ppi, C)).astype(np.float32))
+    gpk2 = base.clone().cuda()
+    ops.roi_align_bwd_pk(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gpk2)
+    gk2 = gpk2.float().cpu().numpy().reshape(N, ppi, C)
+    b = base.float().numpy().reshape(N, ppi, C)
+    o = 0
+    for l, (h, w) in enumerate(sizes[:nlev]):
+        sl = slice(o, o + h * w)
+        ref_l = refg[l].reshape(N, h * w, C)
+        # a running bf16 sum of n terms: ~sqrt(n) * 2^-9 relative (tests at toy size: 0.2-0.4 %)
+        assert np.linalg.norm(gk[:, sl] - ref_l) <= 8e-3 * np.linalg.norm(ref_l), l
+        tot = ref_l + b[:, sl]
+        assert np.linalg.norm(gk2[:, sl] - tot) <= 8e-3 * np.linalg.norm(tot), l
+        o += h * w
+    assert np.all(gk[:, o:] == 0) and np.array_equal(gk2[:, o:], b[:, o:])
+
+
 def test_roi_align_fwd_bwd():
     ops = _ops()
     rng = np.random.default_rng(5)
