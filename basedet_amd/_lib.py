@@ -44,6 +44,9 @@ SIGNATURES = {
     "bd_version": (_I, []),
     "bd_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
+    "bd_conv2d_fwd_bits": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "bd_conv2d_dgrad_bits": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
+    "bd_conv_set_dense1x1": (_I, [_I]),
     "bd_conv2d_wgrad_workspace_bytes": (_Z, [_D]),
     "bd_conv2d_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_conv2d_wgrad_bias_workspace_bytes": (_Z, [_D]),

@@ -115,13 +115,14 @@ class ConvLayer:
             self._desc_cache[key] = d
         return d
 
-    def forward(self, x, gin, gout, y, add=None, relu=False):
+    def forward(self, x, gin, gout, y, add=None, relu=False, bits=None):
         flags = (ops.EPI_RELU if relu else 0) | (ops.EPI_ADD_BEFORE if add is not None else 0)
-        return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags)
+        return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags, bits=bits)
 
-    def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None):
+    def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None):
         """dx (+)= conv^T(g).  first=False accumulates onto dx (pre-mask); mask = forward activation whose
-        ReLU gates dx; add_after = tensor added after masking (P6: gradient that bypasses the ReLU)."""
+        ReLU gates dx (maskbits: the same gate bit-packed, written by the producing forward launch); add_after = tensor added
+        after masking (P6: gradient that bypasses the ReLU)."""
         flags, add = 0, None
         if add_after is not None:
             flags |= ops.EPI_ADD_AFTER
@@ -129,9 +130,11 @@ class ConvLayer:
         elif not first:
             flags |= ops.EPI_ADD_BEFORE
             add = dx
-        if mask is not None:
+        if mask is not None or maskbits is not None:
             flags |= ops.EPI_MASK
-        return ops.conv2d_dgrad(self.desc(gin, gout), g, self.w_dgrad, dx, add=add, mask=mask, flags=flags)
+        if maskbits is not None:
+            mask = None
+        return ops.conv2d_dgrad(self.desc(gin, gout), g, self.w_dgrad, dx, add=add, mask=mask, flags=flags, maskbits=maskbits)
 
     def wgrad(self, x, g, gin, gout, ws, colsum_ws=None):
         d = self.desc(gin, gout)

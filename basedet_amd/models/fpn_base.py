@@ -73,6 +73,7 @@ class FPNDetector:
         # weight-gradient kernels run on a side stream, concurrently with the dgrad chain they do not feed: tails and
         # barrier bubbles of one kernel are filled by the other (set False to serialise, e.g. for per-kernel timing)
         self.async_wgrad = True
+        self.use_mask_bits = True          # bit-packed ReLU gates for the wide 1x1 data gradients (False: bf16 activations as masks)
         self._wstream = torch.cuda.Stream() if (torch.cuda.is_available() and self.device.type == "cuda") else None
         self._tstream = torch.cuda.Stream() if self._wstream is not None else None      # P6/P7 top-block dgrads
 
@@ -292,9 +293,15 @@ class FPNDetector:
                 b.mids = [act(b.gout, blk["ch"])]
             b.idt = act(b.gout, blk["cout"]) if blk["has_ds"] else None
             b.out = act(b.gout, blk["cout"])
+            b.out_bits = None
             if blk["trainable"]:
                 b.g_mids = [torch.empty_like(t) for t in b.mids]
                 b.g_out = torch.empty_like(b.out)
+                # the block output's ReLU gate, bit-packed by the conv3 launch that writes it (1 bit instead of a bf16 per element):
+                # what the NEXT block's conv1 / the FPN lateral read as their data-gradient mask (dense 1x1 launches: conv1x1.hip)
+                if (blk["kind"] == "bottleneck" and self.use_mask_bits
+                        and ops.dense_1x1_bits_ok(blk["convs"][-1].desc(b.gout, b.gout))):
+                    b.out_bits = torch.empty((blk["cout"] // 32, b.gout.pixels), dtype=torch.int32, device=dev)
             pl.blk.append(b)
             gin = b.gout
         # feature taps (last block of layer 2..4 -> res3..res5)
@@ -402,7 +409,7 @@ class FPNDetector:
         for ci, c in enumerate(convs[:-1]):
             c.forward(t, geos[ci], geos[ci + 1], b.mids[ci], relu=True)
             t = b.mids[ci]
-        convs[-1].forward(t, geos[-2], geos[-1], b.out, add=idt, relu=True)
+        convs[-1].forward(t, geos[-2], geos[-1], b.out, add=idt, relu=True, bits=b.out_bits)
         return b.out
 
     def network_forward(self, pl):
@@ -552,7 +559,7 @@ class FPNDetector:
             if is_top:
                 if not pool_top and self._tstream is not None and self.async_wgrad:
                     torch.cuda.current_stream().wait_stream(self._tstream)
-                self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=pool_top, mask=b.out)
+                self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=pool_top, mask=b.out, maskbits=b.out_bits)
             else:
                 self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=True)
         if on_bucket_ready:
@@ -582,18 +589,20 @@ class FPNDetector:
             self._wgrad(convs[0], xin, g, geos[0], geos[1], ws)
             if prev_tr:
                 gx = pl.blk[bi - 1].g_out
+                xbits = pl.blk[bi - 1].out_bits if ops.dense_1x1_bits_ok(convs[0].desc(geos[0], geos[1])) else None
                 # has the input already received a contribution (FPN lateral of res3/res4)?
                 tapped = any(pl.res[s] == bi - 1 for s in st)
                 if blk["ds"] is not None:
                     blk["ds"].dgrad(G, b.gin, b.gout, gx, first=not tapped)
-                    convs[0].dgrad(g, geos[0], geos[1], gx, first=False, mask=xin)
+                    convs[0].dgrad(g, geos[0], geos[1], gx, first=False, mask=xin, maskbits=xbits)
                 else:
                     if tapped:
                         ops.add_bf16(gx, G, gx)
-                        convs[0].dgrad(g, geos[0], geos[1], gx, first=False, mask=xin)
+                        convs[0].dgrad(g, geos[0], geos[1], gx, first=False, mask=xin, maskbits=xbits)
                     else:
                         # identity skip: gx = (dgrad + G) * mask
-                        ops.conv2d_dgrad(convs[0].desc(geos[0], geos[1]), g, convs[0].w_dgrad, gx, add=G, mask=xin,
+                        ops.conv2d_dgrad(convs[0].desc(geos[0], geos[1]), g, convs[0].w_dgrad, gx, add=G,
+                                         mask=None if xbits is not None else xin, maskbits=xbits,
                                          flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
             if on_bucket_ready and (bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]):
                 on_bucket_ready(f"layer{blk['layer']}", side)

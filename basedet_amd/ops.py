@@ -71,14 +71,31 @@ def L():
 
 
 # ---- dense path -------------------------------------------------------------------------------------------
-def conv2d_fwd(d, x, w_packed, bias, y, add=None, flags=0):
+def conv2d_fwd(d, x, w_packed, bias, y, add=None, flags=0, bits=None):
+    """bits: optional uint32 [Cout/32][M] output, the bit-packed ReLU mask of y (dense 1x1 launches only: bd_conv2d_fwd_bits)."""
+    if bits is not None:
+        check(L().bd_conv2d_fwd_bits(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), flags, stream_ptr()),
+              "bd_conv2d_fwd_bits")
+        return y
     check(L().bd_conv2d_fwd(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), flags, stream_ptr()), "bd_conv2d_fwd")
     return y
 
 
-def conv2d_dgrad(d, g, w_packed_t, dx, add=None, mask=None, flags=0):
+def conv2d_dgrad(d, g, w_packed_t, dx, add=None, mask=None, flags=0, maskbits=None):
+    """maskbits: the ReLU mask as written by conv2d_fwd(bits=...) instead of the bf16 activation `mask` (bd_conv2d_dgrad_bits)."""
+    if maskbits is not None:
+        check(L().bd_conv2d_dgrad_bits(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(maskbits), ptr(dx), flags, stream_ptr()),
+              "bd_conv2d_dgrad_bits")
+        return dx
     check(L().bd_conv2d_dgrad(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(dx), flags, stream_ptr()), "bd_conv2d_dgrad")
     return dx
+
+
+def dense_1x1_bits_ok(d):
+    """True when bd_conv2d_fwd_bits / bd_conv2d_dgrad_bits take this descriptor (conv1x1.hip)."""
+    return (d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0
+            and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0]
+            and d.Cin % 32 == 0 and d.Cout % 32 == 0 and d.N * d.in_pix_per_img * max(d.Cin, d.Cout) * 2 < 0x7fffffff)
 
 
 def conv2d_wgrad_workspace_bytes(d):

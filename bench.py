@@ -78,6 +78,10 @@ class KernelTimer:
             is3 = d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and same
             is1 = d.R == 1 and d.S == 1 and d.pad == 0
             if kind == "igemm":
+                dense = (is1 and d.stride == 1 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0
+                         and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0])
+                if dense:
+                    return "conv1x1_dense_kernel"          # conv1x1.hip: every 1x1 / stride 1 launch over one dense level
                 if not is3:
                     # generic kernel: BK = 32 instance for 1x1 filters (and Cin <= 32) and for stride-2 launches of >= 512 tiles,
                     # BK = 64 for the rest
@@ -117,6 +121,10 @@ class KernelTimer:
                 if kind == "igemm":
                     res = 2.0 * (mi * d.Cin if fn.__name__ == "conv2d_dgrad" else mo * d.Cout)
                     nbytes += res * ((k.get("add") is not None) + (k.get("mask") is not None))
+                    if k.get("maskbits") is not None:
+                        nbytes += res / 16.0               # the bit-packed ReLU gate: 1 bit per element
+                    if k.get("bits") is not None:
+                        nbytes += res / 16.0
                 self.meta.setdefault(kern, []).append((fn.__name__, d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
                 return r
             return inner

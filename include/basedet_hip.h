@@ -77,6 +77,19 @@ int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w_packed, co
 int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add,
                     const void* mask, void* dx, int flags, bd_stream_t stream);
 
+/* Bit-packed ReLU masks for the HBM-bound 1x1 layers.  A forward launch with BD_EPI_RELU may also write ybits: one bit per output
+ * element (y > 0), uint32 [Cout/32][M] (M = N * pixels of the level; word (g, m) holds channels 32g .. 32g+31 of pixel m, bit b =
+ * channel 32g + b).  A data-gradient launch reads such a tensor (of ITS output geometry, i.e. the conv's input) instead of the bf16
+ * activation as its BD_EPI_MASK operand: a 16x smaller stream (models/cls/resnet.py:70-113: the block input's ReLU gate in conv1's
+ * backward).  Only the dense 1x1 kernel (1x1 / stride 1 / pad 0 over one dense level, channels % 32 == 0, tensors < 2 GB) serves
+ * these two; any other descriptor returns BD_EINVAL. */
+int bd_conv2d_fwd_bits(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
+                       uint32_t* ybits, int flags, bd_stream_t stream);
+int bd_conv2d_dgrad_bits(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const uint32_t* maskbits,
+                         void* dx, int flags, bd_stream_t stream);
+/* measurement knob: prefetch depth of the dense 1x1 kernel (conv1x1.hip): 0 = off (generic kernel), 2 / 3 / 4 (default) / 6. */
+int bd_conv_set_dense1x1(int depth);
+
 /* dw[Cout][R][S][Cin] (fp32) = sum over pixels g^T x, times row_scale[Cout] (NULL = 1); split over pixels with
  * fp32 partial slabs in ws, reduced in a fixed order (bitwise reproducible).  accumulate != 0 adds to dw. */
 size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d);

@@ -336,3 +336,53 @@ def test_wgrad_bias_multilevel():
     db = torch.empty((Cout,), dtype=torch.float32, device="cuda")
     ops.conv2d_wgrad_bias(d, xp, gy.to(torch.bfloat16).cuda(), dw, db, ws)
     assert rel_l2(db.cpu(), gy.sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("depth", [4, 2, 3, 6, 0])
+def test_dense_1x1_kernel_and_mask_bits(depth):
+    """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) at each prefetch depth (0 = the generic kernel): forward with
+    residual + ReLU and the data gradient with accumulate + mask against torch-CPU fp32; the bit-packed ReLU mask written by the
+    forward launch equals (y > 0) bit for bit, and a data gradient gated by it equals the one gated by the bf16 activation."""
+    ops = _ops()
+    assert ops.L().bd_conv_set_dense1x1(depth) == 0
+    try:
+        for (N, Cin, Cout, H, W) in ((2, 256, 64, 23, 37), (1, 64, 256, 50, 41), (2, 200, 192, 9, 13), (1, 1024, 256, 20, 21), (1, 32, 544, 7, 9)):
+            g = torch.Generator().manual_seed(77 + Cin + Cout)
+            x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
+            w = bf16_round(torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin))
+            bias = torch.randn(Cout, generator=g)
+            res = bf16_round(torch.randn(N, Cout, H, W, generator=g))
+            geo = ops.single(N, H, W)
+            d = ops.conv_desc(geo, geo, Cin, Cout, 1, 1, 1, 0)
+            wf, wd = pack_weights(ops, w)
+            M = N * H * W
+            y = torch.empty((M, Cout), dtype=torch.bfloat16, device="cuda")
+            bits_ok = depth != 0 and ops.dense_1x1_bits_ok(d)
+            ybits = torch.full((Cout // 32, M), -1, dtype=torch.int32, device="cuda") if bits_ok else None
+            ops.conv2d_fwd(d, nchw_to_pm(x), wf, bias.cuda(), y, add=nchw_to_pm(res), flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE, bits=ybits)
+            ref = torch.relu(TF.conv2d(x, w, bias) + res)
+            got = pm_to_nchw(y, N, H, W)
+            assert rel_l2(got, ref) < 1e-2, (depth, Cin, Cout)
+            if bits_ok:
+                yb = (y.float() > 0).cpu().numpy().reshape(M, Cout // 32, 32)
+                want = (yb.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32).T      # [Cout/32][M]
+                assert np.array_equal(ybits.cpu().numpy().view(np.uint32), want)
+            # data gradient of the transposed problem (K = Cout -> Cin), accumulate + mask
+            gy = bf16_round(torch.randn(N, Cout, H, W, generator=g))
+            acc0 = bf16_round(torch.randn(N, Cin, H, W, generator=g))
+            act = torch.relu(bf16_round(torch.randn(N, Cin, H, W, generator=g)))           # the forward activation that gates dx
+            xr = x.clone().requires_grad_(True)
+            TF.conv2d(xr, w).backward(gy)
+            refd = (xr.grad + acc0) * (act > 0)
+            dx = nchw_to_pm(acc0).clone()
+            ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, dx, add=dx, mask=nchw_to_pm(act), flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
+            assert rel_l2(pm_to_nchw(dx, N, H, W), refd) < 1e-2, (depth, Cin, Cout)
+            if bits_ok:
+                ab = (nchw_to_pm(act).float() > 0).cpu().numpy().reshape(M, Cin // 32, 32)
+                abits = (ab.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32).T.copy()
+                dx2 = nchw_to_pm(acc0).clone()
+                ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, dx2, add=dx2, maskbits=torch.from_numpy(abits.view(np.int32)).cuda(),
+                                 flags=ops.EPI_ADD_BEFORE)
+                assert torch.equal(dx, dx2)
+    finally:
+        ops.L().bd_conv_set_dense1x1(4)
