@@ -1,10 +1,11 @@
-"""GroupedRandomSampler / AspectRatioGroupSampler (basedet/data/samplers/group_sampler.py:8-93): every batch holds samples of one
-aspect-ratio group, so that padding to the per-batch maximum wastes little and the device sees few distinct (H, W) plans.
+"""Aspect-ratio grouped batch sampling (behaviour of basedet's GroupedRandomSampler / AspectRatioGroupSampler, group_sampler.py):
+every batch holds images of ONE aspect-ratio group, so padding to the per-batch maximum wastes little and the device sees few
+distinct (H, W) plans.
 
-The reference inherits the permutation and the rank scatter from ``megengine.data.RandomSampler`` (un-vendored); restated here as:
-a seeded permutation of the indices per epoch, padded to a multiple of world_size, rank r taking every world_size-th index."""
-import bisect
-
+Behaviour kept: one seeded permutation of the indices per pass; with world_size > 1 the permutation is padded (by wrapping around)
+to a multiple of world_size and rank r takes every world_size-th entry; an index joins its group's queue and a batch is emitted the
+moment a queue holds batch_size entries; queues that did not fill up carry over into the next pass; the length is undefined.
+(The reference inherits permutation and scatter from megengine.data.RandomSampler, which is not vendored.)"""
 import numpy as np
 
 __all__ = ["GroupedRandomSampler", "AspectRatioGroupSampler"]
@@ -12,54 +13,51 @@ __all__ = ["GroupedRandomSampler", "AspectRatioGroupSampler"]
 
 class GroupedRandomSampler:
     def __init__(self, dataset, batch_size, group_ids, indices=None, world_size=None, rank=None, seed=None):
-        self.batch_size = batch_size
-        self.indices = list(range(len(dataset))) if indices is None else list(indices)
-        self.world_size = 1 if world_size is None else int(world_size)
-        self.rank = 0 if rank is None else int(rank)
-        self.rng = np.random.RandomState(0 if seed is None else seed)
-        self.group_ids = group_ids
-        assert len(group_ids) == len(dataset)
-        # buffer the indices of each group until batch size is reached (group_sampler.py:36-39)
-        self.buffer_per_group = {k: [] for k in np.unique(self.group_ids).tolist()}
+        n = len(dataset)
+        self.group_ids = np.asarray(group_ids)
+        assert self.group_ids.shape[0] == n
+        self.batch_size = int(batch_size)
+        self.indices = np.arange(n) if indices is None else np.asarray(list(indices))
+        self.world_size = int(world_size or 1)
+        self.rank = int(rank or 0)
+        self.rng = np.random.RandomState(seed or 0)
+        self._pending = {}              # group id -> indices waiting for their batch to fill (survives across passes)
 
     def sample(self):
-        return self.rng.permutation(self.indices).tolist()
+        return self.rng.permutation(self.indices)
 
-    def scatter(self, indices):
-        total = (len(indices) + self.world_size - 1) // self.world_size * self.world_size
-        indices = indices + indices[: total - len(indices)]
-        return indices[self.rank: total: self.world_size]
+    def scatter(self, order):
+        order = np.asarray(order)
+        short = -len(order) % self.world_size
+        if short:
+            order = np.concatenate([order, order[:short]])
+        return order[self.rank::self.world_size]
 
     def batch(self):
-        """group_sampler.py:41-55."""
-        indices = list(self.sample())
+        order = self.sample()
         if self.world_size > 1:
-            indices = self.scatter(indices)
-        batch_index = []
-        for ind in indices:
-            group_id = self.group_ids[ind]
-            group_buffer = self.buffer_per_group[group_id]
-            group_buffer.append(ind)
-            if len(group_buffer) == self.batch_size:
-                batch_index.append(group_buffer)
-                self.buffer_per_group[group_id] = []
-        return iter(batch_index)
+            order = self.scatter(order)
+        batches = []
+        for idx, gid in zip(order.tolist(), self.group_ids[order].tolist()):
+            queue = self._pending.setdefault(gid, [])
+            queue.append(idx)
+            if len(queue) >= self.batch_size:
+                batches.append(queue)
+                self._pending[gid] = []
+        return iter(batches)
 
-    def __iter__(self):
-        return self.batch()
+    __iter__ = batch
 
     def __len__(self):
         raise NotImplementedError("length of GroupedRandomSampler is not well-defined.")
 
 
 class AspectRatioGroupSampler(GroupedRandomSampler):
-    """group_sampler.py:60-93: group id = bisect_right(sorted(aspect_grouping), height / width)."""
+    """Groups by height / width against the sorted ``aspect_grouping`` thresholds: a ratio equal to a threshold falls into the
+    upper group (bisect-right rule)."""
 
     def __init__(self, dataset, batch_size, aspect_grouping=(1,), *args, **kwargs):
-        aspect_ratios = []
-        for i in range(len(dataset)):
-            info = dataset.get_img_info(i)
-            aspect_ratios.append(info["height"] / info["width"])
-        bins = sorted(aspect_grouping)
-        group_ids = [bisect.bisect_right(bins, r) for r in aspect_ratios]
+        infos = (dataset.get_img_info(i) for i in range(len(dataset)))
+        ratios = np.fromiter((info["height"] / info["width"] for info in infos), dtype=np.float64, count=len(dataset))
+        group_ids = np.searchsorted(np.sort(np.asarray(aspect_grouping, np.float64)), ratios, side="right")
         super().__init__(dataset, batch_size, group_ids, *args, **kwargs)

@@ -345,6 +345,8 @@ def main():
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight-gradient kernels on the main stream for the whole run (what the instrumented steps do): "
                          "use it under rocprofv3 so that per-kernel durations are not inflated by concurrent kernels")
+    ap.add_argument("--dense1x1", type=int, default=None, help="ablation: bd_conv_set_dense1x1 (0 = generic kernel for the dense 1x1 launches)")
+    ap.add_argument("--no-mask-bits", action="store_true", help="ablation: bf16 activations instead of bit-packed ReLU gates as dgrad masks")
     ap.add_argument("--conv-knob", type=int, default=None,
                     help="ablation: bd_conv_set_patch3x3 bit mask (include/basedet_hip.h) applied before the run")
     args = ap.parse_args()
@@ -442,6 +444,10 @@ def worker(args):
         model.async_wgrad = False
     if args.conv_knob is not None:
         ops.L().bd_conv_set_patch3x3(args.conv_knob)
+    if args.dense1x1 is not None:
+        ops.L().bd_conv_set_dense1x1(args.dense1x1)
+    if args.no_mask_bits:
+        model.use_mask_bits = False
     for _ in range(args.warmup):
         sched.step(it); it += 1
         last = solver.minimize(model, batch)
