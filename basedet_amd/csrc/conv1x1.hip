@@ -1,18 +1,17 @@
 // Dense 1x1 convolution (forward and data gradient) = a plain GEMM  D[m][co] = sum_k X[m][k] * W[co][k]  over the pixels of ONE
 // dense level (source pixel index == destination pixel index == m), with the fused epilogue of conv_igemm.hip.
 //
-// These are the HBM-bound layers of the step (ResNet bottleneck 1x1s, FPN laterals: 40-110 FLOP per byte).  The generic kernel keeps
-// ONE K step of loads in flight per workgroup, three workgroups per CU: 24 KB of activation bytes in flight per CU, which at the
-// ~2 us a loaded HBM round trip takes is ~3 TB/s -- what it measured (0.39 of the 8 TB/s roof).  This kernel is that tile (128
-// channels x 128 pixels, BK = 32, swizzled 64-byte LDS rows, 16x16x32 MFMA, channels on the MFMA row) with the LATENCY structure
-// changed:
-//   * the staging loads run DEPTH K steps ahead through DEPTH register sets (16 VGPRs each): gfx950 retires vmcnt in issue order, so
-//     weights and activations share one queue and both are prefetched at the same distance; two workgroups per CU x (DEPTH - 1)
-//     steps x 8 KB of activations are in flight instead of 3 x 1 x 8 KB;
-//   * the epilogue's operand streams (residual / accumulated gradient, ReLU mask) are requested before the LAST K step's MFMAs, into
-//     the registers the finished staging sets leave free;
+// The ResNet bottleneck 1x1s and the FPN laterals: 40-225 FLOP per byte, the largest share of the step after the 3x3 convolutions.
+// Same tile as the generic kernel (128 channels x 128 pixels, BK = 32, swizzled 64-byte LDS rows, 16x16x32 MFMA, channels on the MFMA
+// row), specialised so that
+//   * there is no tap / sub-segment / pixel-decode state: 121 VGPRs instead of 160 -> FOUR workgroups per CU instead of three;
 //   * the ReLU mask of a data gradient may come BIT-PACKED (1 bit per element instead of a bf16: a 16x smaller stream), written by
 //     the forward launch that produced the activation (ybits): bits[g * M + m], bit b = channel 32 g + b of pixel m is > 0.
+// What was measured on the way (scripts/micro_1x1_step.py, bench.py --dense1x1): running the staging loads 2, 4
+// or 6 K steps ahead through extra register sets -- at three or two workgroups per CU -- and requesting the epilogue operands before
+// the last K step changed nothing on the 200x336 / 100x168 layers (4.2-4.8 / 3.5-3.9 TB/s either way) and LOST 10-35 % on the K >=
+// 1024 layers, where the kernel is bound by its MFMA loop (one barrier per 16 MFMAs), not by memory: occupancy, not prefetch depth,
+// is what fills that loop's bubbles.  DEPTH = 2 at three workgroups per CU is kept as the one alternative (bd_conv_set_dense1x1(2)).
 #include "common.h"
 
 namespace {
@@ -36,8 +35,9 @@ struct P1 {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
-template <int DEPTH>
-__global__ __launch_bounds__(256, 2) void conv1x1_dense_kernel(const P1 p) {
+template <int DEPTH, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
+    constexpr bool EARLY = false;       // (epilogue operands requested before the last K step: measured, no gain -- see the header)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -129,9 +129,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dense_kernel(const P1 p) {
     const bool want_add = add_before || add_after;
     const bool mask_bf = (p.flags & BD_EPI_MASK) && p.mask;
     const bool mask_bits = (p.flags & BD_EPI_MASK) && p.maskbits && !p.mask;
-    u32x4_t e_add[8];
-    unsigned e_bits[8];
+    u32x4_t e_add[EARLY ? 8 : 1];
+    unsigned e_bits[EARLY ? 8 : 1];
     auto epi_request = [&]() {
+        if (!EARLY) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -190,7 +191,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dense_kernel(const P1 p) {
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];
-            const u32x4_t av = e_add[j * 2 + half];
+            u32x4_t av = {0u, 0u, 0u, 0u};
+            unsigned mbits = 0u;
+            if (EARLY) { av = e_add[j * 2 + half]; mbits = e_bits[j * 2 + half]; }
+            else {
+                if (ok && want_add) av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                if (ok && mask_bits) mbits = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m];
+            }
             if (add_before) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dense_kernel(const P1 p) {
                 }
             }
             if (mask_bits) {
-                const unsigned byte = e_bits[j * 2 + half] >> (8 * cg);
+                const unsigned byte = mbits >> (8 * cg);
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (!((byte >> k) & 1u)) v[k] = 0.f;
@@ -236,13 +243,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dense_kernel(const P1 p) {
     }
 }
 
-int g_conv1x1_depth = 4;        // bd_conv_set_dense1x1: 0 = off (generic kernel), else the prefetch depth (2, 3, 4 or 6)
+int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (generic kernel); 1 = one K step ahead, four workgroups per CU; 2 = two ahead, three per CU
 
 }  // namespace
 
 extern "C" int bd_conv_set_dense1x1(int depth) {
-    if (!(depth == 0 || depth == 2 || depth == 3 || depth == 4 || depth == 6)) {
-        bd_set_error("bd_conv_set_dense1x1: depth %d (0, 2, 3, 4 or 6)", depth);
+    if (!(depth == 0 || depth == 1 || depth == 2)) {
+        bd_set_error("bd_conv_set_dense1x1: variant %d (0, 1 or 2)", depth);
         return BD_EINVAL;
     }
     g_conv1x1_depth = depth;
@@ -266,10 +273,8 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     const int grid = p.m_tiles * p.n_tiles;
     const size_t lds = 4 * TILE_BYTES;
     switch (g_conv1x1_depth) {
-        case 2: hipLaunchKernelGGL((conv1x1_dense_kernel<2>), dim3(grid), dim3(256), lds, stream, p); break;
-        case 3: hipLaunchKernelGGL((conv1x1_dense_kernel<3>), dim3(grid), dim3(256), lds, stream, p); break;
-        case 6: hipLaunchKernelGGL((conv1x1_dense_kernel<6>), dim3(grid), dim3(256), lds, stream, p); break;
-        default: hipLaunchKernelGGL((conv1x1_dense_kernel<4>), dim3(grid), dim3(256), lds, stream, p); break;
+        case 2: hipLaunchKernelGGL((conv1x1_dense_kernel<2, 3>), dim3(grid), dim3(256), lds, stream, p); break;
+        default: hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4>), dim3(grid), dim3(256), lds, stream, p); break;
     }
     return 0;
 }

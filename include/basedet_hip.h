@@ -87,7 +87,8 @@ int bd_conv2d_fwd_bits(const bd_conv_desc* d, const void* x, const void* w_packe
                        uint32_t* ybits, int flags, bd_stream_t stream);
 int bd_conv2d_dgrad_bits(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const uint32_t* maskbits,
                          void* dx, int flags, bd_stream_t stream);
-/* measurement knob: prefetch depth of the dense 1x1 kernel (conv1x1.hip): 0 = off (generic kernel), 2 / 3 / 4 (default) / 6. */
+/* measurement knob: variant of the dense 1x1 kernel (conv1x1.hip): 0 = off (generic kernel); 1 (default) = one K step ahead, four
+ * workgroups per CU; 2 = two steps ahead, three per CU. */
 int bd_conv_set_dense1x1(int depth);
 
 /* dw[Cout][R][S][Cin] (fp32) = sum over pixels g^T x, times row_scale[Cout] (NULL = 1); split over pixels with

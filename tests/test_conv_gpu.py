@@ -338,9 +338,10 @@ def test_wgrad_bias_multilevel():
     assert rel_l2(db.cpu(), gy.sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("depth", [4, 2, 3, 6, 0])
+@pytest.mark.parametrize("depth", [1, 2, 0])
 def test_dense_1x1_kernel_and_mask_bits(depth):
-    """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) at each prefetch depth (0 = the generic kernel): forward with
+    """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_set_dense1x1: prefetch depth x workgroups
+    per CU; 0 = the generic kernel): forward with
     residual + ReLU and the data gradient with accumulate + mask against torch-CPU fp32; the bit-packed ReLU mask written by the
     forward launch equals (y > 0) bit for bit, and a data gradient gated by it equals the one gated by the bf16 activation."""
     ops = _ops()
@@ -385,4 +386,4 @@ def test_dense_1x1_kernel_and_mask_bits(depth):
                                  flags=ops.EPI_ADD_BEFORE)
                 assert torch.equal(dx, dx2)
     finally:
-        ops.L().bd_conv_set_dense1x1(4)
+        ops.L().bd_conv_set_dense1x1(1)
