@@ -55,6 +55,11 @@ class ConvLayer:
         self.w_fwd = torch.empty((self.cout, k * k, cin), dtype=torch.bfloat16, device=device)
         self.w_dgrad = torch.empty((cin, k * k, self.cout), dtype=torch.bfloat16, device=device) if trainable else None
         self._desc_cache = {}
+        # fp8 forward (BASELINE config 5, enable_fp8): e4m3 weights with one scale per output channel + the input cast to e4m3
+        self.fp8 = False
+        self.w_q8 = self.w_scale8 = None
+        self.act_scale = 1.0
+        self.q8_scratch = None          # callable(nbytes) -> uint8 scratch tensor on the stream this layer's forward runs on
 
     # -- parameters -------------------------------------------------------------------------------
     def bind(self, arena, params):
@@ -102,8 +107,20 @@ class ConvLayer:
         if self.gb is not None:
             out[self.name + ".bias"] = self.gb[: self.cout_real].cpu().clone()
 
+    def enable_fp8(self, q8_scratch, act_scale=1.0):
+        """Forward through bd_conv2d_fwd_fp8 (csrc/conv_fp8.hip).  The backward pass keeps the bf16 weights and activations."""
+        assert self.cin % 16 == 0 and self.cout % 8 == 0
+        self.fp8, self.q8_scratch, self.act_scale = True, q8_scratch, float(act_scale)
+        self.w_q8 = torch.empty((self.cout, self.k * self.k, self.cin), dtype=torch.uint8, device=self.device)
+        self.w_scale8 = torch.empty((self.cout,), dtype=torch.float32, device=self.device)
+
+    def pack_fp8(self):
+        ops.weight_pack_fp8(self.w, self.row_scale, self.cout, self.k * self.k, self.cin, self.act_scale, self.w_q8, self.w_scale8)
+
     def pack(self):
         ops.weight_pack(self.w, self.row_scale, self.w_fwd, self.w_dgrad, self.cout, self.k * self.k, self.cin)
+        if self.fp8:
+            self.pack_fp8()
 
     # -- kernels ----------------------------------------------------------------------------------
     def desc(self, gin: Geom, gout: Geom):
@@ -117,6 +134,9 @@ class ConvLayer:
 
     def forward(self, x, gin, gout, y, add=None, relu=False, bits=None):
         flags = (ops.EPI_RELU if relu else 0) | (ops.EPI_ADD_BEFORE if add is not None else 0)
+        if self.fp8 and bits is None:
+            xq = ops.quantize_fp8(x, self.act_scale, self.q8_scratch(x.numel())[: x.numel()])
+            return ops.conv2d_fwd_fp8(self.desc(gin, gout), xq, self.w_q8, self.w_scale8, self.b, y, add=add, flags=flags)
         return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags, bits=bits)
 
     def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None):

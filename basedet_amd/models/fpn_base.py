@@ -19,7 +19,7 @@ import torch
 from .. import ops
 from ..ops import Geom
 from . import params as P
-from .engine import ConvLayer, ParamArena
+from .engine import ConvLayer, FCLayer, ParamArena
 
 
 def _round_up(v, m):
@@ -130,6 +130,18 @@ class FPNDetector:
         for c in list(self.convs.values()) + list(self.vparams.values()):
             c.reserve(self.arena)
         self.arena.allocate()
+        # BASELINE config 5: fp8-e4m3 weights (one scale per output channel) for the forward of the 3x3 convolutions -- where a
+        # quantised copy of the input is read nine times; the HBM-bound 1x1 layers and the whole backward pass stay bf16
+        self.weight_dtype = m.get("WEIGHT_DTYPE", "bf16")
+        self._q8 = {}
+        if self.weight_dtype == "fp8_e4m3":
+            side = {id(getattr(self, n)) for n in ("p6", "p7") if hasattr(self, n)}
+            for c in self.convs.values():
+                if c.k == 3 and c.cin % 16 == 0 and c.cin >= 64 and not isinstance(c, FCLayer):
+                    key = "side" if id(c) in side else "main"          # P6 / P7 run on a side stream: their own scratch
+                    c.enable_fp8(lambda n, key=key: self._q8_buf(key, n), m.get("FP8_ACT_SCALE", 1.0))
+        else:
+            assert self.weight_dtype == "bf16", self.weight_dtype
         self._bind_params(params)
 
     def _bind_params(self, params):
@@ -147,6 +159,13 @@ class FPNDetector:
             c.bind(self.arena, params)
         self._bn_params = {k: np.asarray(v, np.float32).copy() for k, v in params.items() if (".bn" in k or "downsample.1" in k)}
         self.repack_weights()
+
+    def _q8_buf(self, key, nbytes):
+        """Scratch for the e4m3 copy of a convolution's input, one per stream (grown on demand; stream-ordered reuse)."""
+        t = self._q8.get(key)
+        if t is None or t.numel() < nbytes:
+            t = self._q8[key] = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
+        return t
 
     def load_weights(self, weights, strict=False):
         """BaseNet.load_weights (models/base_net.py:83-89) -> utils/checkpoint.py load_matched_weights: `weights` is a dict
@@ -167,6 +186,9 @@ class FPNDetector:
             ent = [(c.w, c.row_scale, c.w_fwd, c.w_dgrad, c.cout, c.k * c.k, c.cin) for c in self.convs.values() if c.trainable]
             self._pack_table = ops.build_pack_table(ent, self.device)
         ops.weight_pack_multi(self._pack_table)
+        for c in self.convs.values():
+            if c.fp8 and c.trainable:
+                c.pack_fp8()
 
     # reference module protocol ------------------------------------------------------------------------
     def train(self, mode=True):

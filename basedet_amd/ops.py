@@ -91,6 +91,23 @@ def conv2d_dgrad(d, g, w_packed_t, dx, add=None, mask=None, flags=0, maskbits=No
     return dx
 
 
+def quantize_fp8(x, scale, q):
+    """q (uint8, same element count) = e4m3(clamp(x * scale)) of a bf16 tensor."""
+    check(L().bd_quantize_fp8(ptr(x), x.numel(), float(scale), ptr(q), stream_ptr()), "bd_quantize_fp8")
+    return q
+
+
+def weight_pack_fp8(w, row_scale, Cout, RS, Cin, act_scale, wq, wscale):
+    check(L().bd_weight_pack_fp8(ptr(w), ptr(row_scale), Cout, RS, Cin, float(act_scale), ptr(wq), ptr(wscale), stream_ptr()),
+          "bd_weight_pack_fp8")
+
+
+def conv2d_fwd_fp8(d, xq, wq, wscale, bias, y, add=None, flags=0):
+    check(L().bd_conv2d_fwd_fp8(C.byref(d), ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(y), flags, stream_ptr()),
+          "bd_conv2d_fwd_fp8")
+    return y
+
+
 def dense_1x1_bits_ok(d):
     """True when bd_conv2d_fwd_bits / bd_conv2d_dgrad_bits take this descriptor (conv1x1.hip)."""
     return (d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0

@@ -129,6 +129,23 @@ class KernelTimer:
                 return r
             return inner
 
+        def wrap_fp8(fn):
+            def inner(d, xq, wq, wscale, bias, y, add=None, flags=0):
+                if not self.enabled:
+                    return fn(d, xq, wq, wscale, bias, y, add=add, flags=flags)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = fn(d, xq, wq, wscale, bias, y, add=add, flags=flags)
+                e.record()
+                mi = sum(d.Hi[i] * d.Wi[i] for i in range(d.nseg)) * d.N
+                mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
+                nbytes = 1.0 * mi * d.Cin + 2.0 * mo * d.Cout * (2 if add is not None else 1) + 1.0 * d.Cin * d.Cout * d.R * d.S
+                self.records.setdefault("conv_fp8_kernel", []).append((s, e, flops(d)))
+                self.meta.setdefault("conv_fp8_kernel", []).append(("conv2d_fwd_fp8", d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
+                return r
+            return inner
+
+        ops.conv2d_fwd_fp8 = wrap_fp8(ops.conv2d_fwd_fp8)
         ops.conv2d_fwd = wrap(ops.conv2d_fwd, "igemm")
         ops.conv2d_dgrad = wrap(ops.conv2d_dgrad, "igemm")
         ops.conv2d_wgrad = wrap(ops.conv2d_wgrad, "wgrad")
@@ -167,6 +184,8 @@ class KernelTimer:
         wrap_stream("maxpool3x3s2_fwd", "maxpool3x3s2_kernel",
                     lambda k: k["N"] * k["Cn"] * 2.0 * (k["H"] * k["W"] + ((k["H"] - 1) // 2 + 1) * ((k["W"] - 1) // 2 + 1)))
         # pad + normalise: fp32 NCHW in (3 channels), bf16 [N][Hp+6][Wp+8][4] out
+        # e4m3 cast of a convolution's input: 2 B read + 1 B written per element
+        wrap_stream("quantize_fp8", "quantize_fp8_kernel", lambda k: k["x"].numel() * 3.0)
         wrap_stream("pad_normalize", "pad_normalize_kernel",
                     lambda k: k["x"].numel() * 4.0 + k["x"].shape[0] * (k["Hp"] + 6) * (k["Wp"] + 8) * 8.0)
 
@@ -547,8 +566,9 @@ def worker(args):
                 tf = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
                 gbs = sm["bytes"] / (sm["ms"] * 1e-3) / 1e9
                 # which roof is lower for this kernel's mix of launches: arithmetic intensity against the machine balance
-                hbm_bound = sm["flops"] / sm["bytes"] < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-                ach, peak, unit = (gbs, PEAK_HBM_GBS, "GB/s") if hbm_bound else (tf, PEAK_BF16_TFLOPS, "TFLOP/s")
+                mfma_peak = PEAK_FP8_TFLOPS if kern == "conv_fp8_kernel" else PEAK_BF16_TFLOPS      # e4m3 operands: ~5 PFLOP/s dense
+                hbm_bound = sm["flops"] / sm["bytes"] < mfma_peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+                ach, peak, unit = (gbs, PEAK_HBM_GBS, "GB/s") if hbm_bound else (tf, mfma_peak, "TFLOP/s")
                 entries.append({"bound": "hbm" if hbm_bound else "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak,
                                 "unit": unit, "frac": round(ach / peak, 4),
                                 "traffic": pmc.get(kern, {}).get("hbm_bytes_per_launch"),

@@ -492,6 +492,23 @@ int bd_sgd_momentum_step(float* w, float* v, const float* g, int64_t n, float lr
                          float grad_scale, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3) forward convolutions on the block-scaled MFMA (BASELINE config 5, "fp8 weights").  The reference's
+ * mixed-precision hook is fp16 autocast + GradScaler (solver/default_solver.py:66-76, tools/det_train.py:77-78); there is
+ * no fp8 counterpart, so the tolerance is stated against the fp32 oracle (tests/test_fp8_gpu.py).
+ * ------------------------------------------------------------------------------------------------------- */
+/* q[i] = e4m3(clamp(x[i] * scale, +-448)); x bf16, n % 16 == 0. */
+int bd_quantize_fp8(const void* x_bf16, int64_t n, float scale, void* q, bd_stream_t stream);
+/* wq [Cout][RS][Cin] = e4m3(w * row_scale / s_co), s_co = max |w_co * row_scale| / 448 (one scale per output channel);
+ * wscale[co] = s_co / act_scale is the epilogue multiplier of bd_conv2d_fwd_fp8.  w fp32 [Cout][RS][Cin], row_scale = folded FrozenBN
+ * scale or NULL. */
+int bd_weight_pack_fp8(const float* w, const float* row_scale, int Cout, int RS, int Cin, float act_scale, void* wq, float* wscale,
+                       bd_stream_t stream);
+/* y (bf16) = epi(conv(xq, wq) * wscale[co] + bias [+ add]); xq = bd_quantize_fp8 of the NHWC input, same geometry rules as
+ * bd_conv2d_fwd (any filter / stride 1-2 / multi-level); Cin % 16 == 0, Cout % 8 == 0; flags: BD_EPI_RELU, BD_EPI_ADD_BEFORE. */
+int bd_conv2d_fwd_fp8(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
+                      void* y, int flags, bd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Operator surface of basedet.layers / basedet.structures as stand-alone fp32 entry points (callers written against the
  * reference's Python signatures; the training step uses the fused label-driven kernels above).  Every *_elem function
  * writes loss (value per element, may be NULL) and/or the gradient w.r.t. the prediction times gout (NULL = ones).
