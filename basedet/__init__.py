@@ -8,8 +8,7 @@ import sys
 
 import basedet_amd
 
-_SUBMODULES = ("configs", "layers", "structures", "models", "solver", "utils", "data", "evaluators", "engine", "tools",
-               "tools.det_train")
+_SUBMODULES = ("configs", "layers", "structures", "models", "solver", "utils", "data", "evaluators", "engine")
 
 for _name in _SUBMODULES:
     _mod = importlib.import_module("basedet_amd." + _name)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "bd_nms_workspace_bytes": (_Z, [_I]),
     "bd_batched_nms": (_I, [_P, _P, _P, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "bd_focal_loss_fwd_bwd": (_I, [_P, _P, _L, _I, _F, _F, _P, _I, _F, _P, _P, _P]),
+    "bd_focal_set_fast": (_I, [_I]),
     "bd_smooth_l1_fwd_bwd": (_I, [_P, _P, _P, _L, _I, _I, _F, _P, _I, _F, _P, _P, _P]),
     "bd_giou_ltrb_fwd_bwd": (_I, [_P, _P, _P, _P, _L, _P, _F, _P, _P, _P]),
     "bd_bce_logits_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _L, _P, _P, _P, _P]),

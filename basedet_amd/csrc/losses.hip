@@ -40,6 +40,74 @@ __device__ __forceinline__ void focal_elem(float x, bool t, float alpha, float g
     grad = a * (dce * mod + ce * dmod * dpt);
 }
 
+// gamma == 2 (the configured value, retinanet_cfg.py:30): with z = x for a negative target and -x for the positive one, q = sigmoid(z)
+// is the probability of the WRONG answer and  ce = log(1 + e^-|x|) + max(z, 0),  loss = a * ce * q^2,
+// d loss / dx = s * a * q^2 * (q + 2 ce (1 - q))  (s = +1 / -1, a = 1 - alpha / alpha): ~15 vector instructions + exp, log, rcp.
+__device__ __forceinline__ void focal_g2(float x, float z, float a_signed, float a_abs, float& loss, float& grad) {
+    const float e = __expf(-fabsf(x));
+    const float t1 = 1.f + e;
+    const float inv = __frcp_rn(t1);
+    const float q = z >= 0.f ? inv : e * inv;
+    const float ce = __logf(t1) + fmaxf(z, 0.f);
+    const float q2 = q * q;
+    loss = a_abs * ce * q2;
+    grad = a_signed * q2 * (q + 2.f * ce * (1.f - q));
+}
+
+// The 8 logits of a vector are treated as negatives; the (at most one) positive among them is recomputed in a rare branch.
+__global__ __launch_bounds__(256) void focal_g2_kernel(const bf16_raw* __restrict__ logits, const int* __restrict__ labels,
+                                                       long long rows, int K, float alpha, const void* norm, int norm_is_float,
+                                                       float grad_scale, float* __restrict__ loss_sum, bf16_raw* __restrict__ dlogits) {
+    __shared__ float red[4];
+    const float inv_norm = 1.f / load_norm(norm, norm_is_float);
+    const float gs = grad_scale * inv_norm;
+    const float a_neg = alpha >= 0.f ? 1.f - alpha : 1.f, a_pos = alpha >= 0.f ? alpha : 1.f;
+    const int kv = K / 8;
+    const long long nvec = rows * kv;
+    float acc = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long row = i0 / kv;
+    int ch = (int)(i0 - row * kv);
+    const long long dq = stride / kv;
+    const int dr = (int)(stride - dq * kv);
+    for (long long i = i0; i < nvec; i += stride) {
+        const int c0 = ch * 8;
+        const int lab = labels[row];
+        row += dq; ch += dr;
+        if (ch >= kv) { ch -= kv; ++row; }
+        u32x4_t o = {0u, 0u, 0u, 0u};
+        if (lab >= 0) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(logits + i * 8);
+            float g[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float l0, l1;
+                focal_g2(bf_lo(v[k]), bf_lo(v[k]), a_neg, a_neg, l0, g[2 * k]);
+                focal_g2(bf_hi(v[k]), bf_hi(v[k]), a_neg, a_neg, l1, g[2 * k + 1]);
+                acc += l0 + l1;
+            }
+            const int pos = lab - 1 - c0;
+            if (pos >= 0 && pos < 8) {                      // this vector holds the row's positive class: redo that one element
+                const unsigned w = v[pos >> 1];
+                const float x = (pos & 1) ? bf_hi(w) : bf_lo(w);
+                float ln, gn, lp, gp;
+                focal_g2(x, x, a_neg, a_neg, ln, gn);
+                focal_g2(x, -x, -a_pos, a_pos, lp, gp);
+                acc += lp - ln;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k == pos) g[k] = gp;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = pack_bf2(g[2 * k] * gs, g[2 * k + 1] * gs);
+        }
+        *reinterpret_cast<u32x4_t*>(dlogits + i * 8) = o;
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s * inv_norm);
+}
+
 __global__ __launch_bounds__(256) void focal_kernel(const bf16_raw* __restrict__ logits, const int* __restrict__ labels,
                                                     long long rows, int K, float alpha, float gamma, const void* norm,
                                                     int norm_is_float, float grad_scale, float* __restrict__ loss_sum,
@@ -331,15 +399,23 @@ inline int loss_grid(long long n) {
 
 }  // namespace
 
+static int g_focal_fast = 1;
+extern "C" int bd_focal_set_fast(int on) { g_focal_fast = on ? 1 : 0; return BD_OK; }      // 0: the general-gamma kernel also for gamma = 2 (A/B)
+
 extern "C" int bd_focal_loss_fwd_bwd(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha, float gamma,
                                      const void* norm, int norm_is_float, float grad_scale, float* loss_sum, void* dlogits,
                                      bd_stream_t stream) {
     BD_REQUIRE(logits && labels && norm && loss_sum && dlogits, "focal_loss: null pointer");
     BD_REQUIRE(K > 0 && K % 8 == 0, "focal_loss: K=%d must be a multiple of 8", K);
     if (rows == 0) return BD_OK;
-    hipLaunchKernelGGL(focal_kernel, dim3(loss_grid(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_raw*)logits, labels, (long long)rows, K, alpha, gamma, norm, norm_is_float, grad_scale,
-                       loss_sum, (bf16_raw*)dlogits);
+    if (gamma == 2.f && g_focal_fast)
+        hipLaunchKernelGGL(focal_g2_kernel, dim3(loss_grid(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_raw*)logits, labels, (long long)rows, K, alpha, norm, norm_is_float, grad_scale, loss_sum,
+                           (bf16_raw*)dlogits);
+    else
+        hipLaunchKernelGGL(focal_kernel, dim3(loss_grid(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_raw*)logits, labels, (long long)rows, K, alpha, gamma, norm, norm_is_float, grad_scale,
+                           loss_sum, (bf16_raw*)dlogits);
     BD_CHECK_LAUNCH("bd_focal_loss_fwd_bwd");
     return BD_OK;
 }

@@ -10,6 +10,8 @@ import socket
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))      # run as a script: repo root
+
 
 def default_parser():
     p = argparse.ArgumentParser()
@@ -56,7 +58,7 @@ def main():
         for r in range(args.ngpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.ngpus), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-            procs.append(subprocess.Popen([sys.executable, "-m", "basedet_amd.tools.det_train"] + sys.argv[1:], env=env))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
         rc = 0
         for p in procs:
             rc = p.wait() or rc

@@ -296,6 +296,8 @@ int bd_batched_nms(const float* boxes, const float* scores, const int32_t* idxs,
 int bd_focal_loss_fwd_bwd(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha,
                           float gamma, const void* norm, int norm_is_float, float grad_scale,
                           float* loss_sum, void* dlogits, bd_stream_t stream);
+/* measurement knob: 1 (default) = the gamma == 2 instance (one sigmoid / log per logit, the positive class patched in), 0 = general kernel. */
+int bd_focal_set_fast(int on);
 
 /* smooth_l1_loss (layers/losses/smooth_l1_loss.py:7-34) over rows with label > 0 (retinanet.py:158-162).
  * Row r = pixel*A + a; pred/dpred are bf16 with `ld` channels per pixel (ld >= 4*A, ld % 4 == 0), element

@@ -1,12 +1,15 @@
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into
-profiles/r01_pmc_traffic.json: HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests
+profiles/r02_pmc_traffic.json (with the digest of the kernel sources it was collected on: bench.py refuses it for another build): HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests
 at 64 B -- MI355X_MICROARCH.md, HBM section).   python scripts/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(d, counter):
@@ -36,10 +39,11 @@ def main():
         kernels[k] = {"launches": n, "fetch_size_kb": round(fk, 1), "write_size_kb": round(wk, 1),
                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
     src = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 2 --warmup 1 "
-           "--no-cpu-baseline --no-roofline`, retinanet_r50_800x1344 batch 16; values in KB per launch (mean over all launches of "
+           "--no-cpu-baseline --no-roofline --ref-protocol-steps 0`, retinanet_r50_800x1344 batch 16; values in KB per launch (mean over all launches of "
            "the kernel); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests at 64 B, "
            "MI355X_MICROARCH.md section HBM); aggregated by scripts/pmc_traffic.py")
-    json.dump({"source": src, "kernels": kernels}, open(out, "w"), indent=1)
+    from basedet_amd import build as _b
+    json.dump({"source": src, "build_digest": _b._digest(), "kernels": kernels}, open(out, "w"), indent=1)
     for k in list(kernels)[:8]:
         print(k, kernels[k])
 

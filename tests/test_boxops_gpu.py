@@ -183,17 +183,23 @@ def test_focal_and_l1_losses():
     norm = torch.tensor([nfg], dtype=torch.int32, device="cuda")
     loss = torch.zeros((1,), dtype=torch.float32, device="cuda")
     dl = torch.empty((rows, K), dtype=torch.bfloat16, device="cuda")
-    ops.focal_loss_fwd_bwd(x.cuda(), _dev(labels), rows, K, 0.25, 2.0, norm, 1.0, loss, dl)
     xf = x.float().numpy().astype(np.float64)
     t = np.zeros((rows, K)); fg = labels > 0
     t[fg, labels[fg] - 1] = 1
     valid = labels >= 0
-    ref_loss = ob.sigmoid_focal_loss(xf[valid], t[valid], 0.25, 2.0).sum() / max(1, nfg)
-    ref_grad = ob.sigmoid_focal_loss_grad(xf, t, 0.25, 2.0) * valid[:, None] / max(1, nfg)
-    assert abs(float(loss.item()) - ref_loss) / ref_loss < 2e-3
-    got = dl.float().cpu().numpy()
-    assert np.allclose(got, ref_grad, rtol=2e-2, atol=1e-7)
-    assert np.all(got[~valid] == 0)
+    # the gamma == 2 instance (default), the general kernel on the same inputs, and a non-integer gamma through the general kernel
+    for fast, alpha, gamma in ((1, 0.25, 2.0), (0, 0.25, 2.0), (1, 0.25, 1.5), (1, -1.0, 2.0)):
+        ops.L().bd_focal_set_fast(fast)
+        loss.zero_()
+        ops.focal_loss_fwd_bwd(x.cuda(), _dev(labels), rows, K, alpha, gamma, norm, 1.0, loss, dl)
+        ops.L().bd_focal_set_fast(1)
+        ref_loss = ob.sigmoid_focal_loss(xf[valid], t[valid], alpha, gamma).sum() / max(1, nfg)
+        assert abs(float(loss.item()) - ref_loss) / ref_loss < 2e-3, (fast, alpha, gamma)
+        got = dl.float().cpu().numpy()
+        if gamma == 2.0 and alpha == 0.25:
+            ref_grad = ob.sigmoid_focal_loss_grad(xf, t, alpha, gamma) * valid[:, None] / max(1, nfg)
+            assert np.allclose(got, ref_grad, rtol=2e-2, atol=1e-7), fast
+        assert np.all(got[~valid] == 0)
     # smooth L1 (beta = 0 -> L1) with padded channel layout: A = 9 anchors, ld = 40
     pixels, A, ld = 500, 9, 40
     pred = torch.from_numpy(rng.normal(0, 1, (pixels, ld)).astype(np.float32)).to(torch.bfloat16)

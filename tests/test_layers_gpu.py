@@ -302,7 +302,7 @@ def test_basedet_train_entry_runs_a_user_config(tmp_path):
     path.write_text(_USER_CFG)
     r = subprocess.run([sys.executable, "-m", "basedet.tools.det_train", "-f", str(path), "--iters", "3", "SOLVER.WARM_ITERS", "2"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-1000:])
     lines = [l for l in r.stdout.splitlines() if "total_loss" in l]
     assert len(lines) == 3 and "iter 3/" in lines[-1], r.stdout[-2000:]
     loss = float(lines[-1].split("total_loss")[1].split()[0])

@@ -307,7 +307,8 @@ def test_roi_align_bwd_pk_full_size():
         # a running bf16 sum of n terms: ~sqrt(n) * 2^-9 relative (tests at toy size: 0.2-0.4 %)
         assert np.linalg.norm(gk[:, sl] - ref_l) <= 8e-3 * np.linalg.norm(ref_l), l
         tot = ref_l + b[:, sl]
-        assert np.linalg.norm(gk2[:, sl] - tot) <= 8e-3 * np.linalg.norm(tot), l
+        # on top of a base of comparable size every add also rounds the BASE to bf16 again: measured 0.6-0.9 % per level
+        assert np.linalg.norm(gk2[:, sl] - tot) <= 1.5e-2 * np.linalg.norm(tot), l
         o += h * w
     assert np.all(gk[:, o:] == 0) and np.array_equal(gk2[:, o:], b[:, o:])
 
