@@ -81,5 +81,21 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_driver(verbose=False):
+    """tools/abi_driver.cpp: a C++ caller of the C ABI with no Python / torch in the process (links the in-tree library by rpath)."""
+    src = os.path.join(HERE, "..", "tools", "abi_driver.cpp")
+    out = os.path.join(OUT_DIR, "abi_driver")
+    lib = build(force=False, verbose=verbose)
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return out
+    cmd = [HIPCC, "-O2", "-std=c++17", "-x", "hip", f"--offload-arch={ARCH}", "-I", os.path.join(HERE, "..", "include"), src,
+           "-o", out, "-L", OUT_DIR, "-l:" + os.path.basename(LIB), "-Wl,-rpath,$ORIGIN", "-Wno-unused-result"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_driver(verbose=True))

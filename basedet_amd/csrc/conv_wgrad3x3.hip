@@ -14,6 +14,7 @@
 // only shifts the LDS row of the X fragment by (r*10 + s) rows -- a compile-time address immediate.
 // MFMA k -> pixel map (same for A and B): k = 8*g4 + j  <->  patch row 4*kk + 2*(g4>>1) + (j>>2),
 // column 4*(g4&1) + (j&3); a half-wave therefore reads 8 consecutive LDS rows = all 64 banks (conflict-free).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -275,7 +276,8 @@ int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patch
     for (int s = 0; s < d->nseg; ++s) ppi += cdiv(d->Ho[s], ph) * cdiv(d->Wo[s], PATCH);
     const int total = ppi * d->N;
     const int tiles = cdiv(d->Cin, TILE_CI) * cdiv(d->Cout, TILE_CO);
-    int splits = 512 / tiles;
+    static const int target = getenv("BD_WGRAD3_TARGET") ? atoi(getenv("BD_WGRAD3_TARGET")) : 512;   // workgroups per launch (measurement knob)
+    int splits = target / tiles;
     if (splits < 1) splits = 1;
     if (splits > total) splits = total;
     const int per = cdiv(total, splits);

@@ -368,6 +368,56 @@ def test_faster_rcnn_minimize_runs():
     assert v < first, (first, v)
 
 
+def test_faster_rcnn_roi_backward_variants_train_alike():
+    """The training default of the RoIAlign backward accumulates with packed-bf16 atomics on top of the RPN head's gradient (running
+    bf16 sums, arrival order not fixed).  Thirty steps from the same start with the same sampling keys every step: its loss
+    trajectory must stay with the fp32-scatter variant's (same mathematical gradient, fp32 accumulation) -- the two may differ by the
+    bf16 rounding of dL/dP only, not drift apart."""
+    from basedet_amd.models import FasterRCNN
+    from basedet_amd.solver import DetSolver
+    traj = {}
+    for pk in (True, False):
+        cfg, params, batch = _frcnn_setup(2, (128, 160), seed=3)
+        model = FasterRCNN(cfg, params=params)
+        model.roi_bwd_pk = pk
+        pl = model._plan(2, 128, 160)
+        rng = np.random.default_rng(9)
+        Gmax = batch["gt_boxes"].shape[1]
+        keys = dict(rpn_pos=rng.random((2, pl.A_total), dtype=np.float32), rpn_neg=rng.random((2, pl.A_total), dtype=np.float32),
+                    rcnn_fg=rng.random((2, pl.rois.shape[1] + Gmax), dtype=np.float32),
+                    rcnn_bg=rng.random((2, pl.rois.shape[1] + Gmax), dtype=np.float32))
+        b = dict(batch, sample_keys=keys)
+        solver = DetSolver.build(cfg, model)
+        solver.optimizer.param_groups[0]["lr"] = 0.0005
+        traj[pk] = [float(solver.minimize(model, b)["total_loss"]) for _ in range(30)]
+    a, c = np.array(traj[True]), np.array(traj[False])
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(c))
+    assert a[-1] < a[0] and c[-1] < c[0]
+    # observed: the two trajectories agree to < 1 % at every step
+    assert np.max(np.abs(a - c) / c) < 5e-2, (a, c)
+
+
+def test_all_empty_batch_is_all_background():
+    """A batch in which no image has an annotation (the pad collator then yields gt_boxes of shape (N, 0, 5)): every anchor / point is
+    background, the regression losses are zero and the step runs (the oracle defines this case the same way)."""
+    from basedet_amd.configs import FCOSConfig
+    from basedet_amd.models import FCOS, RetinaNet, params as P
+    from basedet_amd.solver import DetSolver
+    cfg, params, batch = _setup("resnet18", 2, (128, 160))
+    empty = dict(data=batch["data"], gt_boxes=np.zeros((2, 0, 5), np.float32), im_info=batch["im_info"].copy())
+    empty["im_info"][:, 4] = 0
+    model = RetinaNet(cfg, params=params)
+    out = DetSolver.build(cfg, model).minimize(model, empty)
+    assert int((model._cur.labels > 0).sum()) == 0 and int((model._cur.labels == 0).sum()) == model._cur.labels.numel()
+    assert float(out["reg_loss"]) == 0.0 and np.isfinite(float(out["cls_loss"])) and float(out["cls_loss"]) > 0
+    fc = FCOSConfig()
+    fc.merge(dict(MODEL=dict(BATCHSIZE=2, BACKBONE=dict(NAME="resnet18", OUT_FEATURE_CHANNELS=[128, 256, 512]), FPN=dict(TOP_BLOCK_IN_CHANNELS=512))))
+    fm = FCOS(fc, params=P.init_fcos_params(fc, seed=0))
+    out = DetSolver.build(fc, fm).minimize(fm, empty)
+    assert int((fm._cur.labels > 0).sum()) == 0
+    assert float(out["reg_loss"]) == 0.0 and float(out["ctr_loss"]) == 0.0 and np.isfinite(float(out["total_loss"]))
+
+
 def test_state_dict_roundtrip_and_load_weights(tmp_path):
     """state_dict() returns the reference layouts bit-exactly (incl. the permuted fc1 columns and the fused predictors of
     Faster R-CNN); load_weights (models/base_net.py:83-89) of a saved checkpoint reproduces the losses."""
