@@ -74,7 +74,11 @@ class FasterRCNN(FPNDetector):
         self.pre_k = {True: m.RPN.TRAIN_PREV_NMS_TOPK, False: m.RPN.TEST_PREV_NMS_TOPK}
         self.post_k = {True: m.RPN.TRAIN_POST_NMS_TOPK, False: m.RPN.TEST_POST_NMS_TOPK}
         self.deterministic_roi_bwd = False
-        self.roi_bwd_pk = True              # packed-bf16 atomics straight into the bf16 gradient pyramid (half the atomics of the fp32 scatter)
+        # RoIAlign backward: fp32 atomic scatter + one conversion pass by default.  roi_bwd_pk = True accumulates with packed-bf16 atomics
+        # straight into the bf16 gradient pyramid (half the atomic operations, no staging buffer: ~10 % on the whole step) at the price
+        # of running bf16 sums on top of the RPN head's gradient (rel-L2 0.6-0.9 % per level instead of 0.1 %, arrival-order dependent):
+        # opt-in (bench.py --roi-bwd-pk).  deterministic_roi_bwd = True is the fixed-order gather.
+        self.roi_bwd_pk = False
         self._gen = torch.Generator(device=dev) if self.device.type == "cuda" else None
         if self._gen is not None:
             self._gen.manual_seed(0)

@@ -364,6 +364,8 @@ def main():
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight-gradient kernels on the main stream for the whole run (what the instrumented steps do): "
                          "use it under rocprofv3 so that per-kernel durations are not inflated by concurrent kernels")
+    ap.add_argument("--roi-bwd-pk", action="store_true",
+                    help="Faster R-CNN: packed-bf16 atomic RoIAlign backward (running bf16 sums; default is the fp32 scatter)")
     ap.add_argument("--dense1x1", type=int, default=None, help="ablation: bd_conv_set_dense1x1 (0 = generic kernel for the dense 1x1 launches)")
     ap.add_argument("--no-mask-bits", action="store_true", help="ablation: bf16 activations instead of bit-packed ReLU gates as dgrad masks")
     ap.add_argument("--conv-knob", type=int, default=None,
@@ -467,6 +469,8 @@ def worker(args):
         ops.L().bd_conv_set_dense1x1(args.dense1x1)
     if args.no_mask_bits:
         model.use_mask_bits = False
+    if args.roi_bwd_pk:
+        model.roi_bwd_pk = True
     for _ in range(args.warmup):
         sched.step(it); it += 1
         last = solver.minimize(model, batch)

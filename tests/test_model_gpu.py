@@ -368,33 +368,39 @@ def test_faster_rcnn_minimize_runs():
     assert v < first, (first, v)
 
 
-def test_faster_rcnn_roi_backward_variants_train_alike():
-    """The training default of the RoIAlign backward accumulates with packed-bf16 atomics on top of the RPN head's gradient (running
-    bf16 sums, arrival order not fixed).  Thirty steps from the same start with the same sampling keys every step: its loss
-    trajectory must stay with the fp32-scatter variant's (same mathematical gradient, fp32 accumulation) -- the two may differ by the
-    bf16 rounding of dL/dP only, not drift apart."""
+def test_faster_rcnn_roi_backward_variants_agree():
+    """RoIAlign backward variants inside the model (dL/dP already holds the RPN head's gradient when the RoI contributions arrive):
+    the fp32 atomic scatter (the default), the deterministic gather and the packed-bf16 atomics (opt-in: running bf16 sums, ~10 %
+    faster step) must give the same parameter gradients for one step with identical sampling keys -- per parameter rel-L2 <= 2e-2
+    against the deterministic variant (observed: fp32 scatter <= 3e-3, packed bf16 <= 8e-3)."""
     from basedet_amd.models import FasterRCNN
-    from basedet_amd.solver import DetSolver
-    traj = {}
-    for pk in (True, False):
+    grads = {}
+    for name in ("det", "fp32", "pk"):
         cfg, params, batch = _frcnn_setup(2, (128, 160), seed=3)
         model = FasterRCNN(cfg, params=params)
-        model.roi_bwd_pk = pk
+        assert model.roi_bwd_pk is False and model.deterministic_roi_bwd is False          # the default is the fp32 scatter
+        model.roi_bwd_pk = name == "pk"
+        model.deterministic_roi_bwd = name == "det"
         pl = model._plan(2, 128, 160)
         rng = np.random.default_rng(9)
         Gmax = batch["gt_boxes"].shape[1]
         keys = dict(rpn_pos=rng.random((2, pl.A_total), dtype=np.float32), rpn_neg=rng.random((2, pl.A_total), dtype=np.float32),
                     rcnn_fg=rng.random((2, pl.rois.shape[1] + Gmax), dtype=np.float32),
                     rcnn_bg=rng.random((2, pl.rois.shape[1] + Gmax), dtype=np.float32))
-        b = dict(batch, sample_keys=keys)
-        solver = DetSolver.build(cfg, model)
-        solver.optimizer.param_groups[0]["lr"] = 0.0005
-        traj[pk] = [float(solver.minimize(model, b)["total_loss"]) for _ in range(30)]
-    a, c = np.array(traj[True]), np.array(traj[False])
-    assert np.all(np.isfinite(a)) and np.all(np.isfinite(c))
-    assert a[-1] < a[0] and c[-1] < c[0]
-    # observed: the two trajectories agree to < 1 % at every step
-    assert np.max(np.abs(a - c) / c) < 5e-2, (a, c)
+        model(dict(batch, sample_keys=keys))
+        model.backward()
+        torch.cuda.synchronize()
+        grads[name] = model.reference_grads()
+    worst = {}
+    for name in ("fp32", "pk"):
+        w = 0.0
+        for n, r in grads["det"].items():
+            g = grads[name][n].double().reshape(-1)
+            r = r.double().reshape(-1)
+            w = max(w, float((g - r).norm() / (r.norm() + 1e-30)))
+        worst[name] = w
+    print("worst per-parameter gradient rel-L2 vs the deterministic RoIAlign backward:", worst)
+    assert worst["fp32"] < 2e-2 and worst["pk"] < 2e-2, worst
 
 
 def test_all_empty_batch_is_all_background():
