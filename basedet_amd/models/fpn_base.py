@@ -408,15 +408,18 @@ class FPNDetector:
     def _host_to_device(self, image):
         """data_to_input's `Tensor(image)` (layers/common/pre_processing.py:13): a host batch of any float dtype (the loaders yield
         float64 / uint8-valued float32) becomes fp32 in a pinned staging buffer -- the conversion is torch's multi-threaded host copy
-        -- and goes to HBM with one asynchronous DMA on the current stream.  The staging buffer is reused: the next call first waits
-        for the previous transfer's event."""
+        -- and goes to HBM by asynchronous DMA on the current stream, image by image, so that the conversion of image i + 1 runs
+        under the transfer of image i.  The staging buffer is reused: the next call first waits for the previous transfers' event."""
         st = getattr(self, "_stage", None)
         if st is None or st[0].shape != image.shape:
-            st = self._stage = [torch.empty(image.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event()]
+            st = self._stage = [torch.empty(image.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event(),
+                                torch.empty(image.shape, dtype=torch.float32, device=self.device)]
         else:
             st[1].synchronize()
-        st[0].copy_(image)
-        dev = st[0].to(self.device, non_blocking=True)
+        host, dev = st[0], st[2]
+        for i in range(image.shape[0]):
+            host[i].copy_(image[i])
+            dev[i].copy_(host[i], non_blocking=True)
         st[1].record()
         return dev
 

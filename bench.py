@@ -173,7 +173,7 @@ class KernelTimer:
             setattr(ops, name, inner)
 
         # focal: 2 B logit read + 2 B gradient write per logit, 4 B label per row
-        wrap_stream("focal_loss_fwd_bwd", "focal_kernel", lambda k: k["rows"] * k["K"] * 4.0 + k["rows"] * 4.0)
+        wrap_stream("focal_loss_fwd_bwd", "focal_g2_kernel", lambda k: k["rows"] * k["K"] * 4.0 + k["rows"] * 4.0)
         # SGD: read w, v, g; write w, v (fp32)
         wrap_stream("sgd_momentum_step", "sgd_kernel", lambda k: k["w"].numel() * 20.0)
         # stem: bf16 [N][H+6][W+8][4] in, bf16 [N][H/2][W/2][64] out
