@@ -364,6 +364,8 @@ def main():
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight-gradient kernels on the main stream for the whole run (what the instrumented steps do): "
                          "use it under rocprofv3 so that per-kernel durations are not inflated by concurrent kernels")
+    ap.add_argument("--main-priority", type=int, default=None,
+                    help="ablation: 0 = run the step's main chain on the caller's stream instead of the solver's high-priority stream")
     ap.add_argument("--roi-bwd-pk", action="store_true",
                     help="Faster R-CNN: packed-bf16 atomic RoIAlign backward (running bf16 sums; default is the fp32 scatter)")
     ap.add_argument("--dense1x1", type=int, default=None, help="ablation: bd_conv_set_dense1x1 (0 = generic kernel for the dense 1x1 launches)")
@@ -471,6 +473,8 @@ def worker(args):
         model.use_mask_bits = False
     if args.roi_bwd_pk:
         model.roi_bwd_pk = True
+    if args.main_priority is not None:            # ablation: 0 = the step on the caller's (default-priority) stream
+        solver.high_priority_main = args.main_priority < 0
     for _ in range(args.warmup):
         sched.step(it); it += 1
         last = solver.minimize(model, batch)
