@@ -120,6 +120,8 @@ SIGNATURES = {
     "bd_quantize_fp8": (_I, [_P, _L, _F, _P, _P]),
     "bd_weight_pack_fp8": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "bd_conv2d_fwd_fp8": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "bd_conv2d_fwd_fp8_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
+    "bd_conv_fp8_set_patch": (_I, [_I]),
     "bd_sigmoid_focal_loss_elem": (_I, [_P, _P, _L, _F, _F, _P, _P, _P, _P]),
     "bd_bce_elem": (_I, [_P, _P, _L, _I, _P, _P, _P, _P]),
     "bd_smooth_l1_elem": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),

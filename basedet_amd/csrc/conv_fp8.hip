@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void weight_pack_fp8_kernel(const float* __res
 struct F8Params {
     IgemmParams g;            // src = e4m3 activations, w = e4m3 weights (byte pointers carried as bf16_raw*), dst bf16
     const float* wscale;
+    unsigned char* dst8;      // optional e4m3 twin of the output (dst * q_scale), read by a following fp8 convolution
+    float q_scale;
 };
 
 __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const F8Params fp) {
@@ -262,11 +264,22 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const F8Params fp) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
             *reinterpret_cast<u32x4_t*>(p.dst + idx) = o;
+            if (fp.dst8) {
+                u32x2_t o8;
+                o8[0] = pack4_fp8(v[0] * fp.q_scale, v[1] * fp.q_scale, v[2] * fp.q_scale, v[3] * fp.q_scale);
+                o8[1] = pack4_fp8(v[4] * fp.q_scale, v[5] * fp.q_scale, v[6] * fp.q_scale, v[7] * fp.q_scale);
+                *reinterpret_cast<u32x2_t*>(fp.dst8 + idx) = o8;
+            }
         }
     }
 }
 
+int g_fp8_patch = 1;        // bd_conv_fp8_set_patch: 0 = every shape through the generic per-tap kernel (A/B)
+
 }  // namespace
+
+int bd_conv3x3_pp8_launch(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
+                          void* y, void* y8, float q_scale, int flags, hipStream_t stream);
 
 extern "C" {
 
@@ -291,13 +304,28 @@ int bd_weight_pack_fp8(const float* w, const float* row_scale, int Cout, int RS,
     return BD_OK;
 }
 
+int bd_conv_fp8_set_patch(int on) { g_fp8_patch = on ? 1 : 0; return BD_OK; }
+
+int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
+                         void* y, void* y8, float q_scale, int flags, bd_stream_t stream);
+
 int bd_conv2d_fwd_fp8(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
                       void* y, int flags, bd_stream_t stream) {
+    return bd_conv2d_fwd_fp8_ex(d, xq, wq, wscale, bias, add, y, nullptr, 1.f, flags, stream);
+}
+
+int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
+                         void* y, void* y8, float q_scale, int flags, bd_stream_t stream) {
     BD_REQUIRE(d && xq && wq && wscale && y, "conv2d_fwd_fp8: null pointer");
     BD_REQUIRE(d->nseg >= 1 && d->nseg <= MAX_SUB && (d->stride == 1 || d->stride == 2) && d->R * d->S <= 32, "conv2d_fwd_fp8: bad descriptor");
     BD_REQUIRE(d->Cin % 16 == 0 && d->Cout % 8 == 0, "conv2d_fwd_fp8: Cin %% 16 and Cout %% 8 must be 0 (got %d, %d)", d->Cin, d->Cout);
     BD_REQUIRE(!(flags & (BD_EPI_MASK | BD_EPI_ADD_AFTER)), "conv2d_fwd_fp8: forward flags only");
+    if (g_fp8_patch && bd_conv3x3_pp8_launch(d, xq, wq, wscale, bias, add, y, y8, q_scale, flags, (hipStream_t)stream) == 0) {
+        BD_CHECK_LAUNCH("bd_conv2d_fwd_fp8(patch)");
+        return BD_OK;
+    }
     F8Params fp{};
+    fp.dst8 = (unsigned char*)y8; fp.q_scale = q_scale;
     IgemmParams& p = fp.g;
     fp.wscale = wscale;
     p.src = (const bf16_raw*)xq; p.w = (const bf16_raw*)wq; p.bias = bias; p.add = (const bf16_raw*)add; p.mask = nullptr; p.dst = (bf16_raw*)y;

@@ -343,6 +343,11 @@ class FPNDetector:
         ch = self.fpn_ch
         pl.P = act(pl.pyr, ch)
         pl.g_P = act(pl.pyr, ch)
+        # e4m3 twin of the pyramid: written by the fp8 launches that produce P (FPN output convolutions, P6, P7), read by the heads'
+        # first convolutions instead of a cast pass.  Only when EVERY level is written by an fp8 convolution (LastLevelP6P7).
+        writers = [self.output[s] for s in self.fpn_stages] + ([self.p6, self.p7] if self.TOP_BLOCK == "p6p7" else [])
+        pl.P8 = (torch.empty((pl.pyr.pixels, ch), dtype=torch.uint8, device=dev)
+                 if self.TOP_BLOCK == "p6p7" and all(c.fp8 for c in writers) else None)
         pl.lat = {s: act(pl.blk[pl.res[s]].gout, ch) for s in self.fpn_stages}
         pl.g_lat = {s: torch.empty_like(pl.lat[s]) for s in self.fpn_stages}
         g6 = pl.pyr.level(len(self.fpn_stages))
@@ -408,18 +413,16 @@ class FPNDetector:
     def _host_to_device(self, image):
         """data_to_input's `Tensor(image)` (layers/common/pre_processing.py:13): a host batch of any float dtype (the loaders yield
         float64 / uint8-valued float32) becomes fp32 in a pinned staging buffer -- the conversion is torch's multi-threaded host copy
-        -- and goes to HBM by asynchronous DMA on the current stream, image by image, so that the conversion of image i + 1 runs
-        under the transfer of image i.  The staging buffer is reused: the next call first waits for the previous transfers' event."""
+        -- and goes to HBM with one asynchronous DMA on the current stream.  (Converting and sending image by image, to overlap the
+        two, measured slower: 251 vs 299-352 img/s in bench.py's reference-protocol leg.)  The staging buffer is reused: the next call
+        first waits for the previous transfer's event."""
         st = getattr(self, "_stage", None)
         if st is None or st[0].shape != image.shape:
-            st = self._stage = [torch.empty(image.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event(),
-                                torch.empty(image.shape, dtype=torch.float32, device=self.device)]
+            st = self._stage = [torch.empty(image.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event()]
         else:
             st[1].synchronize()
-        host, dev = st[0], st[2]
-        for i in range(image.shape[0]):
-            host[i].copy_(image[i])
-            dev[i].copy_(host[i], non_blocking=True)
+        st[0].copy_(image)
+        dev = st[0].to(self.device, non_blocking=True)
         st[1].record()
         return dev
 
@@ -458,9 +461,9 @@ class FPNDetector:
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side) if side is not None else _nullcontext():
-                self.p6.forward(b5.out, b5.gout, g6, pl.P)
+                self.p6.forward(b5.out, b5.gout, g6, pl.P, y8=pl.P8)
                 self._relu_level(pl.P, g6, pl.p6_relu)
-                self.p7.forward(pl.p6_relu, pl.g_p6r, g7, pl.P)
+                self.p7.forward(pl.p6_relu, pl.g_p6r, g7, pl.P, y8=pl.P8)
         prev, prev_geo = None, None
         for li in range(nl - 1, -1, -1):
             s = st[li]
@@ -468,7 +471,7 @@ class FPNDetector:
             self.lateral[s].forward(b.out, b.gout, b.gout, pl.lat[s])
             if prev is not None:
                 ops.upsample2x_add_fwd(prev, prev_geo, pl.lat[s], b.gout, self.fpn_ch)
-            self.output[s].forward(pl.lat[s], b.gout, pl.pyr.level(li), pl.P)
+            self.output[s].forward(pl.lat[s], b.gout, pl.pyr.level(li), pl.P, y8=pl.P8)
             prev, prev_geo = pl.lat[s], b.gout
         if self.TOP_BLOCK == "p6p7":
             if side is not None:

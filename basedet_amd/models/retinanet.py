@@ -76,6 +76,10 @@ class RetinaNet(FPNDetector):
         pl.d_logits = torch.empty_like(pl.logits)
         pl.d_offsets = torch.empty_like(pl.offsets)
         pl.g_tower = [[act(pl.pyr, ch) for _ in range(nc)] for _ in range(2)]   # one gradient buffer per tower layer
+        # fp8 forward: every tower activation gets an e4m3 twin, written by the launch that produces it (no cast passes in the head)
+        tw = lambda: torch.empty((pl.pyr.pixels, ch), dtype=torch.uint8, device=dev)      # noqa: E731
+        pl.cls_act8 = [tw() if c.fp8 else None for c in self.cls_tower]
+        pl.box_act8 = [tw() if c.fp8 else None for c in self.box_tower]
         # anchors (regenerated per forward in the reference, retinanet.py:116; cached per shape here)
         tot = pl.pyr.pix_per_img * A
         pl.anchors = torch.empty((tot, 4), dtype=torch.float32, device=dev)
@@ -94,14 +98,14 @@ class RetinaNet(FPNDetector):
     # ---- forward -----------------------------------------------------------------------------------------
     def head_forward(self, pl):
         # head (retina_head.py:103-112), all five levels per launch
-        t = pl.P
-        for c, a in zip(self.cls_tower, pl.cls_act):
-            c.forward(t, pl.pyr, pl.pyr, a, relu=True); t = a
-        self.cls_score.forward(t, pl.pyr, pl.pyr, pl.logits)
-        t = pl.P
-        for c, a in zip(self.box_tower, pl.box_act):
-            c.forward(t, pl.pyr, pl.pyr, a, relu=True); t = a
-        self.bbox_pred.forward(t, pl.pyr, pl.pyr, pl.offsets)
+        t, t8 = pl.P, getattr(pl, "P8", None)
+        for c, a, a8 in zip(self.cls_tower, pl.cls_act, pl.cls_act8):
+            c.forward(t, pl.pyr, pl.pyr, a, relu=True, x8=t8, y8=a8); t, t8 = a, a8
+        self.cls_score.forward(t, pl.pyr, pl.pyr, pl.logits, x8=t8)
+        t, t8 = pl.P, getattr(pl, "P8", None)
+        for c, a, a8 in zip(self.box_tower, pl.box_act, pl.box_act8):
+            c.forward(t, pl.pyr, pl.pyr, a, relu=True, x8=t8, y8=a8); t, t8 = a, a8
+        self.bbox_pred.forward(t, pl.pyr, pl.pyr, pl.offsets, x8=t8)
 
     def get_losses(self, inputs):
         """RetinaNet.get_losses (retinanet.py:120-170)."""

@@ -102,9 +102,10 @@ def weight_pack_fp8(w, row_scale, Cout, RS, Cin, act_scale, wq, wscale):
           "bd_weight_pack_fp8")
 
 
-def conv2d_fwd_fp8(d, xq, wq, wscale, bias, y, add=None, flags=0):
-    check(L().bd_conv2d_fwd_fp8(C.byref(d), ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(y), flags, stream_ptr()),
-          "bd_conv2d_fwd_fp8")
+def conv2d_fwd_fp8(d, xq, wq, wscale, bias, y, add=None, flags=0, y8=None, q_scale=1.0):
+    """y8: optional uint8 twin of y (e4m3(y * q_scale)) for a following fp8 convolution."""
+    check(L().bd_conv2d_fwd_fp8_ex(C.byref(d), ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(y), ptr(y8), float(q_scale), flags,
+                                   stream_ptr()), "bd_conv2d_fwd_fp8")
     return y
 
 

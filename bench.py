@@ -130,18 +130,21 @@ class KernelTimer:
             return inner
 
         def wrap_fp8(fn):
-            def inner(d, xq, wq, wscale, bias, y, add=None, flags=0):
+            def inner(d, xq, wq, wscale, bias, y, add=None, flags=0, y8=None, q_scale=1.0):
                 if not self.enabled:
-                    return fn(d, xq, wq, wscale, bias, y, add=add, flags=flags)
+                    return fn(d, xq, wq, wscale, bias, y, add=add, flags=flags, y8=y8, q_scale=q_scale)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                r = fn(d, xq, wq, wscale, bias, y, add=add, flags=flags)
+                r = fn(d, xq, wq, wscale, bias, y, add=add, flags=flags, y8=y8, q_scale=q_scale)
                 e.record()
                 mi = sum(d.Hi[i] * d.Wi[i] for i in range(d.nseg)) * d.N
                 mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
-                nbytes = 1.0 * mi * d.Cin + 2.0 * mo * d.Cout * (2 if add is not None else 1) + 1.0 * d.Cin * d.Cout * d.R * d.S
-                self.records.setdefault("conv_fp8_kernel", []).append((s, e, flops(d)))
-                self.meta.setdefault("conv_fp8_kernel", []).append(("conv2d_fwd_fp8", d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
+                nbytes = 1.0 * mi * d.Cin + 2.0 * mo * d.Cout * (2 if add is not None else 1) + 1.0 * d.Cin * d.Cout * d.R * d.S \
+                    + (1.0 * mo * d.Cout if y8 is not None else 0.0)
+                same = all(d.Hi[i] == d.Ho[i] and d.Wi[i] == d.Wo[i] for i in range(d.nseg))
+                kern8 = "conv3x3_pp8_kernel" if (d.R == 3 and d.stride == 1 and same and d.Cout > 128 and d.Cin % 16 == 0) else "conv_fp8_kernel"
+                self.records.setdefault(kern8, []).append((s, e, flops(d)))
+                self.meta.setdefault(kern8, []).append(("conv2d_fwd_fp8", d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
                 return r
             return inner
 
@@ -574,7 +577,7 @@ def worker(args):
                 tf = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
                 gbs = sm["bytes"] / (sm["ms"] * 1e-3) / 1e9
                 # which roof is lower for this kernel's mix of launches: arithmetic intensity against the machine balance
-                mfma_peak = PEAK_FP8_TFLOPS if kern == "conv_fp8_kernel" else PEAK_BF16_TFLOPS      # e4m3 operands: ~5 PFLOP/s dense
+                mfma_peak = PEAK_FP8_TFLOPS if kern in ("conv_fp8_kernel", "conv3x3_pp8_kernel") else PEAK_BF16_TFLOPS      # e4m3 operands: ~5 PFLOP/s dense
                 hbm_bound = sm["flops"] / sm["bytes"] < mfma_peak * 1e12 / (PEAK_HBM_GBS * 1e9)
                 ach, peak, unit = (gbs, PEAK_HBM_GBS, "GB/s") if hbm_bound else (tf, mfma_peak, "TFLOP/s")
                 entries.append({"bound": "hbm" if hbm_bound else "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak,

@@ -509,6 +509,12 @@ int bd_weight_pack_fp8(const float* w, const float* row_scale, int Cout, int RS,
  * bd_conv2d_fwd (any filter / stride 1-2 / multi-level); Cin % 16 == 0, Cout % 8 == 0; flags: BD_EPI_RELU, BD_EPI_ADD_BEFORE. */
 int bd_conv2d_fwd_fp8(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
                       void* y, int flags, bd_stream_t stream);
+/* ... and also writes y8 (may be NULL) = e4m3(clamp(y * q_scale)), the input of a following fp8 convolution (saves its cast pass).
+ * 3x3 / stride 1 launches with Cout > 128 take the fp8 instance of the staggered patch kernel (conv3x3_pp8.hip), the rest the
+ * generic per-tap kernel (conv_fp8.hip); bd_conv_fp8_set_patch(0) forces the generic kernel (measurement knob). */
+int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
+                         void* y, void* y8, float q_scale, int flags, bd_stream_t stream);
+int bd_conv_fp8_set_patch(int on);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Operator surface of basedet.layers / basedet.structures as stand-alone fp32 entry points (callers written against the

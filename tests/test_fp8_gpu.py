@@ -31,7 +31,7 @@ def _ops():
     return ops
 
 
-def _run(ops, N, Cin, Cout, sizes, R, stride, x_lv, w, bias, add_lv=None, relu=False, act_scale=1.0):
+def _run(ops, N, Cin, Cout, sizes, R, stride, x_lv, w, bias, add_lv=None, relu=False, act_scale=1.0, twin=False):
     pad = R // 2
     gin = ops.Geom(N, [h for h, _ in sizes], [w_ for _, w_ in sizes])
     gout = gin.conv_out(R, stride, pad)
@@ -53,13 +53,29 @@ def _run(ops, N, Cin, Cout, sizes, R, stride, x_lv, w, bias, add_lv=None, relu=F
     ops.quantize_fp8(x, act_scale, xq)
     y = torch.empty((gout.pixels, Cout), dtype=torch.bfloat16, device="cuda")
     flags = (ops.EPI_RELU if relu else 0) | (ops.EPI_ADD_BEFORE if add is not None else 0)
-    ops.conv2d_fwd_fp8(d, xq, wq, ws, None if bias is None else bias.cuda(), y, add=add, flags=flags)
+    y8 = torch.zeros((gout.pixels, Cout), dtype=torch.uint8, device="cuda") if twin else None
+    ops.conv2d_fwd_fp8(d, xq, wq, ws, None if bias is None else bias.cuda(), y, add=add, flags=flags, y8=y8, q_scale=0.5)
+    if twin:
+        # the e4m3 twin is e4m3(y_fp32 * q_scale): within half an e4m3 ulp (2^-4 relative; 2^-10 absolute in the subnormals) of y * q_scale
+        dec = y8.view(torch.float8_e4m3fn).float().cpu()
+        want = (y.float().cpu() * 0.5).clamp(-448, 448)
+        assert bool(((dec - want).abs() <= want.abs() * 2.0 ** -4 * 1.01 + 2.0 ** -10 + want.abs() * 2.0 ** -8).all())
     yv = y.float().cpu().view(N, gout.pix_per_img, Cout)
     return [yv[:, o:o + h * w_].reshape(N, h, w_, Cout).permute(0, 3, 1, 2) for h, w_, o in zip(gout.H, gout.W, gout.off)], (wq, ws, xq)
 
 
+@pytest.fixture(params=[1, 0], ids=["patch", "generic"])
+def fp8_kernel(request):
+    """1: 3x3 / stride 1 / Cout > 128 launches take the fp8 instance of the staggered patch kernel (conv3x3_pp8.hip); 0: every shape
+    through the generic per-tap kernel (conv_fp8.hip)."""
+    ops = _ops()
+    ops.L().bd_conv_fp8_set_patch(request.param)
+    yield request.param
+    ops.L().bd_conv_fp8_set_patch(1)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_fp8_conv_structure_is_exact_on_e4m3_inputs(case):
+def test_fp8_conv_structure_is_exact_on_e4m3_inputs(case, fp8_kernel):
     """Inputs and weights drawn from e4m3 numbers (weights: every channel's largest magnitude is 448 / 64 = 7 so that the per-channel
     scale is the exact power of two 2^-6): products and partial sums are exact in fp32, the only rounding is the bf16 store."""
     ops = _ops()
@@ -71,7 +87,7 @@ def test_fp8_conv_structure_is_exact_on_e4m3_inputs(case):
     w = wv[torch.randint(0, len(wv) - 2, (Cout, Cin, R, R), generator=g)]
     w[:, 0, 0, 0] = 7.0                                            # max |w| per output channel = 7 -> scale 7 / 448 = 2^-6
     bias = torch.randn(Cout, generator=g)
-    got, (wq, ws, xq) = _run(ops, N, Cin, Cout, sizes, R, stride, x_lv, w, bias)
+    got, (wq, ws, xq) = _run(ops, N, Cin, Cout, sizes, R, stride, x_lv, w, bias, twin=True)
     assert torch.equal(ws.cpu(), torch.full((Cout,), 2.0 ** -6))
     for xl, gl in zip(x_lv, got):
         ref = bf16_round(TF.conv2d(xl, w, bias, stride=stride, padding=R // 2))
@@ -82,8 +98,8 @@ def test_fp8_conv_structure_is_exact_on_e4m3_inputs(case):
         assert bool(((gl - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-6).all()), float((gl - ref).abs().max())
 
 
-@pytest.mark.parametrize("case", CASES[:5])
-def test_fp8_conv_tolerance_on_random_data(case):
+@pytest.mark.parametrize("case", CASES[:5] + [(1, 256, 720, [(25, 42), (13, 21)], 3, 1), (2, 1024, 512, [(10, 12)], 3, 1)])
+def test_fp8_conv_tolerance_on_random_data(case, fp8_kernel):
     ops = _ops()
     N, Cin, Cout, sizes, R, stride = case
     g = torch.Generator().manual_seed(11 + Cin + Cout)
