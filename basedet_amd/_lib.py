@@ -45,6 +45,7 @@ SIGNATURES = {
     "bd_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_fwd_bits": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "bd_conv2d_fwd_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_dgrad_bits": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv_set_dense1x1": (_I, [_I]),
     "bd_conv2d_wgrad_workspace_bytes": (_Z, [_D]),

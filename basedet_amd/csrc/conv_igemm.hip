@@ -470,7 +470,7 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
 }
 
 int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits,
-                            void* y, unsigned* ybits, long long M, int CK, int CO, int flags, hipStream_t stream);
+                            void* y, unsigned* ybits, void* y8, float q_scale, long long M, int CK, int CO, int flags, hipStream_t stream);
 
 namespace {
 // 1x1 / stride 1 / pad 0 over one dense level: source pixel index == destination pixel index (conv1x1.hip)
@@ -481,20 +481,20 @@ bool is_dense_1x1(const bd_conv_desc* d) {
 }  // namespace
 
 static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
-                           unsigned* ybits, int flags, bd_stream_t stream) {
+                           unsigned* ybits, void* y8, float q_scale, int flags, bd_stream_t stream) {
     if (int e = check_desc(d)) return e;
     BD_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_fwd: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_fwd: Cout=%d must be a multiple of 8", d->Cout);
     BD_REQUIRE(!(flags & BD_EPI_MASK), "conv2d_fwd: BD_EPI_MASK is a dgrad-only flag");
     if (is_dense_1x1(d) &&
-        bd_conv1x1_dense_launch(x, w_packed, bias, add, nullptr, nullptr, y, ybits, (long long)d->N * d->out_pix_per_img, d->Cin, d->Cout,
-                                flags, (hipStream_t)stream) == 0) {
+        bd_conv1x1_dense_launch(x, w_packed, bias, add, nullptr, nullptr, y, ybits, y8, q_scale, (long long)d->N * d->out_pix_per_img,
+                                d->Cin, d->Cout, flags, (hipStream_t)stream) == 0) {
         BD_CHECK_LAUNCH("bd_conv2d_fwd(dense 1x1)");
         return BD_OK;
     }
-    BD_REQUIRE(ybits == nullptr, "conv2d_fwd_bits: the bit-packed ReLU mask is written by the dense 1x1 kernel only (1x1 / stride 1 over one "
-               "dense level, Cout %% 32 == 0, tensors < 2 GB)");
+    BD_REQUIRE(ybits == nullptr && y8 == nullptr, "conv2d_fwd_bits / _ex: the bit-packed ReLU mask and the e4m3 twin are written by the dense "
+               "1x1 kernel only (1x1 / stride 1 over one dense level, Cout %% 32 == 0, tensors < 2 GB)");
     if (g_use_patch3x3 && is_3x3s1(d)) {
         bd_conv3x3_patch_launch(d, 0, x, w_packed, bias, add, nullptr, y, flags, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_fwd(3x3 patch)");
@@ -533,13 +533,18 @@ static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_p
 
 extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* add, void* y, int flags, bd_stream_t stream) {
-    return conv2d_fwd_impl(d, x, w_packed, bias, add, y, nullptr, flags, stream);
+    return conv2d_fwd_impl(d, x, w_packed, bias, add, y, nullptr, nullptr, 1.f, flags, stream);
+}
+
+extern "C" int bd_conv2d_fwd_ex(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
+                                uint32_t* ybits, void* y8, float q_scale, int flags, bd_stream_t stream) {
+    return conv2d_fwd_impl(d, x, w_packed, bias, add, y, ybits, y8, q_scale, flags, stream);
 }
 
 extern "C" int bd_conv2d_fwd_bits(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
                                   uint32_t* ybits, int flags, bd_stream_t stream) {
     BD_REQUIRE(ybits != nullptr, "conv2d_fwd_bits: null ybits");
-    return conv2d_fwd_impl(d, x, w_packed, bias, add, y, ybits, flags, stream);
+    return conv2d_fwd_impl(d, x, w_packed, bias, add, y, ybits, nullptr, 1.f, flags, stream);
 }
 
 static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
@@ -550,8 +555,8 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad: BD_EPI_RELU is a forward-only flag");
     if (is_dense_1x1(d) &&
-        bd_conv1x1_dense_launch(g, w_packed_t, nullptr, add, mask, maskbits, dx, nullptr, (long long)d->N * d->in_pix_per_img, d->Cout,
-                                d->Cin, flags, (hipStream_t)stream) == 0) {
+        bd_conv1x1_dense_launch(g, w_packed_t, nullptr, add, mask, maskbits, dx, nullptr, nullptr, 1.f, (long long)d->N * d->in_pix_per_img,
+                                d->Cout, d->Cin, flags, (hipStream_t)stream) == 0) {
         BD_CHECK_LAUNCH("bd_conv2d_dgrad(dense 1x1)");
         return BD_OK;
     }

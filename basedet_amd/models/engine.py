@@ -132,7 +132,7 @@ class ConvLayer:
             self._desc_cache[key] = d
         return d
 
-    def forward(self, x, gin, gout, y, add=None, relu=False, bits=None, x8=None, y8=None):
+    def forward(self, x, gin, gout, y, add=None, relu=False, bits=None, x8=None, y8=None, q_scale=1.0):
         """x8: the e4m3 twin of x when a producing fp8 launch wrote one (else x is cast by bd_quantize_fp8); y8: twin of y to write
         for a following fp8 convolution.  Both are ignored on the bf16 path."""
         flags = (ops.EPI_RELU if relu else 0) | (ops.EPI_ADD_BEFORE if add is not None else 0)
@@ -140,7 +140,8 @@ class ConvLayer:
             xq = x8 if x8 is not None else ops.quantize_fp8(x, self.act_scale, self.q8_scratch(x.numel())[: x.numel()])
             return ops.conv2d_fwd_fp8(self.desc(gin, gout), xq, self.w_q8, self.w_scale8, self.b, y, add=add, flags=flags, y8=y8,
                                       q_scale=self.act_scale)
-        return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags, bits=bits)
+        return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags, bits=bits,
+                              y8=y8 if (y8 is not None and ops.dense_1x1_bits_ok(self.desc(gin, gout))) else None, q_scale=q_scale)
 
     def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None):
         """dx (+)= conv^T(g).  first=False accumulates onto dx (pre-mask); mask = forward activation whose

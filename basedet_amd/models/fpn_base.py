@@ -137,7 +137,11 @@ class FPNDetector:
         if self.weight_dtype == "fp8_e4m3":
             side = {id(getattr(self, n)) for n in ("p6", "p7") if hasattr(self, n)}
             for c in self.convs.values():
-                if c.k == 3 and c.cin % 16 == 0 and c.cin >= 64 and not isinstance(c, FCLayer):
+                # the staggered fp8 patch kernel serves 3x3 / stride 1 with Cout > 128 (1.6x the bf16 kernel); the top block's stride-2
+                # convolutions go through the generic fp8 kernel (faster than their bf16 launches, and they complete the pyramid's e4m3
+                # twin); narrower or strided backbone layers are FASTER on their bf16 kernels and stay there
+                if (c.k == 3 and c.cin % 16 == 0 and not isinstance(c, FCLayer)
+                        and ((c.stride == 1 and c.cout > 128) or id(c) in side)):
                     key = "side" if id(c) in side else "main"          # P6 / P7 run on a side stream: their own scratch
                     c.enable_fp8(lambda n, key=key: self._q8_buf(key, n), m.get("FP8_ACT_SCALE", 1.0))
         else:
@@ -315,6 +319,11 @@ class FPNDetector:
                 b.mids = [act(b.gout, blk["ch"])]
             b.idt = act(b.gout, blk["cout"]) if blk["has_ds"] else None
             b.out = act(b.gout, blk["cout"])
+            # e4m3 twin of conv1's output, written by the dense 1x1 launch for the fp8 conv2 that follows
+            b.mid8 = None
+            if (blk["kind"] == "bottleneck" and blk["convs"][1].fp8
+                    and ops.dense_1x1_bits_ok(blk["convs"][0].desc(gin, gin))):
+                b.mid8 = torch.empty((gin.pixels, blk["ch"]), dtype=torch.uint8, device=dev)
             b.out_bits = None
             if blk["trainable"]:
                 b.g_mids = [torch.empty_like(t) for t in b.mids]
@@ -434,9 +443,12 @@ class FPNDetector:
             idt = b.idt
         geos = [b.gin] + b.mid_geo + [b.gout]
         t = x
+        t8 = None
         for ci, c in enumerate(convs[:-1]):
-            c.forward(t, geos[ci], geos[ci + 1], b.mids[ci], relu=True)
-            t = b.mids[ci]
+            y8 = b.mid8 if (ci == 0 and getattr(b, "mid8", None) is not None) else None
+            c.forward(t, geos[ci], geos[ci + 1], b.mids[ci], relu=True, x8=t8, y8=y8,
+                      q_scale=convs[ci + 1].act_scale if y8 is not None else 1.0)
+            t, t8 = b.mids[ci], y8
         convs[-1].forward(t, geos[-2], geos[-1], b.out, add=idt, relu=True, bits=b.out_bits)
         return b.out
 

@@ -71,8 +71,13 @@ def L():
 
 
 # ---- dense path -------------------------------------------------------------------------------------------
-def conv2d_fwd(d, x, w_packed, bias, y, add=None, flags=0, bits=None):
-    """bits: optional uint32 [Cout/32][M] output, the bit-packed ReLU mask of y (dense 1x1 launches only: bd_conv2d_fwd_bits)."""
+def conv2d_fwd(d, x, w_packed, bias, y, add=None, flags=0, bits=None, y8=None, q_scale=1.0):
+    """bits: optional uint32 [Cout/32][M] output, the bit-packed ReLU mask of y; y8: optional uint8 e4m3 twin of y (dense 1x1 launches
+    only: bd_conv2d_fwd_bits / bd_conv2d_fwd_ex)."""
+    if y8 is not None:
+        check(L().bd_conv2d_fwd_ex(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), ptr(y8), float(q_scale), flags,
+                                   stream_ptr()), "bd_conv2d_fwd_ex")
+        return y
     if bits is not None:
         check(L().bd_conv2d_fwd_bits(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), flags, stream_ptr()),
               "bd_conv2d_fwd_bits")

@@ -87,6 +87,10 @@ int bd_conv2d_fwd_bits(const bd_conv_desc* d, const void* x, const void* w_packe
                        uint32_t* ybits, int flags, bd_stream_t stream);
 int bd_conv2d_dgrad_bits(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const uint32_t* maskbits,
                          void* dx, int flags, bd_stream_t stream);
+/* bd_conv2d_fwd with both optional side outputs of the dense 1x1 kernel: ybits (may be NULL) as above, and y8 (may be NULL) =
+ * e4m3(clamp(y * q_scale)), the input of a following fp8 3x3 convolution (bd_conv2d_fwd_fp8: saves its cast pass). */
+int bd_conv2d_fwd_ex(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
+                     uint32_t* ybits, void* y8, float q_scale, int flags, bd_stream_t stream);
 /* measurement knob: variant of the dense 1x1 kernel (conv1x1.hip): 0 = off (generic kernel); 1 (default) = one K step ahead, four
  * workgroups per CU; 2 = two steps ahead, three per CU. */
 int bd_conv_set_dense1x1(int depth);
