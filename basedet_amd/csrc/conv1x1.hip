@@ -11,7 +11,7 @@
 // or 6 K steps ahead through extra register sets -- at three or two workgroups per CU -- and requesting the epilogue operands before
 // the last K step changed nothing on the 200x336 / 100x168 layers (4.2-4.8 / 3.5-3.9 TB/s either way) and LOST 10-35 % on the K >=
 // 1024 layers, where the kernel is bound by its MFMA loop (one barrier per 16 MFMAs), not by memory: occupancy, not prefetch depth,
-// is what fills that loop's bubbles.  DEPTH = 2 at three workgroups per CU is kept as the one alternative (bd_conv_set_dense1x1(2)).
+// is what fills that loop's bubbles.  (Those variants are gone; the DEPTH parameter below is what is left of them.)
 #include "common.h"
 
 namespace {
@@ -259,13 +259,13 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     }
 }
 
-int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (generic kernel); 1 = one K step ahead, four workgroups per CU; 2 = two ahead, three per CU
+int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (the generic kernel takes the dense 1x1 launches: A/B), 1 = on
 
 }  // namespace
 
 extern "C" int bd_conv_set_dense1x1(int depth) {
-    if (!(depth == 0 || depth == 1 || depth == 2)) {
-        bd_set_error("bd_conv_set_dense1x1: variant %d (0, 1 or 2)", depth);
+    if (!(depth == 0 || depth == 1)) {
+        bd_set_error("bd_conv_set_dense1x1: %d (0 or 1)", depth);
         return BD_EINVAL;
     }
     g_conv1x1_depth = depth;
@@ -288,9 +288,6 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
     const int grid = p.m_tiles * p.n_tiles;
     const size_t lds = 4 * TILE_BYTES;
-    switch (g_conv1x1_depth) {
-        case 2: hipLaunchKernelGGL((conv1x1_dense_kernel<2, 3>), dim3(grid), dim3(256), lds, stream, p); break;
-        default: hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4>), dim3(grid), dim3(256), lds, stream, p); break;
-    }
+    hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4>), dim3(grid), dim3(256), lds, stream, p);
     return 0;
 }

@@ -91,8 +91,8 @@ int bd_conv2d_dgrad_bits(const bd_conv_desc* d, const void* g, const void* w_pac
  * e4m3(clamp(y * q_scale)), the input of a following fp8 3x3 convolution (bd_conv2d_fwd_fp8: saves its cast pass). */
 int bd_conv2d_fwd_ex(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
                      uint32_t* ybits, void* y8, float q_scale, int flags, bd_stream_t stream);
-/* measurement knob: variant of the dense 1x1 kernel (conv1x1.hip): 0 = off (generic kernel); 1 (default) = one K step ahead, four
- * workgroups per CU; 2 = two steps ahead, three per CU. */
+/* measurement knob: 1 (default) = the dense 1x1 kernel (conv1x1.hip) takes every 1x1 / stride 1 launch over one dense level,
+ * 0 = the generic kernel does (A/B; the *_bits / _ex entry points then return BD_EINVAL). */
 int bd_conv_set_dense1x1(int depth);
 
 /* dw[Cout][R][S][Cin] (fp32) = sum over pixels g^T x, times row_scale[Cout] (NULL = 1); split over pixels with

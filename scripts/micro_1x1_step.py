@@ -67,7 +67,7 @@ def timeit(run, iters=20):
 
 
 def main():
-    depths = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
+    depths = [int(a) for a in sys.argv[1:]] or [0, 1]
     tot = {(dp, b): 0.0 for dp in depths for b in (0, 1)}
     print(f"{'launch':40s} " + " ".join(f"d{dp}{'b' if b else ' '}:us/GB/s" .rjust(16) for dp in depths for b in ((0, 1) if dp else (0,))))
     for tag, H, W, Cin, Cout, mode, add, mask, cnt in L:

@@ -338,7 +338,7 @@ def test_wgrad_bias_multilevel():
     assert rel_l2(db.cpu(), gy.sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("depth", [1, 2, 0])
+@pytest.mark.parametrize("depth", [1, 0])
 def test_dense_1x1_kernel_and_mask_bits(depth):
     """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_set_dense1x1: prefetch depth x workgroups
     per CU; 0 = the generic kernel): forward with
