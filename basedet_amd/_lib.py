@@ -46,6 +46,7 @@ SIGNATURES = {
     "bd_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_fwd_bits": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_fwd_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
+    "bd_conv2d_dgrad_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_dgrad_bits": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv_set_dense1x1": (_I, [_I]),
     "bd_conv2d_wgrad_workspace_bytes": (_Z, [_D]),
@@ -123,6 +124,9 @@ SIGNATURES = {
     "bd_conv2d_fwd_fp8": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_fwd_fp8_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv_fp8_set_patch": (_I, [_I]),
+    "bd_quantize_bf8": (_I, [_P, _L, _F, _P, _P]),
+    "bd_weight_pack_fp8_t": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "bd_conv2d_dgrad_fp8": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_sigmoid_focal_loss_elem": (_I, [_P, _P, _L, _F, _F, _P, _P, _P, _P]),
     "bd_bce_elem": (_I, [_P, _P, _L, _I, _P, _P, _P, _P]),
     "bd_smooth_l1_elem": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),

@@ -28,8 +28,9 @@ struct P1 {
     const unsigned* maskbits;
     bf16_raw* y;
     unsigned* ybits;
-    unsigned char* y8;        // optional e4m3 twin of y (y * q_scale) for a following fp8 convolution (conv3x3_pp8.hip)
-    float q_scale;
+    unsigned char* y8;        // optional one-byte twin of y (y * q_scale) for a following fp8 launch (conv3x3_pp8.hip):
+    float q_scale;            // e4m3 for activations (y8_bf8 = 0), e5m2 for gradients (y8_bf8 = 1)
+    int y8_bf8;
     int M, CK, CO, flags;
     unsigned x_bytes, w_bytes;
     int m_tiles, n_tiles;
@@ -40,6 +41,14 @@ __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float 
     c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
     int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
     v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+__device__ __forceinline__ unsigned pack4_e5m2(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -57344.f), 57344.f); b = fminf(fmaxf(b, -57344.f), 57344.f);
+    c = fminf(fmaxf(c, -57344.f), 57344.f); d = fminf(fmaxf(d, -57344.f), 57344.f);
+    int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
     return (unsigned)v;
 }
 
@@ -241,8 +250,13 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
             if (ok) *reinterpret_cast<u32x4_t*>(p.y + idx) = o;
             if (p.y8 && ok) {
                 u32x2_t o8;
-                o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
-                o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                if (p.y8_bf8) {
+                    o8[0] = pack4_e5m2(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                    o8[1] = pack4_e5m2(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                } else {
+                    o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                    o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                }
                 *reinterpret_cast<u32x2_t*>(p.y8 + idx) = o8;
             }
             if (p.ybits) {
@@ -275,14 +289,15 @@ extern "C" int bd_conv_set_dense1x1(int depth) {
 // Called by bd_conv2d_fwd / bd_conv2d_dgrad (conv_igemm.hip) for 1x1 / stride 1 / pad 0 launches over one dense level.
 // Returns 0 when the launch was taken, 1 when the shape is left to the generic kernel.
 int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits,
-                            void* y, unsigned* ybits, void* y8, float q_scale, long long M, int CK, int CO, int flags, hipStream_t stream) {
+                            void* y, unsigned* ybits, void* y8, float q_scale, int y8_bf8, long long M, int CK, int CO, int flags,
+                            hipStream_t stream) {
     if (g_conv1x1_depth == 0) return 1;
     const long long xb = M * CK * 2, wb = (long long)CO * CK * 2;
     if (xb >= 0x7fffffffll || wb >= 0x7fffffffll || M >= (1ll << 24)) return 1;
     if ((maskbits || ybits) && (CO % 32 != 0)) return 1;
     P1 p{};
     p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.bias = bias; p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask;
-    p.maskbits = maskbits; p.y = (bf16_raw*)y; p.ybits = ybits; p.y8 = (unsigned char*)y8; p.q_scale = q_scale;
+    p.maskbits = maskbits; p.y = (bf16_raw*)y; p.ybits = ybits; p.y8 = (unsigned char*)y8; p.q_scale = q_scale; p.y8_bf8 = y8_bf8;
     p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);

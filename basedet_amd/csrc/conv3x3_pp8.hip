@@ -63,13 +63,23 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
     return (unsigned)v;
 }
 
+__device__ __forceinline__ unsigned pack4_bf8(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -57344.f), 57344.f); b = fminf(fmaxf(b, -57344.f), 57344.f);
+    c = fminf(fmaxf(c, -57344.f), 57344.f); d = fminf(fmaxf(d, -57344.f), 57344.f);
+    int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
+// MODE 0: forward (activations e4m3).  MODE 1: data gradient (mirrored taps; the gradient operand is e5m2 = "bf8", scaled by the
+// caller's static gradient scale; weights [Cin][9][Cout] e4m3 with one scale per INPUT channel).
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
-    constexpr int MODE = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wbuf = smem;                                   // [3][W_SLOT]
     unsigned char* xbuf = smem + W_BYTES;                         // [X_BYTES]
@@ -212,7 +222,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
         }
     };
     auto load_b = [&](int t) {
-        const int dy = t / 3, dx = t - 3 * (t / 3);
+        int dy = t / 3, dx = t - 3 * (t / 3);
+        if (MODE == 1) { dy = 2 - dy; dx = 2 - dx; }           // dgrad: mirrored tap
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const u32x4_t l = *reinterpret_cast<const u32x4_t*>(b_base[0] + ((j + dy) * IW + dx) * X_PITCH);
@@ -228,8 +239,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 // tied accumulator (D = C) in inline asm, as in the bf16 kernel
-                asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
-                             : "+v"(acc[i0 + i][j]) : "v"(fa[i]), "v"(fb[j]), "v"(one));
+                if (MODE == 0)
+                    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                                 : "+v"(acc[i0 + i][j]) : "v"(fa[i]), "v"(fb[j]), "v"(one));
+                else                                            // B operand (the gradient) in e5m2
+                    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] blgp:1"
+                                 : "+v"(acc[i0 + i][j]) : "v"(fa[i]), "v"(fb[j]), "v"(one));
     };
 
     const int kblocks = (p.CK + 127) >> 7;
@@ -359,10 +374,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
             *reinterpret_cast<u32x4_t*>(p.dst + idx) = o;
-            if (p.dst8) {            // e4m3 twin for a following fp8 convolution (saves its cast pass)
+            if (p.dst8) {            // one-byte twin for a following fp8 launch (saves its cast pass): e4m3 activations, e5m2 gradients
                 u32x2_t o8;
-                o8[0] = pack4_fp8(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
-                o8[1] = pack4_fp8(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                if (MODE == 0) {
+                    o8[0] = pack4_fp8(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                    o8[1] = pack4_fp8(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                } else {
+                    o8[0] = pack4_bf8(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                    o8[1] = pack4_bf8(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                }
                 *reinterpret_cast<u32x2_t*>(p.dst8 + idx) = o8;
             }
         }
@@ -371,27 +391,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
 
 }  // namespace
 
-// 0 = launched, 1 = shape not handled here (the caller falls back to the generic fp8 kernel of conv_fp8.hip)
-int bd_conv3x3_pp8_launch(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
-                          void* y, void* y8, float q_scale, int flags, hipStream_t stream) {
+// 0 = launched, 1 = shape not handled here (the caller falls back to the generic fp8 kernel / the bf16 path)
+// mode 0: xq = e4m3 activations [pix][Cin], wq [Cout][9][Cin];  mode 1: xq = e5m2 gradients [pix][Cout], wq [Cin][9][Cout]
+int bd_conv3x3_pp8_launch(const bd_conv_desc* d, int mode, const void* xq, const void* wq, const float* wscale, const float* bias,
+                          const void* add, const void* mask, void* y, void* y8, float q_scale, int flags, hipStream_t stream) {
     if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 1;
     for (int s = 0; s < d->nseg; ++s)
         if (d->Hi[s] != d->Ho[s] || d->Wi[s] != d->Wo[s]) return 1;
     PParams p{};
-    p.CK = d->Cin; p.CO = d->Cout;
-    p.src_ppi = d->in_pix_per_img; p.dst_ppi = d->out_pix_per_img;
+    p.CK = mode == 0 ? d->Cin : d->Cout;
+    p.CO = mode == 0 ? d->Cout : d->Cin;
+    p.src_ppi = mode == 0 ? d->in_pix_per_img : d->out_pix_per_img;
+    p.dst_ppi = mode == 0 ? d->out_pix_per_img : d->in_pix_per_img;
     if (p.CK % 16 != 0 || p.CO <= 128 || p.CO % 8 != 0) return 1;
     if ((long long)d->N * p.src_ppi * p.CK >= 0x7fffffffll || (long long)d->N * p.dst_ppi >= 0x7fffffffll ||
         (long long)p.CO * 9 * p.CK >= 0x7fffffffll) return 1;
     p.src = (const unsigned char*)xq; p.w = (const unsigned char*)wq; p.wscale = wscale; p.bias = bias;
-    p.add = (const bf16_raw*)add; p.mask = nullptr; p.dst = (bf16_raw*)y; p.dst8 = (unsigned char*)y8; p.q_scale = q_scale;
+    p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)y; p.dst8 = (unsigned char*)y8; p.q_scale = q_scale;
     p.flags = flags; p.nseg = d->nseg;
     p.src_bytes = (unsigned)((long long)d->N * p.src_ppi * p.CK);
     int ps = 0;
     for (int s = 0; s < d->nseg; ++s) {
         PSeg& sg = p.seg[s];
         sg.patch_start = ps; sg.H = d->Ho[s]; sg.W = d->Wo[s]; sg.pw = cdiv(d->Wo[s], PW);
-        sg.src_off = d->in_off[s]; sg.dst_off = d->out_off[s];
+        sg.src_off = mode == 0 ? d->in_off[s] : d->out_off[s];
+        sg.dst_off = mode == 0 ? d->out_off[s] : d->in_off[s];
         ps += cdiv(d->Ho[s], PH) * sg.pw;
     }
     p.patches_per_img = ps;
@@ -400,9 +424,11 @@ int bd_conv3x3_pp8_launch(const bd_conv_desc* d, const void* xq, const void* wq,
     const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_pp8_kernel, dim3(grid), dim3(512), LDS_BYTES, stream, p);
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_pp8_kernel<0>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((conv3x3_pp8_kernel<1>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
     return 0;
 }

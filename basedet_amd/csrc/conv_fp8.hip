@@ -50,6 +50,59 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16_raw* __res
     }
 }
 
+__device__ __forceinline__ unsigned pack4_bf8(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -57344.f), 57344.f); b = fminf(fmaxf(b, -57344.f), 57344.f);
+    c = fminf(fmaxf(c, -57344.f), 57344.f); d = fminf(fmaxf(d, -57344.f), 57344.f);
+    int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+// x bf16 -> e5m2(x * scale): the gradient operand of the fp8 data-gradient kernel
+__global__ __launch_bounds__(256) void quantize_bf8_kernel(const bf16_raw* __restrict__ x, long long n16, float scale,
+                                                          u32x4_t* __restrict__ q) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(x + i * 16);
+        const u32x4_t b = *reinterpret_cast<const u32x4_t*>(x + i * 16 + 8);
+        u32x4_t o;
+        o[0] = pack4_bf8(bf_lo(a[0]) * scale, bf_hi(a[0]) * scale, bf_lo(a[1]) * scale, bf_hi(a[1]) * scale);
+        o[1] = pack4_bf8(bf_lo(a[2]) * scale, bf_hi(a[2]) * scale, bf_lo(a[3]) * scale, bf_hi(a[3]) * scale);
+        o[2] = pack4_bf8(bf_lo(b[0]) * scale, bf_hi(b[0]) * scale, bf_lo(b[1]) * scale, bf_hi(b[1]) * scale);
+        o[3] = pack4_bf8(bf_lo(b[2]) * scale, bf_hi(b[2]) * scale, bf_lo(b[3]) * scale, bf_hi(b[3]) * scale);
+        q[i] = o;
+    }
+}
+
+// data-gradient weights: one workgroup per INPUT channel ci: s = max over (tap, co) of |w[co][tap][ci] * row_scale[co]| / 448,
+// wq_t[ci][tap][co] = e4m3(w * row_scale / s), out_scale[ci] = s / grad_scale
+__global__ __launch_bounds__(256) void weight_pack_fp8_t_kernel(const float* __restrict__ w, const float* __restrict__ row_scale, int Cout,
+                                                               int RS, int Cin, float grad_scale, unsigned char* __restrict__ wq_t,
+                                                               float* __restrict__ out_scale) {
+    __shared__ float red[4];
+    const int ci = blockIdx.x;
+    const int n = RS * Cout;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int tap = i / Cout, co = i - tap * Cout;
+        m = fmaxf(m, fabsf(w[((long long)co * RS + tap) * Cin + ci] * (row_scale ? row_scale[co] : 1.f)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s = m > 0.f ? m / FP8_MAX : 1.f;
+    const float inv = 1.f / s;
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {          // Cout % 4 == 0: the four entries share a tap
+        const int tap = i / Cout, co = i - tap * Cout;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = w[((long long)(co + k) * RS + tap) * Cin + ci] * (row_scale ? row_scale[co + k] : 1.f) * inv;
+        *reinterpret_cast<unsigned*>(wq_t + (long long)ci * n + i) = pack4_fp8(v[0], v[1], v[2], v[3]);
+    }
+    if (threadIdx.x == 0) out_scale[ci] = s / grad_scale;
+}
+
 // one workgroup per output channel: s = max |w * row_scale| / 448, wq = e4m3(w * row_scale / s), out_scale = s / act_scale
 __global__ __launch_bounds__(256) void weight_pack_fp8_kernel(const float* __restrict__ w, const float* __restrict__ row_scale, int row_len,
                                                              float act_scale, unsigned char* __restrict__ wq, float* __restrict__ out_scale) {
@@ -278,8 +331,8 @@ int g_fp8_patch = 1;        // bd_conv_fp8_set_patch: 0 = every shape through th
 
 }  // namespace
 
-int bd_conv3x3_pp8_launch(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
-                          void* y, void* y8, float q_scale, int flags, hipStream_t stream);
+int bd_conv3x3_pp8_launch(const bd_conv_desc* d, int mode, const void* xq, const void* wq, const float* wscale, const float* bias,
+                          const void* add, const void* mask, void* y, void* y8, float q_scale, int flags, hipStream_t stream);
 
 extern "C" {
 
@@ -306,6 +359,40 @@ int bd_weight_pack_fp8(const float* w, const float* row_scale, int Cout, int RS,
 
 int bd_conv_fp8_set_patch(int on) { g_fp8_patch = on ? 1 : 0; return BD_OK; }
 
+int bd_quantize_bf8(const void* x_bf16, int64_t n, float scale, void* q, bd_stream_t stream) {
+    BD_REQUIRE(x_bf16 && q, "quantize_bf8: null pointer");
+    BD_REQUIRE(n % 16 == 0 && scale > 0.f, "quantize_bf8: n %% 16 != 0 or scale <= 0");
+    if (n == 0) return BD_OK;
+    const long long n16 = n / 16;
+    const int grid = (int)std::min<long long>(cdiv64(n16, 256), 256 * 16);
+    hipLaunchKernelGGL(quantize_bf8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x_bf16, n16, scale, (u32x4_t*)q);
+    BD_CHECK_LAUNCH("bd_quantize_bf8");
+    return BD_OK;
+}
+
+int bd_weight_pack_fp8_t(const float* w, const float* row_scale, int Cout, int RS, int Cin, float grad_scale, void* wq_t, float* wscale_t,
+                         bd_stream_t stream) {
+    BD_REQUIRE(w && wq_t && wscale_t, "weight_pack_fp8_t: null pointer");
+    BD_REQUIRE(Cout > 0 && RS > 0 && Cin > 0 && Cout % 4 == 0 && grad_scale > 0.f, "weight_pack_fp8_t: bad sizes");
+    hipLaunchKernelGGL(weight_pack_fp8_t_kernel, dim3(Cin), dim3(256), 0, (hipStream_t)stream, w, row_scale, Cout, RS, Cin, grad_scale,
+                       (unsigned char*)wq_t, wscale_t);
+    BD_CHECK_LAUNCH("bd_weight_pack_fp8_t");
+    return BD_OK;
+}
+
+int bd_conv2d_dgrad_fp8(const bd_conv_desc* d, const void* g8, const void* wq_t, const float* wscale_t, const void* add, const void* mask,
+                        void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream) {
+    BD_REQUIRE(d && g8 && wq_t && wscale_t && dx, "conv2d_dgrad_fp8: null pointer");
+    BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad_fp8: BD_EPI_RELU is a forward-only flag");
+    BD_REQUIRE(d->Cout % 16 == 0 && d->Cin % 8 == 0, "conv2d_dgrad_fp8: Cout %% 16 and Cin %% 8 must be 0 (got %d, %d)", d->Cout, d->Cin);
+    if (bd_conv3x3_pp8_launch(d, 1, g8, wq_t, wscale_t, nullptr, add, mask, dx, dx8, q_scale, flags, (hipStream_t)stream) != 0) {
+        bd_set_error("conv2d_dgrad_fp8: only 3x3 / stride 1 / pad 1 with Cin > 128 (the fp8 patch kernel); use bd_conv2d_dgrad");
+        return BD_EINVAL;
+    }
+    BD_CHECK_LAUNCH("bd_conv2d_dgrad_fp8");
+    return BD_OK;
+}
+
 int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
                          void* y, void* y8, float q_scale, int flags, bd_stream_t stream);
 
@@ -320,7 +407,7 @@ int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, 
     BD_REQUIRE(d->nseg >= 1 && d->nseg <= MAX_SUB && (d->stride == 1 || d->stride == 2) && d->R * d->S <= 32, "conv2d_fwd_fp8: bad descriptor");
     BD_REQUIRE(d->Cin % 16 == 0 && d->Cout % 8 == 0, "conv2d_fwd_fp8: Cin %% 16 and Cout %% 8 must be 0 (got %d, %d)", d->Cin, d->Cout);
     BD_REQUIRE(!(flags & (BD_EPI_MASK | BD_EPI_ADD_AFTER)), "conv2d_fwd_fp8: forward flags only");
-    if (g_fp8_patch && bd_conv3x3_pp8_launch(d, xq, wq, wscale, bias, add, y, y8, q_scale, flags, (hipStream_t)stream) == 0) {
+    if (g_fp8_patch && bd_conv3x3_pp8_launch(d, 0, xq, wq, wscale, bias, add, nullptr, y, y8, q_scale, flags, (hipStream_t)stream) == 0) {
         BD_CHECK_LAUNCH("bd_conv2d_fwd_fp8(patch)");
         return BD_OK;
     }

@@ -470,7 +470,8 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
 }
 
 int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits,
-                            void* y, unsigned* ybits, void* y8, float q_scale, long long M, int CK, int CO, int flags, hipStream_t stream);
+                            void* y, unsigned* ybits, void* y8, float q_scale, int y8_bf8, long long M, int CK, int CO, int flags,
+                            hipStream_t stream);
 
 namespace {
 // 1x1 / stride 1 / pad 0 over one dense level: source pixel index == destination pixel index (conv1x1.hip)
@@ -488,7 +489,7 @@ static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_p
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_fwd: Cout=%d must be a multiple of 8", d->Cout);
     BD_REQUIRE(!(flags & BD_EPI_MASK), "conv2d_fwd: BD_EPI_MASK is a dgrad-only flag");
     if (is_dense_1x1(d) &&
-        bd_conv1x1_dense_launch(x, w_packed, bias, add, nullptr, nullptr, y, ybits, y8, q_scale, (long long)d->N * d->out_pix_per_img,
+        bd_conv1x1_dense_launch(x, w_packed, bias, add, nullptr, nullptr, y, ybits, y8, q_scale, 0, (long long)d->N * d->out_pix_per_img,
                                 d->Cin, d->Cout, flags, (hipStream_t)stream) == 0) {
         BD_CHECK_LAUNCH("bd_conv2d_fwd(dense 1x1)");
         return BD_OK;
@@ -548,20 +549,20 @@ extern "C" int bd_conv2d_fwd_bits(const bd_conv_desc* d, const void* x, const vo
 }
 
 static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
-                             const unsigned* maskbits, void* dx, int flags, bd_stream_t stream) {
+                             const unsigned* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream) {
     if (int e = check_desc(d)) return e;
     BD_REQUIRE(g && w_packed_t && dx, "conv2d_dgrad: null pointer");
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_dgrad: Cout=%d must be a multiple of 8 (pad the gradient)", d->Cout);
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad: BD_EPI_RELU is a forward-only flag");
     if (is_dense_1x1(d) &&
-        bd_conv1x1_dense_launch(g, w_packed_t, nullptr, add, mask, maskbits, dx, nullptr, nullptr, 1.f, (long long)d->N * d->in_pix_per_img,
+        bd_conv1x1_dense_launch(g, w_packed_t, nullptr, add, mask, maskbits, dx, nullptr, dx8, q_scale, 1, (long long)d->N * d->in_pix_per_img,
                                 d->Cout, d->Cin, flags, (hipStream_t)stream) == 0) {
         BD_CHECK_LAUNCH("bd_conv2d_dgrad(dense 1x1)");
         return BD_OK;
     }
-    BD_REQUIRE(maskbits == nullptr, "conv2d_dgrad_bits: the bit-packed ReLU mask is read by the dense 1x1 kernel only (1x1 / stride 1 over "
-               "one dense level, Cin %% 32 == 0, tensors < 2 GB)");
+    BD_REQUIRE(maskbits == nullptr && dx8 == nullptr, "conv2d_dgrad_bits / _ex: the bit-packed ReLU mask is read, and the e5m2 twin written, by "
+               "the dense 1x1 kernel only (1x1 / stride 1 over one dense level, Cin %% 32 == 0, tensors < 2 GB)");
     if (g_use_patch3x3 && is_3x3s1(d)) {
         bd_conv3x3_patch_launch(d, 1, g, w_packed_t, nullptr, add, mask, dx, flags, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_dgrad(3x3 patch)");
@@ -608,11 +609,17 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
 
 extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add,
                                const void* mask, void* dx, int flags, bd_stream_t stream) {
-    return conv2d_dgrad_impl(d, g, w_packed_t, add, mask, nullptr, dx, flags, stream);
+    return conv2d_dgrad_impl(d, g, w_packed_t, add, mask, nullptr, dx, nullptr, 1.f, flags, stream);
+}
+
+extern "C" int bd_conv2d_dgrad_ex(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
+                                  const uint32_t* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream) {
+    return conv2d_dgrad_impl(d, g, w_packed_t, add, maskbits ? nullptr : mask, maskbits, dx, dx8, q_scale,
+                             maskbits ? (flags | BD_EPI_MASK) : flags, stream);
 }
 
 extern "C" int bd_conv2d_dgrad_bits(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const uint32_t* maskbits,
                                     void* dx, int flags, bd_stream_t stream) {
     BD_REQUIRE(maskbits != nullptr, "conv2d_dgrad_bits: null maskbits");
-    return conv2d_dgrad_impl(d, g, w_packed_t, add, nullptr, maskbits, dx, flags | BD_EPI_MASK, stream);
+    return conv2d_dgrad_impl(d, g, w_packed_t, add, nullptr, maskbits, dx, nullptr, 1.f, flags | BD_EPI_MASK, stream);
 }

@@ -57,8 +57,10 @@ class ConvLayer:
         self._desc_cache = {}
         # fp8 forward (BASELINE config 5, enable_fp8): e4m3 weights with one scale per output channel + the input cast to e4m3
         self.fp8 = False
-        self.w_q8 = self.w_scale8 = None
+        self.fp8_dgrad = False          # data gradient on the fp8 patch kernel too (e5m2 gradients under a static gradient scale)
+        self.w_q8 = self.w_scale8 = self.w_q8t = self.w_scale8t = None
         self.act_scale = 1.0
+        self.grad_scale = 4096.0
         self.q8_scratch = None          # callable(nbytes) -> uint8 scratch tensor on the stream this layer's forward runs on
 
     # -- parameters -------------------------------------------------------------------------------
@@ -107,15 +109,22 @@ class ConvLayer:
         if self.gb is not None:
             out[self.name + ".bias"] = self.gb[: self.cout_real].cpu().clone()
 
-    def enable_fp8(self, q8_scratch, act_scale=1.0):
-        """Forward through bd_conv2d_fwd_fp8 (csrc/conv_fp8.hip).  The backward pass keeps the bf16 weights and activations."""
+    def enable_fp8(self, q8_scratch, act_scale=1.0, dgrad=False, grad_scale=4096.0):
+        """Forward through bd_conv2d_fwd_fp8 (csrc/conv3x3_pp8.hip / conv_fp8.hip); with dgrad=True the data gradient through
+        bd_conv2d_dgrad_fp8 as well (3x3 / stride 1 / Cin > 128).  The weight gradient keeps the bf16 activations and gradients."""
         assert self.cin % 16 == 0 and self.cout % 8 == 0
         self.fp8, self.q8_scratch, self.act_scale = True, q8_scratch, float(act_scale)
         self.w_q8 = torch.empty((self.cout, self.k * self.k, self.cin), dtype=torch.uint8, device=self.device)
         self.w_scale8 = torch.empty((self.cout,), dtype=torch.float32, device=self.device)
+        if dgrad and self.trainable and self.k == 3 and self.stride == 1 and self.cin > 128 and self.cout % 16 == 0:
+            self.fp8_dgrad, self.grad_scale = True, float(grad_scale)
+            self.w_q8t = torch.empty((self.cin, self.k * self.k, self.cout), dtype=torch.uint8, device=self.device)
+            self.w_scale8t = torch.empty((self.cin,), dtype=torch.float32, device=self.device)
 
     def pack_fp8(self):
         ops.weight_pack_fp8(self.w, self.row_scale, self.cout, self.k * self.k, self.cin, self.act_scale, self.w_q8, self.w_scale8)
+        if self.fp8_dgrad:
+            ops.weight_pack_fp8_t(self.w, self.row_scale, self.cout, self.k * self.k, self.cin, self.grad_scale, self.w_q8t, self.w_scale8t)
 
     def pack(self):
         ops.weight_pack(self.w, self.row_scale, self.w_fwd, self.w_dgrad, self.cout, self.k * self.k, self.cin)
@@ -143,7 +152,7 @@ class ConvLayer:
         return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags, bits=bits,
                               y8=y8 if (y8 is not None and ops.dense_1x1_bits_ok(self.desc(gin, gout))) else None, q_scale=q_scale)
 
-    def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None):
+    def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None, g8=None, dx8=None, q_scale=1.0):
         """dx (+)= conv^T(g).  first=False accumulates onto dx (pre-mask); mask = forward activation whose
         ReLU gates dx (maskbits: the same gate bit-packed, written by the producing forward launch); add_after = tensor added
         after masking (P6: gradient that bypasses the ReLU)."""
@@ -158,7 +167,14 @@ class ConvLayer:
             flags |= ops.EPI_MASK
         if maskbits is not None:
             mask = None
-        return ops.conv2d_dgrad(self.desc(gin, gout), g, self.w_dgrad, dx, add=add, mask=mask, flags=flags, maskbits=maskbits)
+        d = self.desc(gin, gout)
+        if self.fp8_dgrad and maskbits is None:
+            # g8: the e5m2 twin of g (g * grad_scale) when the producing launch wrote one, else a cast pass; dx8: twin of dx to write
+            gq = g8 if g8 is not None else ops.quantize_bf8(g, self.grad_scale, self.q8_scratch(g.numel())[: g.numel()])
+            return ops.conv2d_dgrad_fp8(d, gq, self.w_q8t, self.w_scale8t, dx, add=add, mask=mask, flags=flags, dx8=dx8, q_scale=q_scale)
+        if dx8 is not None and not ops.dense_1x1_bits_ok(d):
+            dx8 = None
+        return ops.conv2d_dgrad(d, g, self.w_dgrad, dx, add=add, mask=mask, flags=flags, maskbits=maskbits, dx8=dx8, q_scale=q_scale)
 
     def wgrad(self, x, g, gin, gout, ws, colsum_ws=None):
         d = self.desc(gin, gout)

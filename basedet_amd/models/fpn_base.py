@@ -143,7 +143,8 @@ class FPNDetector:
                 if (c.k == 3 and c.cin % 16 == 0 and not isinstance(c, FCLayer)
                         and ((c.stride == 1 and c.cout > 128) or id(c) in side)):
                     key = "side" if id(c) in side else "main"          # P6 / P7 run on a side stream: their own scratch
-                    c.enable_fp8(lambda n, key=key: self._q8_buf(key, n), m.get("FP8_ACT_SCALE", 1.0))
+                    c.enable_fp8(lambda n, key=key: self._q8_buf(key, n), m.get("FP8_ACT_SCALE", 1.0),
+                                 dgrad=bool(m.get("FP8_DGRAD", True)), grad_scale=m.get("FP8_GRAD_SCALE", 4096.0))
         else:
             assert self.weight_dtype == "bf16", self.weight_dtype
         self._bind_params(params)

@@ -86,8 +86,13 @@ def conv2d_fwd(d, x, w_packed, bias, y, add=None, flags=0, bits=None, y8=None, q
     return y
 
 
-def conv2d_dgrad(d, g, w_packed_t, dx, add=None, mask=None, flags=0, maskbits=None):
-    """maskbits: the ReLU mask as written by conv2d_fwd(bits=...) instead of the bf16 activation `mask` (bd_conv2d_dgrad_bits)."""
+def conv2d_dgrad(d, g, w_packed_t, dx, add=None, mask=None, flags=0, maskbits=None, dx8=None, q_scale=1.0):
+    """maskbits: the ReLU mask as written by conv2d_fwd(bits=...) instead of the bf16 activation `mask` (bd_conv2d_dgrad_bits);
+    dx8: optional uint8 e5m2 twin of dx * q_scale (dense 1x1 launches only: bd_conv2d_dgrad_ex)."""
+    if dx8 is not None:
+        check(L().bd_conv2d_dgrad_ex(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(maskbits), ptr(dx), ptr(dx8),
+                                     float(q_scale), flags, stream_ptr()), "bd_conv2d_dgrad_ex")
+        return dx
     if maskbits is not None:
         check(L().bd_conv2d_dgrad_bits(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(maskbits), ptr(dx), flags, stream_ptr()),
               "bd_conv2d_dgrad_bits")
@@ -112,6 +117,29 @@ def conv2d_fwd_fp8(d, xq, wq, wscale, bias, y, add=None, flags=0, y8=None, q_sca
     check(L().bd_conv2d_fwd_fp8_ex(C.byref(d), ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(y), ptr(y8), float(q_scale), flags,
                                    stream_ptr()), "bd_conv2d_fwd_fp8")
     return y
+
+
+def quantize_bf8(x, scale, q):
+    """q (uint8) = e5m2(clamp(x * scale)) of a bf16 tensor (gradients)."""
+    check(L().bd_quantize_bf8(ptr(x), x.numel(), float(scale), ptr(q), stream_ptr()), "bd_quantize_bf8")
+    return q
+
+
+def weight_pack_fp8_t(w, row_scale, Cout, RS, Cin, grad_scale, wq_t, wscale_t):
+    check(L().bd_weight_pack_fp8_t(ptr(w), ptr(row_scale), Cout, RS, Cin, float(grad_scale), ptr(wq_t), ptr(wscale_t), stream_ptr()),
+          "bd_weight_pack_fp8_t")
+
+
+def conv2d_dgrad_fp8(d, g8, wq_t, wscale_t, dx, add=None, mask=None, flags=0, dx8=None, q_scale=1.0):
+    check(L().bd_conv2d_dgrad_fp8(C.byref(d), ptr(g8), ptr(wq_t), ptr(wscale_t), ptr(add), ptr(mask), ptr(dx), ptr(dx8), float(q_scale),
+                                  flags, stream_ptr()), "bd_conv2d_dgrad_fp8")
+    return dx
+
+
+def fp8_dgrad_ok(d):
+    """True when bd_conv2d_dgrad_fp8 takes this descriptor (conv3x3_pp8.hip, mode 1)."""
+    same = all(d.Hi[i] == d.Ho[i] and d.Wi[i] == d.Wo[i] for i in range(d.nseg))
+    return d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and same and d.Cin > 128 and d.Cin % 8 == 0 and d.Cout % 16 == 0
 
 
 def dense_1x1_bits_ok(d):

@@ -91,6 +91,10 @@ int bd_conv2d_dgrad_bits(const bd_conv_desc* d, const void* g, const void* w_pac
  * e4m3(clamp(y * q_scale)), the input of a following fp8 3x3 convolution (bd_conv2d_fwd_fp8: saves its cast pass). */
 int bd_conv2d_fwd_ex(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
                      uint32_t* ybits, void* y8, float q_scale, int flags, bd_stream_t stream);
+/* bd_conv2d_dgrad of the dense 1x1 kernel with its optional side input / output: maskbits (may be NULL: then `mask` is the bf16 form)
+ * and dx8 (may be NULL) = e5m2(clamp(dx * q_scale)), the gradient operand of a following bd_conv2d_dgrad_fp8. */
+int bd_conv2d_dgrad_ex(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
+                       const uint32_t* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream);
 /* measurement knob: 1 (default) = the dense 1x1 kernel (conv1x1.hip) takes every 1x1 / stride 1 launch over one dense level,
  * 0 = the generic kernel does (A/B; the *_bits / _ex entry points then return BD_EINVAL). */
 int bd_conv_set_dense1x1(int depth);
@@ -519,6 +523,16 @@ int bd_conv2d_fwd_fp8(const bd_conv_desc* d, const void* xq, const void* wq, con
 int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
                          void* y, void* y8, float q_scale, int flags, bd_stream_t stream);
 int bd_conv_fp8_set_patch(int on);
+/* fp8 DATA GRADIENT of a 3x3 / stride 1 / pad 1 convolution with Cin > 128 (the patch kernel's mirrored-tap mode): the gradient operand
+ * g8 is e5m2 ("bf8": the format fp8 training uses for gradients) = bd_quantize_bf8(g, grad_scale) or the dx8 twin of the producing
+ * launch; wq_t [Cin][RS][Cout] e4m3 with one scale per INPUT channel and wscale_t[ci] = s_ci / grad_scale from bd_weight_pack_fp8_t.
+ * dx (bf16) = epi(conv_transpose(g8, wq_t) * wscale_t [+ add]); add / mask / flags as bd_conv2d_dgrad; dx8 (may be NULL) =
+ * e5m2(clamp(dx * q_scale)). */
+int bd_quantize_bf8(const void* x_bf16, int64_t n, float scale, void* q, bd_stream_t stream);
+int bd_weight_pack_fp8_t(const float* w, const float* row_scale, int Cout, int RS, int Cin, float grad_scale, void* wq_t, float* wscale_t,
+                         bd_stream_t stream);
+int bd_conv2d_dgrad_fp8(const bd_conv_desc* d, const void* g8, const void* wq_t, const float* wscale_t, const void* add, const void* mask,
+                        void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Operator surface of basedet.layers / basedet.structures as stand-alone fp32 entry points (callers written against the

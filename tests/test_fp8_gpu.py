@@ -168,3 +168,84 @@ def test_retinanet_fp8_step_tolerance():
     rel = float((logits8 - logits16).norm() / logits16.norm())
     print("logits rel-L2 fp8 vs bf16:", rel)
     assert rel < 8e-2, rel
+
+
+DG_CASES = [
+    # N, Cin, Cout, sizes, (the data gradient produces Cin channels: the patch kernel needs Cin > 128)
+    (2, 256, 256, [(13, 21)]),
+    (1, 256, 720, [(12, 20), (6, 10), (3, 5)]),            # the class-score gradient: K = 720 (tail of the sixth 128-channel block)
+    (2, 192, 80, [(9, 11)]),                               # channel tail on the produced side (192 of 256), K = 80
+]
+
+
+def _run_dgrad(ops, N, Cin, Cout, sizes, g_lv, w, grad_scale, add_lv=None, mask_lv=None, twin=False):
+    geo = ops.Geom(N, [h for h, _ in sizes], [w_ for _, w_ in sizes])
+    d = ops.conv_desc(geo, geo, Cin, Cout, 3, 3, 1, 1)
+
+    def pack(levels, C):
+        t = torch.empty((N, geo.pix_per_img, C), dtype=torch.bfloat16)
+        for (h, w_), o, xl in zip(sizes, geo.off, levels):
+            t[:, o:o + h * w_] = xl.permute(0, 2, 3, 1).reshape(N, h * w_, C).to(torch.bfloat16)
+        return t.reshape(-1, C).cuda()
+
+    g = pack(g_lv, Cout)
+    g8 = torch.empty((g.numel(),), dtype=torch.uint8, device="cuda")
+    ops.quantize_bf8(g, grad_scale, g8)
+    wq = torch.empty((Cin, 9, Cout), dtype=torch.uint8, device="cuda")
+    ws = torch.empty((Cin,), dtype=torch.float32, device="cuda")
+    ops.weight_pack_fp8_t(w.permute(0, 2, 3, 1).contiguous().cuda(), None, Cout, 9, Cin, grad_scale, wq, ws)
+    dx = torch.empty((geo.pixels, Cin), dtype=torch.bfloat16, device="cuda")
+    add = pack(add_lv, Cin) if add_lv is not None else None
+    mask = pack(mask_lv, Cin) if mask_lv is not None else None
+    flags = (ops.EPI_ADD_BEFORE if add is not None else 0) | (ops.EPI_MASK if mask is not None else 0)
+    dx8 = torch.zeros((geo.pixels, Cin), dtype=torch.uint8, device="cuda") if twin else None
+    ops.conv2d_dgrad_fp8(d, g8, wq, ws, dx, add=add, mask=mask, flags=flags, dx8=dx8, q_scale=grad_scale)
+    if twin:
+        dec = dx8.view(torch.float8_e5m2).float().cpu()
+        want = (dx.float().cpu() * grad_scale).clamp(-57344, 57344)
+        assert bool(((dec - want).abs() <= want.abs() * 2.0 ** -3 * 1.01 + 2.0 ** -17 + want.abs() * 2.0 ** -8).all())
+    v = dx.float().cpu().view(N, geo.pix_per_img, Cin)
+    return [v[:, o:o + h * w_].reshape(N, h, w_, Cin).permute(0, 3, 1, 2) for (h, w_), o in zip(sizes, geo.off)], ws
+
+
+@pytest.mark.parametrize("case", DG_CASES)
+def test_fp8_dgrad_structure_is_exact_on_representable_inputs(case):
+    """Gradient values that are e5m2 numbers (after the power-of-two gradient scale) and weights that are e4m3 numbers with a per-input-
+    channel maximum of 7 (scale exactly 2^-6): the fp8 data gradient must reproduce torch's fp32 conv-transpose up to the bf16 store."""
+    ops = _ops()
+    N, Cin, Cout, sizes = case
+    g = torch.Generator().manual_seed(21 + Cin + Cout)
+    GS = 2.0 ** 12
+    gv = torch.tensor([0.0, 1.0, -1.0, 1.5, 0.5, -0.75, 2.0, -3.0, 0.25]) / GS              # e5m2 numbers / GS
+    g_lv = [gv[torch.randint(0, len(gv), (N, Cout, h, w), generator=g)] for h, w in sizes]
+    wv = torch.tensor([0.0, 0.875, -0.875, 1.75, -3.5, 0.4375])
+    w = wv[torch.randint(0, len(wv), (Cout, Cin, 3, 3), generator=g)]
+    w[0, :, 0, 0] = 7.0                                                                     # max over (co, tap) per input channel = 7
+    got, ws = _run_dgrad(ops, N, Cin, Cout, sizes, g_lv, w, GS, twin=True)
+    assert torch.equal(ws.cpu(), torch.full((Cin,), 2.0 ** -6 / GS))
+    for gl, dl in zip(g_lv, got):
+        ref = bf16_round(TF.conv_transpose2d(gl, w, stride=1, padding=1))
+        bad = dl != ref
+        assert float(bad.float().mean()) < 1e-3, float(bad.float().mean())
+        assert bool(((dl - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-9).all()), float((dl - ref).abs().max())
+
+
+@pytest.mark.parametrize("case", DG_CASES[:2])
+def test_fp8_dgrad_tolerance_on_random_data(case):
+    """e5m2 keeps two mantissa bits: measured rel-L2 of the data gradient against fp32 on the same bf16 inputs 6-8 % (bound 1.2e-1),
+    with the accumulate + ReLU-mask epilogue."""
+    ops = _ops()
+    N, Cin, Cout, sizes = case
+    g = torch.Generator().manual_seed(31 + Cin + Cout)
+    g_lv = [bf16_round(torch.randn(N, Cout, h, w, generator=g) * 3e-4) for h, w in sizes]      # gradient-sized values
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    add_lv = [bf16_round(torch.randn(N, Cin, h, w_, generator=g) * 1e-4) for h, w_ in sizes]
+    mask_lv = [torch.relu(bf16_round(torch.randn(N, Cin, h, w_, generator=g))) for h, w_ in sizes]
+    got, _ = _run_dgrad(ops, N, Cin, Cout, sizes, g_lv, w, 2.0 ** 12, add_lv=add_lv, mask_lv=mask_lv)
+    num = den = 0.0
+    for gl, al, ml, dl in zip(g_lv, add_lv, mask_lv, got):
+        ref = (TF.conv_transpose2d(gl, w, stride=1, padding=1) + al) * (ml > 0)
+        num += float((dl - ref).double().pow(2).sum()); den += float(ref.double().pow(2).sum())
+    rel = (num / den) ** 0.5
+    print(f"fp8 dgrad rel-L2 vs fp32 {case[:3]}: {rel:.4f}")
+    assert rel < 1.2e-1, rel
