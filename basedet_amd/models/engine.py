@@ -176,6 +176,10 @@ class ConvLayer:
             dx8 = None
         return ops.conv2d_dgrad(d, g, self.w_dgrad, dx, add=add, mask=mask, flags=flags, maskbits=maskbits, dx8=dx8, q_scale=q_scale)
 
+    def dgrad_writes_twin(self, gin, gout):
+        """True when dgrad(..., dx8=t) fills t: the fp8 patch kernel and the dense 1x1 kernel do, the other bf16 kernels do not."""
+        return self.fp8_dgrad or ops.dense_1x1_bits_ok(self.desc(gin, gout))
+
     def wgrad(self, x, g, gin, gout, ws, colsum_ws=None):
         d = self.desc(gin, gout)
         if self.gb is not None:      # weight + bias gradient in one entry point (fused in the 3x3 patch kernel; colsum_ws is unused)

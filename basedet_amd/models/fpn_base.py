@@ -134,6 +134,8 @@ class FPNDetector:
         # quantised copy of the input is read nine times; the HBM-bound 1x1 layers and the whole backward pass stay bf16
         self.weight_dtype = m.get("WEIGHT_DTYPE", "bf16")
         self._q8 = {}
+        # e5m2 twins of gradients written by the producing launch (False: every fp8 data gradient casts its input in a pass; a test knob)
+        self.fp8_grad_twins = bool(m.get("FP8_GRAD_TWINS", True))
         if self.weight_dtype == "fp8_e4m3":
             side = {id(getattr(self, n)) for n in ("p6", "p7") if hasattr(self, n)}
             for c in self.convs.values():
@@ -326,9 +328,13 @@ class FPNDetector:
                     and ops.dense_1x1_bits_ok(blk["convs"][0].desc(gin, gin))):
                 b.mid8 = torch.empty((gin.pixels, blk["ch"]), dtype=torch.uint8, device=dev)
             b.out_bits = None
+            b.g_mid8 = None
             if blk["trainable"]:
                 b.g_mids = [torch.empty_like(t) for t in b.mids]
                 b.g_out = torch.empty_like(b.out)
+                if (blk["kind"] == "bottleneck" and blk["convs"][1].fp8_dgrad and self.fp8_grad_twins
+                        and blk["convs"][2].dgrad_writes_twin(b.gout, b.gout)):
+                    b.g_mid8 = torch.empty((b.gout.pixels, blk["ch"]), dtype=torch.uint8, device=dev)
                 # the block output's ReLU gate, bit-packed by the conv3 launch that writes it (1 bit instead of a bf16 per element):
                 # what the NEXT block's conv1 / the FPN lateral read as their data-gradient mask (dense 1x1 launches: conv1x1.hip)
                 if (blk["kind"] == "bottleneck" and self.use_mask_bits
@@ -559,6 +565,7 @@ class FPNDetector:
         pl = self._cur
         ws, cws = pl.wgrad_ws, pl.colsum_ws
         pyr = pl.pyr
+        pl.g_P8_ready = False                       # set by a head whose last data gradients wrote the e5m2 twin of dL/dP
         self.head_backward(pl, ws, cws)
         side = (self._wstream,) if (self.async_wgrad and self._wstream is not None) else ()
         if on_bucket_ready:
@@ -588,7 +595,7 @@ class FPNDetector:
             b = pl.blk[pl.res[s]]
             lvl = pyr.level(li)
             self._wgrad(self.output[s], pl.lat[s], pl.g_P, b.gout, lvl, ws, cws)
-            self.output[s].dgrad(pl.g_P, b.gout, lvl, pl.g_lat[s], first=True)
+            self.output[s].dgrad(pl.g_P, b.gout, lvl, pl.g_lat[s], first=True, g8=pl.g_P8 if pl.g_P8_ready else None)
             if li > 0:   # gradient arriving through the top-down path from the finer level
                 sf = st[li - 1]
                 ops.upsample2x_add_bwd(pl.g_lat[sf], pl.blk[pl.res[sf]].gout, pl.g_lat[s], b.gout, self.fpn_ch, accumulate=True)
@@ -623,10 +630,14 @@ class FPNDetector:
                 self._wgrad(blk["ds"], xin, G, b.gin, b.gout, ws)
             # main branch, last conv backwards
             g = G
+            g8 = None
             for ci in range(len(convs) - 1, 0, -1):
                 self._wgrad(convs[ci], b.mids[ci - 1], g, geos[ci], geos[ci + 1], ws)
-                convs[ci].dgrad(g, geos[ci], geos[ci + 1], b.g_mids[ci - 1], mask=b.mids[ci - 1])
-                g = b.g_mids[ci - 1]
+                # fp8 mode: conv3's (dense 1x1) data gradient also writes the e5m2 twin that conv2's fp8 data gradient reads
+                nxt = b.g_mid8 if (ci == len(convs) - 1 and getattr(b, "g_mid8", None) is not None) else None
+                convs[ci].dgrad(g, geos[ci], geos[ci + 1], b.g_mids[ci - 1], mask=b.mids[ci - 1], g8=g8, dx8=nxt,
+                                q_scale=convs[ci - 1].grad_scale)
+                g, g8 = b.g_mids[ci - 1], nxt
             self._wgrad(convs[0], xin, g, geos[0], geos[1], ws)
             if prev_tr:
                 gx = pl.blk[bi - 1].g_out

@@ -80,6 +80,10 @@ class RetinaNet(FPNDetector):
         tw = lambda: torch.empty((pl.pyr.pixels, ch), dtype=torch.uint8, device=dev)      # noqa: E731
         pl.cls_act8 = [tw() if c.fp8 else None for c in self.cls_tower]
         pl.box_act8 = [tw() if c.fp8 else None for c in self.box_tower]
+        # fp8 data gradients: e5m2 twins of the tower gradients and of dL/dP, written by the launch that produces them
+        tg = self.fp8_grad_twins
+        pl.g_tower8 = [[tw() if (c.fp8_dgrad and tg) else None for c in tower] for tower in (self.cls_tower, self.box_tower)]
+        pl.g_P8 = tw() if (tg and all(t[0].fp8_dgrad for t in (self.cls_tower, self.box_tower))) else None
         # anchors (regenerated per forward in the reference, retinanet.py:116; cached per shape here)
         tot = pl.pyr.pix_per_img * A
         pl.anchors = torch.empty((tot, 4), dtype=torch.float32, device=dev)
@@ -135,19 +139,28 @@ class RetinaNet(FPNDetector):
     def head_backward(self, pl, ws, cws):
         pyr = pl.pyr
         # ---- head: cls tower then box tower; both end in g_P.  g_tower[t][i] = dL/d(pre-activation of tower conv i)
+        # fp8 mode: a tower gradient's e5m2 twin g8[i] is written by the data-gradient launch that produces it and read by the next
+        # one (no cast passes inside a tower); a twin is valid only if its producer writes one (the 40-channel box regressor does not)
         for ti, (tower, acts, pred, dpred) in enumerate(((self.cls_tower, pl.cls_act, self.cls_score, pl.d_logits),
                                                          (self.box_tower, pl.box_act, self.bbox_pred, pl.d_offsets))):
-            gbuf = pl.g_tower[ti]
+            gbuf, g8 = pl.g_tower[ti], pl.g_tower8[ti]
             n = len(tower)
+            gs = tower[n - 1].grad_scale
             self._wgrad(pred, acts[-1], dpred, pyr, pyr, ws, cws)
-            pred.dgrad(dpred, pyr, pyr, gbuf[n - 1], mask=acts[-1])
+            tw = g8[n - 1] if pred.dgrad_writes_twin(pyr, pyr) else None       # None also when twins are off (g8 holds no buffers)
+            pred.dgrad(dpred, pyr, pyr, gbuf[n - 1], mask=acts[-1], dx8=tw, q_scale=gs)
             for i in range(n - 1, -1, -1):
                 x = acts[i - 1] if i > 0 else pl.P
                 self._wgrad(tower[i], x, gbuf[i], pyr, pyr, ws, cws)
                 if i > 0:
-                    tower[i].dgrad(gbuf[i], pyr, pyr, gbuf[i - 1], mask=acts[i - 1])
+                    nxt = g8[i - 1] if tower[i].dgrad_writes_twin(pyr, pyr) else None
+                    tower[i].dgrad(gbuf[i], pyr, pyr, gbuf[i - 1], mask=acts[i - 1], g8=tw, dx8=nxt, q_scale=gs)
+                    tw = nxt
                 else:
-                    tower[i].dgrad(gbuf[i], pyr, pyr, pl.g_P, first=(ti == 0))
+                    tower[i].dgrad(gbuf[i], pyr, pyr, pl.g_P, first=(ti == 0), g8=tw,
+                                   dx8=pl.g_P8 if tower[i].dgrad_writes_twin(pyr, pyr) else None, q_scale=gs)
+        # the box tower's launch wrote the twin of the FINAL dL/dP (it accumulates onto the class tower's contribution)
+        pl.g_P8_ready = pl.g_P8 is not None
 
     def _debug_head(self, pl, out, lvl):
         for i in range(pl.pyr.nlev):

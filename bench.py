@@ -148,6 +148,24 @@ class KernelTimer:
                 return r
             return inner
 
+        def wrap_fp8_dgrad(fn):
+            def inner(d, g8, wq_t, wscale_t, dx, add=None, mask=None, flags=0, dx8=None, q_scale=1.0):
+                if not self.enabled:
+                    return fn(d, g8, wq_t, wscale_t, dx, add=add, mask=mask, flags=flags, dx8=dx8, q_scale=q_scale)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = fn(d, g8, wq_t, wscale_t, dx, add=add, mask=mask, flags=flags, dx8=dx8, q_scale=q_scale)
+                e.record()
+                mi = sum(d.Hi[i] * d.Wi[i] for i in range(d.nseg)) * d.N
+                mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
+                nbytes = 1.0 * mo * d.Cout + 2.0 * mi * d.Cin * (1 + (add is not None) + (mask is not None)) + 1.0 * d.Cin * d.Cout * 9 \
+                    + (1.0 * mi * d.Cin if dx8 is not None else 0.0)
+                self.records.setdefault("conv3x3_pp8_kernel", []).append((s, e, flops(d)))
+                self.meta.setdefault("conv3x3_pp8_kernel", []).append(("conv2d_dgrad_fp8", d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
+                return r
+            return inner
+
+        ops.conv2d_dgrad_fp8 = wrap_fp8_dgrad(ops.conv2d_dgrad_fp8)
         ops.conv2d_fwd_fp8 = wrap_fp8(ops.conv2d_fwd_fp8)
         ops.conv2d_fwd = wrap(ops.conv2d_fwd, "igemm")
         ops.conv2d_dgrad = wrap(ops.conv2d_dgrad, "igemm")
@@ -189,6 +207,7 @@ class KernelTimer:
         # pad + normalise: fp32 NCHW in (3 channels), bf16 [N][Hp+6][Wp+8][4] out
         # e4m3 cast of a convolution's input: 2 B read + 1 B written per element
         wrap_stream("quantize_fp8", "quantize_fp8_kernel", lambda k: k["x"].numel() * 3.0)
+        wrap_stream("quantize_bf8", "quantize_bf8_kernel", lambda k: k["x"].numel() * 3.0)
         wrap_stream("pad_normalize", "pad_normalize_kernel",
                     lambda k: k["x"].numel() * 4.0 + k["x"].shape[0] * (k["Hp"] + 6) * (k["Wp"] + 8) * 8.0)
 
