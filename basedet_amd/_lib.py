@@ -54,6 +54,7 @@ SIGNATURES = {
     "bd_conv2d_wgrad_bias_workspace_bytes": (_Z, [_D]),
     "bd_conv2d_wgrad_bias": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_stem_conv7x7_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "bd_stem_pool_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "bd_stem_weight_pack": (_I, [_P, _P, _P, _P]),
     "bd_weight_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "bd_weight_pack_blocks": (_I, [_I, _I, _I]),

@@ -132,6 +132,7 @@ class FPNDetector:
         self.arena.allocate()
         # BASELINE config 5: fp8-e4m3 weights (one scale per output channel) for the forward of the 3x3 convolutions -- where a
         # quantised copy of the input is read nine times; the HBM-bound 1x1 layers and the whole backward pass stay bf16
+        self.fuse_stem_pool = bool(m.get("FUSE_STEM_POOL", True))
         self.weight_dtype = m.get("WEIGHT_DTYPE", "bf16")
         self._q8 = {}
         # e5m2 twins of gradients written by the producing launch (False: every fp8 data gradient casts its input in a pass; a test knob)
@@ -306,7 +307,8 @@ class FPNDetector:
         g2 = ops.single(N, Hp // 2, Wp // 2)
         g4 = ops.single(N, (Hp // 2 - 1) // 2 + 1, (Wp // 2 - 1) // 2 + 1)
         pl.g_stem, pl.g_pool = g2, g4
-        pl.stem_out, pl.pool_out = act(g2, 64), act(g4, 64)
+        # the fused stem + max-pool launch never materialises the half-resolution stem output (MODEL.FUSE_STEM_POOL False: two launches)
+        pl.stem_out, pl.pool_out = (None if self.fuse_stem_pool else act(g2, 64)), act(g4, 64)
         # backbone
         pl.blk = []
         gin = g4
@@ -463,8 +465,11 @@ class FPNDetector:
         """RetinaNet.network_forward (retinanet.py:109-118): backbone + FPN + head; logits/offsets come out already
         in the (N, sum HWA, K) layout of permute_to_N_Any_K + concat (function.py:26-32, retinanet.py:127-132)."""
         N = pl.N
-        ops.stem_conv7x7_fwd(N, pl.Hp, pl.Wp, pl.x_halo, self.stem_packed, self.stem_shift, pl.stem_out)
-        ops.maxpool3x3s2_fwd(pl.stem_out, N, pl.g_stem.H[0], pl.g_stem.W[0], 64, pl.pool_out)
+        if self.fuse_stem_pool:
+            ops.stem_pool_fwd(N, pl.Hp, pl.Wp, pl.x_halo, self.stem_packed, self.stem_shift, pl.pool_out)
+        else:
+            ops.stem_conv7x7_fwd(N, pl.Hp, pl.Wp, pl.x_halo, self.stem_packed, self.stem_shift, pl.stem_out)
+            ops.maxpool3x3s2_fwd(pl.stem_out, N, pl.g_stem.H[0], pl.g_stem.W[0], 64, pl.pool_out)
         x = pl.pool_out
         for blk, b in zip(self.blocks, pl.blk):
             x = self._block_forward(blk, b, x)

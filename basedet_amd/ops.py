@@ -236,6 +236,11 @@ def pad_normalize_nchw(x, Hp, Wp, mean, std, out):
     return out
 
 
+def stem_pool_fwd(N, H, W, x_halo, w_stem, bias, y_pool):
+    """stem_conv7x7_fwd + maxpool3x3s2_fwd in one launch (bit-identical; the half-resolution tensor is never written)."""
+    check(L().bd_stem_pool_fwd(N, H, W, ptr(x_halo), ptr(w_stem), ptr(bias), ptr(y_pool), stream_ptr()), "bd_stem_pool_fwd")
+
+
 def maxpool3x3s2_fwd(x, N, H, W, Cn, y):
     check(L().bd_maxpool3x3s2_fwd(ptr(x), N, H, W, Cn, ptr(y), stream_ptr()), "bd_maxpool3x3s2_fwd")
     return y

@@ -135,6 +135,11 @@ int bd_wgrad_set_transpose_read(int use_tr);
  * w_stem: bf16 [64][7][8][4] as written by bd_stem_weight_pack; y: bf16 NHWC [N][H/2][W/2][64]. */
 int bd_stem_conv7x7_fwd(int N, int H, int W, const void* x_halo, const void* w_stem, const float* bias,
                         void* y, bd_stream_t stream);
+/* The same stem followed by M.MaxPool2d(3, 2, 1) (models/cls/resnet.py:146,238-241) in one pass: y_pool = bf16 NHWC
+ * [N][(H/2-1)/2+1][(W/2-1)/2+1][64], bit-identical to bd_stem_conv7x7_fwd + bd_maxpool3x3s2_fwd; the half-resolution
+ * stem output is never written (the stem is frozen: solver/default_solver.py:83-94, so nothing else reads it). */
+int bd_stem_pool_fwd(int N, int H, int W, const void* x_halo, const void* w_stem, const float* bias, void* y_pool,
+                     bd_stream_t stream);
 int bd_stem_weight_pack(const float* w /*[64][7][7][3] fp32*/, const float* row_scale, void* w_stem,
                         bd_stream_t stream);
 

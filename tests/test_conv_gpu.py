@@ -179,6 +179,34 @@ def test_stem_conv_and_pad_normalize():
     ops.maxpool3x3s2_fwd(y, N, Hp // 2, Wp // 2, 64, p)
     refp = TF.max_pool2d(got, 3, 2, 1)
     assert torch.equal(pm_to_nchw(p, N, Hp // 4, Wp // 4), refp)
+    pf = torch.zeros_like(p)
+    ops.stem_pool_fwd(N, Hp, Wp, xh, wst, shift.cuda(), pf)
+    assert torch.equal(pf, p)
+
+
+@pytest.mark.parametrize("N,Hp,Wp", [(1, 32, 32), (2, 96, 160), (3, 224, 416), (1, 800, 1344), (2, 34, 58)])
+def test_stem_pool_fused_is_bit_identical(N, Hp, Wp):
+    """bd_stem_pool_fwd (one launch, no half-resolution tensor) == bd_stem_conv7x7_fwd + bd_maxpool3x3s2_fwd, bit for bit: strip and
+    chunk edges (pooled widths that are / are not multiples of 7, heights that are / are not multiples of 10, odd stem sizes)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(Hp * 7 + Wp)
+    xh = torch.zeros((N, Hp + 6, Wp + 8, 4), dtype=torch.bfloat16)
+    xh[:, 3:3 + Hp, 4:4 + Wp, :3] = torch.randn(N, Hp, Wp, 3, generator=g).to(torch.bfloat16)
+    xh = xh.cuda()
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    shift = (torch.randn(64, generator=g) * 0.1).cuda()
+    wst = torch.empty((64, 7, 8, 4), dtype=torch.bfloat16, device="cuda")
+    ops.stem_weight_pack(oihw_to_ohwi(w).cuda(), None, wst)
+    Ho, Wo = Hp // 2, Wp // 2
+    Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    y = torch.empty((N * Ho * Wo, 64), dtype=torch.bfloat16, device="cuda")
+    ops.stem_conv7x7_fwd(N, Hp, Wp, xh, wst, shift, y)
+    p = torch.empty((N * Hq * Wq, 64), dtype=torch.bfloat16, device="cuda")
+    ops.maxpool3x3s2_fwd(y, N, Ho, Wo, 64, p)
+    pf = torch.full_like(p, -1.0)
+    ops.stem_pool_fwd(N, Hp, Wp, xh, wst, shift, pf)
+    torch.cuda.synchronize()
+    assert torch.equal(pf, p), int((pf != p).sum())
 
 
 def test_upsample_add_fwd_bwd():
