@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int TP = 128, TC = 128, BK = 32;
+constexpr int EPI_BATCH = 4;       // epilogue units (16 B per lane) whose operands are requested together
 constexpr int TILE_BYTES = 128 * 64;
 
 struct P1 {
@@ -56,7 +57,6 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + (
 
 template <int DEPTH, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
-    constexpr bool EARLY = false;       // (epilogue operands requested before the last K step: measured, no gain -- see the header)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,25 +148,6 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     const bool want_add = add_before || add_after;
     const bool mask_bf = (p.flags & BD_EPI_MASK) && p.mask;
     const bool mask_bits = (p.flags & BD_EPI_MASK) && p.maskbits && !p.mask;
-    u32x4_t e_add[EARLY ? 8 : 1];
-    unsigned e_bits[EARLY ? 8 : 1];
-    auto epi_request = [&]() {
-        if (!EARLY) return;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int m = m0 + wp * 64 + j * 16 + (lane & 15);
-                const bool ok = m < p.M && cbase + 32 * half < p.CO;
-                const long long idx = (long long)m * p.CO + cbase + 32 * half;
-                u32x4_t a = {0u, 0u, 0u, 0u};
-                unsigned bits = 0u;
-                if (ok && want_add) a = *reinterpret_cast<const u32x4_t*>(p.add + idx);
-                if (ok && mask_bits) bits = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m];
-                e_add[j * 2 + half] = a; e_bits[j * 2 + half] = bits;
-            }
-    };
-
     // ---- main loop: step t is computed from LDS buffer t & 1 while the loads of steps t+1 .. t+DEPTH are in flight ------------------
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u)
@@ -180,7 +161,6 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
             if (t < nsteps) {                                       // workgroup-uniform
                 // set u held step t (written to LDS in the previous iteration): it is free for step t + DEPTH
                 if (t + DEPTH < nsteps) stage_load(t + DEPTH, ra[u], rb[u]);
-                if (t + 1 == nsteps) epi_request();                 // last step: the staging sets are dead, their registers take the epilogue operands
                 compute(t & 1);
                 if (t + 1 < nsteps) stage_write((t + 1) & 1, ra[(u + 1) % DEPTH], rb[(u + 1) % DEPTH]);
                 __syncthreads();
@@ -189,6 +169,10 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------------------
+    // All of the tile's residual / mask / gate operands are REQUESTED first (8 x 16 B per lane, into the registers the staging sets and
+    // fragments have left), then consumed in order: as a load - use - store chain per 16 bytes (what the compiler makes of the plain
+    // loop: every unit waits on vmcnt(0), i.e. also on the previous unit's store) a wave keeps 1 KB in flight and the epilogue -- half
+    // of this class's bytes -- runs at the latency of 16 dependent round trips per tile.
     float bias[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) bias[k] = 0.f;
@@ -201,22 +185,34 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
             }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+    for (int part = 0; part < 8 / EPI_BATCH; ++part) {
+    u32x4_t e_aux[EPI_BATCH];     // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
+    unsigned e_bits[EPI_BATCH];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {       // 8 channels = 16 bytes per half
+    for (int qq = 0; qq < EPI_BATCH; ++qq) {
+        const int q = part * EPI_BATCH + qq;
+        const int j = q >> 1, half = q & 1;
+        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+        const bool ok = m < p.M && cbase + 32 * half < p.CO;
+        const long long idx = (long long)m * p.CO + cbase + 32 * half;
+        e_aux[qq] = (u32x4_t){0u, 0u, 0u, 0u}; e_bits[qq] = 0u;
+        if (ok && want_add) e_aux[qq] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+        else if (ok && mask_bf) e_aux[qq] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+        if (ok && mask_bits) e_bits[qq] = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qq = 0; qq < EPI_BATCH; ++qq) {
+        const int q = part * EPI_BATCH + qq;
+        const int j = q >> 1, half = q & 1;
+        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+        {
             const bool ok = m < p.M && cbase + 32 * half < p.CO;      // CO % 8 == 0
             const long long idx = (long long)m * p.CO + cbase + 32 * half;
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];
-            u32x4_t av = {0u, 0u, 0u, 0u};
-            unsigned mbits = 0u;
-            if (EARLY) { av = e_add[j * 2 + half]; mbits = e_bits[j * 2 + half]; }
-            else {
-                if (ok && want_add) av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
-                if (ok && mask_bits) mbits = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m];
-            }
+            const u32x4_t av = e_aux[qq];
             if (add_before) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
@@ -225,9 +221,9 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
             }
-            if (mask_bf) {            // the bf16 form of the mask is requested here (the small-channel consumers; the wide ones come bit-packed)
-                u32x4_t mv = {0u, 0u, 0u, 0u};
-                if (ok) mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+            if (mask_bf) {
+                u32x4_t mv = e_aux[qq];
+                if (want_add) { mv = (u32x4_t){0u, 0u, 0u, 0u}; if (ok) mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx); }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (!(bf_lo(mv[k]) > 0.f)) v[2 * k] = 0.f;
@@ -235,7 +231,7 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
                 }
             }
             if (mask_bits) {
-                const unsigned byte = mbits >> (8 * cg);
+                const unsigned byte = e_bits[qq] >> (8 * cg);
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (!((byte >> k) & 1u)) v[k] = 0.f;
@@ -271,15 +267,225 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
             }
         }
     }
+    }   // parts
 }
 
-int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (the generic kernel takes the dense 1x1 launches: A/B), 1 = on
+// ---- 256 x 256 tile, persistent, four-stage LDS-DMA ring -----------------------------------------------------------------------------
+// Across the step's sixteen launch classes the 128 x 128 kernel above moves a near-constant 6.3 - 9.6 TB/s BETWEEN L2 AND THE CUs (every
+// activation tile is fetched Cout / 128 times, the weight matrix M / 128 times) while its HBM-level rate falls from 4.5 TB/s (res2: 2
+// re-reads) to 1.5 - 2.5 TB/s (res5: 16): what bounds it is the bytes it keeps in flight per CU (4 workgroups x one 16 KB K step) over a
+// ~2.5 us loaded round trip.  This kernel halves the L2 -> CU bytes per output (256 channels x 256 pixels per tile: 8 waves = 2
+// channel halves x 4 pixel quarters, wave tile 128 x 64, acc[8][4] as in conv3x3_pp.hip) and keeps THREE 32 KB K steps in flight at
+// all times: both operands go by LDS-DMA straight into a four-stage ring (no staging registers, no LDS writes, one raw barrier per 32
+// MFMAs, swizzle and channel permutation on the SOURCE address), and the workgroup is persistent -- the ring runs on across tile
+// boundaries, so the next tile's first three K steps are in flight while this tile's epilogue reads and writes its operands.
+constexpr int BG_T = 256, BG_BK = 32;
+constexpr int BG_HALF = BG_T * 64;             // one operand tile of a stage: 256 rows x 64 B
+constexpr int BG_STAGE = 2 * BG_HALF;          // 32768
+constexpr int BG_NSTAGE = 4;
+constexpr int BG_LDS = BG_NSTAGE * BG_STAGE;   // 131072
+typedef __attribute__((address_space(3))) void lds_void_1x1_t;
+
+__global__ __launch_bounds__(512, 1) void conv1x1_big_kernel(const P1 p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;       // channel half (128 rows)
+    const int wp = wave & 3;        // pixel quarter (64 pixels)
+    const int total = p.m_tiles * p.n_tiles;
+    const int grid = gridDim.x;
+    // tile of (round i, workgroup b): with a grid that is a multiple of 8 the round's ids are dealt XCD-major, so that the channel tiles
+    // of one pixel tile (consecutive ids) run on ONE XCD and share its L2
+    auto tile_of = [&](int i) {
+        const int b = blockIdx.x;
+        const int id = (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b;
+        return i * grid + id;
+    };
+
+    constexpr unsigned X_NONE = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.w), 0, p.w_bytes, 0x00020000);
+    const int nsteps = p.CK / BG_BK;               // the host takes CK % 32 == 0 only
+
+    // ---- producer: K step ps of this workgroup's pi-th tile goes to ring stage (flat index & 3).  An operand tile of a stage = 16
+    // pieces of 1 KiB (16 rows x 64 B); this wave owns pieces wave and wave + 8 of both; lane -> row lane >> 2, position lane & 3,
+    // source chunk = position ^ ((row >> 1) & 3).  Past the last tile the offsets are X_NONE (zeros land in a stage nobody reads): the
+    // number of DMA instructions in flight stays what the counted waits assume.
+    unsigned a_src[2], b_src[2];
+    int pi = 0, ps = 0, pflat = 0;
+    auto producer_tile = [&]() {
+        const int t = tile_of(pi);
+        const bool live = t < total;
+        const int tm = t / p.n_tiles, tn = t - tm * p.n_tiles;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int lrow = 16 * (wave + 8 * k) + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((lrow >> 1) & 3);
+            const int rho = lrow & 15;
+            const int co = tn * BG_T + (lrow & 192) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
+            a_src[k] = (live && co < p.CO) ? (unsigned)(co * p.CK + chunk * 8) * 2u : X_NONE;
+            const int m = tm * BG_T + lrow;
+            b_src[k] = (live && m < p.M) ? (unsigned)(m * p.CK + chunk * 8) * 2u : X_NONE;
+        }
+    };
+    auto produce = [&]() {
+        int so = ps * (BG_BK * 2);
+        asm volatile("" : "+s"(so));
+        unsigned char* At = smem + (pflat & (BG_NSTAGE - 1)) * BG_STAGE;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_1x1_t*)(At + (wave + 8 * k) * 1024), 16, a_src[k], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_1x1_t*)(At + BG_HALF + (wave + 8 * k) * 1024), 16, b_src[k], so, 0, 0);
+        }
+        ++pflat;
+        if (++ps == nsteps) { ps = 0; ++pi; producer_tile(); }
+    };
+    producer_tile();
+#pragma unroll
+    for (int u = 0; u < BG_NSTAGE - 1; ++u) produce();
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int cg = lane >> 4;
+    const bool do_relu = p.flags & BD_EPI_RELU;
+    const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
+    const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
+    const bool want_add = add_before || add_after;
+    const bool mask_bf = (p.flags & BD_EPI_MASK) && p.mask;
+    const bool mask_bits = (p.flags & BD_EPI_MASK) && p.maskbits && !p.mask;
+    int cflat = 0;
+    for (int ci = 0; tile_of(ci) < total; ++ci) {
+    const int tile = tile_of(ci);
+    const int tile_m = tile / p.n_tiles;
+    const int tile_n = tile - tile_m * p.n_tiles;
+    const int m0 = tile_m * BG_T;
+    const int co0 = tile_n * BG_T;
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nsteps; ++t, ++cflat) {
+        // stages cflat, +1, +2 are in flight (4 DMA instructions each; the epilogue's own loads and stores are younger and only make
+        // the wait stricter): at most two stages may still be outstanding
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // all pieces landed; stage (cflat+3)&3 is free
+        produce();
+        const unsigned char* At = smem + (cflat & (BG_NSTAGE - 1)) * BG_STAGE;
+        const unsigned char* Bt = At + BG_HALF;
+        bf16x8_t fa[8], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(Bt + lds_off(wp * 64 + j * 16 + frow, fchunk));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(At + lds_off(wm * 128 + i * 16 + frow, fchunk));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: lane group cg holds channels cbase + 32 h + 0..7 (h = 0..3) of pixel m0 + wp*64 + j*16 + (lane & 15).  Two halves
+    // (h pairs); a half first REQUESTS all of its operands (8 x residual / mask / gate words: up to 16 KB per wave in flight -- with
+    // eight waves per CU a load-use-store chain per 16 bytes would leave the epilogue, half of this kernel's bytes, latency-bound),
+    // then computes and stores
+    const int cbase = co0 + wm * 128 + 8 * cg;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        u32x4_t e_aux[8];             // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
+        unsigned e_bits[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int h = 2 * hh + (q >> 2), jq = q & 3;
+            const int m = m0 + wp * 64 + jq * 16 + (lane & 15);
+            const bool ok = m < p.M && cbase + 32 * h < p.CO;
+            const long long idx = (long long)m * p.CO + cbase + 32 * h;
+            e_aux[q] = (u32x4_t){0u, 0u, 0u, 0u}; e_bits[q] = 0u;
+            if (ok && want_add) e_aux[q] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+            else if (ok && mask_bf) e_aux[q] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+            if (ok && mask_bits) e_bits[q] = p.maskbits[(long long)((co0 + wm * 128 + 32 * h) >> 5) * p.M + m];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int h = 2 * hh + (q >> 2), jq = q & 3;
+            float bias[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bias[k] = 0.f;
+            if (p.bias && cbase + 32 * h < p.CO) {
+                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 32 * h);
+                const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 32 * h + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { bias[k] = b0[k]; bias[4 + k] = b1[k]; }
+            }
+            const int m = m0 + wp * 64 + jq * 16 + (lane & 15);
+            const bool ok = m < p.M && cbase + 32 * h < p.CO;      // CO % 8 == 0
+            const long long idx = (long long)m * p.CO + cbase + 32 * h;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = acc[2 * h + (k >> 2)][jq][k & 3] + bias[k];
+            const u32x4_t av = e_aux[q];
+            if (add_before) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
+            }
+            if (do_relu) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (mask_bf) {
+                u32x4_t mv = e_aux[q];
+                if (want_add) { mv = (u32x4_t){0u, 0u, 0u, 0u}; if (ok) mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx); }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!(bf_lo(mv[k]) > 0.f)) v[2 * k] = 0.f;
+                    if (!(bf_hi(mv[k]) > 0.f)) v[2 * k + 1] = 0.f;
+                }
+            }
+            if (mask_bits) {
+                const unsigned byte = e_bits[q] >> (8 * cg);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (!((byte >> k) & 1u)) v[k] = 0.f;
+            }
+            if (add_after) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
+            }
+            u32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+            if (ok) *reinterpret_cast<u32x4_t*>(p.y + idx) = o;
+            if (p.y8 && ok) {
+                u32x2_t o8;
+                if (p.y8_bf8) {
+                    o8[0] = pack4_e5m2(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                    o8[1] = pack4_e5m2(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                } else {
+                    o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                    o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                }
+                *reinterpret_cast<u32x2_t*>(p.y8 + idx) = o8;
+            }
+            if (p.ybits) {
+                unsigned byte = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) byte |= (v[k] > 0.f ? 1u : 0u) << k;
+                unsigned word = byte << (8 * cg);
+                word |= __shfl_xor(word, 16, 64);
+                word |= __shfl_xor(word, 32, 64);
+                if (ok && cg == (jq & 3)) p.ybits[(long long)((co0 + wm * 128 + 32 * h) >> 5) * p.M + m] = word;
+            }
+        }
+    }
+    }   // tiles
+}
+
+int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (generic kernel), 1 = the 128^2 tile (default), 2 = the 256^2 tile wherever legal (A/B), 3 = as 1
 
 }  // namespace
 
 extern "C" int bd_conv_set_dense1x1(int depth) {
-    if (!(depth == 0 || depth == 1)) {
-        bd_set_error("bd_conv_set_dense1x1: %d (0 or 1)", depth);
+    if (depth < 0 || depth > 3) {
+        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 3)", depth);
         return BD_EINVAL;
     }
     g_conv1x1_depth = depth;
@@ -300,6 +506,25 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     p.maskbits = maskbits; p.y = (bf16_raw*)y; p.ybits = ybits; p.y8 = (unsigned char*)y8; p.q_scale = q_scale; p.y8_bf8 = y8_bf8;
     p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    {
+        // the 256^2 tile: full 32-channel K steps and at least one full channel tile.  Measured (scripts/micro_1x1_step.py, the step's 16
+        // launch classes): on par or slower than the 128^2 tile everywhere (6.2 - 6.5 vs 5.5 - 5.8 ms over the step's launches; its
+        // one workgroup per CU quantises worse on the 263-tile res4 layers and its epilogue has 8 waves per CU to hide latency with,
+        // not 16), so it runs on request only (bd_conv_set_dense1x1(2): A/B)
+        const int mt = (int)cdiv64(M, BG_T), nt = cdiv(CO, BG_T);
+        const bool legal = CK % BG_BK == 0 && CO >= BG_T && g_conv1x1_depth != 3;
+        if (legal && g_conv1x1_depth == 2) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS);
+                attr_set = true;
+            }
+            p.m_tiles = mt; p.n_tiles = nt;
+            const long long tiles = (long long)mt * nt;
+            hipLaunchKernelGGL(conv1x1_big_kernel, dim3((int)(tiles < 256 ? tiles : 256)), dim3(512), BG_LDS, stream, p);
+            return 0;
+        }
+    }
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
     const int grid = p.m_tiles * p.n_tiles;
     const size_t lds = 4 * TILE_BYTES;

@@ -71,38 +71,51 @@ __global__ __launch_bounds__(256) void focal_g2_kernel(const bf16_raw* __restric
     int ch = (int)(i0 - row * kv);
     const long long dq = stride / kv;
     const int dr = (int)(stride - dq * kv);
-    for (long long i = i0; i < nvec; i += stride) {
-        const int c0 = ch * 8;
-        const int lab = labels[row];
-        row += dq; ch += dr;
-        if (ch >= kv) { ch -= kv; ++row; }
-        u32x4_t o = {0u, 0u, 0u, 0u};
-        if (lab >= 0) {
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(logits + i * 8);
-            float g[8];
+    // four vectors per pass, their label and logit loads issued before any arithmetic (the logits are read whatever the label says:
+    // ignored rows are rare, and a load that waits for the label serialises two memory latencies per 8 logits)
+    constexpr int U = 4;
+    for (long long i = i0; i < nvec; i += U * stride) {
+        int lab[U], c0[U];
+        u32x4_t v[U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float l0, l1;
-                focal_g2(bf_lo(v[k]), bf_lo(v[k]), a_neg, a_neg, l0, g[2 * k]);
-                focal_g2(bf_hi(v[k]), bf_hi(v[k]), a_neg, a_neg, l1, g[2 * k + 1]);
-                acc += l0 + l1;
-            }
-            const int pos = lab - 1 - c0;
-            if (pos >= 0 && pos < 8) {                      // this vector holds the row's positive class: redo that one element
-                const unsigned w = v[pos >> 1];
-                const float x = (pos & 1) ? bf_hi(w) : bf_lo(w);
-                float ln, gn, lp, gp;
-                focal_g2(x, x, a_neg, a_neg, ln, gn);
-                focal_g2(x, -x, -a_pos, a_pos, lp, gp);
-                acc += lp - ln;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k == pos) g[k] = gp;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = pack_bf2(g[2 * k] * gs, g[2 * k + 1] * gs);
+        for (int u = 0; u < U; ++u) {
+            const bool live = i + u * stride < nvec;
+            c0[u] = ch * 8;
+            lab[u] = live ? labels[row] : -1;
+            v[u] = live ? *reinterpret_cast<const u32x4_t*>(logits + (i + u * stride) * 8) : (u32x4_t){0u, 0u, 0u, 0u};
+            row += dq; ch += dr;
+            if (ch >= kv) { ch -= kv; ++row; }
         }
-        *reinterpret_cast<u32x4_t*>(dlogits + i * 8) = o;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i + u * stride >= nvec) break;
+            u32x4_t o = {0u, 0u, 0u, 0u};
+            if (lab[u] >= 0) {
+                float g[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float l0, l1;
+                    focal_g2(bf_lo(v[u][k]), bf_lo(v[u][k]), a_neg, a_neg, l0, g[2 * k]);
+                    focal_g2(bf_hi(v[u][k]), bf_hi(v[u][k]), a_neg, a_neg, l1, g[2 * k + 1]);
+                    acc += l0 + l1;
+                }
+                const int pos = lab[u] - 1 - c0[u];
+                if (pos >= 0 && pos < 8) {                      // this vector holds the row's positive class: redo that one element
+                    const unsigned w = v[u][pos >> 1];
+                    const float x = (pos & 1) ? bf_hi(w) : bf_lo(w);
+                    float ln, gn, lp, gp;
+                    focal_g2(x, x, a_neg, a_neg, ln, gn);
+                    focal_g2(x, -x, -a_pos, a_pos, lp, gp);
+                    acc += lp - ln;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k == pos) g[k] = gp;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = pack_bf2(g[2 * k] * gs, g[2 * k + 1] * gs);
+            }
+            *reinterpret_cast<u32x4_t*>(dlogits + (i + u * stride) * 8) = o;
+        }
     }
     const float s = block_sum_256(acc, red);
     if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s * inv_norm);

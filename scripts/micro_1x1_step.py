@@ -1,5 +1,6 @@
-"""The dense 1x1 launches of one RetinaNet-R50 step (800x1344, batch 16) with their epilogue operands, timed per prefetch depth of
-conv1x1.hip (0 = the generic kernel): algorithmic GB/s per launch class.   python scripts/micro_1x1_step.py [depths...]"""
+"""The dense 1x1 launches of one RetinaNet-R50 step (800x1344, batch 16) with their epilogue operands, timed per bd_conv_set_dense1x1
+mode (0 = the generic kernel, 1 = default choice, 2 = the 256^2 LDS-DMA tile wherever legal, 3 = the 128^2 tile only): algorithmic GB/s
+per launch class.   python scripts/micro_1x1_step.py [modes...]"""
 import os
 import sys
 _here = os.path.dirname(os.path.abspath(__file__))
@@ -67,7 +68,7 @@ def timeit(run, iters=20):
 
 
 def main():
-    depths = [int(a) for a in sys.argv[1:]] or [0, 1]
+    depths = [int(a) for a in sys.argv[1:]] or [3, 2]
     tot = {(dp, b): 0.0 for dp in depths for b in (0, 1)}
     print(f"{'launch':40s} " + " ".join(f"d{dp}{'b' if b else ' '}:us/GB/s" .rjust(16) for dp in depths for b in ((0, 1) if dp else (0,))))
     for tag, H, W, Cin, Cout, mode, add, mask, cnt in L:

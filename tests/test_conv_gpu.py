@@ -366,16 +366,17 @@ def test_wgrad_bias_multilevel():
     assert rel_l2(db.cpu(), gy.sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("depth", [1, 0])
+@pytest.mark.parametrize("depth", [1, 0, 2, 3])
 def test_dense_1x1_kernel_and_mask_bits(depth):
-    """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_set_dense1x1: prefetch depth x workgroups
-    per CU; 0 = the generic kernel): forward with
+    """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_set_dense1x1: 0 = the generic kernel,
+    1 = the default choice between the 128^2 and the 256^2 LDS-DMA tile, 2 = 256^2 wherever legal, 3 = 128^2 only): forward with
     residual + ReLU and the data gradient with accumulate + mask against torch-CPU fp32; the bit-packed ReLU mask written by the
     forward launch equals (y > 0) bit for bit, and a data gradient gated by it equals the one gated by the bf16 activation."""
     ops = _ops()
     assert ops.L().bd_conv_set_dense1x1(depth) == 0
     try:
-        for (N, Cin, Cout, H, W) in ((2, 256, 64, 23, 37), (1, 64, 256, 50, 41), (2, 200, 192, 9, 13), (1, 1024, 256, 20, 21), (1, 32, 544, 7, 9)):
+        for (N, Cin, Cout, H, W) in ((2, 256, 64, 23, 37), (1, 64, 256, 50, 41), (2, 200, 192, 9, 13), (1, 1024, 256, 20, 21), (1, 32, 544, 7, 9),
+                                     (1, 320, 448, 13, 19), (3, 512, 512, 17, 31)):
             g = torch.Generator().manual_seed(77 + Cin + Cout)
             x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
             w = bf16_round(torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin))
@@ -413,5 +414,23 @@ def test_dense_1x1_kernel_and_mask_bits(depth):
                 ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, dx2, add=dx2, maskbits=torch.from_numpy(abits.view(np.int32)).cuda(),
                                  flags=ops.EPI_ADD_BEFORE)
                 assert torch.equal(dx, dx2)
+                # one-byte twins (e4m3 of the forward output, e5m2 of the data gradient): the same bytes from either tile
+                if depth in (2, 3):
+                    tw = {}
+                    for dd in (2, 3):
+                        ops.L().bd_conv_set_dense1x1(dd)
+                        y8 = torch.zeros((M, Cout), dtype=torch.uint8, device="cuda")
+                        y2 = torch.empty_like(y)
+                        ops.conv2d_fwd(d, nchw_to_pm(x), wf, bias.cuda(), y2, add=nchw_to_pm(res), flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE,
+                                       y8=y8, q_scale=0.5)
+                        dx8 = torch.zeros((M, Cin), dtype=torch.uint8, device="cuda")
+                        dx3 = nchw_to_pm(acc0).clone()
+                        ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, dx3, add=dx3, mask=nchw_to_pm(act), flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK,
+                                         dx8=dx8, q_scale=64.0)
+                        tw[dd] = (y2.clone(), y8.clone(), dx3.clone(), dx8.clone())
+                    ops.L().bd_conv_set_dense1x1(depth)
+                    for a, b in zip(tw[2], tw[3]):
+                        assert torch.equal(a, b)
+                    assert torch.equal(tw[2][0], y) and torch.equal(tw[2][2], dx)
     finally:
         ops.L().bd_conv_set_dense1x1(1)
