@@ -53,9 +53,13 @@ __device__ __forceinline__ unsigned pack4_e5m2(float a, float b, float c, float 
     return (unsigned)v;
 }
 
+typedef __attribute__((address_space(3))) void lds_void_1x1_t;
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
-template <int DEPTH, int WAVES>
+// DMA: the operands go by LDS-DMA (no staging registers / LDS writes) into a THREE-stage ring, two K steps in flight per workgroup under a
+// counted vmcnt and one raw barrier per step (48 KB of LDS: three workgroups per CU); taken for CK % 32 == 0 and long K (see the launcher).
+template <int DEPTH, int WAVES, bool DMA>
 __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -148,6 +152,45 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     const bool want_add = add_before || add_after;
     const bool mask_bf = (p.flags & BD_EPI_MASK) && p.mask;
     const bool mask_bits = (p.flags & BD_EPI_MASK) && p.maskbits && !p.mask;
+    if constexpr (DMA) {
+        // ---- main loop, LDS-DMA ring: a stage = two operand tiles of 8 pieces of 1 KiB (16 rows x 64 B); this wave owns pieces wave and
+        // wave + 4 of both; lane -> row lane >> 2, position lane & 3, source chunk = position ^ ((row >> 1) & 3) (lds_off on the source side)
+        unsigned a_src[2], b_src[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int lrow = 16 * (wave + 4 * k) + (lane >> 2);
+            const int ch = (lane & 3) ^ ((lrow >> 1) & 3);
+            const int rho = lrow & 15;
+            const int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
+            a_src[k] = co < p.CO ? (unsigned)(co * p.CK + ch * 8) * 2u : X_NONE;
+            const int m = m0 + lrow;
+            b_src[k] = m < p.M ? (unsigned)(m * p.CK + ch * 8) * 2u : X_NONE;
+        }
+        const int uwave = __builtin_amdgcn_readfirstlane(wave);
+        auto dma = [&](int step, int stage) {
+            int so = step * BK * 2;
+            asm volatile("" : "+s"(so));
+            unsigned char* At = smem + stage * 2 * TILE_BYTES;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_1x1_t*)(At + (uwave + 4 * k) * 1024), 16, a_src[k], so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_1x1_t*)(At + TILE_BYTES + (uwave + 4 * k) * 1024), 16, b_src[k], so, 0, 0);
+            }
+        };
+        dma(0, 0);
+        if (nsteps > 1) dma(1, 1);
+        int cs = 0, ps = 2;                       // consumer / producer stage
+        for (int t = 0; t < nsteps; ++t) {
+            // stages t and t + 1 are in flight (4 DMA instructions each): stage t has landed when at most 4 are outstanding
+            if (t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // everyone's pieces; stage ps is free
+            if (t + 2 < nsteps) dma(t + 2, ps);
+            compute(cs);
+            cs = cs == 2 ? 0 : cs + 1;
+            ps = ps == 2 ? 0 : ps + 1;
+        }
+    } else {
     // ---- main loop: step t is computed from LDS buffer t & 1 while the loads of steps t+1 .. t+DEPTH are in flight ------------------
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u)
@@ -168,6 +211,8 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
         }
     }
 
+    }
+
     // ---- epilogue -------------------------------------------------------------------------------------------------------------------
     // All of the tile's residual / mask / gate operands are REQUESTED first (8 x 16 B per lane, into the registers the staging sets and
     // fragments have left), then consumed in order: as a load - use - store chain per 16 bytes (what the compiler makes of the plain
@@ -184,13 +229,14 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
                 bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
             }
     }
+    constexpr int EB = EPI_BATCH;
 #pragma unroll
-    for (int part = 0; part < 8 / EPI_BATCH; ++part) {
-    u32x4_t e_aux[EPI_BATCH];     // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
-    unsigned e_bits[EPI_BATCH];
+    for (int part = 0; part < 8 / EB; ++part) {
+    u32x4_t e_aux[EB];     // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
+    unsigned e_bits[EB];
 #pragma unroll
-    for (int qq = 0; qq < EPI_BATCH; ++qq) {
-        const int q = part * EPI_BATCH + qq;
+    for (int qq = 0; qq < EB; ++qq) {
+        const int q = part * EB + qq;
         const int j = q >> 1, half = q & 1;
         const int m = m0 + wp * 64 + j * 16 + (lane & 15);
         const bool ok = m < p.M && cbase + 32 * half < p.CO;
@@ -202,8 +248,8 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int qq = 0; qq < EPI_BATCH; ++qq) {
-        const int q = part * EPI_BATCH + qq;
+    for (int qq = 0; qq < EB; ++qq) {
+        const int q = part * EB + qq;
         const int j = q >> 1, half = q & 1;
         const int m = m0 + wp * 64 + j * 16 + (lane & 15);
         {
@@ -284,7 +330,6 @@ constexpr int BG_HALF = BG_T * 64;             // one operand tile of a stage: 2
 constexpr int BG_STAGE = 2 * BG_HALF;          // 32768
 constexpr int BG_NSTAGE = 4;
 constexpr int BG_LDS = BG_NSTAGE * BG_STAGE;   // 131072
-typedef __attribute__((address_space(3))) void lds_void_1x1_t;
 
 __global__ __launch_bounds__(512, 1) void conv1x1_big_kernel(const P1 p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -477,8 +522,11 @@ __global__ __launch_bounds__(512, 1) void conv1x1_big_kernel(const P1 p) {
         }
     }
     }   // tiles
+    // the producer ran three (empty) stages past the last tile: let those DMA writes land before the LDS can be handed to another workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+int g_conv1x1_dma_k = 512;      // BD_DENSE1X1_DMA_K: smallest CK that takes the LDS-DMA ring variant
 int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (generic kernel), 1 = the 128^2 tile (default), 2 = the 256^2 tile wherever legal (A/B), 3 = as 1
 
 }  // namespace
@@ -489,6 +537,7 @@ extern "C" int bd_conv_set_dense1x1(int depth) {
         return BD_EINVAL;
     }
     g_conv1x1_depth = depth;
+    if (const char* e = getenv("BD_DENSE1X1_DMA_K")) g_conv1x1_dma_k = atoi(e);
     return BD_OK;
 }
 
@@ -527,7 +576,15 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     }
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
     const int grid = p.m_tiles * p.n_tiles;
+    // 512 <= CK <= 1024 (res3 / res4 conv1 and conv3's data gradient, the laterals): the three-stage LDS-DMA ring (two K steps in flight
+    // per workgroup, three workgroups per CU) is 3 - 11 % faster; shorter K (the epilogue is most of the tile) and the 16 800-pixel res5
+    // layers (K = 2048: everything L2-resident, four workgroups per CU hide more) stay on the register-staged loop.  Measured per class
+    // with scripts/micro_1x1_step.py; BD_DENSE1X1_DMA_K (read by bd_conv_set_dense1x1) moves the lower bound for A/B.
+    if (CK % BK == 0 && CK >= g_conv1x1_dma_k && (CK <= 1024 || g_conv1x1_dma_k < 512)) {
+        hipLaunchKernelGGL((conv1x1_dense_kernel<1, 3, true>), dim3(grid), dim3(256), 6 * TILE_BYTES, stream, p);
+        return 0;
+    }
     const size_t lds = 4 * TILE_BYTES;
-    hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, false>), dim3(grid), dim3(256), lds, stream, p);
     return 0;
 }

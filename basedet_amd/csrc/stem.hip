@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_raw* __res
             row(t + 1, 1);
         }
     }
+    // the ring runs SP_AHEAD pairs ahead of the last row: let those DMA writes land before the wave ends and its LDS can be handed
+    // to another workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ void stem_weight_pack_kernel(const float* __restrict__ w, const float* __restrict__ row_scale,

@@ -184,10 +184,11 @@ def test_stem_conv_and_pad_normalize():
     assert torch.equal(pf, p)
 
 
-@pytest.mark.parametrize("N,Hp,Wp", [(1, 32, 32), (2, 96, 160), (3, 224, 416), (1, 800, 1344), (2, 34, 58)])
+@pytest.mark.parametrize("N,Hp,Wp", [(1, 32, 32), (2, 96, 160), (3, 224, 416), (1, 800, 1344), (2, 34, 58), (5, 800, 1344)])
 def test_stem_pool_fused_is_bit_identical(N, Hp, Wp):
     """bd_stem_pool_fwd (one launch, no half-resolution tensor) == bd_stem_conv7x7_fwd + bd_maxpool3x3s2_fwd, bit for bit: strip and
-    chunk edges (pooled widths that are / are not multiples of 7, heights that are / are not multiples of 10, odd stem sizes)."""
+    chunk edges (pooled widths that are / are not multiples of 7, heights that are / are not multiples of 10, odd stem sizes); the 5-image
+    case has more strips (4 800) than resident waves (2 048): a wave walks several strips through the same ring."""
     ops = _ops()
     g = torch.Generator().manual_seed(Hp * 7 + Wp)
     xh = torch.zeros((N, Hp + 6, Wp + 8, 4), dtype=torch.bfloat16)
@@ -366,13 +367,18 @@ def test_wgrad_bias_multilevel():
     assert rel_l2(db.cpu(), gy.sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("depth", [1, 0, 2, 3])
-def test_dense_1x1_kernel_and_mask_bits(depth):
+@pytest.mark.parametrize("depth", [1, 0, 2, 3, 101])
+def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
     """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_set_dense1x1: 0 = the generic kernel,
     1 = the default choice between the 128^2 and the 256^2 LDS-DMA tile, 2 = 256^2 wherever legal, 3 = 128^2 only): forward with
     residual + ReLU and the data gradient with accumulate + mask against torch-CPU fp32; the bit-packed ReLU mask written by the
     forward launch equals (y > 0) bit for bit, and a data gradient gated by it equals the one gated by the bf16 activation."""
     ops = _ops()
+    if depth == 101:          # the 128^2 tile's LDS-DMA ring variant for every K that allows it (default: CK >= 512 only)
+        monkeypatch.setenv("BD_DENSE1X1_DMA_K", "32")
+        depth = 1
+    else:
+        monkeypatch.setenv("BD_DENSE1X1_DMA_K", "512")
     assert ops.L().bd_conv_set_dense1x1(depth) == 0
     try:
         for (N, Cin, Cout, H, W) in ((2, 256, 64, 23, 37), (1, 64, 256, 50, 41), (2, 200, 192, 9, 13), (1, 1024, 256, 20, 21), (1, 32, 544, 7, 9),
