@@ -35,6 +35,7 @@ struct P1 {
     int M, CK, CO, flags;
     unsigned x_bytes, w_bytes;
     int m_tiles, n_tiles;
+    const float* wscale;      // fp8 kernel: per-output-channel epilogue multiplier (bd_weight_pack_fp8 / _t)
 };
 
 __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
@@ -316,6 +317,188 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     }   // parts
 }
 
+// ---- one-byte operands (BASELINE config 5) ----------------------------------------------------------------------------------------------
+// The 1x1 class is bound by the bytes it moves between L2 and the CUs (see the 256^2 section below), so with e4m3 activations /
+// e5m2 gradients and e4m3 weights a K step of the same 128-byte rows carries twice the channels: the 128^2 tile of the kernel above on
+// v_mfma_scale_f32_16x16x128_f8f6f4 (all block scales 2^0; MODE 1 declares the pixel operand e5m2: a data gradient), both operands by
+// LDS-DMA into a two-stage ring of 32 KB stages (two workgroups per CU), per-channel weight scale in the epilogue, and the epilogue of
+// the bf16 kernel (residual / bit-packed or bf16 gates / ybits / one-byte twin) with all eight units requested up front.
+constexpr int F8_TILE = 128 * 128;          // one operand tile of a stage: 128 rows x 128 B
+typedef __attribute__((ext_vector_type(8))) int i32x8_1x1_t;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv1x1_fp8_kernel(const P1 p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wp = wave & 1;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.n_tiles;
+    const int tile_n = bid - tile_m * p.n_tiles;
+    const int m0 = tile_m * TP;
+    const int co0 = tile_n * TC;
+    constexpr unsigned X_NONE = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.w), 0, p.w_bytes, 0x00020000);
+    // DMA pieces: an operand tile = 16 pieces of 1 KiB (8 rows x 128 B); this wave owns pieces wave + 4k; lane -> row lane >> 3,
+    // position lane & 7, source chunk = position ^ (row & 7)
+    unsigned a_src[4], b_src[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int lrow = 8 * (wave + 4 * k) + (lane >> 3);
+        const int ch = (lane & 7) ^ (lrow & 7);
+        const int rho = lrow & 15;
+        const int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
+        a_src[k] = co < p.CO ? (unsigned)(co * p.CK + ch * 16) : X_NONE;
+        const int m = m0 + lrow;
+        b_src[k] = m < p.M ? (unsigned)(m * p.CK + ch * 16) : X_NONE;
+    }
+    auto dma = [&](int step, int stage) {
+        int so = step * 128;
+        asm volatile("" : "+s"(so));
+        unsigned char* At = smem + stage * 2 * F8_TILE;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_1x1_t*)(At + (wave + 4 * k) * 1024), 16, a_src[k], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_1x1_t*)(At + F8_TILE + (wave + 4 * k) * 1024), 16, b_src[k], so, 0, 0);
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = lane >> 4;        // the lane's 32 consecutive k = chunks 2 fk, 2 fk + 1 of the row
+    const int one = 0x7f7f7f7f;
+    const int nsteps = p.CK / 128;                     // the host takes CK % 128 == 0 only
+    auto frag = [&](const unsigned char* T, int row) {
+        const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(T + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
+        const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(T + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
+        return (i32x8_1x1_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+    dma(0, 0);
+    for (int t = 0; t < nsteps; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        // this wave's pieces of step t
+        asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // everyone's; the other stage is free
+        if (t + 1 < nsteps) dma(t + 1, (t + 1) & 1);
+        const unsigned char* At = smem + (t & 1) * 2 * F8_TILE;
+        const unsigned char* Bt = At + F8_TILE;
+        i32x8_1x1_t a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = frag(At, wc * 64 + i * 16 + frow);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = frag(Bt, wp * 64 + j * 16 + frow);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i][j], 0, MODE == 1 ? 1 : 0, 0, one, 0, one);
+    }
+
+    // ---- epilogue (the bf16 kernel's, with the per-channel weight scale) ----------------------------------------------------------------
+    const int cg = lane >> 4;
+    const int cbase = co0 + wc * 64 + 8 * cg;
+    const bool do_relu = p.flags & BD_EPI_RELU;
+    const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
+    const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
+    const bool want_add = add_before || add_after;
+    const bool mask_bf = (p.flags & BD_EPI_MASK) && p.mask;
+    const bool mask_bits = (p.flags & BD_EPI_MASK) && p.maskbits && !p.mask;
+    float bias[16], scl[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { bias[k] = 0.f; scl[k] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (cbase + 32 * (q >> 1) + 4 * (q & 1) < p.CO) {
+            const f32x4_t sv = *reinterpret_cast<const f32x4_t*>(p.wscale + cbase + 32 * (q >> 1) + 4 * (q & 1));
+            scl[4 * q] = sv[0]; scl[4 * q + 1] = sv[1]; scl[4 * q + 2] = sv[2]; scl[4 * q + 3] = sv[3];
+            if (p.bias) {
+                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + cbase + 32 * (q >> 1) + 4 * (q & 1));
+                bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
+            }
+        }
+    u32x4_t e_aux[8];             // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
+    unsigned e_bits[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = q >> 1, half = q & 1;
+        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+        const bool ok = m < p.M && cbase + 32 * half < p.CO;
+        const long long idx = (long long)m * p.CO + cbase + 32 * half;
+        e_aux[q] = (u32x4_t){0u, 0u, 0u, 0u}; e_bits[q] = 0u;
+        if (ok && want_add) e_aux[q] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+        else if (ok && mask_bf) e_aux[q] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+        if (ok && mask_bits) e_bits[q] = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = q >> 1, half = q & 1;
+        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+        const bool ok = m < p.M && cbase + 32 * half < p.CO;      // CO % 8 == 0
+        const long long idx = (long long)m * p.CO + cbase + 32 * half;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] * scl[8 * half + k] + bias[8 * half + k];
+        const u32x4_t av = e_aux[q];
+        if (add_before) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
+        }
+        if (do_relu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (mask_bf) {
+            u32x4_t mv = e_aux[q];
+            if (want_add) { mv = (u32x4_t){0u, 0u, 0u, 0u}; if (ok) mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(bf_lo(mv[k]) > 0.f)) v[2 * k] = 0.f;
+                if (!(bf_hi(mv[k]) > 0.f)) v[2 * k + 1] = 0.f;
+            }
+        }
+        if (mask_bits) {
+            const unsigned byte = e_bits[q] >> (8 * cg);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (!((byte >> k) & 1u)) v[k] = 0.f;
+        }
+        if (add_after) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+        if (ok) *reinterpret_cast<u32x4_t*>(p.y + idx) = o;
+        if (p.y8 && ok) {
+            u32x2_t o8;
+            if (p.y8_bf8) {
+                o8[0] = pack4_e5m2(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                o8[1] = pack4_e5m2(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+            } else {
+                o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+            }
+            *reinterpret_cast<u32x2_t*>(p.y8 + idx) = o8;
+        }
+        if (p.ybits) {
+            unsigned byte = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) byte |= (v[k] > 0.f ? 1u : 0u) << k;
+            unsigned word = byte << (8 * cg);
+            word |= __shfl_xor(word, 16, 64);
+            word |= __shfl_xor(word, 32, 64);
+            if (ok && cg == (j & 3)) p.ybits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m] = word;
+        }
+    }
+}
+
 // ---- 256 x 256 tile, persistent, four-stage LDS-DMA ring -----------------------------------------------------------------------------
 // Across the step's sixteen launch classes the 128 x 128 kernel above moves a near-constant 6.3 - 9.6 TB/s BETWEEN L2 AND THE CUs (every
 // activation tile is fetched Cout / 128 times, the weight matrix M / 128 times) while its HBM-level rate falls from 4.5 TB/s (res2: 2
@@ -587,4 +770,39 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     const size_t lds = 4 * TILE_BYTES;
     hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, false>), dim3(grid), dim3(256), lds, stream, p);
     return 0;
+}
+
+// fp8 form of a dense 1x1 launch (1x1 / stride 1 / pad 0 over one dense level): mode 0 = forward (xq e4m3), mode 1 = data gradient
+// (xq = e5m2 gradient of the conv output; "CK" is then Cout and "CO" Cin).  See include/basedet_hip.h.
+extern "C" int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, const void* wq, const float* wscale, const float* bias,
+                              const void* add, const void* mask, const uint32_t* maskbits, void* y, uint32_t* ybits, void* y8, float q_scale,
+                              int flags, bd_stream_t stream) {
+    BD_REQUIRE(d && xq && wq && wscale && y, "conv1x1_fp8: null pointer");
+    BD_REQUIRE(mode == 0 || mode == 1, "conv1x1_fp8: mode %d (0 forward, 1 data gradient)", mode);
+    BD_REQUIRE(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->nseg == 1 && d->in_off[0] == 0 && d->out_off[0] == 0 &&
+               d->in_pix_per_img == (long long)d->Hi[0] * d->Wi[0] && d->out_pix_per_img == (long long)d->Ho[0] * d->Wo[0],
+               "conv1x1_fp8: 1x1 / stride 1 / pad 0 over one dense level only");
+    const long long M = (long long)d->N * d->in_pix_per_img;
+    const int CK = mode == 0 ? d->Cin : d->Cout, CO = mode == 0 ? d->Cout : d->Cin;
+    BD_REQUIRE(CK % 128 == 0 && CO % 32 == 0, "conv1x1_fp8: K = %d must be a multiple of 128, the produced channels (%d) of 32", CK, CO);
+    BD_REQUIRE(M * CK < 0x7fffffffll && M * CO * 2 < 0x7fffffffffll && M < (1ll << 24), "conv1x1_fp8: tensor too large for 32-bit offsets");
+    BD_REQUIRE(!(mode == 0 && (flags & BD_EPI_MASK)) && !(mode == 1 && (flags & BD_EPI_RELU)), "conv1x1_fp8: flag / mode mismatch");
+    P1 p{};
+    p.x = (const bf16_raw*)xq; p.w = (const bf16_raw*)wq; p.wscale = wscale; p.bias = bias; p.add = (const bf16_raw*)add;
+    p.mask = maskbits ? nullptr : (const bf16_raw*)mask; p.maskbits = maskbits; p.y = (bf16_raw*)y; p.ybits = ybits;
+    p.y8 = (unsigned char*)y8; p.q_scale = q_scale; p.y8_bf8 = mode;
+    p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags | (maskbits ? BD_EPI_MASK : 0);
+    p.x_bytes = (unsigned)(M * CK); p.w_bytes = (unsigned)((long long)CO * CK);
+    p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
+    const int grid = p.m_tiles * p.n_tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fp8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * F8_TILE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * F8_TILE);
+        attr_set = true;
+    }
+    if (mode == 0) hipLaunchKernelGGL((conv1x1_fp8_kernel<0>), dim3(grid), dim3(256), 4 * F8_TILE, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv1x1_fp8_kernel<1>), dim3(grid), dim3(256), 4 * F8_TILE, (hipStream_t)stream, p);
+    BD_CHECK_LAUNCH("bd_conv1x1_fp8");
+    return BD_OK;
 }

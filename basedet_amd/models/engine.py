@@ -58,6 +58,8 @@ class ConvLayer:
         # fp8 forward (BASELINE config 5, enable_fp8): e4m3 weights with one scale per output channel + the input cast to e4m3
         self.fp8 = False
         self.fp8_dgrad = False          # data gradient on the fp8 patch kernel too (e5m2 gradients under a static gradient scale)
+        self.fp8_1x1 = False            # dense 1x1 launches on one-byte operands when the producer wrote the input's twin (bd_conv1x1_fp8)
+        self.fp8_1x1_dgrad = False
         self.w_q8 = self.w_scale8 = self.w_q8t = self.w_scale8t = None
         self.act_scale = 1.0
         self.grad_scale = 4096.0
@@ -121,14 +123,35 @@ class ConvLayer:
             self.w_q8t = torch.empty((self.cin, self.k * self.k, self.cout), dtype=torch.uint8, device=self.device)
             self.w_scale8t = torch.empty((self.cin,), dtype=torch.float32, device=self.device)
 
+    def enable_fp8_1x1(self, act_scale=1.0, dgrad=False, grad_scale=4096.0):
+        """1x1 / stride 1 layers: forward through bd_conv1x1_fp8 whenever the caller hands over the e4m3 twin of the input (never a cast
+        pass: the launch is memory-bound, a cast would cost what the one-byte operand saves), with dgrad=True the data gradient too
+        (from the e5m2 twin of the output gradient).  Weight gradients stay bf16."""
+        assert self.k == 1 and self.stride == 1 and self.cin % 32 == 0 and self.cout % 32 == 0
+        self.act_scale, self.grad_scale = float(act_scale), float(grad_scale)
+        if self.cin % 128 == 0:
+            self.fp8_1x1 = True
+            self.w_q8 = torch.empty((self.cout, 1, self.cin), dtype=torch.uint8, device=self.device)
+            self.w_scale8 = torch.empty((self.cout,), dtype=torch.float32, device=self.device)
+        if dgrad and self.trainable and self.cout % 128 == 0:
+            self.fp8_1x1_dgrad = True
+            self.w_q8t = torch.empty((self.cin, 1, self.cout), dtype=torch.uint8, device=self.device)
+            self.w_scale8t = torch.empty((self.cin,), dtype=torch.float32, device=self.device)
+
     def pack_fp8(self):
+        if self.k == 1 and (self.fp8_1x1 or self.fp8_1x1_dgrad):
+            if self.fp8_1x1:
+                ops.weight_pack_fp8(self.w, self.row_scale, self.cout, 1, self.cin, self.act_scale, self.w_q8, self.w_scale8)
+            if self.fp8_1x1_dgrad:
+                ops.weight_pack_fp8_t(self.w, self.row_scale, self.cout, 1, self.cin, self.grad_scale, self.w_q8t, self.w_scale8t)
+            return
         ops.weight_pack_fp8(self.w, self.row_scale, self.cout, self.k * self.k, self.cin, self.act_scale, self.w_q8, self.w_scale8)
         if self.fp8_dgrad:
             ops.weight_pack_fp8_t(self.w, self.row_scale, self.cout, self.k * self.k, self.cin, self.grad_scale, self.w_q8t, self.w_scale8t)
 
     def pack(self):
         ops.weight_pack(self.w, self.row_scale, self.w_fwd, self.w_dgrad, self.cout, self.k * self.k, self.cin)
-        if self.fp8:
+        if self.fp8 or self.fp8_1x1 or self.fp8_1x1_dgrad:
             self.pack_fp8()
 
     # -- kernels ----------------------------------------------------------------------------------
@@ -145,6 +168,9 @@ class ConvLayer:
         """x8: the e4m3 twin of x when a producing fp8 launch wrote one (else x is cast by bd_quantize_fp8); y8: twin of y to write
         for a following fp8 convolution.  Both are ignored on the bf16 path."""
         flags = (ops.EPI_RELU if relu else 0) | (ops.EPI_ADD_BEFORE if add is not None else 0)
+        if self.fp8_1x1 and x8 is not None and ops.conv1x1_fp8_ok(self.desc(gin, gout), 0):
+            return ops.conv1x1_fp8(self.desc(gin, gout), 0, x8, self.w_q8, self.w_scale8, self.b, y, add=add, bits=bits, y8=y8,
+                                   q_scale=q_scale, flags=flags)
         if self.fp8 and bits is None:
             xq = x8 if x8 is not None else ops.quantize_fp8(x, self.act_scale, self.q8_scratch(x.numel())[: x.numel()])
             return ops.conv2d_fwd_fp8(self.desc(gin, gout), xq, self.w_q8, self.w_scale8, self.b, y, add=add, flags=flags, y8=y8,
@@ -152,7 +178,8 @@ class ConvLayer:
         return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags, bits=bits,
                               y8=y8 if (y8 is not None and ops.dense_1x1_bits_ok(self.desc(gin, gout))) else None, q_scale=q_scale)
 
-    def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None, g8=None, dx8=None, q_scale=1.0):
+    def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None, g8=None, dx8=None, q_scale=1.0,
+              add_before=None):
         """dx (+)= conv^T(g).  first=False accumulates onto dx (pre-mask); mask = forward activation whose
         ReLU gates dx (maskbits: the same gate bit-packed, written by the producing forward launch); add_after = tensor added
         after masking (P6: gradient that bypasses the ReLU)."""
@@ -160,6 +187,9 @@ class ConvLayer:
         if add_after is not None:
             flags |= ops.EPI_ADD_AFTER
             add = add_after
+        elif add_before is not None:                 # dx = (conv^T(g) + add_before) * mask: the identity skip's gradient joins here
+            flags |= ops.EPI_ADD_BEFORE
+            add = add_before
         elif not first:
             flags |= ops.EPI_ADD_BEFORE
             add = dx
@@ -168,6 +198,9 @@ class ConvLayer:
         if maskbits is not None:
             mask = None
         d = self.desc(gin, gout)
+        if self.fp8_1x1_dgrad and g8 is not None and ops.conv1x1_fp8_ok(d, 1):
+            return ops.conv1x1_fp8(d, 1, g8, self.w_q8t, self.w_scale8t, None, dx, add=add, mask=mask, maskbits=maskbits, y8=dx8,
+                                   q_scale=q_scale, flags=flags)
         if self.fp8_dgrad and maskbits is None:
             # g8: the e5m2 twin of g (g * grad_scale) when the producing launch wrote one, else a cast pass; dx8: twin of dx to write
             gq = g8 if g8 is not None else ops.quantize_bf8(g, self.grad_scale, self.q8_scratch(g.numel())[: g.numel()])

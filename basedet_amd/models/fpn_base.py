@@ -148,6 +148,15 @@ class FPNDetector:
                     key = "side" if id(c) in side else "main"          # P6 / P7 run on a side stream: their own scratch
                     c.enable_fp8(lambda n, key=key: self._q8_buf(key, n), m.get("FP8_ACT_SCALE", 1.0),
                                  dgrad=bool(m.get("FP8_DGRAD", True)), grad_scale=m.get("FP8_GRAD_SCALE", 4096.0))
+            # the bottleneck 1x1s around an fp8 3x3 (res4 / res5 blocks after the first): their launches are bound by the bytes they move
+            # between L2 and the CUs, and the twins of their inputs are written by the producing launches anyway
+            if bool(m.get("FP8_1X1", True)):
+                for blk in self.blocks:
+                    if blk["kind"] == "bottleneck" and blk["convs"][1].fp8 and blk["convs"][1].stride == 1:
+                        for c in (blk["convs"][0], blk["convs"][2]):
+                            if c.cin % 32 == 0 and c.cout % 32 == 0:
+                                c.enable_fp8_1x1(m.get("FP8_ACT_SCALE", 1.0), dgrad=bool(m.get("FP8_DGRAD", True)),
+                                                 grad_scale=m.get("FP8_GRAD_SCALE", 4096.0))
         else:
             assert self.weight_dtype == "bf16", self.weight_dtype
         self._bind_params(params)
@@ -195,7 +204,7 @@ class FPNDetector:
             self._pack_table = ops.build_pack_table(ent, self.device)
         ops.weight_pack_multi(self._pack_table)
         for c in self.convs.values():
-            if c.fp8 and c.trainable:
+            if (c.fp8 or c.fp8_1x1 or c.fp8_1x1_dgrad) and c.trainable:
                 c.pack_fp8()
 
     # reference module protocol ------------------------------------------------------------------------
@@ -331,6 +340,23 @@ class FPNDetector:
                 b.mid8 = torch.empty((gin.pixels, blk["ch"]), dtype=torch.uint8, device=dev)
             b.out_bits = None
             b.g_mid8 = None
+            # one-byte twins for the fp8 1x1 launches: conv2's output (conv3 reads it), the block output (the next block's conv1 reads
+            # it), and in the backward pass the block's output gradient (conv3's data gradient) and conv2's data gradient (conv1's)
+            b.mid8b = b.out8 = b.g_out8 = b.g_mid8a = None
+            b.g_out8_ready = False
+            if blk["kind"] == "bottleneck":
+                u8 = lambda geo, ch: torch.empty((geo.pixels, ch), dtype=torch.uint8, device=dev)
+                nxt = self.blocks[len(pl.blk) + 1] if len(pl.blk) + 1 < len(self.blocks) else None
+                if blk["convs"][2].fp8_1x1 and blk["convs"][1].fp8 and blk["convs"][1].stride == 1:
+                    b.mid8b = u8(b.gout, blk["ch"])
+                if nxt is not None and nxt["kind"] == "bottleneck" and nxt["convs"][0].fp8_1x1 \
+                        and ops.dense_1x1_bits_ok(blk["convs"][2].desc(b.gout, b.gout)):
+                    b.out8 = u8(b.gout, blk["cout"])
+                if blk["trainable"] and self.fp8_grad_twins:
+                    if blk["convs"][2].fp8_1x1_dgrad and nxt is not None and nxt["kind"] == "bottleneck" and nxt["trainable"]:
+                        b.g_out8 = u8(b.gout, blk["cout"])
+                    if blk["convs"][0].fp8_1x1_dgrad and blk["convs"][1].fp8_dgrad:
+                        b.g_mid8a = u8(gin, blk["ch"])
             if blk["trainable"]:
                 b.g_mids = [torch.empty_like(t) for t in b.mids]
                 b.g_out = torch.empty_like(b.out)
@@ -444,21 +470,25 @@ class FPNDetector:
         st[1].record()
         return dev
 
-    def _block_forward(self, blk, b, x):
+    def _block_forward(self, blk, b, x, x8=None):
+        """x8: the e4m3 twin of the block input when the previous block's conv3 wrote one (fp8 mode)."""
         convs = blk["convs"]
         idt = x
         if blk["ds"] is not None:
             blk["ds"].forward(x, b.gin, b.gout, b.idt)
             idt = b.idt
         geos = [b.gin] + b.mid_geo + [b.gout]
-        t = x
-        t8 = None
+        t, t8 = x, x8
         for ci, c in enumerate(convs[:-1]):
-            y8 = b.mid8 if (ci == 0 and getattr(b, "mid8", None) is not None) else None
+            y8 = None
+            if ci == 0 and getattr(b, "mid8", None) is not None:
+                y8 = b.mid8
+            elif ci == 1 and getattr(b, "mid8b", None) is not None:
+                y8 = b.mid8b
             c.forward(t, geos[ci], geos[ci + 1], b.mids[ci], relu=True, x8=t8, y8=y8,
                       q_scale=convs[ci + 1].act_scale if y8 is not None else 1.0)
             t, t8 = b.mids[ci], y8
-        convs[-1].forward(t, geos[-2], geos[-1], b.out, add=idt, relu=True, bits=b.out_bits)
+        convs[-1].forward(t, geos[-2], geos[-1], b.out, add=idt, relu=True, bits=b.out_bits, x8=t8, y8=getattr(b, "out8", None))
         return b.out
 
     def network_forward(self, pl):
@@ -471,8 +501,10 @@ class FPNDetector:
             ops.stem_conv7x7_fwd(N, pl.Hp, pl.Wp, pl.x_halo, self.stem_packed, self.stem_shift, pl.stem_out)
             ops.maxpool3x3s2_fwd(pl.stem_out, N, pl.g_stem.H[0], pl.g_stem.W[0], 64, pl.pool_out)
         x = pl.pool_out
+        x8 = None
         for blk, b in zip(self.blocks, pl.blk):
-            x = self._block_forward(blk, b, x)
+            x = self._block_forward(blk, b, x, x8)
+            x8 = getattr(b, "out8", None)
         # FPN (fpn_backbone.py:123-160): top-down from the coarsest level
         st = self.fpn_stages
         nl = len(st)
@@ -571,6 +603,8 @@ class FPNDetector:
         ws, cws = pl.wgrad_ws, pl.colsum_ws
         pyr = pl.pyr
         pl.g_P8_ready = False                       # set by a head whose last data gradients wrote the e5m2 twin of dL/dP
+        for b in pl.blk:
+            b.g_out8_ready = False
         self.head_backward(pl, ws, cws)
         side = (self._wstream,) if (self.async_wgrad and self._wstream is not None) else ()
         if on_bucket_ready:
@@ -635,11 +669,17 @@ class FPNDetector:
                 self._wgrad(blk["ds"], xin, G, b.gin, b.gout, ws)
             # main branch, last conv backwards
             g = G
-            g8 = None
+            # fp8 mode: the e5m2 twin of the block's output gradient, written by the next block's conv1 data gradient (its last writer)
+            g8 = b.g_out8 if (getattr(b, "g_out8", None) is not None and b.g_out8_ready) else None
             for ci in range(len(convs) - 1, 0, -1):
                 self._wgrad(convs[ci], b.mids[ci - 1], g, geos[ci], geos[ci + 1], ws)
-                # fp8 mode: conv3's (dense 1x1) data gradient also writes the e5m2 twin that conv2's fp8 data gradient reads
-                nxt = b.g_mid8 if (ci == len(convs) - 1 and getattr(b, "g_mid8", None) is not None) else None
+                # conv3's (dense 1x1) data gradient also writes the e5m2 twin that conv2's fp8 data gradient reads, conv2's the one
+                # conv1's reads
+                nxt = None
+                if len(convs) == 3:
+                    nxt = getattr(b, "g_mid8", None) if ci == 2 else getattr(b, "g_mid8a", None)
+                if nxt is not None and not convs[ci].dgrad_writes_twin(geos[ci], geos[ci + 1]):
+                    nxt = None
                 convs[ci].dgrad(g, geos[ci], geos[ci + 1], b.g_mids[ci - 1], mask=b.mids[ci - 1], g8=g8, dx8=nxt,
                                 q_scale=convs[ci - 1].grad_scale)
                 g, g8 = b.g_mids[ci - 1], nxt
@@ -649,18 +689,22 @@ class FPNDetector:
                 xbits = pl.blk[bi - 1].out_bits if ops.dense_1x1_bits_ok(convs[0].desc(geos[0], geos[1])) else None
                 # has the input already received a contribution (FPN lateral of res3/res4)?
                 tapped = any(pl.res[s] == bi - 1 for s in st)
+                # conv1's data gradient is the LAST writer of the previous block's output gradient: it also writes that gradient's e5m2
+                # twin (fp8 mode) for the previous block's conv3
+                pb = pl.blk[bi - 1]
+                gx8 = getattr(pb, "g_out8", None)
+                kw = dict(mask=xin, maskbits=xbits, g8=g8, dx8=gx8, q_scale=convs[0].grad_scale)
                 if blk["ds"] is not None:
                     blk["ds"].dgrad(G, b.gin, b.gout, gx, first=not tapped)
-                    convs[0].dgrad(g, geos[0], geos[1], gx, first=False, mask=xin, maskbits=xbits)
+                    convs[0].dgrad(g, geos[0], geos[1], gx, first=False, **kw)
                 else:
                     if tapped:
                         ops.add_bf16(gx, G, gx)
-                        convs[0].dgrad(g, geos[0], geos[1], gx, first=False, mask=xin, maskbits=xbits)
+                        convs[0].dgrad(g, geos[0], geos[1], gx, first=False, **kw)
                     else:
                         # identity skip: gx = (dgrad + G) * mask
-                        ops.conv2d_dgrad(convs[0].desc(geos[0], geos[1]), g, convs[0].w_dgrad, gx, add=G,
-                                         mask=None if xbits is not None else xin, maskbits=xbits,
-                                         flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
+                        convs[0].dgrad(g, geos[0], geos[1], gx, add_before=G, **kw)
+                pb.g_out8_ready = gx8 is not None and (convs[0].fp8_1x1_dgrad and g8 is not None or convs[0].dgrad_writes_twin(geos[0], geos[1]))
             if on_bucket_ready and (bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]):
                 on_bucket_ready(f"layer{blk['layer']}", side)
         self._join_wgrads()

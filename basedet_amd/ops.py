@@ -136,6 +136,19 @@ def conv2d_dgrad_fp8(d, g8, wq_t, wscale_t, dx, add=None, mask=None, flags=0, dx
     return dx
 
 
+def conv1x1_fp8(d, mode, xq, wq, wscale, bias, y, add=None, mask=None, maskbits=None, bits=None, y8=None, q_scale=1.0, flags=0):
+    """Dense 1x1 launch on one-byte operands: mode 0 forward (xq e4m3), mode 1 data gradient (xq = e5m2 gradient)."""
+    check(L().bd_conv1x1_fp8(C.byref(d), mode, ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(mask), ptr(maskbits), ptr(y),
+                             ptr(bits), ptr(y8), float(q_scale), flags, stream_ptr()), "bd_conv1x1_fp8")
+    return y
+
+
+def conv1x1_fp8_ok(d, mode):
+    """True when bd_conv1x1_fp8 takes this descriptor."""
+    K, CO = (d.Cin, d.Cout) if mode == 0 else (d.Cout, d.Cin)
+    return dense_1x1_bits_ok(d) and K % 128 == 0 and CO % 32 == 0
+
+
 def fp8_dgrad_ok(d):
     """True when bd_conv2d_dgrad_fp8 takes this descriptor (conv3x3_pp8.hip, mode 1)."""
     same = all(d.Hi[i] == d.Ho[i] and d.Wi[i] == d.Wo[i] for i in range(d.nseg))

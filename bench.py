@@ -165,6 +165,27 @@ class KernelTimer:
                 return r
             return inner
 
+        def wrap_fp8_1x1(fn):
+            def inner(d, mode, xq, wq, wscale, bias, y, add=None, mask=None, maskbits=None, bits=None, y8=None, q_scale=1.0, flags=0):
+                kw = dict(add=add, mask=mask, maskbits=maskbits, bits=bits, y8=y8, q_scale=q_scale, flags=flags)
+                if not self.enabled:
+                    return fn(d, mode, xq, wq, wscale, bias, y, **kw)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = fn(d, mode, xq, wq, wscale, bias, y, **kw)
+                e.record()
+                m = d.Hi[0] * d.Wi[0] * d.N
+                K, CO = (d.Cin, d.Cout) if mode == 0 else (d.Cout, d.Cin)
+                # one-byte operand + weights, bf16 output (+ residual, + bf16 or bit-packed gate), optional twin / gate bits out
+                nbytes = 1.0 * m * K + 1.0 * K * CO + 2.0 * m * CO * (1 + (add is not None) + (mask is not None and maskbits is None)) \
+                    + (m * CO / 8.0 if maskbits is not None else 0.0) + (m * CO / 8.0 if bits is not None else 0.0) \
+                    + (1.0 * m * CO if y8 is not None else 0.0)
+                self.records.setdefault("conv1x1_fp8_kernel", []).append((s, e, flops(d)))
+                self.meta.setdefault("conv1x1_fp8_kernel", []).append(("conv1x1_fp8 " + ("fwd" if mode == 0 else "dgrad"), d.Cin, d.Cout, 1, 1, 1, d.Ho[0], d.Wo[0], nbytes))
+                return r
+            return inner
+
+        ops.conv1x1_fp8 = wrap_fp8_1x1(ops.conv1x1_fp8)
         ops.conv2d_dgrad_fp8 = wrap_fp8_dgrad(ops.conv2d_dgrad_fp8)
         ops.conv2d_fwd_fp8 = wrap_fp8(ops.conv2d_fwd_fp8)
         ops.conv2d_fwd = wrap(ops.conv2d_fwd, "igemm")

@@ -538,6 +538,15 @@ int bd_weight_pack_fp8_t(const float* w, const float* row_scale, int Cout, int R
                          bd_stream_t stream);
 int bd_conv2d_dgrad_fp8(const bd_conv_desc* d, const void* g8, const void* wq_t, const float* wscale_t, const void* add, const void* mask,
                         void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream);
+/* fp8 form of the dense 1x1 launches (the ResNet bottleneck's conv1 / conv3, models/cls/resnet.py:70-113; 1x1 / stride 1 / pad 0 over one
+ * dense level, K % 128 == 0, produced channels % 32 == 0).  mode 0 = forward: xq = e4m3 twin of the NHWC input (x * act_scale), wq /
+ * wscale from bd_weight_pack_fp8 (RS = 1); mode 1 = data gradient: xq = e5m2 twin of the output gradient (g * grad_scale), wq / wscale
+ * from bd_weight_pack_fp8_t.  y (bf16) = epi(conv(xq, wq) * wscale[c] + bias [+ add]) with the side inputs / outputs of
+ * bd_conv2d_fwd_ex / bd_conv2d_dgrad_ex: mask or maskbits (mode 1), ybits (mode 0), y8 = e4m3 (mode 0) / e5m2 (mode 1) of y * q_scale;
+ * each may be NULL. */
+int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, const void* wq, const float* wscale, const float* bias,
+                   const void* add, const void* mask, const uint32_t* maskbits, void* y, uint32_t* ybits, void* y8, float q_scale,
+                   int flags, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Operator surface of basedet.layers / basedet.structures as stand-alone fp32 entry points (callers written against the

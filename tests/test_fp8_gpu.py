@@ -182,7 +182,7 @@ def test_retinanet_r50_fp8_backward_variants():
     names = P.trainable_names(params, cfg.MODEL.BACKBONE.FREEZE_AT)
 
     def run(**kw):
-        for k in ("WEIGHT_DTYPE", "FP8_DGRAD", "FP8_GRAD_TWINS"):
+        for k in ("WEIGHT_DTYPE", "FP8_DGRAD", "FP8_GRAD_TWINS", "FP8_1X1"):
             cfg.MODEL.pop(k, None)
         for k, v in kw.items():
             cfg.MODEL[k] = v
@@ -198,6 +198,12 @@ def test_retinanet_r50_fp8_backward_variants():
     mb, lb, gb = run(WEIGHT_DTYPE="fp8_e4m3", FP8_GRAD_TWINS=False)
     mc, lc, gc = run(WEIGHT_DTYPE="fp8_e4m3")
     assert not any(c.fp8_dgrad for c in ma.convs.values()) and any(c.fp8_dgrad for c in mc.convs.values())
+    # the bottleneck 1x1s around the fp8 3x3s run on one-byte operands too (forward and data gradient), fed by producer-written twins
+    assert any(c.fp8_1x1 for c in mc.convs.values()) and any(c.fp8_1x1_dgrad for c in mc.convs.values())
+    assert any(b.out8 is not None for b in mc._cur.blk) and any(b.mid8b is not None for b in mc._cur.blk)
+    assert any(b.g_out8 is not None and b.g_out8_ready for b in mc._cur.blk) and any(b.g_mid8a is not None for b in mc._cur.blk)
+    md, ld, gd = run(WEIGHT_DTYPE="fp8_e4m3", FP8_1X1=False)         # (d): the 1x1 layers on bf16, as (c) otherwise
+    assert not any(c.fp8_1x1 for c in md.convs.values())
     assert mc._cur.g_P8 is not None and mb._cur.g_P8 is None
     assert any(getattr(b, "g_mid8", None) is not None for b in mc._cur.blk)
     for k in la:                                   # the same forward; the loss sums are float atomics (order-dependent last bits)
@@ -210,6 +216,11 @@ def test_retinanet_r50_fp8_backward_variants():
         return float(torch.dot(x, y) / (x.norm() * y.norm()))
 
     f16, fa, fb, fc = flat(g16), flat(ga), flat(gb), flat(gc)
+    c_cd = cos(fc, flat(gd))
+    print(f"cosine fp8 1x1 layers vs bf16 1x1 layers (both with fp8 3x3): {c_cd:.5f}; losses {lc} vs {ld}")
+    assert c_cd >= 0.99, c_cd
+    for k in lc:
+        assert abs(lc[k] - ld[k]) < 2e-2 * abs(ld[k]), (k, lc, ld)
     for f in (fa, fb, fc):
         assert bool(torch.isfinite(f).all())
     c_bc, c_ab, c_ac = cos(fb, fc), cos(fa, fb), cos(fa, fc)
@@ -310,3 +321,146 @@ def test_fp8_dgrad_tolerance_on_random_data(case):
     rel = (num / den) ** 0.5
     print(f"fp8 dgrad rel-L2 vs fp32 {case[:3]}: {rel:.4f}")
     assert rel < 1.2e-1, rel
+
+
+# ---- the dense 1x1 launches on one-byte operands (csrc/conv1x1.hip: conv1x1_fp8_kernel) -----------------------------------------------
+D1_CASES = [
+    # N, Cin, Cout, H, W
+    (2, 256, 128, 13, 17),
+    (1, 1024, 256, 20, 21),
+    (1, 128, 544, 9, 11),            # produced-channel tail (544 = 4 x 128 + 32), one K step
+    (3, 512, 512, 7, 31),
+]
+
+
+def _exact_weights(Cout, Cin, g, col=False):
+    """Weights whose per-channel scale is the exact power of two 2^-6: every output channel (col=False) / input channel (col=True)
+    has largest magnitude 7 = 448 / 64, all values e4m3 numbers / 64."""
+    wv = torch.tensor([0.0, 0.875, -0.875, 1.75, -3.5, 0.4375])
+    w = wv[torch.randint(0, len(wv), (Cout, Cin), generator=g)]
+    if col:
+        w[0, :] = 7.0
+    else:
+        w[:, 0] = 7.0
+    return w
+
+
+@pytest.mark.parametrize("case", D1_CASES)
+def test_fp8_dense_1x1_forward_is_exact_on_e4m3_inputs(case):
+    """bd_conv1x1_fp8 mode 0 on e4m3-valued inputs and power-of-two-scaled weights: exact fp32 sums, so equal to the fp32 convolution up
+    to the bf16 store (ties aside); residual + ReLU epilogue; ybits = (y > 0) bit for bit; the e4m3 twin within half an e4m3 ulp."""
+    ops = _ops()
+    N, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(31 + Cin + Cout)
+    vals = torch.tensor([0.0, 0.25, 0.5, 1.0, 1.5, -0.5, -1.0, 2.0, 3.0, -0.125])
+    x = vals[torch.randint(0, len(vals), (N, Cin, H, W), generator=g)]
+    w = _exact_weights(Cout, Cin, g)
+    bias = torch.randn(Cout, generator=g)
+    res = bf16_round(torch.randn(N, Cout, H, W, generator=g))
+    geo = ops.single(N, H, W)
+    d = ops.conv_desc(geo, geo, Cin, Cout, 1, 1, 1, 0)
+    assert ops.conv1x1_fp8_ok(d, 0)
+    M = N * H * W
+    xp = nchw_to_pm(x)
+    xq = torch.empty((M * Cin,), dtype=torch.uint8, device="cuda")
+    ops.quantize_fp8(xp, 1.0, xq)
+    wq = torch.empty((Cout, 1, Cin), dtype=torch.uint8, device="cuda")
+    ws = torch.empty((Cout,), dtype=torch.float32, device="cuda")
+    ops.weight_pack_fp8(w.view(Cout, 1, Cin).contiguous().cuda(), None, Cout, 1, Cin, 1.0, wq, ws)
+    assert torch.equal(ws.cpu(), torch.full((Cout,), 2.0 ** -6))
+    y = torch.empty((M, Cout), dtype=torch.bfloat16, device="cuda")
+    ybits = torch.full((Cout // 32, M), -1, dtype=torch.int32, device="cuda")
+    y8 = torch.zeros((M, Cout), dtype=torch.uint8, device="cuda")
+    ops.conv1x1_fp8(d, 0, xq, wq, ws, bias.cuda(), y, add=nchw_to_pm(res), bits=ybits, y8=y8, q_scale=0.5,
+                    flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE)
+    ref = bf16_round(torch.relu(TF.conv2d(x, w.view(Cout, Cin, 1, 1), bias) + res))
+    got = pm_to_nchw(y, N, H, W)
+    bad = got != ref
+    assert float(bad.float().mean()) < 1e-3, float(bad.float().mean())
+    assert bool(((got - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-6).all())
+    yb = (y.float() > 0).cpu().numpy().reshape(M, Cout // 32, 32)
+    want = (yb.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32).T
+    assert np.array_equal(ybits.cpu().numpy().view(np.uint32), want)
+    dec = y8.view(torch.float8_e4m3fn).float().cpu()
+    wantq = (y.float().cpu() * 0.5).clamp(-448, 448)
+    assert bool(((dec - wantq).abs() <= wantq.abs() * 2.0 ** -4 * 1.01 + 2.0 ** -10 + wantq.abs() * 2.0 ** -8).all())
+
+
+@pytest.mark.parametrize("case", D1_CASES)
+def test_fp8_dense_1x1_dgrad_is_exact_on_representable_inputs(case):
+    """bd_conv1x1_fp8 mode 1 (e5m2 gradients x e4m3 transposed weights, per-input-channel scale 2^-6 / grad_scale): on e5m2-valued
+    gradients the data gradient equals the fp32 transposed convolution up to the bf16 store; accumulate + bf16 gate, the bit-packed gate
+    gives the same bits, and the e5m2 twin is within half an e5m2 ulp."""
+    ops = _ops()
+    N, Cin, Cout, H, W = case
+    Cin, Cout = Cout, Cin                     # the data gradient's K is Cout: reuse the cases with K % 128 == 0 on that side
+    if Cout % 128 != 0 or Cin % 32 != 0:
+        pytest.skip("K = Cout must be a multiple of 128")
+    g = torch.Generator().manual_seed(41 + Cin + Cout)
+    GS = 64.0
+    gv = torch.tensor([0.0, 0.25, 0.5, 1.0, 1.5, -0.5, -1.0, 2.0, 3.0, -0.125]) / GS          # g * GS are e5m2 numbers
+    gy = gv[torch.randint(0, len(gv), (N, Cout, H, W), generator=g)]
+    w = _exact_weights(Cout, Cin, g, col=True)
+    acc0 = bf16_round(torch.randn(N, Cin, H, W, generator=g) * 0.1)
+    act = torch.relu(bf16_round(torch.randn(N, Cin, H, W, generator=g)))
+    geo = ops.single(N, H, W)
+    d = ops.conv_desc(geo, geo, Cin, Cout, 1, 1, 1, 0)
+    assert ops.conv1x1_fp8_ok(d, 1)
+    M = N * H * W
+    g8 = torch.empty((M * Cout,), dtype=torch.uint8, device="cuda")
+    ops.quantize_bf8(nchw_to_pm(gy), GS, g8)
+    wq = torch.empty((Cin, 1, Cout), dtype=torch.uint8, device="cuda")
+    ws = torch.empty((Cin,), dtype=torch.float32, device="cuda")
+    ops.weight_pack_fp8_t(w.view(Cout, 1, Cin).contiguous().cuda(), None, Cout, 1, Cin, GS, wq, ws)
+    assert torch.equal(ws.cpu(), torch.full((Cin,), 2.0 ** -6 / GS))
+    dx = nchw_to_pm(acc0).clone()
+    dx8 = torch.zeros((M, Cin), dtype=torch.uint8, device="cuda")
+    ops.conv1x1_fp8(d, 1, g8, wq, ws, None, dx, add=dx, mask=nchw_to_pm(act), y8=dx8, q_scale=GS, flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
+    ref = bf16_round((TF.conv_transpose2d(gy, w.view(Cout, Cin, 1, 1)) + acc0) * (act > 0))
+    got = pm_to_nchw(dx, N, H, W)
+    bad = got != ref
+    assert float(bad.float().mean()) < 1e-3, float(bad.float().mean())
+    assert bool(((got - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-6).all())
+    ab = (nchw_to_pm(act).float() > 0).cpu().numpy().reshape(M, Cin // 32, 32)
+    abits = (ab.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32).T.copy()
+    dx2 = nchw_to_pm(acc0).clone()
+    ops.conv1x1_fp8(d, 1, g8, wq, ws, None, dx2, add=dx2, maskbits=torch.from_numpy(abits.view(np.int32)).cuda(), flags=ops.EPI_ADD_BEFORE)
+    assert torch.equal(dx, dx2)
+    dec = dx8.view(torch.float8_e5m2).float().cpu()
+    wantq = (dx.float().cpu() * GS).clamp(-57344, 57344)
+    assert bool(((dec - wantq).abs() <= wantq.abs() * 2.0 ** -3 * 1.01 + 2.0 ** -17 + wantq.abs() * 2.0 ** -8).all())
+
+
+def test_fp8_dense_1x1_tolerance_on_random_data():
+    """Stated tolerance of the one-byte 1x1 launches on random data: forward rel-L2 <= 6e-2 against the fp32 result of the same bf16
+    inputs (e4m3 x e4m3), data gradient <= 1.2e-1 (e5m2 gradients keep 2 mantissa bits)."""
+    ops = _ops()
+    N, Cin, Cout, H, W = 2, 1024, 256, 20, 21
+    g = torch.Generator().manual_seed(7)
+    x = torch.relu(bf16_round(torch.randn(N, Cin, H, W, generator=g)))
+    w = torch.randn(Cout, Cin, generator=g) / np.sqrt(Cin)
+    geo = ops.single(N, H, W)
+    d = ops.conv_desc(geo, geo, Cin, Cout, 1, 1, 1, 0)
+    M = N * H * W
+    xq = torch.empty((M * Cin,), dtype=torch.uint8, device="cuda")
+    ops.quantize_fp8(nchw_to_pm(x), 1.0, xq)
+    wq = torch.empty((Cout, 1, Cin), dtype=torch.uint8, device="cuda")
+    ws = torch.empty((Cout,), dtype=torch.float32, device="cuda")
+    ops.weight_pack_fp8(w.view(Cout, 1, Cin).contiguous().cuda(), None, Cout, 1, Cin, 1.0, wq, ws)
+    y = torch.empty((M, Cout), dtype=torch.bfloat16, device="cuda")
+    ops.conv1x1_fp8(d, 0, xq, wq, ws, None, y)
+    rel = rel_l2(pm_to_nchw(y, N, H, W), TF.conv2d(x, w.view(Cout, Cin, 1, 1)))
+    print("fp8 1x1 forward rel-L2:", rel)
+    assert rel < 6e-2, rel
+    GS = 4096.0
+    gy = bf16_round(torch.randn(N, Cout, H, W, generator=g) * 1e-3)
+    g8 = torch.empty((M * Cout,), dtype=torch.uint8, device="cuda")
+    ops.quantize_bf8(nchw_to_pm(gy), GS, g8)
+    wqt = torch.empty((Cin, 1, Cout), dtype=torch.uint8, device="cuda")
+    wst = torch.empty((Cin,), dtype=torch.float32, device="cuda")
+    ops.weight_pack_fp8_t(w.view(Cout, 1, Cin).contiguous().cuda(), None, Cout, 1, Cin, GS, wqt, wst)
+    dx = torch.empty((M, Cin), dtype=torch.bfloat16, device="cuda")
+    ops.conv1x1_fp8(d, 1, g8, wqt, wst, None, dx)
+    reld = rel_l2(pm_to_nchw(dx, N, H, W), TF.conv_transpose2d(gy, w.view(Cout, Cin, 1, 1)))
+    print("fp8 1x1 data-gradient rel-L2:", reld)
+    assert reld < 1.2e-1, reld
