@@ -56,6 +56,20 @@ __device__ __forceinline__ unsigned pack4_e5m2(float a, float b, float c, float 
 
 typedef __attribute__((address_space(3))) void lds_void_1x1_t;
 
+// One-byte twin of a pixel's 64 wave-channels: lane group cg holds 8 bytes of each 32-channel half; the lane pairs (cg, cg ^ 1) swap one
+// piece so that every lane stores 16 contiguous bytes (64-byte runs per pixel and instruction instead of 32-byte ones): even cg ends up
+// with bytes [8 cg, 8 cg + 16) of half 0, odd cg with bytes [8 (cg - 1), 8 (cg - 1) + 16) of half 1.  `keep` = this lane's piece of the
+// half it stores, `send` = its piece of the other half.  Returns the 16 bytes; *off = byte offset inside the pixel's 64-byte run.
+__device__ __forceinline__ u32x4_t twin_pair(u32x2_t h0, u32x2_t h1, int cg, int* off) {
+    const bool odd = cg & 1;
+    const u32x2_t send = odd ? h0 : h1;
+    u32x2_t recv;
+    recv[0] = (unsigned)__shfl_xor((int)send[0], 16, 64);
+    recv[1] = (unsigned)__shfl_xor((int)send[1], 16, 64);
+    *off = odd ? 32 + 8 * (cg - 1) : 8 * cg;
+    return odd ? (u32x4_t){recv[0], recv[1], h1[0], h1[1]} : (u32x4_t){h0[0], h0[1], recv[0], recv[1]};
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
 // DMA: the operands go by LDS-DMA (no staging registers / LDS writes) into a THREE-stage ring, two K steps in flight per workgroup under a
@@ -380,11 +394,37 @@ __global__ __launch_bounds__(256, 2) void conv1x1_fp8_kernel(const P1 p) {
         const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(T + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
         return (i32x8_1x1_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
+    // epilogue operands (residual / gates) are requested before the LAST K step's matrix work: two workgroups per CU leave little else
+    // to overlap their latency with
+    const int cg = lane >> 4;
+    const int cbase = co0 + wc * 64 + 8 * cg;
+    const bool do_relu = p.flags & BD_EPI_RELU;
+    const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
+    const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
+    const bool want_add = add_before || add_after;
+    const bool mask_bf = (p.flags & BD_EPI_MASK) && p.mask;
+    const bool mask_bits = (p.flags & BD_EPI_MASK) && p.maskbits && !p.mask;
+    u32x4_t e_aux[8];             // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
+    unsigned e_bits[8];
+    auto epi_request = [&]() {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = q >> 1, half = q & 1;
+        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+        const bool ok = m < p.M && cbase + 32 * half < p.CO;
+        const long long idx = (long long)m * p.CO + cbase + 32 * half;
+        e_aux[q] = (u32x4_t){0u, 0u, 0u, 0u}; e_bits[q] = 0u;
+        if (ok && want_add) e_aux[q] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+        else if (ok && mask_bf) e_aux[q] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+        if (ok && mask_bits) e_bits[q] = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m];
+    }
+    };
     dma(0, 0);
     for (int t = 0; t < nsteps; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        // this wave's pieces of step t
         asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // everyone's; the other stage is free
         if (t + 1 < nsteps) dma(t + 1, (t + 1) & 1);
+        else epi_request();
         const unsigned char* At = smem + (t & 1) * 2 * F8_TILE;
         const unsigned char* Bt = At + F8_TILE;
         i32x8_1x1_t a[4], b[4];
@@ -400,14 +440,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_fp8_kernel(const P1 p) {
     }
 
     // ---- epilogue (the bf16 kernel's, with the per-channel weight scale) ----------------------------------------------------------------
-    const int cg = lane >> 4;
-    const int cbase = co0 + wc * 64 + 8 * cg;
-    const bool do_relu = p.flags & BD_EPI_RELU;
-    const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
-    const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
-    const bool want_add = add_before || add_after;
-    const bool mask_bf = (p.flags & BD_EPI_MASK) && p.mask;
-    const bool mask_bits = (p.flags & BD_EPI_MASK) && p.maskbits && !p.mask;
     float bias[16], scl[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { bias[k] = 0.f; scl[k] = 0.f; }
@@ -421,20 +453,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_fp8_kernel(const P1 p) {
                 bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
             }
         }
-    u32x4_t e_aux[8];             // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
-    unsigned e_bits[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int j = q >> 1, half = q & 1;
-        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
-        const bool ok = m < p.M && cbase + 32 * half < p.CO;
-        const long long idx = (long long)m * p.CO + cbase + 32 * half;
-        e_aux[q] = (u32x4_t){0u, 0u, 0u, 0u}; e_bits[q] = 0u;
-        if (ok && want_add) e_aux[q] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
-        else if (ok && mask_bf) e_aux[q] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
-        if (ok && mask_bits) e_bits[q] = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m];
-    }
     __builtin_amdgcn_sched_barrier(0);
+    u32x2_t twin_h0 = {0u, 0u};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int j = q >> 1, half = q & 1;
@@ -476,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_fp8_kernel(const P1 p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
         if (ok) *reinterpret_cast<u32x4_t*>(p.y + idx) = o;
-        if (p.y8 && ok) {
+        if (p.y8) {              // (workgroup-uniform) both halves of the pixel are packed, then the lane pairs swap: 16-byte stores
             u32x2_t o8;
             if (p.y8_bf8) {
                 o8[0] = pack4_e5m2(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
@@ -485,7 +505,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_fp8_kernel(const P1 p) {
                 o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
                 o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
             }
-            *reinterpret_cast<u32x2_t*>(p.y8 + idx) = o8;
+            if (half == 0) twin_h0 = o8;
+            else {
+                int off;
+                const u32x4_t t16 = twin_pair(twin_h0, o8, cg, &off);
+                const int cch = co0 + wc * 64 + off;               // first channel of this lane's 16 bytes
+                if (m < p.M && cch < p.CO) *reinterpret_cast<u32x4_t*>(p.y8 + (long long)m * p.CO + cch) = t16;
+            }
         }
         if (p.ybits) {
             unsigned byte = 0u;

@@ -123,17 +123,20 @@ class ConvLayer:
             self.w_q8t = torch.empty((self.cin, self.k * self.k, self.cout), dtype=torch.uint8, device=self.device)
             self.w_scale8t = torch.empty((self.cin,), dtype=torch.float32, device=self.device)
 
-    def enable_fp8_1x1(self, act_scale=1.0, dgrad=False, grad_scale=4096.0):
+    def enable_fp8_1x1(self, act_scale=1.0, dgrad=False, grad_scale=4096.0, expanding=True):
         """1x1 / stride 1 layers: forward through bd_conv1x1_fp8 whenever the caller hands over the e4m3 twin of the input (never a cast
         pass: the launch is memory-bound, a cast would cost what the one-byte operand saves), with dgrad=True the data gradient too
         (from the e5m2 twin of the output gradient).  Weight gradients stay bf16."""
         assert self.k == 1 and self.stride == 1 and self.cin % 32 == 0 and self.cout % 32 == 0
         self.act_scale, self.grad_scale = float(act_scale), float(grad_scale)
-        if self.cin % 128 == 0:
+        # expanding=False keeps only the REDUCING direction (K >= 2 x produced channels: conv1 forward, conv3's data gradient), where the
+        # one-byte operand is most of the launch's bytes; the expanding direction is all epilogue (bf16 residual in, bf16 + twin + gate
+        # bits out).  See FPNDetector._build_layers for what was measured
+        if self.cin % 128 == 0 and (self.cin >= 2 * self.cout or expanding):
             self.fp8_1x1 = True
             self.w_q8 = torch.empty((self.cout, 1, self.cin), dtype=torch.uint8, device=self.device)
             self.w_scale8 = torch.empty((self.cout,), dtype=torch.float32, device=self.device)
-        if dgrad and self.trainable and self.cout % 128 == 0:
+        if dgrad and self.trainable and self.cout % 128 == 0 and (self.cout >= 2 * self.cin or expanding):
             self.fp8_1x1_dgrad = True
             self.w_q8t = torch.empty((self.cin, 1, self.cout), dtype=torch.uint8, device=self.device)
             self.w_scale8t = torch.empty((self.cin,), dtype=torch.float32, device=self.device)

@@ -395,6 +395,8 @@ def main():
     ap.add_argument("--workload", default="retinanet_r50_800x1344", choices=sorted(TRAIN_GFLOP_PER_IMG))
     ap.add_argument("--fp8", action="store_true",
                     help="fp8 (e4m3) weights for the forward / data-gradient convolutions (BASELINE config 5: retinanet_r101_800x1344)")
+    ap.add_argument("--model-opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="ablation: set cfg.MODEL.KEY (e.g. FP8_1X1=0, FP8_DGRAD=0, FUSE_STEM_POOL=0); repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ref-protocol-steps", type=int, default=10,
@@ -473,6 +475,9 @@ def worker(args):
     cfg.MODEL.BATCHSIZE = args.batch
     if args.fp8:
         cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
+    for kv in args.model_opt:
+        k, v = kv.split("=", 1)
+        cfg.MODEL[k] = (float(v) if "." in v else int(v)) if v.lstrip("-").replace(".", "", 1).isdigit() else v
     # random-init weights of the named architecture; the last FrozenBN gamma of every residual branch is 0.2
     # (stand-in for ImageNet statistics: identity BN overflows a random ResNet-50; same FLOPs and bytes)
     if cfg.MODEL.NAME in ("FCOS", "ATSS", "OTA"):
