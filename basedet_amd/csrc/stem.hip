@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_raw* __restri
 // eight stem rows ahead, under a counted vmcnt; the horizontal 3-max is two DPP row shifts, the vertical one a running register.
 // Column halo: 16 computed stem columns per 14 used (x 1.14), row halo one stem row per chunk.
 constexpr int SP_PAIRS = 16;       // ring: 16 row pairs x 1 KiB (a pair = two input rows x 64 pixels x 8 B) per wave
-constexpr int SP_AHEAD = 8;        // DMA distance in stem rows
+constexpr int SP_AHEAD = 8;        // DMA distance in stem rows (12 measured the same)
 typedef __attribute__((address_space(3))) void sp_lds_void_t;
 typedef __attribute__((ext_vector_type(2))) short i16x2_t;
 
@@ -147,6 +147,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_raw* __res
         // byte offset of (image n, halo row 2 s_begin, halo column 2 c0): negative above / left of the tensor -> the range check
         // returns zeros (those stem rows / columns are padding and are zeroed below in any case)
         const long long base = (((long long)n * Hb + 2 * s_begin) * Wb + 2 * c0) * 8 + lane_off;
+        // (a strip needs input pixels 2 c0 .. 2 c0 + 37 of a row; the ring row holds 64.  Requesting only the 40 measured SLOWER -- 174 vs
+        // 145 us, with HBM traffic down from 708 to 518 MB per launch: the kernel waits on DMA latency, and the surplus pixels are the next
+        // strip's, fetched ahead of it into L2)
         auto dma = [&](int j) {
             const long long o = base + j * pair_stride;
             const unsigned vo = (o < 0 || o + 16 > x_bytes) ? 0x80000000u : (unsigned)o;

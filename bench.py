@@ -16,8 +16,10 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     -- the kernel with the largest share of the step (per-kernel entries: roofline_others).  Each kernel is priced against
                   the roof its launches sit under: "mfma" (algorithmic FLOPs / time vs 2.5 PFLOP/s) when their arithmetic intensity
                   exceeds the machine balance, else "hbm" (algorithmic bytes -- every operand once -- / time vs 8 TB/s); durations
-                  are HIP events on the launch stream during the timed steps, `traffic` the PMC-measured HBM bytes per launch
-                  (profiles/r02_pmc_traffic.json; refused -- null -- when it was collected on a different build of the kernels)
+                  are HIP events on the launch stream during the timed steps, `traffic` the PMC-measured HBM bytes per launch:
+                  at N = 1 measured IN the run (after the timed region rank 0 starts `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+                  child processes around three steps of the same workload: measure_traffic; --no-pmc skips them), else read from
+                  profiles/r02_pmc_traffic.json (refused -- null -- when that was collected on a different build of the kernels)
   cpu_baseline -- the CPU oracle's (oracle/model.py, torch-CPU fp32) training step on the host cores, bounded sample.
 """
 import argparse
@@ -336,6 +338,50 @@ def _print_result(saved_fd, line):
     os.close(saved_fd)
 
 
+def measure_traffic(args, timeout_s=240):
+    """roofline.traffic measured IN this run: after the timed region rank 0 starts two child processes, `rocprofv3 --pmc FETCH_SIZE`
+    and `rocprofv3 --pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md, HBM section) around three steps of the same
+    workload, and converts the per-kernel means to HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE
+    counts 128-byte requests at 64 B).  Returns ({kernel: {"hbm_bytes_per_launch": n}}, note); ({}, reason) when it cannot run (no
+    rocprofv3, already under a profiler, a pass failed or timed out) -- the caller then falls back to the committed file."""
+    import shutil
+    import tempfile
+    if any(k.startswith(("ROCP_", "ROCPROFILER_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {}, "bench.py itself runs under a profiler: the in-run PMC passes were skipped"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found: traffic not measured"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pmc_traffic
+    tmp = tempfile.mkdtemp(prefix="bd_pmc_", dir="/tmp")
+    tail = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-pmc",
+            "--ref-protocol-steps", "0", "--workload", args.workload, "--batch", str(args.batch)] + (["--fp8"] if args.fp8 else [])
+    for kv in args.model_opt:
+        tail += ["--model-opt", kv]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + tail, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return {}, f"rocprofv3 --pmc {counter} exited with {r.returncode}: traffic not measured"
+            res[counter] = pmc_traffic.load(d, counter)
+    except subprocess.TimeoutExpired:
+        return {}, f"a rocprofv3 --pmc pass exceeded {timeout_s} s: traffic not measured"
+    except Exception as e:                                          # noqa: BLE001 (a missing csv, a parse error: report, do not fail the bench)
+        return {}, f"in-run PMC passes failed ({type(e).__name__}: {e}): traffic not measured"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    (f, fc), (w, wc) = res["FETCH_SIZE"], res["WRITE_SIZE"]
+    out = {k: {"hbm_bytes_per_launch": int((2 * f[k] / fc[k] + w.get(k, 0.0) / max(1, wc.get(k, 0))) * 1024)} for k in f}
+    return out, ("traffic measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child processes after the timed region, "
+                 "3 steps each, mean per launch), HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024")
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -397,6 +443,8 @@ def main():
                     help="fp8 (e4m3) weights for the forward / data-gradient convolutions (BASELINE config 5: retinanet_r101_800x1344)")
     ap.add_argument("--model-opt", action="append", default=[], metavar="KEY=VALUE",
                     help="ablation: set cfg.MODEL.KEY (e.g. FP8_1X1=0, FP8_DGRAD=0, FUSE_STEM_POOL=0); repeatable")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ref-protocol-steps", type=int, default=10,
@@ -609,7 +657,11 @@ def worker(args):
             # workload / batch AND the kernel build they were collected on (source digest recorded by scripts/pmc_traffic.py)
             pmc, pmc_note = {}, None
             pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if name == "retinanet_r50_800x1344" and args.batch == 16 and os.path.exists(pmc_path):
+            if world == 1 and not args.no_pmc:
+                pmc, pmc_note = measure_traffic(args)
+            if pmc:
+                pass
+            elif name == "retinanet_r50_800x1344" and args.batch == 16 and os.path.exists(pmc_path):
                 from basedet_amd import build as _b
                 with open(pmc_path) as f:
                     rec = json.load(f)

@@ -4,9 +4,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2p
 mkdir -p $O
 cd $R
-B="bench.py --steps 10 --warmup 3 --no-cpu-baseline --ref-protocol-steps 0 --serial-wgrad"
+B="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --ref-protocol-steps 0 --serial-wgrad"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $B > $O/bench_under_rocprof.json 2> $O/kt.err
-P="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --ref-protocol-steps 0"
+P="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-pmc --ref-protocol-steps 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $P > /dev/null 2> $O/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $P > /dev/null 2> $O/write.err
 python3 scripts/pmc_traffic.py $O/fetch $O/write $O/r02_pmc_traffic.json > $O/traffic.txt 2>&1
