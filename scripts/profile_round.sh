@@ -3,6 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2p
 mkdir -p $O
+rm -f $O/workloads.txt
 cd $R
 B="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --ref-protocol-steps 0 --serial-wgrad"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $B > $O/bench_under_rocprof.json 2> $O/kt.err
@@ -21,5 +22,11 @@ done
 python3 bench.py --workload faster_rcnn_r50_800x1344 --roi-bwd-pk --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('faster_rcnn pk', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 python3 bench.py --workload retinanet_r101_800x1344 --fp8 --steps 20 --warmup 5 --no-cpu-baseline --ref-protocol-steps 0 > $O/r02_bench_r101_fp8.json 2>/dev/null
 python3 bench.py --workload retinanet_r101_800x1344 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline --ref-protocol-steps 0 > $O/r02_bench_r101_bf16_b32.json 2>/dev/null
+for a in "--batch 16" "--batch 32" "--batch 16 --fp8" "--batch 32 --fp8" "--batch 32 --fp8 --model-opt FP8_1X1=0" "--batch 32 --fp8 --model-opt FP8_DGRAD=0 --model-opt FP8_1X1=0"; do
+  python3 bench.py $a --steps 30 --warmup 8 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r50 $a', d['value'], d['ms_per_step'])" >> $O/workloads.txt
+done
+for a in "--batch 32 --fp8 --model-opt FP8_1X1=0" "--batch 32 --fp8 --model-opt FP8_DGRAD=0 --model-opt FP8_1X1=0"; do
+  python3 bench.py --workload retinanet_r101_800x1344 $a --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r101 $a', d['value'], d['ms_per_step'])" >> $O/workloads.txt
+done
 BD_FORCE_ALLREDUCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>$O/torchrun.err | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('torchrun world1 forced allreduce', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 cat $O/workloads.txt; cat $O/traffic.txt | head -12; cat $O/sq.txt | head; head -c 600 $O/r02_bench.json
