@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BASEDET_HIP_LIB") or os.path.join(_HERE, "lib", "libbasedet_hip.so")   # override: A/B of two builds
 
 BD_MAX_SEGS = 8
-EPI_RELU, EPI_ADD_BEFORE, EPI_ADD_AFTER, EPI_MASK = 1, 2, 4, 8
+EPI_RELU, EPI_ADD_BEFORE, EPI_ADD_AFTER, EPI_MASK, EPI_SPARSE = 1, 2, 4, 8, 16
 
 
 class BasedetHipError(RuntimeError):

@@ -552,6 +552,7 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
                              const unsigned* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream) {
     if (int e = check_desc(d)) return e;
     BD_REQUIRE(g && w_packed_t && dx, "conv2d_dgrad: null pointer");
+    if (d->stride == 1) flags &= ~BD_EPI_SPARSE;          // every pixel of a stride-1 data gradient is reached
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_dgrad: Cout=%d must be a multiple of 8 (pad the gradient)", d->Cout);
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad: BD_EPI_RELU is a forward-only flag");
@@ -576,11 +577,23 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
     long long m = 0;
     int ns = 0;
     const int st = d->stride;
+    const bool sparse = (flags & BD_EPI_SPARSE) && st > 1;
+    BD_REQUIRE(!(flags & BD_EPI_SPARSE) || ((flags & BD_EPI_ADD_BEFORE) && add == dx),
+               "conv2d_dgrad: BD_EPI_SPARSE needs an in-place accumulate (BD_EPI_ADD_BEFORE with add == dx)");
+    p.flags = flags & ~BD_EPI_SPARSE;
     for (int s = 0; s < d->nseg; ++s) {
         for (int qy = 0; qy < st; ++qy)
             for (int qx = 0; qx < st; ++qx) {
                 const int Hs = (d->Hi[s] - qy + st - 1) / st, Ws = (d->Wi[s] - qx + st - 1) / st;
                 if (Hs <= 0 || Ws <= 0) continue;
+                // BD_EPI_SPARSE: a parity class that no tap reaches (row parity: some r with (qy + pad - r) % st == 0, same for columns)
+                // keeps what dx holds: the 1x1 / stride-2 shortcut then touches a quarter of the pixels
+                if (sparse) {
+                    bool ry = false, rx = false;
+                    for (int r = 0; r < d->R; ++r) ry = ry || ((qy + d->pad - r) % st + st) % st == 0;
+                    for (int c = 0; c < d->S; ++c) rx = rx || ((qx + d->pad - c) % st + st) % st == 0;
+                    if (!(ry && rx)) continue;
+                }
                 BD_REQUIRE(ns < MAX_SUB, "conv2d_dgrad: too many sub-segments (levels x stride^2 > %d)", MAX_SUB);
                 SubSeg& ss = p.sub[ns++];
                 ss.m_start = (int)m;

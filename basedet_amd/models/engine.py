@@ -182,7 +182,7 @@ class ConvLayer:
                               y8=y8 if (y8 is not None and ops.dense_1x1_bits_ok(self.desc(gin, gout))) else None, q_scale=q_scale)
 
     def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None, g8=None, dx8=None, q_scale=1.0,
-              add_before=None):
+              add_before=None, sparse=False):
         """dx (+)= conv^T(g).  first=False accumulates onto dx (pre-mask); mask = forward activation whose
         ReLU gates dx (maskbits: the same gate bit-packed, written by the producing forward launch); add_after = tensor added
         after masking (P6: gradient that bypasses the ReLU)."""
@@ -196,6 +196,8 @@ class ConvLayer:
         elif not first:
             flags |= ops.EPI_ADD_BEFORE
             add = dx
+            if sparse and self.stride > 1:       # strided shortcut accumulating in place: pixels no tap reaches keep their (final) value
+                flags |= ops.EPI_SPARSE
         if mask is not None or maskbits is not None:
             flags |= ops.EPI_MASK
         if maskbits is not None:

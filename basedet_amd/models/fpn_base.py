@@ -133,6 +133,7 @@ class FPNDetector:
         # BASELINE config 5: fp8-e4m3 weights (one scale per output channel) for the forward of the 3x3 convolutions -- where a
         # quantised copy of the input is read nine times; the HBM-bound 1x1 layers and the whole backward pass stay bf16
         self.fuse_stem_pool = bool(m.get("FUSE_STEM_POOL", True))
+        self.sparse_shortcut_grad = bool(m.get("SPARSE_SHORTCUT_GRAD", True))   # False: the shortcut's data gradient as a full-resolution pass (A/B)
         self.weight_dtype = m.get("WEIGHT_DTYPE", "bf16")
         self._q8 = {}
         # e5m2 twins of gradients written by the producing launch (False: every fp8 data gradient casts its input in a pass; a test knob)
@@ -697,7 +698,13 @@ class FPNDetector:
                 pb = pl.blk[bi - 1]
                 gx8 = getattr(pb, "g_out8", None)
                 kw = dict(mask=xin, maskbits=xbits, g8=g8, dx8=gx8, q_scale=convs[0].grad_scale)
-                if blk["ds"] is not None:
+                if blk["ds"] is not None and gx8 is None and self.sparse_shortcut_grad:
+                    # conv1 first (writes every pixel, gated), then the stride-2 shortcut adds its gradient IN PLACE at the quarter of
+                    # the pixels it reaches ((a m + b) m = (a + b) m for a 0 / 1 gate m): instead of a full-resolution tensor that is
+                    # three quarters zeros being written, read back and summed
+                    convs[0].dgrad(g, geos[0], geos[1], gx, first=not tapped, **kw)
+                    blk["ds"].dgrad(G, b.gin, b.gout, gx, first=False, mask=xin, sparse=True)
+                elif blk["ds"] is not None:         # (the last writer must be the launch that can write the e5m2 twin)
                     blk["ds"].dgrad(G, b.gin, b.gout, gx, first=not tapped)
                     convs[0].dgrad(g, geos[0], geos[1], gx, first=False, **kw)
                 else:

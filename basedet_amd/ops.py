@@ -9,7 +9,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, EPI_ADD_AFTER, EPI_ADD_BEFORE, EPI_MASK, EPI_RELU, check, f32arr, i32arr, ptr, stream_ptr
+from ._lib import ConvDesc, EPI_ADD_AFTER, EPI_ADD_BEFORE, EPI_MASK, EPI_RELU, EPI_SPARSE, check, f32arr, i32arr, ptr, stream_ptr
 
 
 @dataclass

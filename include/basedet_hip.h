@@ -39,6 +39,9 @@ extern "C" {
 #define BD_EPI_ADD_BEFORE 2      /* y = acc + bias + add[idx]   (residual add, then relu/mask) */
 #define BD_EPI_ADD_AFTER 4       /* y = mask(acc + bias) + add[idx]                        */
 #define BD_EPI_MASK 8            /* y = mask[idx] > 0 ? y : 0   (ReLU backward from the stored forward output) */
+#define BD_EPI_SPARSE 16         /* strided data gradient accumulating in place (BD_EPI_ADD_BEFORE, add == dx): input pixels that no
+                                  * filter tap reaches (3 of 4 for a 1x1 / stride-2 shortcut) are left untouched -- the caller states that
+                                  * dx there already holds its final (masked) value */
 
 typedef void* bd_stream_t; /* hipStream_t */
 

@@ -440,3 +440,41 @@ def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
                     assert torch.equal(tw[2][0], y) and torch.equal(tw[2][2], dx)
     finally:
         ops.L().bd_conv_set_dense1x1(1)
+
+
+@pytest.mark.parametrize("R", [1, 3])
+def test_strided_dgrad_sparse_accumulate(R):
+    """BD_EPI_SPARSE: a stride-2 data gradient accumulating in place leaves the input pixels no tap reaches untouched (1x1: three of
+    four), and equals the dense accumulate everywhere (the gate is idempotent: dx already holds gated values)."""
+    ops = _ops()
+    N, Cin, Cout, H, W = 2, 64, 128, 14, 22
+    pad = R // 2
+    g = torch.Generator().manual_seed(9 + R)
+    w = bf16_round(torch.randn(Cout, Cin, R, R, generator=g) / np.sqrt(Cin * R * R))
+    gin = ops.single(N, H, W)
+    gout = gin.conv_out(R, 2, pad)
+    d = ops.conv_desc(gin, gout, Cin, Cout, R, R, 2, pad)
+    Ho, Wo = gout.H[0], gout.W[0]
+    gy = bf16_round(torch.randn(N, Cout, Ho, Wo, generator=g))
+    act = torch.relu(bf16_round(torch.randn(N, Cin, H, W, generator=g)))
+    dx0 = bf16_round(torch.randn(N, Cin, H, W, generator=g)) * (act > 0)                 # what an earlier launch left: already gated
+    wf, wd = pack_weights(ops, w)
+    dense = nchw_to_pm(dx0).clone()
+    ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, dense, add=dense, mask=nchw_to_pm(act), flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
+    sparse = nchw_to_pm(dx0).clone()
+    ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, sparse, add=sparse, mask=nchw_to_pm(act), flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK | ops.EPI_SPARSE)
+    assert torch.equal(dense, sparse)
+    xr = torch.zeros(N, Cin, H, W, requires_grad=True)
+    TF.conv2d(xr, w, stride=2, padding=pad).backward(gy)
+    ref = (xr.grad + dx0) * (act > 0)
+    assert rel_l2(pm_to_nchw(sparse, N, H, W), ref) < 1e-2
+    if R == 1:                        # untouched means untouched: poison the unreached pixels, they must survive
+        poison = nchw_to_pm(dx0).clone().view(N, H, W, Cin)
+        poison[:, 1::2] = 7.0
+        poison[:, :, 1::2] = 7.0
+        poison = poison.view(-1, Cin).contiguous()
+        keep = poison.clone()
+        ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, poison, add=poison, mask=nchw_to_pm(act), flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK | ops.EPI_SPARSE)
+        pv, kv = poison.view(N, H, W, Cin), keep.view(N, H, W, Cin)
+        assert torch.equal(pv[:, 1::2], kv[:, 1::2]) and torch.equal(pv[:, :, 1::2], kv[:, :, 1::2])
+        assert torch.equal(pv[:, ::2, ::2], sparse.view(N, H, W, Cin)[:, ::2, ::2])
