@@ -338,7 +338,7 @@ def _print_result(saved_fd, line):
     os.close(saved_fd)
 
 
-def measure_traffic(args, timeout_s=240):
+def measure_traffic(args, timeout_s=120):
     """roofline.traffic measured IN this run: after the timed region rank 0 starts two child processes, `rocprofv3 --pmc FETCH_SIZE`
     and `rocprofv3 --pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md, HBM section) around three steps of the same
     workload, and converts the per-kernel means to HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE
@@ -399,6 +399,8 @@ def launch_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # as torch.distributed.run does: N ranks with a full-size OpenMP pool each would oversubscribe the host's cores
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // n))))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
     line = None
