@@ -128,6 +128,8 @@ SIGNATURES = {
     "bd_quantize_bf8": (_I, [_P, _L, _F, _P, _P]),
     "bd_weight_pack_fp8_t": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "bd_conv2d_dgrad_fp8": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
+    "bd_conv2d_wgrad_fp8_workspace_bytes": (_Z, [_D]),
+    "bd_conv2d_wgrad_fp8": (_I, [_D, _P, _P, _F, _P, _P, _I, _P, _Z, _P]),
     "bd_conv1x1_fp8": (_I, [_D, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_sigmoid_focal_loss_elem": (_I, [_P, _P, _L, _F, _F, _P, _P, _P, _P]),
     "bd_bce_elem": (_I, [_P, _P, _L, _I, _P, _P, _P, _P]),

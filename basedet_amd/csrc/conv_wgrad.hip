@@ -291,6 +291,13 @@ extern "C" int bd_wgrad_set_transpose_read(int use_tr) {
     return BD_OK;
 }
 
+// the fixed-order slab reduce for the other translation units (conv_wgrad3x3_fp8.hip)
+void bd_wgrad_reduce_launch(const float* slab, int splits, long long n, int row_len, const float* row_scale, float* dw, int accumulate,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n / 4, 64)), dim3(256), 0, stream, slab, splits, n, row_len, row_scale, dw,
+                       accumulate);
+}
+
 extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
     if (!d || d->nseg < 1 || d->nseg > BD_MAX_SEGS) return 0;
     const Plan pl = make_plan(d);

@@ -58,6 +58,7 @@ class ConvLayer:
         # fp8 forward (BASELINE config 5, enable_fp8): e4m3 weights with one scale per output channel + the input cast to e4m3
         self.fp8 = False
         self.fp8_dgrad = False          # data gradient on the fp8 patch kernel too (e5m2 gradients under a static gradient scale)
+        self.fp8_wgrad = False          # 3x3 weight gradient from the one-byte twins of x and g (bd_conv2d_wgrad_fp8) when both are handed over
         self.fp8_1x1 = False            # dense 1x1 launches on one-byte operands when the producer wrote the input's twin (bd_conv1x1_fp8)
         self.fp8_1x1_dgrad = False
         self.w_q8 = self.w_scale8 = self.w_q8t = self.w_scale8t = None
@@ -111,13 +112,15 @@ class ConvLayer:
         if self.gb is not None:
             out[self.name + ".bias"] = self.gb[: self.cout_real].cpu().clone()
 
-    def enable_fp8(self, q8_scratch, act_scale=1.0, dgrad=False, grad_scale=4096.0):
+    def enable_fp8(self, q8_scratch, act_scale=1.0, dgrad=False, grad_scale=4096.0, wgrad=False):
         """Forward through bd_conv2d_fwd_fp8 (csrc/conv3x3_pp8.hip / conv_fp8.hip); with dgrad=True the data gradient through
         bd_conv2d_dgrad_fp8 as well (3x3 / stride 1 / Cin > 128).  The weight gradient keeps the bf16 activations and gradients."""
         assert self.cin % 16 == 0 and self.cout % 8 == 0
         self.fp8, self.q8_scratch, self.act_scale = True, q8_scratch, float(act_scale)
         self.w_q8 = torch.empty((self.cout, self.k * self.k, self.cin), dtype=torch.uint8, device=self.device)
         self.w_scale8 = torch.empty((self.cout,), dtype=torch.float32, device=self.device)
+        if wgrad and self.trainable and self.k == 3 and self.stride == 1 and self.cin % 16 == 0 and self.cout % 16 == 0:
+            self.fp8_wgrad, self.grad_scale = True, float(grad_scale)
         if dgrad and self.trainable and self.k == 3 and self.stride == 1 and self.cin > 128 and self.cout % 16 == 0:
             self.fp8_dgrad, self.grad_scale = True, float(grad_scale)
             self.w_q8t = torch.empty((self.cin, self.k * self.k, self.cout), dtype=torch.uint8, device=self.device)
@@ -218,8 +221,15 @@ class ConvLayer:
         """True when dgrad(..., dx8=t) fills t: the fp8 patch kernel and the dense 1x1 kernel do, the other bf16 kernels do not."""
         return self.fp8_dgrad or ops.dense_1x1_bits_ok(self.desc(gin, gout))
 
-    def wgrad(self, x, g, gin, gout, ws, colsum_ws=None):
+    def wgrad(self, x, g, gin, gout, ws, colsum_ws=None, x8=None, g8=None):
+        """x8 / g8: the e4m3 twin of x (x * act_scale) and the e5m2 twin of g (g * grad_scale) when their producers wrote them: the
+        weight gradient then runs on the one-byte kernel (the bias gradient stays a column sum of the bf16 g)."""
         d = self.desc(gin, gout)
+        if self.fp8_wgrad and x8 is not None and g8 is not None:
+            ops.conv2d_wgrad_fp8(d, x8, g8, 1.0 / (self.act_scale * self.grad_scale), self.gw, ws, row_scale=self.row_scale)
+            if self.gb is not None:
+                ops.colsum_bf16(g, g.shape[0], self.cout, self.gb, colsum_ws)
+            return
         if self.gb is not None:      # weight + bias gradient in one entry point (fused in the 3x3 patch kernel; colsum_ws is unused)
             ops.conv2d_wgrad_bias(d, x, g, self.gw, self.gb, ws, row_scale=self.row_scale)
         else:
@@ -227,7 +237,8 @@ class ConvLayer:
 
     def wgrad_ws_bytes(self, gin, gout):
         d = self.desc(gin, gout)
-        return ops.conv2d_wgrad_bias_workspace_bytes(d) if self.gb is not None else ops.conv2d_wgrad_workspace_bytes(d)
+        n = ops.conv2d_wgrad_bias_workspace_bytes(d) if self.gb is not None else ops.conv2d_wgrad_workspace_bytes(d)
+        return max(n, ops.conv2d_wgrad_fp8_workspace_bytes(d)) if self.fp8_wgrad else n
 
 
 class FusedPredConv(ConvLayer):

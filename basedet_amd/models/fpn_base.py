@@ -148,7 +148,13 @@ class FPNDetector:
                         and ((c.stride == 1 and c.cout > 128) or id(c) in side)):
                     key = "side" if id(c) in side else "main"          # P6 / P7 run on a side stream: their own scratch
                     c.enable_fp8(lambda n, key=key: self._q8_buf(key, n), m.get("FP8_ACT_SCALE", 1.0),
-                                 dgrad=bool(m.get("FP8_DGRAD", True)), grad_scale=m.get("FP8_GRAD_SCALE", 4096.0))
+                                 dgrad=bool(m.get("FP8_DGRAD", True)), grad_scale=m.get("FP8_GRAD_SCALE", 4096.0),
+                                 # FP8_WGRAD (default 0 = bf16 weight gradients): 1 = the one-byte kernel (bd_conv2d_wgrad_fp8) for the
+                                 # bias-free layers (backbone conv2), 2 = also the towers.  Exact and 1.1 - 1.45x its bf16 launch in
+                                 # isolation, but not faster in the step: R101 batch 32, same box, 469.5 / 470.8 img/s at 0, 466.3 /
+                                 # 468.6 at 1, 468.0 / 467.5 at 2 (bound by its transposing LDS reads, one 8-wave workgroup per CU next
+                                 # to the main stream's kernels, and the towers' bias gradient becomes a separate column-sum pass)
+                                 wgrad=(int(m.get("FP8_WGRAD", 0)) >= (2 if c.has_bias else 1)) and bool(m.get("FP8_DGRAD", True)))
             # the bottleneck 1x1s around an fp8 3x3 (res4 / res5 blocks after the first) on one-byte operands.  In isolation the reducing
             # direction (conv1 forward, conv3's data gradient: the input is most of the bytes) is 1.5 - 1.6x faster than its bf16 launch
             # and the expanding one about even; in the step the extra twins the neighbouring launches must write take most of it back:
@@ -588,15 +594,15 @@ class FPNDetector:
     # ------------------------------------------------------------------------------------------------
     # backward (replaces GradManager.backward, solver/default_solver.py:118-124)
     # ------------------------------------------------------------------------------------------------
-    def _wgrad(self, conv, x, g, gin, gout, ws, cws=None):
+    def _wgrad(self, conv, x, g, gin, gout, ws, cws=None, x8=None, g8=None):
         """conv.wgrad on the side stream: it only needs x and g as they are NOW (everything enqueued so far on the main
         stream), and nothing on the main stream reads its outputs before `_join_wgrads`.  Callers must not overwrite g/x
         later in the same backward pass (the heads keep one gradient buffer per layer for that reason)."""
         if not (self.async_wgrad and self._wstream is not None):
-            return conv.wgrad(x, g, gin, gout, ws, cws)
+            return conv.wgrad(x, g, gin, gout, ws, cws, x8=x8, g8=g8)
         self._wstream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._wstream):
-            conv.wgrad(x, g, gin, gout, ws, cws)
+            conv.wgrad(x, g, gin, gout, ws, cws, x8=x8, g8=g8)
 
     def _join_wgrads(self):
         if self.async_wgrad and self._wstream is not None:
@@ -676,7 +682,9 @@ class FPNDetector:
             # fp8 mode: the e5m2 twin of the block's output gradient, written by the next block's conv1 data gradient (its last writer)
             g8 = b.g_out8 if (getattr(b, "g_out8", None) is not None and b.g_out8_ready) else None
             for ci in range(len(convs) - 1, 0, -1):
-                self._wgrad(convs[ci], b.mids[ci - 1], g, geos[ci], geos[ci + 1], ws)
+                # conv2's weight gradient from the twins both neighbours wrote (conv1's forward output, conv3's data gradient)
+                wx8 = getattr(b, "mid8", None) if (ci == 1 and len(convs) == 3) else None
+                self._wgrad(convs[ci], b.mids[ci - 1], g, geos[ci], geos[ci + 1], ws, x8=wx8, g8=g8 if wx8 is not None else None)
                 # conv3's (dense 1x1) data gradient also writes the e5m2 twin that conv2's fp8 data gradient reads, conv2's the one
                 # conv1's reads
                 nxt = None

@@ -149,9 +149,12 @@ class RetinaNet(FPNDetector):
             self._wgrad(pred, acts[-1], dpred, pyr, pyr, ws, cws)
             tw = g8[n - 1] if pred.dgrad_writes_twin(pyr, pyr) else None       # None also when twins are off (g8 holds no buffers)
             pred.dgrad(dpred, pyr, pyr, gbuf[n - 1], mask=acts[-1], dx8=tw, q_scale=gs)
+            act8 = pl.cls_act8 if ti == 0 else pl.box_act8
             for i in range(n - 1, -1, -1):
                 x = acts[i - 1] if i > 0 else pl.P
-                self._wgrad(tower[i], x, gbuf[i], pyr, pyr, ws, cws)
+                # the weight gradient reads the same twins: the tower input's (forward) and the gradient's (tw: written with gbuf[i])
+                x8 = (act8[i - 1] if i > 0 else pl.P8) if tw is not None else None
+                self._wgrad(tower[i], x, gbuf[i], pyr, pyr, ws, cws, x8=x8, g8=tw)
                 if i > 0:
                     nxt = g8[i - 1] if tower[i].dgrad_writes_twin(pyr, pyr) else None
                     tower[i].dgrad(gbuf[i], pyr, pyr, gbuf[i - 1], mask=acts[i - 1], g8=tw, dx8=nxt, q_scale=gs)

@@ -143,6 +143,17 @@ def conv1x1_fp8(d, mode, xq, wq, wscale, bias, y, add=None, mask=None, maskbits=
     return y
 
 
+def conv2d_wgrad_fp8_workspace_bytes(d):
+    return int(L().bd_conv2d_wgrad_fp8_workspace_bytes(C.byref(d)))
+
+
+def conv2d_wgrad_fp8(d, x8, g8, inv_scale, dw, ws, row_scale=None, accumulate=False):
+    """Weight gradient of a 3x3 / stride-1 convolution from the one-byte twins (x8 e4m3, g8 e5m2); dw fp32 [Cout][9][Cin]."""
+    check(L().bd_conv2d_wgrad_fp8(C.byref(d), ptr(x8), ptr(g8), float(inv_scale), ptr(row_scale), ptr(dw), int(accumulate), ptr(ws),
+                                  ws.numel() * ws.element_size(), stream_ptr()), "bd_conv2d_wgrad_fp8")
+    return dw
+
+
 def conv1x1_fp8_ok(d, mode):
     """True when bd_conv1x1_fp8 takes this descriptor."""
     K, CO = (d.Cin, d.Cout) if mode == 0 else (d.Cout, d.Cin)

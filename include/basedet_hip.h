@@ -550,6 +550,14 @@ int bd_conv2d_dgrad_fp8(const bd_conv_desc* d, const void* g8, const void* wq_t,
 int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, const void* wq, const float* wscale, const float* bias,
                    const void* add, const void* mask, const uint32_t* maskbits, void* y, uint32_t* ybits, void* y8, float q_scale,
                    int flags, bd_stream_t stream);
+/* fp8 WEIGHT GRADIENT of a 3x3 / stride 1 / pad 1 convolution (Cin % 16 == 0, Cout % 16 == 0): x8 = e4m3 twin of the activations
+ * (x * act_scale), g8 = e5m2 twin of the output gradient (g * grad_scale), inv_scale = 1 / (act_scale * grad_scale);
+ * dw fp32 [Cout][9][Cin] (= or += with accumulate) = row_scale[co] * sum_pix g * x, as bd_conv2d_wgrad (the weight-gradient leg of the
+ * detectors' backward through M.Conv2d; the reference's precision hook is solver/default_solver.py:66-76).  The bias gradient is
+ * not produced here: bd_colsum_bf16 on the bf16 gradient. */
+size_t bd_conv2d_wgrad_fp8_workspace_bytes(const bd_conv_desc* d);
+int bd_conv2d_wgrad_fp8(const bd_conv_desc* d, const void* x8, const void* g8, float inv_scale, const float* row_scale, float* dw,
+                        int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Operator surface of basedet.layers / basedet.structures as stand-alone fp32 entry points (callers written against the
