@@ -75,3 +75,32 @@ def test_matcher_keeps_the_reference_constructor_contract():
         Matcher([0.5, 0.4], [0, -1, 1])
     with pytest.raises(AssertionError):
         Matcher([0.5], [0, -1, 1])
+
+
+def test_pmc_traffic_parser_and_bench_fallback(tmp_path, monkeypatch):
+    """scripts/pmc_traffic.load (what bench.py's in-run traffic measurement parses) on a synthetic rocprofv3 counter_collection.csv:
+    kernel names are normalised (anonymous namespace, template arguments; the two BK instances of the generic kernel stay apart) and
+    averaged per launch; bench.measure_traffic reports a reason instead of failing when it cannot run the profiler."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    pmc_traffic = importlib.import_module("pmc_traffic")
+    d = tmp_path / "fetch" / "host" / "pid"
+    d.mkdir(parents=True)
+    rows = ["Kernel_Name,Counter_Name,Counter_Value",
+            '"void (anonymous namespace)::conv1x1_dense_kernel<1, 4, false>((anonymous namespace)::P1)",FETCH_SIZE,100',
+            '"void (anonymous namespace)::conv1x1_dense_kernel<1, 3, true>((anonymous namespace)::P1)",FETCH_SIZE,300',
+            '"void (anonymous namespace)::conv_igemm_kernel<32, false, true>(igemm::IgemmParams)",FETCH_SIZE,50',
+            '"void (anonymous namespace)::conv_igemm_kernel<64, false, true>(igemm::IgemmParams)",FETCH_SIZE,70',
+            '"(anonymous namespace)::sgd_kernel(float*, float*, float const*, long long)",FETCH_SIZE,10',
+            '"(anonymous namespace)::sgd_kernel(float*, float*, float const*, long long)",WRITE_SIZE,999']
+    (d / "1_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    tot, cnt = pmc_traffic.load(str(tmp_path / "fetch"), "FETCH_SIZE")
+    assert tot["conv1x1_dense_kernel"] == 400 and cnt["conv1x1_dense_kernel"] == 2
+    assert tot["conv_igemm_kernel<32>"] == 50 and tot["conv_igemm_kernel<64>"] == 70
+    assert tot["sgd_kernel"] == 10 and cnt["sgd_kernel"] == 1
+    bench = importlib.import_module("bench")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "x")                     # "already under a profiler": skipped with a reason, no child process
+    res, note = bench.measure_traffic(None)
+    assert res == {} and "profiler" in note
