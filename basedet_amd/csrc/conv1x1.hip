@@ -618,24 +618,59 @@ __global__ __launch_bounds__(512, 1) void conv1x1_big_kernel(const P1 p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int t = 0; t < nsteps; ++t, ++cflat) {
-        // stages cflat, +1, +2 are in flight (4 DMA instructions each; the epilogue's own loads and stores are younger and only make
-        // the wait stricter): at most two stages may still be outstanding
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // all pieces landed; stage (cflat+3)&3 is free
+    // LDS reads run UNDER the matrix instructions: with one barrier per step all eight waves are in phase, and reading a step's
+    // fragments and then issuing its MFMAs makes the CU alternate between an LDS phase (12 KB per wave: ~770 cycles) and a matrix
+    // phase (32 MFMAs per wave, two waves per SIMD: 1 024 cycles).  (Measured: the same 6.5 ms over the step's launches with and
+    // without this overlap -- the kernel's time per tile is set elsewhere: see the launcher.)  A step is two halves of 16
+    // MFMAs (channel tiles 0-3 / 4-7): the first half runs over the reads of the second half's channel fragments, the second over
+    // the reads of the next step's pixel fragments and first channel half (64 fragment registers: a full second set spilled, and a
+    // reloaded spill waits in vmcnt order behind the ring's DMA).  The stage whose fragments sit in registers is free, so the
+    // producer stays three stages ahead of the stage being read.
+    bf16x8_t fa_lo[4], fa_hi[4], fb[2][4];
+    auto stage_of = [&](int flat) { return smem + (flat & (BG_NSTAGE - 1)) * BG_STAGE; };
+    auto read_b = [&](int flat, int set) {
+        const unsigned char* Bt = stage_of(flat) + BG_HALF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const bf16x8_t*>(Bt + lds_off(wp * 64 + j * 16 + frow, fchunk));
+    };
+    auto read_a = [&](int flat, int half, bf16x8_t (&f)[4]) {
+        const unsigned char* At = stage_of(flat);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8_t*>(At + lds_off(wm * 128 + (4 * half + i) * 16 + frow, fchunk));
+    };
+    auto step_sync = [&]() {
+        // stages cflat', +1, +2 are in flight (4 DMA instructions each; epilogue loads / stores are younger and only make the wait
+        // stricter): the oldest has landed when at most 8 are outstanding.  lgkmcnt: this wave's earlier fragment reads have returned,
+        // so after the barrier the stage they came from may be overwritten
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
         produce();
-        const unsigned char* At = smem + (cflat & (BG_NSTAGE - 1)) * BG_STAGE;
-        const unsigned char* Bt = At + BG_HALF;
-        bf16x8_t fa[8], fb[4];
+    };
+    auto mfmas = [&](int half, const bf16x8_t (&f)[4], int set) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(Bt + lds_off(wp * 64 + j * 16 + frow, fchunk));
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(At + lds_off(wm * 128 + i * 16 + frow, fchunk));
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[i], fb[set][j], acc[4 * half + i][j], 0, 0, 0);
+    };
+    auto one_step = [&](int t, int set) {             // set: compile-time at both call sites
+        read_a(cflat + t, 1, fa_hi);
+        mfmas(0, fa_lo, set);
+        if (t + 1 < nsteps) {
+            step_sync();
+            read_b(cflat + t + 1, set ^ 1);
+            read_a(cflat + t + 1, 0, fa_lo);
+        }
+        mfmas(1, fa_hi, set);
+    };
+    step_sync();
+    read_b(cflat, 0);
+    read_a(cflat, 0, fa_lo);
+    for (int t = 0; t < nsteps; t += 2) {            // two steps per trip: the pixel-fragment sets are compile-time register names
+        one_step(t, 0);
+        if (t + 1 < nsteps) one_step(t + 1, 1);
     }
+    cflat += nsteps;
 
     // ---- epilogue: lane group cg holds channels cbase + 32 h + 0..7 (h = 0..3) of pixel m0 + wp*64 + j*16 + (lane & 15).  Two halves
     // (h pairs); a half first REQUESTS all of its operands (8 x residual / mask / gate words: up to 16 KB per wave in flight -- with
