@@ -5,8 +5,10 @@
 // of cdna_hip_programming.md ("The 256^2 8-phase template"):
 //   * workgroup tile 256 output channels x 256 pixels, 8 waves = 2 channel halves x 4 patches, wave tile 128 x 64 (acc[8][4]):
 //     24 ds_read_b128 per 64 MFMAs instead of 32, and the activations are read once for all 256 output channels;
-//   * one tap (K = 64) = four phases of 16 MFMAs (a 64 x 32 quadrant of the wave tile).  A phase is
-//         [ds_read the quadrant's fragments + one weight DMA piece]  s_barrier  [16 MFMAs]  s_barrier
+//     (v_mfma_f32_32x32x16_bf16 instead of 16x16x32 -- same reads, same barriers -- measured the same: the kernel runs at ~80 % of what
+//     the matrix pipe delivers at the clock the chip holds under this load, MI355X_MICROARCH.md)
+//   * one tap (K = 64) = two phases of 32 MFMAs (the K halves; round 2: four phases of 16 measured 1 - 3 % slower).  A phase is
+//         [ds_read the K half's fragments + two weight DMA pieces]  s_barrier  [32 MFMAs]  s_barrier
 //     and the two channel halves (waves 0-3 / 4-7 = the two waves of every SIMD) run ONE barrier apart, so that on each SIMD one
 //     wave is in its MFMA segment while its partner is in its load segment: the matrix pipe never waits for LDS;
 //   * weights: ring of three 32 KB tap slots filled by LDS-DMA two taps ahead (counted vmcnt, raw s_barrier: the pieces stay
@@ -188,12 +190,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     // one tap = four phases: (A rows 0-63, K half 0) (A rows 64-127, K half 0) (rows 0-63, half 1) (rows 64-127, half 1); the B
     // fragments of a K half (all four patch rows) are read in the first phase of the pair and stay for the second: 24 ds_read_b128 per
     // tap, 32 fragment registers
-    bf16x8_t fa[4], fb[4];
-    auto load_a = [&](int i0, int kk, int slot) {
+    bf16x8_t fa[8], fb[4];
+    auto load_a = [&](int kk, int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const unsigned char* base = slot == 2 ? a_hi[kk] : a_base[kk] + slot * W_SLOT;
-            fa[i] = *reinterpret_cast<const bf16x8_t*>(base + (i0 + i) * 2048);
+            fa[i] = *reinterpret_cast<const bf16x8_t*>(base + i * 2048);
         }
     };
     auto load_b = [&](int kk, int t) {
@@ -203,14 +205,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
         for (int j = 0; j < 4; ++j)
             fb[j] = *reinterpret_cast<const bf16x8_t*>(b_base + ((j + dy) * IW + dx) * X_PITCH + kk * 64);
     };
-    auto mfma_half = [&](int i0) {
+    auto mfma_khalf = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 // tied accumulator (D = C) in inline asm: under this register pressure the allocator otherwise rotates the 32
                 // accumulator quads through the whole file and ends up spilling the staged activations
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i0 + i][j]) : "v"(fa[i]), "v"(fb[j]));
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[i]), "v"(fb[j]));
     };
 
     const int kblocks = (p.CK + 63) >> 6;
@@ -234,27 +236,39 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int kk = 0; kk < 2; ++kk) {
+                // A tap is TWO phases of 32 MFMAs (the K halves of the 64-channel block; 12 ds_read_b128 and two weight DMA pieces each).
+                // With four phases of 16 the load segment (6 reads + a DMA piece, whose issue costs 100 - 185 cycles next to the reads)
+                // was as long as the other group's 256-cycle MFMA segment and every phase paid its two barriers: the matrix pipe was
+                // busy 56 % of the time.
                 // ---------------- load segment ----------------
-                const int slot = t % 3, kk = q >> 1;
-                if ((q & 1) == 0) { load_b(kk, t); PP_FENCE(); }
-                load_a((q & 1) * 4, kk, slot);
+                const int slot = t % 3;
+                load_b(kk, t);
                 PP_FENCE();
-                if (q == 2) {
-                    // retire the pieces of tap t+1 (issued in the four phases up to (t, 0)); the piece of (t, 1) stays in flight
+                load_a(kk, slot);
+                PP_FENCE();
+                if (kk == 1) {
+                    // retire the pieces of tap t+1 (the last of them was issued in phase (t, 0)); piece 0 of tap t+2 stays in flight
                     if (last_kb && t >= 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                     if (t == 6 && !last_kb) load_x(cb + 1);        // consumed by the swap after tap 8
                     PP_FENCE();
                 }
-                // weight DMA, one piece per phase: (t, 1..3) and (t+1, 0) fill the slot of tap t+2 -- its previous tenant, tap t-1, was
-                // last read in phase (t-1, 3), two barriers before (t, 1)
-                if (q == 0) {
+                // weight DMA, two pieces per phase: (t, 0) issues the last piece of tap t+1 and the first of tap t+2, (t, 1) pieces 1 and 2 of
+                // tap t+2.  The slot of tap t+2 was last read (tap t-1) in the load segment of phase (t-1, 1), one barrier before this
+                // group's (t, 0) -- by the other group, whose reads were issued before that barrier and return within ~100 cycles; the DMA
+                // data needs a memory round trip to arrive
+                if (kk == 0) {
                     if (t + 1 < 9) { if (t > 0 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
                     else if (!last_kb) dma_piece(0, cb + 1, 0, 3);
+                    if (t + 2 < 9) dma_piece(t + 2, cb, (t + 2) % 3, 0);
+                    else if (!last_kb) dma_piece(t - 7, cb + 1, (t + 2) % 3, 0);
                 } else {
-                    if (t + 2 < 9) dma_piece(t + 2, cb, (t + 2) % 3, q - 1);
-                    else if (!last_kb) dma_piece(t - 7, cb + 1, (t + 2) % 3, q - 1);
+#pragma unroll
+                    for (int pc = 1; pc < 3; ++pc) {
+                        if (t + 2 < 9) dma_piece(t + 2, cb, (t + 2) % 3, pc);
+                        else if (!last_kb) dma_piece(t - 7, cb + 1, (t + 2) % 3, pc);
+                    }
                 }
                 PP_FENCE();
                 PP_BARRIER();
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PP_FENCE();
                 __builtin_amdgcn_s_setprio(1);
-                mfma_half((q & 1) * 4);
+                mfma_khalf();
                 __builtin_amdgcn_s_setprio(0);
                 PP_FENCE();
                 PP_BARRIER();
