@@ -57,6 +57,9 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 __device__ __forceinline__ int colperm(int f) { return f < 4 ? 2 * f : (f < 12 ? 2 * (f - 4) + 1 : 2 * (f - 8)); }
 __device__ __forceinline__ int xpos(int chunk) { return (chunk >> 2) * 64 + ((((chunk & 1) << 1) | ((chunk >> 1) & 1)) << 4); }
 
+#ifdef BD_PP_STAMP        // diagnostic build only (scripts/exp/pp_clock.py): in-kernel clock of workgroup 0 = d(s_memtime) / d(s_memrealtime) x 100 MHz
+__device__ unsigned long long g_pp_stamp[2];
+#endif
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
@@ -229,6 +232,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     PP_BARRIER();
     PP_FENCE();
 
+#ifdef BD_PP_STAMP
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int cb = 0; cb < kblocks; ++cb) {
         const bool last_kb = cb + 1 == kblocks;
         if (wm == 1) PP_BARRIER();                 // stagger: the second channel half runs one barrier behind
@@ -293,6 +299,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
         }
     }
 
+#ifdef BD_PP_STAMP
+    if (blockIdx.x == 0 && tid == 0) { g_pp_stamp[0] = __builtin_amdgcn_s_memtime() - st_c0; g_pp_stamp[1] = __builtin_amdgcn_s_memrealtime() - st_r0; }
+#endif
     // ---- epilogue ----
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the inline-asm MFMAs are opaque to the hazard recogniser: let the last ones retire
     const int cg = lane >> 4;
@@ -400,3 +409,9 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     else hipLaunchKernelGGL((conv3x3_pp_kernel<1>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
     return 0;
 }
+
+#ifdef BD_PP_STAMP
+extern "C" int bd_debug_pp_stamp(unsigned long long* out2) {
+    return hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_pp_stamp), 16) == hipSuccess ? 0 : 1;
+}
+#endif
