@@ -451,7 +451,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ref-protocol-steps", type=int, default=10,
                     help="steps of the reference-protocol leg (host float64 batch in, device sync around every step); 0 = skip")
-    ap.add_argument("--roofline-every", type=int, default=20,
+    ap.add_argument("--roofline-every", type=int, default=25,
                     help="record per-kernel HIP events on every n-th timed step (an event pair opens a ~10 us gap in the queue and the "
                          "instrumented step keeps the weight gradients on the main stream: ~2.7 ms per instrumented step; the headline "
                          "stays within ~1 %% of an uninstrumented run)")
