@@ -29,6 +29,7 @@ e.record()
 torch.cuda.synchronize()
 us = s.elapsed_time(e) * 10.0
 fl = 2.0 * geo.pixels * C * C * 9
-st = (ctypes.c_ulonglong * 2)()
+st = (ctypes.c_ulonglong * 8)()
 assert ops.L().bd_debug_pp_stamp(st) == 0
+print(f"workgroup 300 (second round), cycles: setup + prologue {st[2]} (of which address setup before the first load {st[5]}), K loop {st[0]}, epilogue issue {st[3]}, store drain {st[4]}")
 print(f"head conv fwd: {us:.1f} us per launch = {fl / us / 1e6:.0f} TFLOP/s after ~3 s of back-to-back launches; in-kernel clock {st[0] / st[1] * 100:.0f} MHz")
