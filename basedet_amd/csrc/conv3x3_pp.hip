@@ -33,7 +33,7 @@ constexpr int W_BYTES = NSLOT * W_SLOT;        // 98304
 constexpr int LDS_BYTES = W_BYTES + X_BYTES + TILE_CO * 4;   // 161536
 constexpr int MAX_SEG = BD_MAX_SEGS;
 
-struct PSeg { int patch_start, H, W, pw, src_off, dst_off; };
+struct PSeg { int patch_start, H, W, pw, src_off, dst_off; float inv_pw; };
 
 struct PParams {
     const bf16_raw* src;
@@ -46,11 +46,20 @@ struct PParams {
     int src_ppi, dst_ppi;
     unsigned src_bytes;
     int patches_per_img, total_patches, n_tiles;
+    float inv_ppi;           // 1 / patches_per_img (the patch indices are < 2^24: exact quotients by a float multiply and one correction)
     PSeg seg[MAX_SEG];
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// n / d for 0 <= n < 2^24, d > 0, inv = 1.0f / d: the float product is within one of the quotient (an integer division is ~40 VALU instructions)
+__device__ __forceinline__ int pp_div(int n, int d, float inv) {
+    int q = (int)((float)n * inv);
+    const int r = n - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 // activation image bank layout: see conv3x3.hip (column permutation + chunk order 0 2 1 3 make the padded rows conflict-free)
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int pt = bid / p.n_tiles;
+    const int pt = bid / p.n_tiles;          // (n_tiles is 1 .. 3: the compiler's division by a uniform value stays on the scalar path)
     const int ct = bid - pt * p.n_tiles;
     const int co0 = ct * TILE_CO;
 
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
         const int pid = pt * NPATCH + k;
         pH[k] = 0; pWd[k] = 0; py0[k] = 0; px0[k] = 0; psrc[k] = 0; pdst[k] = 0;
         if (pid < p.total_patches) {
-            const int n = pid / p.patches_per_img;
+            const int n = pp_div(pid, p.patches_per_img, p.inv_ppi);
             const int rem = pid - n * p.patches_per_img;
             int s = 0;
 #pragma unroll
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 if (q < p.nseg && rem >= p.seg[q].patch_start) s = q;
             const PSeg sg = p.seg[s];
             const int local = rem - sg.patch_start;
-            const int by = local / sg.pw, bx = local - by * sg.pw;
+            const int by = pp_div(local, sg.pw, sg.inv_pw), bx = local - by * sg.pw;
             py0[k] = by * PH; px0[k] = bx * PW; pH[k] = sg.H; pWd[k] = sg.W;
             psrc[k] = n * p.src_ppi + sg.src_off;
             pdst[k] = n * p.dst_ppi + sg.dst_off;
@@ -347,12 +356,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
             const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h);
             const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h + 4);
             u32x4_t mv[4];
-            if (do_mask) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    mv[j] = (u32x4_t){0u, 0u, 0u, 0u};
-                    if (okh && okj[j]) mv[j] = *reinterpret_cast<const u32x4_t*>(mrow[j] + 32 * h);
-                }
+            for (int j = 0; j < 4; ++j) {
+                mv[j] = (u32x4_t){0u, 0u, 0u, 0u};
+                if (do_mask && okh && okj[j]) mv[j] = *reinterpret_cast<const u32x4_t*>(mrow[j] + 32 * h);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -365,8 +372,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                     v += (f32x2_e){bb[2 * (k & 1)], bb[2 * (k & 1) + 1]};
                     i16x2_e w = __builtin_bit_cast(i16x2_e, __builtin_convertvector(v, bf16x2_e));
                     if (do_mask) {          // keep where the stored activation is > 0: sat(0 - m) >> 15 is all ones exactly for m > 0 (-0.0 = 0x8000 saturates to 32767)
-                        const i16x2_e m = __builtin_bit_cast(i16x2_e, mv[j][k]);
-                        w &= __builtin_elementwise_sub_sat((i16x2_e){0, 0}, m) >> 15;
+                        // (written as the two packed instructions: the vector-builtin form of this gate was compiled into selects that
+                        // read the first mask register for every k -- caught by test_patch_instances_agree_bitwise; op_sel_hi:[0,1]: both halves shift
+                        // by the low half of the inline constant, whose high half is 0)
+                        unsigned gate;
+                        asm("v_pk_sub_i16 %0, 0, %1 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(gate) : "v"(mv[j][k]));
+                        w &= __builtin_bit_cast(i16x2_e, gate);
                     }
                     w = __builtin_elementwise_max(w, relu_floor);
                     o[k] = __builtin_bit_cast(unsigned, w);
@@ -453,13 +464,15 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     int ps = 0;
     for (int s = 0; s < d->nseg; ++s) {
         PSeg& sg = p.seg[s];
-        sg.patch_start = ps; sg.H = d->Ho[s]; sg.W = d->Wo[s]; sg.pw = cdiv(d->Wo[s], PW);
+        sg.patch_start = ps; sg.H = d->Ho[s]; sg.W = d->Wo[s]; sg.pw = cdiv(d->Wo[s], PW); sg.inv_pw = 1.0f / (float)sg.pw;
         sg.src_off = mode == 0 ? d->in_off[s] : d->out_off[s];
         sg.dst_off = mode == 0 ? d->out_off[s] : d->in_off[s];
         ps += cdiv(d->Ho[s], PH) * sg.pw;
     }
     p.patches_per_img = ps;
+    p.inv_ppi = 1.0f / (float)ps;
     p.total_patches = ps * d->N;
+    if (p.total_patches >= (1 << 24)) return 1;
     p.n_tiles = cdiv(p.CO, TILE_CO);
     const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
     {

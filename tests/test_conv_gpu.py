@@ -308,6 +308,9 @@ def test_patch_instances_agree_bitwise(shape):
     res = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
     gy = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
     addx = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
+    gate = torch.relu(torch.randn(gin.pixels, Cin, device="cuda", generator=g)).to(torch.bfloat16)
+    gate.view(torch.int16)[::7, ::3] = -32768            # -0.0
+    gate[::5, 1::4] = -1.5
     outs = []
     for knob in (3 | 64 | 512, 3, 3 | 64 | 256):
         ops.L().bd_conv_set_patch3x3(knob)
@@ -316,12 +319,23 @@ def test_patch_instances_agree_bitwise(shape):
         ops.conv2d_fwd(d, x, w, b, y, add=res, flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE)
         if Cin > 128:                                  # dgrad produces Cin channels; (…, 136, 40): a 40-channel reduction (bbox_pred), K < 64
             ops.conv2d_dgrad(d, gy, wt, dx, add=addx, mask=addx, flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
+        # the epilogue forms without a residual operand (their own code path in the 256-channel instance): forward bias / bias + ReLU,
+        # dgrad plain / gated by a stored activation (zeros, negative zeros and negatives all close the gate)
+        y2, y3 = torch.full_like(y, 3.0), torch.full_like(y, 3.0)
+        dx2, dx3 = torch.full_like(dx, 3.0), torch.full_like(dx, 3.0)
+        ops.conv2d_fwd(d, x, w, b, y2, flags=ops.EPI_RELU)
+        ops.conv2d_fwd(d, x, w, b, y3)
+        if Cin > 128:
+            ops.conv2d_dgrad(d, gy, wt, dx2, mask=gate, flags=ops.EPI_MASK)
+            ops.conv2d_dgrad(d, gy, wt, dx3)
         torch.cuda.synchronize()
-        outs.append((y.clone(), dx.clone()))
+        outs.append((y.clone(), dx.clone(), y2, y3, dx2, dx3))
     ops.L().bd_conv_set_patch3x3(3)
     for k in (1, 2):          # both staggered instances against the plain 128-channel kernel
-        assert torch.equal(outs[0][0], outs[k][0])
-        assert torch.equal(outs[0][1], outs[k][1])
+        for a, b_ in zip(outs[0], outs[k]):
+            assert torch.equal(a, b_)
+    if Cin > 128:             # and the gate itself against its definition
+        assert torch.equal(outs[1][4], torch.where(gate.float() > 0, outs[1][5], torch.zeros_like(outs[1][5])))
 
 
 @pytest.mark.parametrize("case", [(2, 64, 72, 19, 27, 3, 1, 1), (2, 128, 64, 22, 30, 3, 2, 1), (3, 64, 136, 9, 14, 1, 1, 0)])
