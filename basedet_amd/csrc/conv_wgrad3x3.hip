@@ -52,6 +52,10 @@ template <int STRIDE> struct XImg {
 
 struct PSeg { int patch_start, H, W, pw, in_off, out_off, Hi, Wi; };
 
+#ifdef BD_W3_STAMP        // diagnostic build only (scripts/exp/w3_stamp.py): s_memtime cycles per loop phase, per wave of one workgroup
+__device__ unsigned long long g_w3_stamp[4][8];
+#endif
+
 struct W3Params {
     const bf16_raw* x;
     const bf16_raw* g;
@@ -121,47 +125,79 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p)
     constexpr unsigned X_NONE = 0x80000000u;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.g), 0, p.g_bytes, 0x00020000);
-    // element offsets relative to the patch origin, for the current level (the stride-2 instance has six activation passes and no
-    // registers to spare at two waves per SIMD: it recomputes x_vec per patch)
-    int x_vec[STRIDE == 1 ? X_PASSES : 1], g_vec[G_PASSES];
-    int cur_seg = -1;
+    // byte offsets relative to the patch origin, for the current level, X_NONE for unused slots / channel tails
+    int x_vec[X_PASSES], g_vec[G_PASSES];
 
-    auto stage_load = [&](int pid) {
-        const int n = pid / p.patches_per_img;
-        const int rem = pid - n * p.patches_per_img;
-        int s = 0;
+    // Patch cursor (workgroup-uniform, lives in scalar registers): a split walks consecutive patch ids, so after the one decode of its
+    // first id (two integer divisions, a level search, a descriptor fetch) the next patch is an increment with carries -- the decode per
+    // patch was a serial chain of ~150 scalar instructions and a kernel-argument load in front of every MFMA block (stamped: 1 500
+    // cycles of a 3 000-cycle patch step).
+    int c_n = 0, c_s = 0, c_by = 0, c_bx = 0, c_rows = 1;
+    PSeg sg = p.seg[0];
+    auto level_vectors = [&]() {
+#pragma unroll
+        for (int k = 0; k < X_PASSES; ++k)
+            x_vec[k] = (x_iy[k] >= 0 && x_cok) ? ((x_iy[k] * sg.Wi + x_ix[k]) * p.Cin + x_chunk * 8) * 2 : (int)X_NONE;
+#pragma unroll
+        for (int k = 0; k < G_PASSES; ++k) {
+            const int row = (tid >> 3) + 32 * k;
+            g_vec[k] = g_cok ? (((row >> 3) * sg.W + (row & 7)) * p.Cout + g_chunk * 8) * 2 : (int)X_NONE;
+        }
+    };
+    auto seek = [&](int pid) {
+        c_n = pid / p.patches_per_img;
+        const int rem = pid - c_n * p.patches_per_img;
+        c_s = 0;
 #pragma unroll
         for (int k = 1; k < BD_MAX_SEGS; ++k)
-            if (k < p.nseg && rem >= p.seg[k].patch_start) s = k;
-        const PSeg sg = p.seg[s];
-        if (s != cur_seg) {                           // workgroup-uniform
-            cur_seg = s;
-#pragma unroll
-            for (int k = 0; k < (STRIDE == 1 ? X_PASSES : 0); ++k) x_vec[k] = (x_iy[k] * sg.Wi + x_ix[k]) * p.Cin + x_chunk * 8;
-#pragma unroll
-            for (int k = 0; k < G_PASSES; ++k) {
-                const int row = (tid >> 3) + 32 * k;
-                g_vec[k] = ((row >> 3) * sg.W + (row & 7)) * p.Cout + g_chunk * 8;
-            }
-        }
+            if (k < p.nseg && rem >= p.seg[k].patch_start) c_s = k;
+        sg = p.seg[c_s];
         const int local = rem - sg.patch_start;
-        const int by = local / sg.pw, bx = local - by * sg.pw;
+        c_by = local / sg.pw; c_bx = local - c_by * sg.pw;
+        c_rows = (sg.H + PH - 1) / PH;
+        level_vectors();
+    };
+    auto advance = [&]() {
+        if (++c_bx < sg.pw) return;
+        c_bx = 0;
+        if (++c_by < c_rows) return;
+        c_by = 0;
+        if (p.nseg == 1) { ++c_n; return; }
+        if (++c_s == p.nseg) { c_s = 0; ++c_n; }
+        sg = p.seg[c_s];
+        c_rows = (sg.H + PH - 1) / PH;
+        level_vectors();
+    };
+
+    // Interior patches (every pixel of both patches inside the image: a workgroup-uniform test) take the short form: the per-thread
+    // byte offset is a per-level constant (X_NONE already folded in for unused slots / channel tails) and the patch origin rides in the
+    // buffer instruction's scalar offset -- one instruction per load.  A wave issues at most one instruction every four cycles, and the
+    // checked form below is ~130 of them (stamped: 1 000 cycles in front of a 1 152-cycle MFMA block).
+    auto stage_load = [&]() {
+        const int n = c_n, by = c_by, bx = c_bx;
         const int y0 = by * PH, x0 = bx * PW;
         const int ys = STRIDE * y0 - 1, xs = STRIDE * x0 - 1;
         const int xorg = (n * p.in_ppi + sg.in_off + ys * sg.Wi + xs) * p.Cin + ci0;        // may be negative; valid sums are not
         const int gorg = (n * p.out_ppi + sg.out_off + y0 * sg.W + x0) * p.Cout + co0;
+        if (ys >= 0 && xs >= 0 && ys + XI::EXT_H <= sg.Hi && xs + XI::EXT_W <= sg.Wi && y0 + PH <= sg.H && x0 + PW <= sg.W) {
+#pragma unroll
+            for (int k = 0; k < X_PASSES; ++k)
+                rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (unsigned)x_vec[k], xorg * 2, 0);
+#pragma unroll
+            for (int k = 0; k < G_PASSES; ++k) rg[k] = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (unsigned)g_vec[k], gorg * 2, 0);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < X_PASSES; ++k) {
             const int y = ys + x_iy[k], x = xs + x_ix[k];
             const bool ok = x_iy[k] >= 0 && x_cok && y >= 0 && x >= 0 && y < sg.Hi && x < sg.Wi;
-            const int xv = STRIDE == 1 ? x_vec[k] : (x_iy[k] * sg.Wi + x_ix[k]) * p.Cin + x_chunk * 8;
-            rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(xorg + xv) * 2u : X_NONE, 0, 0);
+            rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)xorg * 2u + (unsigned)x_vec[k] : X_NONE, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < G_PASSES; ++k) {
             const int row = (tid >> 3) + 32 * k;
             const bool ok = g_cok && y0 + (row >> 3) < sg.H && x0 + (row & 7) < sg.W;
-            rg[k] = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, ok ? (unsigned)(gorg + g_vec[k]) * 2u : X_NONE, 0, 0);
+            rg[k] = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, ok ? (unsigned)gorg * 2u + (unsigned)g_vec[k] : X_NONE, 0, 0);
         }
     };
     auto stage_write = [&](int buf) {
@@ -170,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p)
 #pragma unroll
         for (int k = 0; k < X_PASSES; ++k) {
             const int c = tid + 256 * k;
-            if (c < X_CHUNKS) *reinterpret_cast<u32x4_t*>(Xt + (c >> 3) * X_PITCH + x_chunk * 16) = rx[k];
+            if (256 * (k + 1) <= X_CHUNKS || c < X_CHUNKS) *reinterpret_cast<u32x4_t*>(Xt + (c >> 3) * X_PITCH + x_chunk * 16) = rx[k];
         }
 #pragma unroll
         for (int k = 0; k < G_PASSES; ++k) {
@@ -207,41 +243,83 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const W3Params p)
         return __builtin_bit_cast(bf16x8_t, v);
     };
 
+    // Fragment reads run one tap ahead of the MFMAs that consume them (two A register sets), and the next sub-step's four G fragments
+    // are fetched under taps 1..4 (two B sets): only the first reads after a barrier are exposed.  The order is pinned with
+    // sched_barrier -- left alone the compiler hoists 16 reads to the top of each sub-step and waits for all of them (lgkmcnt(0))
+    // before the first MFMA.
     auto compute = [&](int buf) {
         const unsigned char* Xt = smem + buf * BUF_BYTES + x_lane_off;
         const unsigned char* Gt = smem + buf * BUF_BYTES + X_BYTES + g_lane_off;
+        constexpr int NT = 9 * XI::KSUB;
+        bf16x8_t a[2], b[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[0][j] = tr_frag(Gt + j * 32, PW * G_PITCH);
+        a[0] = tr_frag(Xt + XI::tap_row(0, 0) * X_PITCH, XW * X_PITCH);
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);      // two workgroups per CU: the wave in its MFMA block wins the issue arbitration (+2 %)
 #pragma unroll
-        for (int kk = 0; kk < XI::KSUB; ++kk) {
-            bf16x8_t b[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = tr_frag(Gt + (4 * kk * PW) * G_PITCH + j * 32, PW * G_PITCH);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, s = t % 3;
-                const bf16x8_t a = tr_frag(Xt + (4 * kk * XW + XI::tap_row(r, s)) * X_PITCH, XW * X_PITCH);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[t][j], 0, 0, 0);
+        for (int i = 0; i < NT; ++i) {
+            const int kk = i / 9, t = i % 9;
+            if (i + 1 < NT) {
+                const int k2 = (i + 1) / 9, t2 = (i + 1) % 9;
+                a[(i + 1) & 1] = tr_frag(Xt + (4 * k2 * XW + XI::tap_row(t2 / 3, t2 % 3)) * X_PITCH, XW * X_PITCH);
             }
+            if (kk + 1 < XI::KSUB && t >= 1 && t <= 4)
+                b[(kk + 1) & 1][t - 1] = tr_frag(Gt + (4 * (kk + 1) * PW) * G_PITCH + (t - 1) * 32, PW * G_PITCH);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 1], b[kk & 1][j], acc[t][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
 
     if (pbeg < pend) {
-        stage_load(pbeg);
+        seek(pbeg);
+        stage_load();
+        advance();
         stage_write(0);
     }
     __syncthreads();
     int cur = 0;
+#ifdef BD_W3_STAMP
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_rbegin = __builtin_amdgcn_s_memrealtime();
+#define W3_T() __builtin_amdgcn_s_memtime()
     for (int pid = pbeg; pid < pend; ++pid) {
         const bool more = pid + 1 < pend;
-        if (more) stage_load(pid + 1);
+        const unsigned long long a0 = W3_T();
+        if (more) { stage_load(); advance(); }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long a1 = W3_T();
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long a2 = W3_T();
+        if (more) stage_write(cur ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long a3 = W3_T();
+        __syncthreads();
+        const unsigned long long a4 = W3_T();
+        st[0] += a1 - a0; st[1] += a2 - a1; st[2] += a3 - a2; st[3] += a4 - a3; st[4] += 1;
+        cur ^= 1;
+    }
+    if (blockIdx.x == 300 % gridDim.x && lane == 0) {
+        for (int k = 0; k < 5; ++k) g_w3_stamp[wave][k] = st[k];
+        g_w3_stamp[wave][5] = __builtin_amdgcn_s_memtime() - st_begin;
+        g_w3_stamp[wave][6] = __builtin_amdgcn_s_memrealtime() - st_rbegin;       // 100 MHz
+    }
+#else
+    for (int pid = pbeg; pid < pend; ++pid) {
+        const bool more = pid + 1 < pend;
+        if (more) { stage_load(); advance(); }
         compute(cur);
         if (more) stage_write(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+#endif
 
     if (do_cs) {            // 32 staging threads share a channel chunk: fixed-order sum through LDS (the loop's last barrier has passed)
         float* red = reinterpret_cast<float*>(smem);
@@ -286,6 +364,12 @@ int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patch
     if (patches_per_img_out) *patches_per_img_out = ppi;
     return splits;
 }
+
+#ifdef BD_W3_STAMP
+extern "C" int bd_debug_w3_stamp(unsigned long long* out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_w3_stamp), sizeof(g_w3_stamp)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, float* csum, int* splits_out, hipStream_t stream) {
     W3Params p{};
