@@ -95,30 +95,39 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     const int co0 = ct * TILE_CO;
 
     // ---- geometry of the four patches (workgroup-uniform) ----
+    // Lane k of every wave decodes patch k (the four decodes side by side instead of a four-times-longer serial chain in front of the
+    // first load), then the results are broadcast into scalar registers, where they live through the MFMA loop.
     int py0[NPATCH], px0[NPATCH], pH[NPATCH], pWd[NPATCH];
     int psrc[NPATCH], pdst[NPATCH];
-#pragma unroll
-    for (int k = 0; k < NPATCH; ++k) {
-        const int pid = pt * NPATCH + k;
-        pH[k] = 0; pWd[k] = 0; py0[k] = 0; px0[k] = 0; psrc[k] = 0; pdst[k] = 0;
+    {
+        const int pid = pt * NPATCH + (lane & (NPATCH - 1));
+        int vH = 0, vW = 0, vy = 0, vx = 0, vs = 0, vd = 0;
         if (pid < p.total_patches) {
             const int n = pp_div(pid, p.patches_per_img, p.inv_ppi);
             const int rem = pid - n * p.patches_per_img;
-            int s = 0;
+            // level search as selects over the (scalar) level table: no per-lane table fetch
+            int g_start = p.seg[0].patch_start, g_H = p.seg[0].H, g_W = p.seg[0].W, g_pw = p.seg[0].pw;
+            int g_src = p.seg[0].src_off, g_dst = p.seg[0].dst_off;
+            float g_inv = p.seg[0].inv_pw;
 #pragma unroll
-            for (int q = 1; q < MAX_SEG; ++q)
-                if (q < p.nseg && rem >= p.seg[q].patch_start) s = q;
-            const PSeg sg = p.seg[s];
-            const int local = rem - sg.patch_start;
-            const int by = pp_div(local, sg.pw, sg.inv_pw), bx = local - by * sg.pw;
-            py0[k] = by * PH; px0[k] = bx * PW; pH[k] = sg.H; pWd[k] = sg.W;
-            psrc[k] = n * p.src_ppi + sg.src_off;
-            pdst[k] = n * p.dst_ppi + sg.dst_off;
+            for (int q = 1; q < MAX_SEG; ++q) {
+                const bool in = q < p.nseg && rem >= p.seg[q].patch_start;
+                g_start = in ? p.seg[q].patch_start : g_start; g_H = in ? p.seg[q].H : g_H; g_W = in ? p.seg[q].W : g_W;
+                g_pw = in ? p.seg[q].pw : g_pw; g_src = in ? p.seg[q].src_off : g_src; g_dst = in ? p.seg[q].dst_off : g_dst;
+                g_inv = in ? p.seg[q].inv_pw : g_inv;
+            }
+            const int local = rem - g_start;
+            const int by = pp_div(local, g_pw, g_inv), bx = local - by * g_pw;
+            vy = by * PH; vx = bx * PW; vH = g_H; vW = g_W;
+            vs = n * p.src_ppi + g_src;
+            vd = n * p.dst_ppi + g_dst;
         }
-        // the divisions run on the vector ALU: move the (uniform) results back to scalar registers, they live through the MFMA loop
-        py0[k] = __builtin_amdgcn_readfirstlane(py0[k]); px0[k] = __builtin_amdgcn_readfirstlane(px0[k]);
-        pH[k] = __builtin_amdgcn_readfirstlane(pH[k]); pWd[k] = __builtin_amdgcn_readfirstlane(pWd[k]);
-        psrc[k] = __builtin_amdgcn_readfirstlane(psrc[k]); pdst[k] = __builtin_amdgcn_readfirstlane(pdst[k]);
+#pragma unroll
+        for (int k = 0; k < NPATCH; ++k) {
+            py0[k] = __builtin_amdgcn_readlane(vy, k); px0[k] = __builtin_amdgcn_readlane(vx, k);
+            pH[k] = __builtin_amdgcn_readlane(vH, k); pWd[k] = __builtin_amdgcn_readlane(vW, k);
+            psrc[k] = __builtin_amdgcn_readlane(vs, k); pdst[k] = __builtin_amdgcn_readlane(vd, k);
+        }
     }
 
     // ---- activation staging: chunk id c = tid + 512 k -> LDS row (tid >> 3) + 64 k, 16-byte chunk tid & 7 ----

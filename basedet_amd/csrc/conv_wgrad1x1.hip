@@ -49,6 +49,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad1x1_kernel(const W1Params p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wci = wave / WCO, wco = wave - wci * WCO;
     int bid = blockIdx.x;
+    {   // XCD-aware bijective remap (as conv_wgrad3x3.hip): the tiles of one pixel split share its activation and gradient rows, so
+        // they get consecutive ids on ONE XCD and the rows come from HBM once per split instead of once per tile
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     const int tiles = p.ci_tiles * p.co_tiles;
     const int split = bid / tiles;
     bid -= split * tiles;

@@ -67,6 +67,29 @@ __global__ __launch_bounds__(256) void ksus(const unsigned* seed, int iters, flo
     if (t == 12345.678f) out[0] = t;
 }
 
+// The register-level pattern of the real kernels, still without LDS or memory: 8 A fragments x 4 B fragments of full-entropy random bf16
+// (sign, 7 mantissa bits, exponents 2^-3 .. 2^0), 32 accumulators -- every MFMA sees different operands.  ~3 s sustained.
+__global__ __launch_bounds__(256) void krot(const unsigned* seed, int iters, float* out, unsigned long long* stamps) {
+    unsigned s = seed[threadIdx.x & 63] ^ (threadIdx.x * 2654435761u);
+    f32x4 acc[8][4];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    union U { bf16x8 v; unsigned u[4]; } a[8], b[4];
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; const unsigned m = s & 0x807f807fu, e = ((s >> 8) & 0x00030003u) << 7; return m | (0x3e003e00u + e); };
+    for (int i = 0; i < 8; ++i) for (int k = 0; k < 4; ++k) a[i].u[k] = rnd();
+    for (int j = 0; j < 4; ++j) for (int k = 0; k < 4; ++k) b[j].u[k] = rnd();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i].v), "v"(b[j].v));
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { stamps[0] = c1 - c0; stamps[1] = r1 - r0; }
+    float t = 0;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) t += acc[i][j][0];
+    if (t == 12345.678f) out[0] = t;
+}
+
 int main() {
     unsigned h[64], *d; float* o;
     hipMalloc(&d, 256); hipMalloc(&o, 4);
@@ -120,6 +143,25 @@ int main() {
         unsigned long long hs[2]; hipMemcpy(hs, st, 16, hipMemcpyDeviceToHost);
         printf("sustained ~3 s, random operands, bf16 K=32, 8 waves/CU: %.0f TFLOP/s; in-kernel clock %.0f MHz\n", flops / (ms * 1e-3) / 1e12,
                (double)hs[0] / (double)hs[1] * 100.0);
+    }
+    {
+        for (int i = 0; i < 64; ++i) h[i] = (unsigned)rand() * 2654435761u;
+        hipMemcpy(d, h, 256, hipMemcpyHostToDevice);
+        unsigned long long* st; hipMalloc(&st, 16);
+        for (int wpc : {4, 8}) {
+            const int iters = 5000, grid = 256 * wpc / 4;
+            const double flops = (double)grid * 4 * iters * 32 * 2.0 * 16 * 16 * 32;
+            float ms = 0;
+            for (int rep = 0; rep < 1400; ++rep) {
+                const bool timed = rep >= 1390;
+                if (timed) hipEventRecord(a);
+                hipLaunchKernelGGL(krot, dim3(grid), dim3(256), 0, 0, d, iters, o, st);
+                if (timed) { hipEventRecord(b); hipEventSynchronize(b); float t; hipEventElapsedTime(&t, a, b); ms = t; }
+            }
+            unsigned long long hs[2]; hipMemcpy(hs, st, 16, hipMemcpyDeviceToHost);
+            printf("sustained, 8 x 4 rotating full-entropy fragments, %d waves/CU: %.0f TFLOP/s (%.2f ms per launch), in-kernel clock %.0f MHz\n", wpc,
+                   flops / (ms * 1e-3) / 1e12, ms, (double)hs[0] / (double)hs[1] * 100.0);
+        }
     }
     return 0;
 }
