@@ -56,6 +56,12 @@ __device__ __forceinline__ unsigned pack4_e5m2(float a, float b, float c, float 
 
 typedef __attribute__((address_space(3))) void lds_void_1x1_t;
 
+// 16 bytes per lane straight into LDS.  (A plain function: called with template-dependent arguments from inside the kernel template, the
+// target builtin made the HOST pass drop the instantiation without a diagnostic -- undefined kernel stubs at link time.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_1x1_t*)lds, 16, voff, soff, 0, 0);
+}
+
 // One-byte twin of a pixel's 64 wave-channels: lane group cg holds 8 bytes of each 32-channel half; the lane pairs (cg, cg ^ 1) swap one
 // piece so that every lane stores 16 contiguous bytes (64-byte runs per pixel and instruction instead of 32-byte ones): even cg ends up
 // with bytes [8 cg, 8 cg + 16) of half 0, odd cg with bytes [8 (cg - 1), 8 (cg - 1) + 16) of half 1.  `keep` = this lane's piece of the
@@ -74,13 +80,20 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + (
 
 // DMA: the operands go by LDS-DMA (no staging registers / LDS writes) into a THREE-stage ring, two K steps in flight per workgroup under a
 // counted vmcnt and one raw barrier per step (48 KB of LDS: three workgroups per CU); taken for CK % 32 == 0 and long K (see the launcher).
-template <int DEPTH, int WAVES, bool DMA>
-__global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
+// NC = 64-channel wave columns: 2 = the 128-channel tile (four waves); 4 = a 256-channel x 128-pixel tile of EIGHT waves (DMA form only):
+// the activation rows are fetched once per 256 output channels instead of once per 128 -- the class is bound by the bytes it moves
+// between L2 and the CUs -- while the pixel granularity of the grid stays 128.
+template <int DEPTH, int WAVES, bool DMA, int NC = 2>
+__global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1 p) {
+    static_assert(NC == 2 || (NC == 4 && DMA), "the 256-channel tile exists in the LDS-DMA form only");
+    constexpr int TCW = 64 * NC;                    // channels per tile
+    constexpr int A_BYTES = TCW * 64;               // weight tile of one stage (64-byte rows)
+    constexpr int STAGE = A_BYTES + TILE_BYTES;     // + the pixel tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wc = wave >> 1;   // channel half
+    const int wc = wave >> 1;   // channel column (64 channels)
     const int wp = wave & 1;    // pixel half
 
     // XCD-aware bijective remap: consecutive tile ids (the channel tiles of one pixel tile, then the next pixel tile) share an XCD's L2
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     const int tile_m = bid / p.n_tiles;
     const int tile_n = bid - tile_m * p.n_tiles;
     const int m0 = tile_m * TP;
-    const int co0 = tile_n * TC;
+    const int co0 = tile_n * TCW;
 
     const int chunk = tid & 3;
     const int row0 = tid >> 2;          // rows row0 and row0 + 64 of both operand tiles
@@ -127,8 +140,8 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
         }
     };
     auto stage_write = [&](int buf, const u32x4_t (&a)[2], const u32x4_t (&b)[2]) {
-        unsigned char* At = smem + buf * 2 * TILE_BYTES;
-        unsigned char* Bt = At + TILE_BYTES;
+        unsigned char* At = smem + buf * STAGE;
+        unsigned char* Bt = At + A_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             *reinterpret_cast<u32x4_t*>(At + lds_off(row0 + i * 64, chunk)) = a[i];
@@ -145,8 +158,8 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     const int frag_row = lane & 15;
     const int frag_chunk = lane >> 4;
     auto compute = [&](int buf) {
-        const unsigned char* At = smem + buf * 2 * TILE_BYTES;
-        const unsigned char* Bt = At + TILE_BYTES;
+        const unsigned char* At = smem + buf * STAGE;
+        const unsigned char* Bt = At + A_BYTES;
         bf16x8_t a[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(At + lds_off(wc * 64 + i * 16 + frag_row, frag_chunk));
@@ -170,14 +183,21 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
     if constexpr (DMA) {
         // ---- main loop, LDS-DMA ring: a stage = two operand tiles of 8 pieces of 1 KiB (16 rows x 64 B); this wave owns pieces wave and
         // wave + 4 of both; lane -> row lane >> 2, position lane & 3, source chunk = position ^ ((row >> 1) & 3) (lds_off on the source side)
-        unsigned a_src[2], b_src[2];
+        // weight tile: TCW / 16 pieces, this wave owns pieces wave and wave + 2 NC; pixel tile: 8 pieces, pieces wave (+ 4 with four waves)
+        constexpr int NWAVE = 2 * NC, B_PIECES = 8 / NWAVE;
+        unsigned a_src[2], b_src[B_PIECES];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int lrow = 16 * (wave + 4 * k) + (lane >> 2);
+            const int lrow = 16 * (wave + NWAVE * k) + (lane >> 2);
             const int ch = (lane & 3) ^ ((lrow >> 1) & 3);
             const int rho = lrow & 15;
-            const int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
+            const int co = co0 + (lrow & (TCW - 64)) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
             a_src[k] = co < p.CO ? (unsigned)(co * p.CK + ch * 8) * 2u : X_NONE;
+        }
+#pragma unroll
+        for (int k = 0; k < B_PIECES; ++k) {
+            const int lrow = 16 * (wave + NWAVE * k) + (lane >> 2);
+            const int ch = (lane & 3) ^ ((lrow >> 1) & 3);
             const int m = m0 + lrow;
             b_src[k] = m < p.M ? (unsigned)(m * p.CK + ch * 8) * 2u : X_NONE;
         }
@@ -185,19 +205,20 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
         auto dma = [&](int step, int stage) {
             int so = step * BK * 2;
             asm volatile("" : "+s"(so));
-            unsigned char* At = smem + stage * 2 * TILE_BYTES;
+            unsigned char* At = smem + stage * STAGE;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_1x1_t*)(At + (uwave + 4 * k) * 1024), 16, a_src[k], so, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_1x1_t*)(At + TILE_BYTES + (uwave + 4 * k) * 1024), 16, b_src[k], so, 0, 0);
-            }
+            for (int k = 0; k < 2; ++k)
+                dma16(w_rsrc, At + (uwave + NWAVE * k) * 1024, a_src[k], so);
+#pragma unroll
+            for (int k = 0; k < B_PIECES; ++k)
+                dma16(x_rsrc, At + A_BYTES + (uwave + NWAVE * k) * 1024, b_src[k], so);
         };
         dma(0, 0);
         if (nsteps > 1) dma(1, 1);
         int cs = 0, ps = 2;                       // consumer / producer stage
         for (int t = 0; t < nsteps; ++t) {
-            // stages t and t + 1 are in flight (4 DMA instructions each): stage t has landed when at most 4 are outstanding
-            if (t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // stages t and t + 1 are in flight (4 DMA instructions each; 3 with eight waves): stage t has landed when at most that many are outstanding
+            if (t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NC == 2 ? 4 : 3) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // everyone's pieces; stage ps is free
             if (t + 2 < nsteps) dma(t + 2, ps);
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(256, WAVES) void conv1x1_dense_kernel(const P1 p) {
                 bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
             }
     }
-    constexpr int EB = EPI_BATCH;
+    constexpr int EB = NC == 4 ? 2 : EPI_BATCH;        // the eight-wave tile runs at a 128-register budget
 #pragma unroll
     for (int part = 0; part < 8 / EB; ++part) {
     u32x4_t e_aux[EB];     // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
@@ -771,17 +792,20 @@ __global__ __launch_bounds__(512, 1) void conv1x1_big_kernel(const P1 p) {
 }
 
 int g_conv1x1_dma_k = 512;      // BD_DENSE1X1_DMA_K: smallest CK that takes the LDS-DMA ring variant
-int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (generic kernel), 1 = the 128^2 tile (default), 2 = the 256^2 tile wherever legal (A/B), 3 = as 1
+int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (generic kernel), 1 = the 128^2 tile (default), 2 = the 256^2 tile wherever legal (A/B), 3 = as 1,
+                                // 4 = the 256-channel x 128-pixel eight-wave tile wherever legal (A/B)
+int g_conv1x1_wide_min_k = 0;   // BD_DENSE1X1_WIDE_K: smallest CK that takes the eight-wave tile in mode 4
 
 }  // namespace
 
 extern "C" int bd_conv_set_dense1x1(int depth) {
-    if (depth < 0 || depth > 3) {
-        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 3)", depth);
+    if (depth < 0 || depth > 4) {
+        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 4)", depth);
         return BD_EINVAL;
     }
     g_conv1x1_depth = depth;
     if (const char* e = getenv("BD_DENSE1X1_DMA_K")) g_conv1x1_dma_k = atoi(e);
+    if (const char* e = getenv("BD_DENSE1X1_WIDE_K")) g_conv1x1_wide_min_k = atoi(e);
     return BD_OK;
 }
 
@@ -817,6 +841,17 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
             hipLaunchKernelGGL(conv1x1_big_kernel, dim3((int)(tiles < 256 ? tiles : 256)), dim3(512), BG_LDS, stream, p);
             return 0;
         }
+    }
+    if (g_conv1x1_depth == 4 && CK % BK == 0 && CO >= 256 && CK >= g_conv1x1_wide_min_k) {
+        constexpr int WIDE_LDS = 3 * (256 * 64 + TILE_BYTES);          // 72 KB: two eight-wave workgroups per CU
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dense_kernel<1, 4, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+            attr_set = true;
+        }
+        p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, 256);
+        hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, true, 4>), dim3(p.m_tiles * p.n_tiles), dim3(512), WIDE_LDS, stream, p);
+        return 0;
     }
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
     const int grid = p.m_tiles * p.n_tiles;

@@ -381,10 +381,10 @@ def test_wgrad_bias_multilevel():
     assert rel_l2(db.cpu(), gy.sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("depth", [1, 0, 2, 3, 101])
+@pytest.mark.parametrize("depth", [1, 0, 2, 3, 4, 101])
 def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
     """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_set_dense1x1: 0 = the generic kernel,
-    1 = the default choice between the 128^2 and the 256^2 LDS-DMA tile, 2 = 256^2 wherever legal, 3 = 128^2 only): forward with
+    1 = the default choice, 2 = 256^2 wherever legal, 3 = 128^2 only, 4 = the eight-wave 256-channel x 128-pixel tile wherever legal): forward with
     residual + ReLU and the data gradient with accumulate + mask against torch-CPU fp32; the bit-packed ReLU mask written by the
     forward launch equals (y > 0) bit for bit, and a data gradient gated by it equals the one gated by the bf16 activation."""
     ops = _ops()
@@ -435,9 +435,9 @@ def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
                                  flags=ops.EPI_ADD_BEFORE)
                 assert torch.equal(dx, dx2)
                 # one-byte twins (e4m3 of the forward output, e5m2 of the data gradient): the same bytes from either tile
-                if depth in (2, 3):
+                if depth in (2, 3, 4):
                     tw = {}
-                    for dd in (2, 3):
+                    for dd in (2, 3, 4):
                         ops.L().bd_conv_set_dense1x1(dd)
                         y8 = torch.zeros((M, Cout), dtype=torch.uint8, device="cuda")
                         y2 = torch.empty_like(y)
@@ -449,8 +449,8 @@ def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
                                          dx8=dx8, q_scale=64.0)
                         tw[dd] = (y2.clone(), y8.clone(), dx3.clone(), dx8.clone())
                     ops.L().bd_conv_set_dense1x1(depth)
-                    for a, b in zip(tw[2], tw[3]):
-                        assert torch.equal(a, b)
+                    for a, b, c in zip(tw[2], tw[3], tw[4]):
+                        assert torch.equal(a, b) and torch.equal(a, c)
                     assert torch.equal(tw[2][0], y) and torch.equal(tw[2][2], dx)
     finally:
         ops.L().bd_conv_set_dense1x1(1)
