@@ -113,6 +113,7 @@ SIGNATURES = {
     "bd_subsample2x_fwd": (_I, [_P, _L, _L, _I, _I, _P, _L, _L, _I, _I, _P]),
     "bd_subsample2x_bwd_add": (_I, [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _P]),
     "bd_f32_to_bf16": (_I, [_P, _P, _L, _P]),
+    "bd_f32_to_bf16_add": (_I, [_P, _P, _L, _P]),
     "bd_rpn_loss_fwd_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _L, _F, _P, _P, _P, _P]),
     "bd_rcnn_loss_fwd_bwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P]),
     "bd_det_scores": (_I, [_P, _P, _I, _I, _L, _I, _P, _P]),

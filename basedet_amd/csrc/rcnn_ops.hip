@@ -977,6 +977,17 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
     }
 }
 
+// dst = bf16(float(dst) + src): the fp32 RoIAlign-backward pyramid joins a gradient that is already in dst (the RPN head's dL/dP)
+__global__ __launch_bounds__(256) void f32_to_bf16_add_kernel(const float* __restrict__ src, bf16_raw* __restrict__ dst, long long n8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src + i * 8), b = *reinterpret_cast<const f32x4_t*>(src + i * 8 + 4);
+        const u32x4_t d = *reinterpret_cast<const u32x4_t*>(dst + i * 8);
+        u32x4_t o = {pack_bf2(a[0] + bf_lo(d[0]), a[1] + bf_hi(d[0])), pack_bf2(a[2] + bf_lo(d[1]), a[3] + bf_hi(d[1])),
+                     pack_bf2(b[0] + bf_lo(d[2]), b[1] + bf_hi(d[2])), pack_bf2(b[2] + bf_lo(d[3]), b[3] + bf_hi(d[3]))};
+        *reinterpret_cast<u32x4_t*>(dst + i * 8) = o;
+    }
+}
+
 inline int next_pow2_i(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -1265,6 +1276,16 @@ extern "C" int bd_f32_to_bf16(const float* src, void* dst, int64_t n, bd_stream_
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (bf16_raw*)dst, (long long)(n / 8));
     BD_CHECK_LAUNCH("bd_f32_to_bf16");
+    return BD_OK;
+}
+
+extern "C" int bd_f32_to_bf16_add(const float* src, void* dst, int64_t n, bd_stream_t stream) {
+    BD_REQUIRE(src && dst && n >= 0 && n % 8 == 0, "f32_to_bf16_add: n must be a multiple of 8");
+    if (n == 0) return BD_OK;
+    long long g = cdiv64(n / 8, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(f32_to_bf16_add_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (bf16_raw*)dst, (long long)(n / 8));
+    BD_CHECK_LAUNCH("bd_f32_to_bf16_add");
     return BD_OK;
 }
 

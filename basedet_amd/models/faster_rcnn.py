@@ -203,9 +203,10 @@ class FasterRCNN(FPNDetector):
         ops.rpn_loss_fwd_bwd(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.rpn_labels, pl.rpn_offsets, pl.pyr.pixels,
                              m.LOSSES.RPN_SMOOTH_L1_BETA, pl.rpn_num_valid, pl.loss_buf[0:2], pl.d_rpn_raw)
         pl.rpn_bwd_done = False
-        if side is not None and self.roi_bwd_pk and not self.deterministic_roi_bwd:
+        if side is not None and not self.deterministic_roi_bwd:
             # the RPN head's backward needs nothing from the proposal chain: it runs now, under it, and leaves the FIRST contribution
-            # to dL/dP; the RoIAlign backward adds its packed atomics on top later (head_backward)
+            # to dL/dP; the RoIAlign backward joins it later (head_backward: the fp32 pyramid through an accumulating conversion,
+            # the packed atomics directly on top)
             self._rpn_head_backward(pl, pl.wgrad_ws, pl.colsum_ws, first=True)
             pl.rpn_bwd_done = True
         # ---- RCNN: sampling, RoIAlign, box head, losses
@@ -258,7 +259,7 @@ class FasterRCNN(FPNDetector):
             pl.g_feat32.zero_()
             ops.roi_align_bwd(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
                               self.pool, 2, pl.g_feat32)
-            ops.f32_to_bf16(pl.g_feat32, pl.g_P)
+            ops.f32_to_bf16(pl.g_feat32, pl.g_P, accumulate=pl.rpn_bwd_done)
         # RPN head (unless get_losses already ran it under the proposal chain)
         if not pl.rpn_bwd_done:
             self._rpn_head_backward(pl, ws, cws, first=False)

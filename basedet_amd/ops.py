@@ -510,8 +510,12 @@ def subsample2x_bwd_add(g_dst, gdst: Geom, g_src, gsrc: Geom, Cn):
                                      gsrc.H[0], gsrc.W[0], Cn, gsrc.N, stream_ptr()), "bd_subsample2x_bwd_add")
 
 
-def f32_to_bf16(src, dst):
-    check(L().bd_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "bd_f32_to_bf16")
+def f32_to_bf16(src, dst, accumulate=False):
+    """dst = bf16(src), or bf16(float(dst) + src) with accumulate."""
+    if accumulate:
+        check(L().bd_f32_to_bf16_add(ptr(src), ptr(dst), src.numel(), stream_ptr()), "bd_f32_to_bf16_add")
+    else:
+        check(L().bd_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "bd_f32_to_bf16")
 
 
 def rpn_loss_fwd_bwd(raw, ldc, A, cls_off, box_off, labels, targets, rows, beta, num_valid, loss2, draw):

@@ -463,6 +463,9 @@ int bd_subsample2x_fwd(const void* src, int64_t src_pix_per_img, int64_t src_off
 int bd_subsample2x_bwd_add(const void* gdst, int64_t dst_pix_per_img, int64_t dst_off, void* gsrc,
                            int64_t src_pix_per_img, int64_t src_off, int Hs, int Ws, int C, int N, bd_stream_t stream);
 int bd_f32_to_bf16(const float* src, void* dst, int64_t n, bd_stream_t stream);
+/* dst = bf16(float(dst) + src): the fp32 RoIAlign-backward pyramid joins the gradient already in dst -- the RPN head's dL/dP, whose
+ * backward runs under the proposal chain (rpn.py:70-132 / rcnn.py:52-83 are independent up to that sum). n % 8 == 0. */
+int bd_f32_to_bf16_add(const float* src, void* dst, int64_t n, bd_stream_t stream);
 
 /* RPN losses (rpn.py:113-131): loss2[0] += mean BCE-with-logits over labels >= 0, loss2[1] += smooth-L1 sum over
  * labels > 0 / max(num_valid, 1); d_raw gets both gradients at the channels of the fused prediction row. */
