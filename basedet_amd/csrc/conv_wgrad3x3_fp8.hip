@@ -11,8 +11,8 @@
 // 8 x 16 output patch; k = 32 g4 + 8 t + j  <->  patch pixel 32 t + 8 g4 + j (row 2t + (g4 >> 1), column 8 (g4 & 1) + j), the same
 // permutation for both operands, chosen so that the two 16-lane groups of a half-wave read 16 consecutive LDS rows: with 64-byte rows
 // at an 80-byte pitch that is every bank exactly once.  A tap only shifts the row of the X fragment by r * 18 + s rows -- an address
-// immediate.  A workgroup stages, per K step, the patch of G (128 pixels x 64 co) and the 10 x 18 input patch of X (180 pixels x 64
-// ci); eight waves, each 16 ci x 32 co of all nine taps (72 fp32 accumulators: the bf16 kernel's 16 x 64 wave tile plus eight-dword
+// immediate.  A workgroup stages, per K step, the patch of G (128 pixels x 32 co) and the 10 x 18 input patch of X (180 pixels x 64
+// ci) -- since round 2's last revision a 64 ci x 32 co tile per FOUR-wave workgroup, two independent workgroups per CU; each wave 16 ci x 32 co of all nine taps (72 fp32 accumulators: the bf16 kernel's 16 x 64 wave tile plus eight-dword
 // fragments spilled, and a reloaded spill waits in vmcnt order behind the prefetch): 18 MFMAs of K = 128 per wave and step.  Split over patches into fp32 slabs, summed
 // by conv_wgrad.hip's fixed-order reduce; products of e4m3 x e5m2 are exact in fp32, the 1 / (act_scale * grad_scale) factor is
 // applied when the slab is written.  The bias gradient is not fused here (it would be a sum of e5m2 values): bd_colsum_bf16 on the
@@ -25,18 +25,21 @@ constexpr int F8_PH = 8, F8_PW = 16;                 // output patch = 128 pixel
 constexpr int F8_XW = F8_PW + 2, F8_XH = F8_PH + 2;  // input patch 10 x 18
 constexpr int F8_XROWS = F8_XW * F8_XH;              // 180
 constexpr int F8_GROWS = F8_PH * F8_PW;              // 128
-constexpr int F8_TILE = 64;                          // channels per tile side (both)
+constexpr int F8_TILE = 64;                          // input channels per tile
+constexpr int F8_TCO = 32;                           // output channels per tile: FOUR waves of 16 ci x 32 co, two independent workgroups per CU
+                                                     // (the eight-wave 64 x 64 form was one workgroup per CU: both waves of a SIMD at the same barrier)
 #ifndef F8_PITCH_OVERRIDE
 #define F8_PITCH_OVERRIDE 80
 #endif
 constexpr int F8_PITCH = F8_PITCH_OVERRIDE;          // 64 B of channels + 16 B pad: 16 consecutive rows x 16 B hit all 64 banks
 constexpr int F8_X_BYTES = F8_XROWS * F8_PITCH;      // 14 400
-constexpr int F8_G_BYTES = F8_GROWS * F8_PITCH;      // 10 240
-constexpr int F8_BUF = F8_X_BYTES + F8_G_BYTES;      // 24 640
+constexpr int F8_GPITCH = 48;                         // 32 B of channels + 16 B pad (12 dwords: 16 consecutive rows x 16 B hit all 64 banks)
+constexpr int F8_G_BYTES = F8_GROWS * F8_GPITCH;     // 6 144
+constexpr int F8_BUF = F8_X_BYTES + F8_G_BYTES;      // 20 544
 #ifndef F8_WGS
 #define F8_WGS 2
 #endif
-constexpr int F8_XP = 2, F8_GP = 1;                  // staging passes: 720 / 512 chunks of 16 B over 512 threads
+constexpr int F8_XP = 3, F8_GP = 1;                  // staging passes: 720 / 256 chunks of 16 B over 256 threads
 
 struct F8Seg { int patch_start, H, W, pw, in_off, out_off; };
 
@@ -56,10 +59,10 @@ struct WF8Params {
 typedef __attribute__((ext_vector_type(8))) int i32x8_w8_t;
 typedef __attribute__((ext_vector_type(2))) int i32x2_w8_t;
 
-__global__ __launch_bounds__(512, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF8Params p) {
+__global__ __launch_bounds__(256, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF8Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cih = wave & 3, coh = wave >> 2;        // this wave's 16 input channels / 32 output channels of the 64 x 64 tile
+    const int cih = wave;                             // this wave's 16 input channels of the 64 x 32 tile (all 32 output channels)
     int bid = blockIdx.x;
     {   // XCD-aware bijective remap (conv_wgrad3x3.hip): the tiles of one split share its patches in one XCD's L2
         const int nwg = gridDim.x;
@@ -70,48 +73,89 @@ __global__ __launch_bounds__(512, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF
     const int split = bid / tiles;
     bid -= split * tiles;
     const int ci_tile = bid / p.co_tiles, co_tile = bid - ci_tile * p.co_tiles;
-    const int ci0 = ci_tile * F8_TILE, co0 = co_tile * F8_TILE;
+    const int ci0 = ci_tile * F8_TILE, co0 = co_tile * F8_TCO;
     const int pbeg = split * p.patches_per_split;
     int pend = pbeg + p.patches_per_split;
     if (pend > p.total_patches) pend = p.total_patches;
 
-    // staging slots: chunk c = tid + 256 k -> LDS row c >> 2, 16-channel chunk tid & 3
-    const int chunk = tid & 3;
-    const bool x_cok = ci0 + chunk * 16 < p.Cin, g_cok = co0 + chunk * 16 < p.Cout;     // Cin, Cout are multiples of 16
+    // staging slots: X chunk c = tid + 256 k -> LDS row c >> 2, 16-channel chunk tid & 3; G: row tid >> 1, 16-channel chunk tid & 1
+    const int chunk = tid & 3, gchunk = tid & 1;
+    const bool x_cok = ci0 + chunk * 16 < p.Cin, g_cok = co0 + gchunk * 16 < p.Cout;     // Cin, Cout are multiples of 16
     u32x4_t rx[F8_XP], rg[F8_GP];
     constexpr unsigned X_NONE = 0x80000000u;          // past the end of either tensor (the host checks < 2 GB): reads as zeros
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.g), 0, p.g_bytes, 0x00020000);
 
-    // (144 accumulators + 40 fragment registers leave nothing for cached per-thread offsets: they are recomputed per patch -- a few
-    // integer operations against 36 MFMAs of 32 cycles)
-    auto stage_load = [&](int pid) {
-        const int n = pid / p.patches_per_img;
-        const int rem = pid - n * p.patches_per_img;
-        int s = 0;
-#pragma unroll
-        for (int k = 1; k < BD_MAX_SEGS; ++k)
-            if (k < p.nseg && rem >= p.seg[k].patch_start) s = k;
-        const F8Seg sg = p.seg[s];
-        const int local = rem - sg.patch_start;
-        const int by = local / sg.pw, bx = local - by * sg.pw;
-        const int y0 = by * F8_PH, x0 = bx * F8_PW;
-        const int ys = y0 - 1, xs = x0 - 1;
-        const int xorg = (n * p.in_ppi + sg.in_off + ys * sg.W + xs) * p.Cin + ci0 + chunk * 16;       // may be negative; valid sums are not
-        const int gorg = (n * p.out_ppi + sg.out_off + y0 * sg.W + x0) * p.Cout + co0 + chunk * 16;
+    // Patch cursor + one-instruction loads for interior patches, as conv_wgrad3x3.hip: a split walks consecutive patch ids (increment
+    // with carries instead of two divisions, a level search and a descriptor fetch per patch), the per-thread byte offsets are per-level
+    // constants with X_NONE folded in, and the patch origin rides in the buffer instruction's scalar offset.  This kernel runs as ONE
+    // eight-wave workgroup per CU -- both waves of a SIMD sit at the same barrier -- so nothing hides the decode: it was the larger part of
+    // a patch step (18 MFMAs of 32 cycles per wave).
+    int c_n = 0, c_s = 0, c_by = 0, c_bx = 0, c_rows = 1;
+    F8Seg sg = p.seg[0];
+    unsigned x_vec[F8_XP], g_vec[F8_GP];
+    auto level_vectors = [&]() {
 #pragma unroll
         for (int k = 0; k < F8_XP; ++k) {
-            const int row = (tid + 512 * k) >> 2;
+            const int row = (tid + 256 * k) >> 2;
             const int iy = row / F8_XW, ix = row - iy * F8_XW;
-            const int y = ys + iy, x = xs + ix;
-            const bool ok = row < F8_XROWS && x_cok && y >= 0 && x >= 0 && y < sg.H && x < sg.W;
-            rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(xorg + (iy * sg.W + ix) * p.Cin) : X_NONE, 0, 0);
+            x_vec[k] = (row < F8_XROWS && x_cok) ? (unsigned)((iy * sg.W + ix) * p.Cin + chunk * 16) : X_NONE;
         }
 #pragma unroll
         for (int k = 0; k < F8_GP; ++k) {
-            const int row = (tid + 512 * k) >> 2;
-            const bool ok = g_cok && y0 + (row >> 4) < sg.H && x0 + (row & 15) < sg.W;
-            rg[k] = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, ok ? (unsigned)(gorg + ((row >> 4) * sg.W + (row & 15)) * p.Cout) : X_NONE, 0, 0);
+            const int row = tid >> 1;
+            g_vec[k] = g_cok ? (unsigned)(((row >> 4) * sg.W + (row & 15)) * p.Cout + gchunk * 16) : X_NONE;
+        }
+    };
+    auto seek = [&](int pid) {
+        c_n = pid / p.patches_per_img;
+        const int rem = pid - c_n * p.patches_per_img;
+        c_s = 0;
+#pragma unroll
+        for (int k = 1; k < BD_MAX_SEGS; ++k)
+            if (k < p.nseg && rem >= p.seg[k].patch_start) c_s = k;
+        sg = p.seg[c_s];
+        const int local = rem - sg.patch_start;
+        c_by = local / sg.pw; c_bx = local - c_by * sg.pw;
+        c_rows = (sg.H + F8_PH - 1) / F8_PH;
+        level_vectors();
+    };
+    auto advance = [&]() {
+        if (++c_bx < sg.pw) return;
+        c_bx = 0;
+        if (++c_by < c_rows) return;
+        c_by = 0;
+        if (p.nseg == 1) { ++c_n; return; }
+        if (++c_s == p.nseg) { c_s = 0; ++c_n; }
+        sg = p.seg[c_s];
+        c_rows = (sg.H + F8_PH - 1) / F8_PH;
+        level_vectors();
+    };
+    auto stage_load = [&]() {
+        const int y0 = c_by * F8_PH, x0 = c_bx * F8_PW;
+        const int ys = y0 - 1, xs = x0 - 1;
+        const int xorg = (c_n * p.in_ppi + sg.in_off + ys * sg.W + xs) * p.Cin + ci0;       // may be negative; valid sums are not
+        const int gorg = (c_n * p.out_ppi + sg.out_off + y0 * sg.W + x0) * p.Cout + co0;
+        if (ys >= 0 && xs >= 0 && ys + F8_XH <= sg.H && xs + F8_XW <= sg.W) {                 // workgroup-uniform: every pixel of both patches exists
+#pragma unroll
+            for (int k = 0; k < F8_XP; ++k) rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, x_vec[k], xorg, 0);
+#pragma unroll
+            for (int k = 0; k < F8_GP; ++k) rg[k] = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_vec[k], gorg, 0);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < F8_XP; ++k) {
+            const int row = (tid + 256 * k) >> 2;
+            const int iy = row / F8_XW, ix = row - iy * F8_XW;
+            const int y = ys + iy, x = xs + ix;
+            const bool ok = y >= 0 && x >= 0 && y < sg.H && x < sg.W;       // unused slots / channel tails: x_vec is X_NONE already
+            rx[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (ok && x_vec[k] != X_NONE) ? (unsigned)xorg + x_vec[k] : X_NONE, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < F8_GP; ++k) {
+            const int row = tid >> 1;
+            const bool ok = y0 + (row >> 4) < sg.H && x0 + (row & 15) < sg.W;
+            rg[k] = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (ok && g_vec[k] != X_NONE) ? (unsigned)gorg + g_vec[k] : X_NONE, 0, 0);
         }
     };
     auto stage_write = [&](int buf) {
@@ -119,13 +163,13 @@ __global__ __launch_bounds__(512, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF
         unsigned char* Gt = Xt + F8_X_BYTES;
 #pragma unroll
         for (int k = 0; k < F8_XP; ++k) {
-            const int row = (tid + 512 * k) >> 2;
+            const int row = (tid + 256 * k) >> 2;
             if (row < F8_XROWS) *reinterpret_cast<u32x4_t*>(Xt + row * F8_PITCH + chunk * 16) = rx[k];
         }
 #pragma unroll
         for (int k = 0; k < F8_GP; ++k) {
-            const int row = (tid + 512 * k) >> 2;
-            *reinterpret_cast<u32x4_t*>(Gt + row * F8_PITCH + chunk * 16) = rg[k];
+            const int row = tid >> 1;
+            *reinterpret_cast<u32x4_t*>(Gt + row * F8_GPITCH + gchunk * 16) = rg[k];
         }
     };
 
@@ -139,15 +183,15 @@ __global__ __launch_bounds__(512, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF
     const int tr_q = idx >> 1, tr_p = idx & 1;        // this lane supplies row tr_q, channels 8 tr_p .. + 7 of the group's 8 x 16 block
     // lane-constant parts of the fragment addresses: patch row (g4 >> 1) of the read's row pair, column 8 (g4 & 1) + tr_q
     const int x_lane_off = ((g4 >> 1) * F8_XW + 8 * (g4 & 1) + tr_q) * F8_PITCH + cih * 16 + 8 * tr_p;
-    const int g_lane_off = ((g4 >> 1) * F8_PW + 8 * (g4 & 1) + tr_q) * F8_PITCH + coh * 32 + 8 * tr_p;
+    const int g_lane_off = ((g4 >> 1) * F8_PW + 8 * (g4 & 1) + tr_q) * F8_GPITCH + 8 * tr_p;
     const int one = 0x7f7f7f7f;                       // E8M0 block scales: 2^0
 
     // one operand fragment = the lane's 32 k = four transposing reads (t = 0 .. 3: patch rows 2t, 2t + 1), 8 bytes each
-    auto frag = [&](const unsigned char* a0, int roww) -> i32x8_w8_t {
+    auto frag = [&](const unsigned char* a0, int row_bytes) -> i32x8_w8_t {       // row_bytes = patch-row pitch in bytes
         i32x8_w8_t f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const i32x2_w8_t v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2_w8_t*)(a0 + 2 * t * roww * F8_PITCH));
+            const i32x2_w8_t v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2_w8_t*)(a0 + 2 * t * row_bytes));
             f[2 * t] = v[0]; f[2 * t + 1] = v[1];
         }
         return f;
@@ -159,11 +203,11 @@ __global__ __launch_bounds__(512, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF
         __builtin_amdgcn_s_setprio(1);
         i32x8_w8_t b[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = frag(Gt + j * 16, F8_PW);
+        for (int j = 0; j < 2; ++j) b[j] = frag(Gt + j * 16, F8_PW * F8_GPITCH);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int r = t / 3, s = t % 3;
-            const i32x8_w8_t a = frag(Xt + (r * F8_XW + s) * F8_PITCH, F8_XW);
+            const i32x8_w8_t a = frag(Xt + (r * F8_XW + s) * F8_PITCH, F8_XW * F8_PITCH);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[t][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b[j], acc[t][j], 0, 1, 0, one, 0, one);   // A e4m3, B e5m2
@@ -172,14 +216,16 @@ __global__ __launch_bounds__(512, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF
     };
 
     if (pbeg < pend) {
-        stage_load(pbeg);
+        seek(pbeg);
+        stage_load();
+        advance();
         stage_write(0);
     }
     __syncthreads();
     int cur = 0;
     for (int pid = pbeg; pid < pend; ++pid) {
         const bool more = pid + 1 < pend;
-        if (more) stage_load(pid + 1);
+        if (more) { stage_load(); advance(); }
         compute(cur);
         if (more) stage_write(cur ^ 1);
         __syncthreads();
@@ -189,7 +235,7 @@ __global__ __launch_bounds__(512, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF
     float* slab = p.slab + (long long)split * p.Cout * 9 * p.Cin;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int co = co0 + coh * 32 + j * 16 + idx;
+        const int co = co0 + j * 16 + idx;
         if (co >= p.Cout) continue;
         const int ci = ci0 + cih * 16 + g4 * 4;
         if (ci >= p.Cin) continue;
@@ -211,7 +257,7 @@ int f8_patches(const bd_conv_desc* d, int* ppi_out) {
 
 int f8_splits(const bd_conv_desc* d) {
     const int total = f8_patches(d, nullptr);
-    const int tiles = cdiv(d->Cin, F8_TILE) * cdiv(d->Cout, F8_TILE);
+    const int tiles = cdiv(d->Cin, F8_TILE) * cdiv(d->Cout, F8_TCO);
     int splits = 512 / tiles;                          // workgroups per launch: two per CU (the bf16 kernel's measured optimum)
     if (splits < 1) splits = 1;
     if (splits > total) splits = total;
@@ -256,7 +302,7 @@ extern "C" int bd_conv2d_wgrad_fp8(const bd_conv_desc* d, const void* x8, const 
     const int total = f8_patches(d, &ppi);
     const int splits = f8_splits(d);
     p.total_patches = total; p.patches_per_img = ppi; p.patches_per_split = cdiv(total, splits);
-    p.ci_tiles = cdiv(d->Cin, F8_TILE); p.co_tiles = cdiv(d->Cout, F8_TILE);
+    p.ci_tiles = cdiv(d->Cin, F8_TILE); p.co_tiles = cdiv(d->Cout, F8_TCO);
     int ps = 0;
     for (int s = 0; s < d->nseg; ++s) {
         F8Seg& sg = p.seg[s];
@@ -270,7 +316,7 @@ extern "C" int bd_conv2d_wgrad_fp8(const bd_conv_desc* d, const void* x8, const 
         attr_set = true;
     }
     const int grid = splits * p.ci_tiles * p.co_tiles;
-    hipLaunchKernelGGL(conv_wgrad3x3_fp8_kernel, dim3(grid), dim3(512), 2 * F8_BUF, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_wgrad3x3_fp8_kernel, dim3(grid), dim3(256), 2 * F8_BUF, (hipStream_t)stream, p);
     BD_CHECK_LAUNCH("bd_conv2d_wgrad_fp8");
     bd_wgrad_reduce_launch((const float*)ws, splits, (long long)d->Cout * 9 * d->Cin, 9 * d->Cin, row_scale, dw, accumulate, (hipStream_t)stream);
     BD_CHECK_LAUNCH("bd_conv2d_wgrad_fp8(reduce)");
