@@ -36,7 +36,23 @@ struct P1 {
     unsigned x_bytes, w_bytes;
     int m_tiles, n_tiles;
     const float* wscale;      // fp8 kernel: per-output-channel epilogue multiplier (bd_weight_pack_fp8 / _t)
+    // 1x1 / stride 2 (the bottleneck shortcuts): the GEMM rows are the pixels of the SMALL grid (dW x dHW / dW per image); s2_src: the
+    // source rows lie at (2y, 2x) of the big grid (forward), s2_dst: the destination / residual / gate rows do (data gradient added in
+    // place at the pixels it reaches).  Mbig = pixels of the big grid (bit-packed gates are indexed by it).
+    int s2_src, s2_dst, dW, dHW, bW, bHW, Mbig;
+    float inv_dW, inv_dHW;
 };
+
+// row of the big grid under small-grid pixel m (m < 2^24: the float quotients are within one of the integer ones)
+__device__ __forceinline__ int s2_big_row(const P1& p, int m) {
+    int n = (int)((float)m * p.inv_dHW);
+    int r = m - n * p.dHW;
+    if (r < 0) { --n; r += p.dHW; } else if (r >= p.dHW) { ++n; r -= p.dHW; }
+    int y = (int)((float)r * p.inv_dW);
+    int x = r - y * p.dW;
+    if (x < 0) { --y; x += p.dW; } else if (x >= p.dW) { ++y; x -= p.dW; }
+    return n * p.bHW + 2 * y * p.bW + 2 * x;
+}
 
 __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
     a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
         const int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
         a_voff[i] = co < p.CO ? (unsigned)(co * p.CK + chunk * 8) * 2u : X_NONE;
         const int m = m0 + lrow;
-        b_voff[i] = m < p.M ? (unsigned)(m * p.CK + chunk * 8) * 2u : X_NONE;
+        b_voff[i] = m < p.M ? (unsigned)((p.s2_src ? s2_big_row(p, m) : m) * p.CK + chunk * 8) * 2u : X_NONE;
     }
     const int nsteps = (p.CK + BK - 1) / BK;
 
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
             const int lrow = 16 * (wave + NWAVE * k) + (lane >> 2);
             const int ch = (lane & 3) ^ ((lrow >> 1) & 3);
             const int m = m0 + lrow;
-            b_src[k] = m < p.M ? (unsigned)(m * p.CK + ch * 8) * 2u : X_NONE;
+            b_src[k] = m < p.M ? (unsigned)((p.s2_src ? s2_big_row(p, m) : m) * p.CK + ch * 8) * 2u : X_NONE;
         }
         const int uwave = __builtin_amdgcn_readfirstlane(wave);
         auto dma = [&](int step, int stage) {
@@ -276,11 +292,12 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
         const int j = q >> 1, half = q & 1;
         const int m = m0 + wp * 64 + j * 16 + (lane & 15);
         const bool ok = m < p.M && cbase + 32 * half < p.CO;
-        const long long idx = (long long)m * p.CO + cbase + 32 * half;
+        const int drow = (p.s2_dst && ok) ? s2_big_row(p, m) : m;
+        const long long idx = (long long)drow * p.CO + cbase + 32 * half;
         e_aux[qq] = (u32x4_t){0u, 0u, 0u, 0u}; e_bits[qq] = 0u;
         if (ok && want_add) e_aux[qq] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
         else if (ok && mask_bf) e_aux[qq] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
-        if (ok && mask_bits) e_bits[qq] = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * p.M + m];
+        if (ok && mask_bits) e_bits[qq] = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * (p.s2_dst ? p.Mbig : p.M) + drow];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -290,7 +307,8 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
         const int m = m0 + wp * 64 + j * 16 + (lane & 15);
         {
             const bool ok = m < p.M && cbase + 32 * half < p.CO;      // CO % 8 == 0
-            const long long idx = (long long)m * p.CO + cbase + 32 * half;
+            const int drow = (p.s2_dst && ok) ? s2_big_row(p, m) : m;
+            const long long idx = (long long)drow * p.CO + cbase + 32 * half;
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = acc[2 * half + (k >> 2)][j][k & 3] + bias[8 * half + k];
@@ -865,6 +883,40 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     }
     const size_t lds = 4 * TILE_BYTES;
     hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, false>), dim3(grid), dim3(256), lds, stream, p);
+    return 0;
+}
+
+// 1x1 / stride 2 / pad 0 over one dense level (the bottleneck shortcut convolutions) on the same kernel: mode 0 = forward (the source rows
+// are the (2y, 2x) pixels of the input), mode 1 = the data gradient ADDED IN PLACE at the pixels it reaches (BD_EPI_SPARSE with
+// BD_EPI_ADD_BEFORE and add == dx; the other pixels of dx keep what they hold).  Called from conv_igemm.hip; 0 = taken.
+int g_conv1x1_s2 = 1;        // bd_conv_set_patch3x3 bit 12 clears it (A/B against the generic kernel)
+int bd_conv1x1_s2_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add, const void* mask,
+                         const unsigned* maskbits, void* dst, int flags, hipStream_t stream) {
+    if (!g_conv1x1_s2 || g_conv1x1_depth == 0) return 1;
+    if (!(d->R == 1 && d->S == 1 && d->stride == 2 && d->pad == 0 && d->nseg == 1 && d->in_off[0] == 0 && d->out_off[0] == 0 &&
+          d->in_pix_per_img == d->Hi[0] * d->Wi[0] && d->out_pix_per_img == d->Ho[0] * d->Wo[0])) return 1;
+    if (d->Ho[0] != (d->Hi[0] - 1) / 2 + 1 || d->Wo[0] != (d->Wi[0] - 1) / 2 + 1) return 1;
+    const long long M = (long long)d->N * d->out_pix_per_img, Mbig = (long long)d->N * d->in_pix_per_img;
+    const int CK = mode == 0 ? d->Cin : d->Cout, CO = mode == 0 ? d->Cout : d->Cin;
+    if (mode == 1 && !((flags & BD_EPI_SPARSE) && (flags & BD_EPI_ADD_BEFORE) && add == dst)) return 1;
+    if (mode == 1 && maskbits && CO % 32 != 0) return 1;
+    // 32-bit byte offsets: the source tensor and the weights below 2 GB, float-reciprocal row decode below 2^24 rows
+    const long long src_bytes = (mode == 0 ? Mbig : M) * CK * 2, wb = (long long)CO * CK * 2;
+    if (src_bytes >= 0x7fffffffll || wb >= 0x7fffffffll || M >= (1ll << 24) || Mbig >= (1ll << 30)) return 1;
+    P1 p{};
+    p.x = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias; p.add = (const bf16_raw*)add; p.mask = maskbits ? nullptr : (const bf16_raw*)mask;
+    p.maskbits = maskbits; p.y = (bf16_raw*)dst; p.q_scale = 1.f;
+    p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags & ~BD_EPI_SPARSE;
+    p.x_bytes = (unsigned)src_bytes; p.w_bytes = (unsigned)wb;
+    p.s2_src = mode == 0; p.s2_dst = mode == 1;
+    p.dW = d->Wo[0]; p.dHW = d->Ho[0] * d->Wo[0]; p.bW = d->Wi[0]; p.bHW = d->Hi[0] * d->Wi[0]; p.Mbig = (int)Mbig;
+    p.inv_dW = 1.0f / (float)p.dW; p.inv_dHW = 1.0f / (float)p.dHW;
+    p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
+    const int grid = p.m_tiles * p.n_tiles;
+    if (CK % BK == 0 && CK >= g_conv1x1_dma_k && (CK <= 1024 || g_conv1x1_dma_k < 512))
+        hipLaunchKernelGGL((conv1x1_dense_kernel<1, 3, true>), dim3(grid), dim3(256), 6 * TILE_BYTES, stream, p);
+    else
+        hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, false>), dim3(grid), dim3(256), 4 * TILE_BYTES, stream, p);
     return 0;
 }
 

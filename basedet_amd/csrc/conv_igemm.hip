@@ -458,6 +458,7 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
 extern int g_patch_dma;
 extern int g_patch_pp;
 extern int g_patch_pp128;
+extern int g_conv1x1_s2;
 extern "C" int bd_conv_set_patch3x3(int enable) {
     g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1;
     g_patch_dma = ((enable >> 3) & 1) ^ 1;
@@ -466,12 +467,16 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_bk32_s2 = ((enable >> 10) & 1) ^ 1;
     g_igemm_prefetch_epi = ((enable >> 5) & 1) ^ 1;
     g_igemm_buf = ((enable >> 11) & 1) ^ 1;
+    g_conv1x1_s2 = ((enable >> 12) & 1) ^ 1;
     return BD_OK;
 }
 
 int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits,
                             void* y, unsigned* ybits, void* y8, float q_scale, int y8_bf8, long long M, int CK, int CO, int flags,
                             hipStream_t stream);
+
+int bd_conv1x1_s2_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add, const void* mask,
+                         const unsigned* maskbits, void* dst, int flags, hipStream_t stream);
 
 namespace {
 // 1x1 / stride 1 / pad 0 over one dense level: source pixel index == destination pixel index (conv1x1.hip)
@@ -492,6 +497,11 @@ static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_p
         bd_conv1x1_dense_launch(x, w_packed, bias, add, nullptr, nullptr, y, ybits, y8, q_scale, 0, (long long)d->N * d->out_pix_per_img,
                                 d->Cin, d->Cout, flags, (hipStream_t)stream) == 0) {
         BD_CHECK_LAUNCH("bd_conv2d_fwd(dense 1x1)");
+        return BD_OK;
+    }
+    if (!ybits && !y8 && d->stride == 2 && d->R == 1 &&
+        bd_conv1x1_s2_launch(d, 0, x, w_packed, bias, add, nullptr, nullptr, y, flags, (hipStream_t)stream) == 0) {
+        BD_CHECK_LAUNCH("bd_conv2d_fwd(1x1 stride 2)");
         return BD_OK;
     }
     BD_REQUIRE(ybits == nullptr && y8 == nullptr, "conv2d_fwd_bits / _ex: the bit-packed ReLU mask and the e4m3 twin are written by the dense "
@@ -560,6 +570,11 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
         bd_conv1x1_dense_launch(g, w_packed_t, nullptr, add, mask, maskbits, dx, nullptr, dx8, q_scale, 1, (long long)d->N * d->in_pix_per_img,
                                 d->Cout, d->Cin, flags, (hipStream_t)stream) == 0) {
         BD_CHECK_LAUNCH("bd_conv2d_dgrad(dense 1x1)");
+        return BD_OK;
+    }
+    if (!dx8 && d->stride == 2 && d->R == 1 &&
+        bd_conv1x1_s2_launch(d, 1, g, w_packed_t, nullptr, add, mask, maskbits, dx, flags, (hipStream_t)stream) == 0) {
+        BD_CHECK_LAUNCH("bd_conv2d_dgrad(1x1 stride 2)");
         return BD_OK;
     }
     BD_REQUIRE(maskbits == nullptr && dx8 == nullptr, "conv2d_dgrad_bits / _ex: the bit-packed ReLU mask is read, and the e5m2 twin written, by "
