@@ -408,6 +408,11 @@ def test_subsample_and_convert():
     y = torch.empty(4096, dtype=torch.bfloat16, device="cuda")
     ops.f32_to_bf16(x, y)
     assert torch.equal(y, x.to(torch.bfloat16))
+    # accumulating form (the fp32 RoIAlign-backward pyramid joins the RPN head's dL/dP): dst = bf16(float(dst) + src), one rounding
+    base = torch.randn(4096, device="cuda").to(torch.bfloat16)
+    y2 = base.clone()
+    ops.f32_to_bf16(x, y2, accumulate=True)
+    assert torch.equal(y2, (base.float() + x).to(torch.bfloat16))
 
 
 def test_rpn_loss():
