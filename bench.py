@@ -73,7 +73,7 @@ class KernelTimer:
             m = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
             return 2.0 * m * d.Cin * d.Cout * d.R * d.S
 
-        def kernel_of(d, kind, dgrad=False):
+        def kernel_of(d, kind, dgrad=False, flags=0):
             """Which HIP kernel serves this descriptor (mirrors the dispatch in csrc/conv_igemm.hip / conv3x3.hip /
             conv3x3_pp.hip / conv_wgrad.hip with the default bd_conv_set_patch3x3 mask)."""
             same = all(d.Hi[i] == d.Ho[i] and d.Wi[i] == d.Wo[i] for i in range(d.nseg))
@@ -82,7 +82,11 @@ class KernelTimer:
             if kind == "igemm":
                 dense = (is1 and d.stride == 1 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0
                          and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0])
-                if dense:
+                # ... and the 1x1 / stride-2 shortcuts since round 2 (strided source rows forward; the in-place sparse data gradient)
+                dense_s2 = (is1 and d.stride == 2 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0
+                            and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0]
+                            and (not dgrad or (flags & ops.EPI_SPARSE)))
+                if dense or dense_s2:
                     return "conv1x1_dense_kernel"          # conv1x1.hip: every 1x1 / stride 1 launch over one dense level
                 if not is3:
                     # generic kernel: BK = 32 instance for 1x1 filters (and Cin <= 32) and for stride-2 launches of >= 512 tiles,
@@ -113,12 +117,14 @@ class KernelTimer:
                 s.record()
                 r = fn(d, *a, **k)
                 e.record()
-                kern = kernel_of(d, kind, fn.__name__ == "conv2d_dgrad")
+                kern = kernel_of(d, kind, fn.__name__ == "conv2d_dgrad", int(k.get("flags") or 0))
                 self.records.setdefault(kern, []).append((s, e, flops(d)))
                 # algorithmic HBM bytes: every operand once -- both activations, the weights, and the epilogue's add / mask
                 # operands (residual, ReLU mask), which have the shape of the result
                 mi = sum(d.Hi[i] * d.Wi[i] for i in range(d.nseg)) * d.N
                 mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
+                if kind == "igemm" and d.R * d.S == 1 and d.stride == 2 and (fn.__name__ != "conv2d_dgrad" or (int(k.get("flags") or 0) & ops.EPI_SPARSE)):
+                    mi = mo          # a 1x1 / stride-2 launch touches the quarter of the big grid's pixels it reaches (forward reads, sparse dgrad writes)
                 nbytes = 2.0 * (mi * d.Cin + mo * d.Cout) + (4.0 if kind == "wgrad" else 2.0) * d.Cin * d.Cout * d.R * d.S
                 if kind == "igemm":
                     res = 2.0 * (mi * d.Cin if fn.__name__ == "conv2d_dgrad" else mo * d.Cout)
