@@ -88,9 +88,9 @@ __global__ __launch_bounds__(256, F8_WGS) void conv_wgrad3x3_fp8_kernel(const WF
 
     // Patch cursor + one-instruction loads for interior patches, as conv_wgrad3x3.hip: a split walks consecutive patch ids (increment
     // with carries instead of two divisions, a level search and a descriptor fetch per patch), the per-thread byte offsets are per-level
-    // constants with X_NONE folded in, and the patch origin rides in the buffer instruction's scalar offset.  This kernel runs as ONE
-    // eight-wave workgroup per CU -- both waves of a SIMD sit at the same barrier -- so nothing hides the decode: it was the larger part of
-    // a patch step (18 MFMAs of 32 cycles per wave).
+    // constants with X_NONE folded in, and the patch origin rides in the buffer instruction's scalar offset.  (Measured first on the
+    // eight-wave form of this kernel -- one workgroup per CU, both waves of a SIMD at the same barrier, nothing to hide the decode
+    // behind: +12-19 % -- and kept in the four-wave form: the decode was the larger part of a patch step of 18 MFMAs of 32 cycles.)
     int c_n = 0, c_s = 0, c_by = 0, c_bx = 0, c_rows = 1;
     F8Seg sg = p.seg[0];
     unsigned x_vec[F8_XP], g_vec[F8_GP];

@@ -127,7 +127,8 @@ int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const void* g, co
  * tile serves Cout <= 64 by default); bit 9 = none of the conv3x3_pp128.hip instances; bit 10 = BK=64 tiles for the stride-2 3x3
  * launches of the generic kernel (by default BK=32 when the grid has >= 512 tiles: more workgroups per CU for their short K loops);
  * bit 11 = 64-bit pointer staging in the generic kernel instead of range-checked buffer loads (taken by default when the source tensor
- * and the packed weights are < 2 GB each). */
+ * and the packed weights are < 2 GB each); bit 12 = the 1x1 / stride-2 launches over one dense level (forward, and the data gradient
+ * with BD_EPI_SPARSE) stay on the generic kernel instead of the dense 1x1 kernel with strided rows. */
 int bd_conv_set_patch3x3(int enable);
 
 /* debug/measurement knob: 1 (default) = operand transposes through ds_read_b64_tr_b16, 0 = scalar 16-bit LDS reads
