@@ -127,6 +127,8 @@ SIGNATURES = {
     "bd_conv2d_fwd_fp8_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv_fp8_set_patch": (_I, [_I]),
     "bd_quantize_bf8": (_I, [_P, _L, _F, _P, _P]),
+    "bd_absmax_bf16": (_I, [_P, _L, _P, _P]),
+    "bd_fp8_set_stochastic_rounding": (_I, [C.c_uint32]),
     "bd_weight_pack_fp8_t": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "bd_conv2d_dgrad_fp8": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_wgrad_fp8_workspace_bytes": (_Z, [_D]),

@@ -20,6 +20,27 @@ __device__ __forceinline__ bf16_raw f2bf(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
     return __builtin_bit_cast(bf16_raw, b);
 }
+// ---- stochastic rounding of the e5m2 gradients (bd_fp8_set_stochastic_rounding) ----------------------------------------------------
+// Round-to-nearest e5m2 (two mantissa bits) makes the SAME error on the same value every step; on a repeated batch those errors add up as a
+// bias and the run drifts.  With a seed set, the quantisers add a pseudo-random fraction below the kept bits before truncating
+// (v_cvt_sr_bf8_f32): unbiased, and -- the random word being a hash of (seed, element index) -- independent of which kernel variant or
+// tile writes the element.
+extern unsigned g_fp8_sr_seed;          // host side, conv_fp8.hip: 0 = round to nearest
+__device__ __forceinline__ unsigned bd_mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned bd_pack4_e5m2_sr(float a, float b, float c, float d, unsigned r) {
+    a = fminf(fmaxf(a, -57344.f), 57344.f); b = fminf(fmaxf(b, -57344.f), 57344.f);
+    c = fminf(fmaxf(c, -57344.f), 57344.f); d = fminf(fmaxf(d, -57344.f), 57344.f);
+    int v = 0;
+    v = __builtin_amdgcn_cvt_sr_bf8_f32(a, r, v, 0);
+    v = __builtin_amdgcn_cvt_sr_bf8_f32(b, r * 0x9e3779b1u + 0x7f4a7c15u, v, 1);
+    v = __builtin_amdgcn_cvt_sr_bf8_f32(c, (r >> 13) ^ (r << 19) ^ 0x2545f491u, v, 2);
+    v = __builtin_amdgcn_cvt_sr_bf8_f32(d, (r >> 7) * 0x85ebca6bu + 0xc2b2ae35u, v, 3);
+    return (unsigned)v;
+}
+
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }

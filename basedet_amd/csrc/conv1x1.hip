@@ -40,6 +40,7 @@ struct P1 {
     // source rows lie at (2y, 2x) of the big grid (forward), s2_dst: the destination / residual / gate rows do (data gradient added in
     // place at the pixels it reaches).  Mbig = pixels of the big grid (bit-packed gates are indexed by it).
     int s2_src, s2_dst, dW, dHW, bW, bHW, Mbig;
+    unsigned sr_seed;         // != 0: stochastic rounding of the e5m2 twin (common.h)
     float inv_dW, inv_dHW;
 };
 
@@ -68,6 +69,20 @@ __device__ __forceinline__ unsigned pack4_e5m2(float a, float b, float c, float 
     int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
     v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
     return (unsigned)v;
+}
+
+// eight consecutive channels (element index idx, a multiple of 8) -> eight e5m2 bytes; seed != 0: stochastic rounding (common.h)
+__device__ __forceinline__ u32x2_t e5m2_pair(const float* v, float qs, unsigned seed, long long idx) {
+    u32x2_t o8;
+    if (seed) {
+        const unsigned g0 = (unsigned)(idx >> 2);
+        o8[0] = bd_pack4_e5m2_sr(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, bd_mix32(seed ^ g0));
+        o8[1] = bd_pack4_e5m2_sr(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs, bd_mix32(seed ^ (g0 + 1)));
+    } else {
+        o8[0] = pack4_e5m2(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
+        o8[1] = pack4_e5m2(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs);
+    }
+    return o8;
 }
 
 typedef __attribute__((address_space(3))) void lds_void_1x1_t;
@@ -347,8 +362,7 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
             if (p.y8 && ok) {
                 u32x2_t o8;
                 if (p.y8_bf8) {
-                    o8[0] = pack4_e5m2(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
-                    o8[1] = pack4_e5m2(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                    o8 = e5m2_pair(v, p.q_scale, p.sr_seed, idx);
                 } else {
                     o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
                     o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
@@ -538,8 +552,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_fp8_kernel(const P1 p) {
         if (p.y8) {              // (workgroup-uniform) both halves of the pixel are packed, then the lane pairs swap: 16-byte stores
             u32x2_t o8;
             if (p.y8_bf8) {
-                o8[0] = pack4_e5m2(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
-                o8[1] = pack4_e5m2(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                o8 = e5m2_pair(v, p.q_scale, p.sr_seed, idx);
             } else {
                 o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
                 o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
@@ -785,8 +798,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_big_kernel(const P1 p) {
             if (p.y8 && ok) {
                 u32x2_t o8;
                 if (p.y8_bf8) {
-                    o8[0] = pack4_e5m2(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
-                    o8[1] = pack4_e5m2(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                    o8 = e5m2_pair(v, p.q_scale, p.sr_seed, idx);
                 } else {
                     o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
                     o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
@@ -837,6 +849,7 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     if (xb >= 0x7fffffffll || wb >= 0x7fffffffll || M >= (1ll << 24)) return 1;
     if ((maskbits || ybits) && (CO % 32 != 0)) return 1;
     P1 p{};
+    p.sr_seed = g_fp8_sr_seed;
     p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.bias = bias; p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask;
     p.maskbits = maskbits; p.y = (bf16_raw*)y; p.ybits = ybits; p.y8 = (unsigned char*)y8; p.q_scale = q_scale; p.y8_bf8 = y8_bf8;
     p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags;
@@ -904,6 +917,7 @@ int bd_conv1x1_s2_launch(const bd_conv_desc* d, int mode, const void* src, const
     const long long src_bytes = (mode == 0 ? Mbig : M) * CK * 2, wb = (long long)CO * CK * 2;
     if (src_bytes >= 0x7fffffffll || wb >= 0x7fffffffll || M >= (1ll << 24) || Mbig >= (1ll << 30)) return 1;
     P1 p{};
+    p.sr_seed = g_fp8_sr_seed;
     p.x = (const bf16_raw*)src; p.w = (const bf16_raw*)w; p.bias = bias; p.add = (const bf16_raw*)add; p.mask = maskbits ? nullptr : (const bf16_raw*)mask;
     p.maskbits = maskbits; p.y = (bf16_raw*)dst; p.q_scale = 1.f;
     p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags & ~BD_EPI_SPARSE;
@@ -936,6 +950,7 @@ extern "C" int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, c
     BD_REQUIRE(M * CK < 0x7fffffffll && M * CO * 2 < 0x7fffffffffll && M < (1ll << 24), "conv1x1_fp8: tensor too large for 32-bit offsets");
     BD_REQUIRE(!(mode == 0 && (flags & BD_EPI_MASK)) && !(mode == 1 && (flags & BD_EPI_RELU)), "conv1x1_fp8: flag / mode mismatch");
     P1 p{};
+    p.sr_seed = g_fp8_sr_seed;
     p.x = (const bf16_raw*)xq; p.w = (const bf16_raw*)wq; p.wscale = wscale; p.bias = bias; p.add = (const bf16_raw*)add;
     p.mask = maskbits ? nullptr : (const bf16_raw*)mask; p.maskbits = maskbits; p.y = (bf16_raw*)y; p.ybits = ybits;
     p.y8 = (unsigned char*)y8; p.q_scale = q_scale; p.y8_bf8 = mode;

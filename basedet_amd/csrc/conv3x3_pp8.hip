@@ -36,6 +36,7 @@ struct PParams {
     const float* wscale;           // [CO]: s_co / act_scale
     unsigned char* dst8;           // optional e4m3 twin of the output (dst * q_scale)
     float q_scale;
+    unsigned sr_seed;              // != 0: stochastic rounding of the e5m2 twin (common.h)
     const float* bias;
     const bf16_raw* add;
     const bf16_raw* mask;
@@ -380,8 +381,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
                     o8[0] = pack4_fp8(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
                     o8[1] = pack4_fp8(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
                 } else {
-                    o8[0] = pack4_bf8(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
-                    o8[1] = pack4_bf8(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                    if (p.sr_seed) {
+                        const unsigned g0 = (unsigned)(idx >> 2);
+                        o8[0] = bd_pack4_e5m2_sr(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale, bd_mix32(p.sr_seed ^ g0));
+                        o8[1] = bd_pack4_e5m2_sr(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale, bd_mix32(p.sr_seed ^ (g0 + 1)));
+                    } else {
+                        o8[0] = pack4_bf8(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                        o8[1] = pack4_bf8(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+                    }
                 }
                 *reinterpret_cast<u32x2_t*>(p.dst8 + idx) = o8;
             }
@@ -407,7 +414,7 @@ int bd_conv3x3_pp8_launch(const bd_conv_desc* d, int mode, const void* xq, const
     if ((long long)d->N * p.src_ppi * p.CK >= 0x7fffffffll || (long long)d->N * p.dst_ppi >= 0x7fffffffll ||
         (long long)p.CO * 9 * p.CK >= 0x7fffffffll) return 1;
     p.src = (const unsigned char*)xq; p.w = (const unsigned char*)wq; p.wscale = wscale; p.bias = bias;
-    p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)y; p.dst8 = (unsigned char*)y8; p.q_scale = q_scale;
+    p.add = (const bf16_raw*)add; p.mask = (const bf16_raw*)mask; p.dst = (bf16_raw*)y; p.dst8 = (unsigned char*)y8; p.q_scale = q_scale; p.sr_seed = g_fp8_sr_seed;
     p.flags = flags; p.nseg = d->nseg;
     p.src_bytes = (unsigned)((long long)d->N * p.src_ppi * p.CK);
     int ps = 0;

@@ -17,6 +17,8 @@
 
 using namespace igemm;
 
+unsigned g_fp8_sr_seed = 0;        // bd_fp8_set_stochastic_rounding: read by every e5m2 quantiser's launcher (common.h)
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
@@ -60,17 +62,44 @@ __device__ __forceinline__ unsigned pack4_bf8(float a, float b, float c, float d
 
 // x bf16 -> e5m2(x * scale): the gradient operand of the fp8 data-gradient kernel
 __global__ __launch_bounds__(256) void quantize_bf8_kernel(const bf16_raw* __restrict__ x, long long n16, float scale,
-                                                          u32x4_t* __restrict__ q) {
+                                                          u32x4_t* __restrict__ q, unsigned sr_seed) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
         const u32x4_t a = *reinterpret_cast<const u32x4_t*>(x + i * 16);
         const u32x4_t b = *reinterpret_cast<const u32x4_t*>(x + i * 16 + 8);
         u32x4_t o;
+        if (sr_seed) {            // element group g = index / 4: the same random word as a producing launch's twin of this element
+            const unsigned g0 = (unsigned)(i * 4);
+            o[0] = bd_pack4_e5m2_sr(bf_lo(a[0]) * scale, bf_hi(a[0]) * scale, bf_lo(a[1]) * scale, bf_hi(a[1]) * scale, bd_mix32(sr_seed ^ g0));
+            o[1] = bd_pack4_e5m2_sr(bf_lo(a[2]) * scale, bf_hi(a[2]) * scale, bf_lo(a[3]) * scale, bf_hi(a[3]) * scale, bd_mix32(sr_seed ^ (g0 + 1)));
+            o[2] = bd_pack4_e5m2_sr(bf_lo(b[0]) * scale, bf_hi(b[0]) * scale, bf_lo(b[1]) * scale, bf_hi(b[1]) * scale, bd_mix32(sr_seed ^ (g0 + 2)));
+            o[3] = bd_pack4_e5m2_sr(bf_lo(b[2]) * scale, bf_hi(b[2]) * scale, bf_lo(b[3]) * scale, bf_hi(b[3]) * scale, bd_mix32(sr_seed ^ (g0 + 3)));
+            q[i] = o;
+            continue;
+        }
         o[0] = pack4_bf8(bf_lo(a[0]) * scale, bf_hi(a[0]) * scale, bf_lo(a[1]) * scale, bf_hi(a[1]) * scale);
         o[1] = pack4_bf8(bf_lo(a[2]) * scale, bf_hi(a[2]) * scale, bf_lo(a[3]) * scale, bf_hi(a[3]) * scale);
         o[2] = pack4_bf8(bf_lo(b[0]) * scale, bf_hi(b[0]) * scale, bf_lo(b[1]) * scale, bf_hi(b[1]) * scale);
         o[3] = pack4_bf8(bf_lo(b[2]) * scale, bf_hi(b[2]) * scale, bf_lo(b[3]) * scale, bf_hi(b[3]) * scale);
         q[i] = o;
     }
+}
+
+// max |x| of a bf16 tensor into out[0] (atomic max on the bit pattern: non-negative floats order like unsigned integers; the caller
+// zeroes out[0] first; NaNs are skipped).  Feeds the delayed scaling of the e5m2 gradients.
+__global__ __launch_bounds__(256) void absmax_bf16_kernel(const bf16_raw* __restrict__ x, long long n8, unsigned* __restrict__ out) {
+    unsigned m = 0u;                          // max over |x| as bf16 bit patterns (sign cleared): same order as the values
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(x + i * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned lo = a[k] & 0x7fffu, hi = (a[k] >> 16) & 0x7fffu;
+            if (lo <= 0x7f80u) m = max(m, lo);            // skip NaNs (exponent all ones, mantissa != 0); inf counts
+            if (hi <= 0x7f80u) m = max(m, hi);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m << 16);       // fp32 bit pattern of the bf16 value
 }
 
 // data-gradient weights: one workgroup per INPUT channel ci: s = max over (tap, co) of |w[co][tap][ci] * row_scale[co]| / 448,
@@ -365,8 +394,23 @@ int bd_quantize_bf8(const void* x_bf16, int64_t n, float scale, void* q, bd_stre
     if (n == 0) return BD_OK;
     const long long n16 = n / 16;
     const int grid = (int)std::min<long long>(cdiv64(n16, 256), 256 * 16);
-    hipLaunchKernelGGL(quantize_bf8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x_bf16, n16, scale, (u32x4_t*)q);
+    hipLaunchKernelGGL(quantize_bf8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x_bf16, n16, scale, (u32x4_t*)q, g_fp8_sr_seed);
     BD_CHECK_LAUNCH("bd_quantize_bf8");
+    return BD_OK;
+}
+
+int bd_fp8_set_stochastic_rounding(uint32_t seed) {
+    g_fp8_sr_seed = seed;
+    return BD_OK;
+}
+
+int bd_absmax_bf16(const void* x_bf16, int64_t n, float* out, bd_stream_t stream) {
+    BD_REQUIRE(x_bf16 && out && n >= 0 && n % 8 == 0, "absmax_bf16: n must be a multiple of 8");
+    if (n == 0) return BD_OK;
+    const long long n8 = n / 8;
+    const int grid = (int)std::min<long long>(cdiv64(n8, 256), 256 * 8);
+    hipLaunchKernelGGL(absmax_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x_bf16, n8, (unsigned*)out);
+    BD_CHECK_LAUNCH("bd_absmax_bf16");
     return BD_OK;
 }
 

@@ -64,6 +64,8 @@ class ConvLayer:
         self.w_q8 = self.w_scale8 = self.w_q8t = self.w_scale8t = None
         self.act_scale = 1.0
         self.grad_scale = 4096.0
+        self.amax_slot = None          # delayed scaling of the e5m2 gradients (fpn_base): where max |g| goes on probe steps
+        self.probe_ctl = None
         self.q8_scratch = None          # callable(nbytes) -> uint8 scratch tensor on the stream this layer's forward runs on
 
     # -- parameters -------------------------------------------------------------------------------
@@ -206,6 +208,8 @@ class ConvLayer:
         if maskbits is not None:
             mask = None
         d = self.desc(gin, gout)
+        if self.amax_slot is not None and self.probe_ctl[0] and (self.fp8_1x1_dgrad or self.fp8_dgrad):
+            ops.absmax_bf16(g, self.amax_slot)
         if self.fp8_1x1_dgrad and g8 is not None and ops.conv1x1_fp8_ok(d, 1):
             return ops.conv1x1_fp8(d, 1, g8, self.w_q8t, self.w_scale8t, None, dx, add=add, mask=mask, maskbits=maskbits, y8=dx8,
                                    q_scale=q_scale, flags=flags)

@@ -169,7 +169,72 @@ class FPNDetector:
                                                  expanding=bool(m.get("FP8_1X1_EXPANDING", True)))
         else:
             assert self.weight_dtype == "bf16", self.weight_dtype
+        # Delayed scaling of the e5m2 gradients (the reference's hook for this is the AMP GradScaler, solver/default_solver.py:66-76): one
+        # scale for all fp8 data gradients (twins pass from layer to layer, so the layers must agree on it), re-derived every
+        # FP8_AMAX_INTERVAL steps from max |g| over the gradients those launches consume -- measured by bd_absmax_bf16 on the probe step,
+        # copied to the host asynchronously and applied FP8_AMAX_DELAY steps later, after that step's data gradients and before its
+        # weight repack, so that quantisation and the folded 1 / scale of the packed weights always agree.  A static scale underflows
+        # once training has shrunk the gradients: 4 096 diverged after ~1 500 steps of the repeated-batch run, 65 536 did not.
+        self._fp8_grad_layers = [c for c in self.convs.values() if c.fp8_dgrad or c.fp8_1x1_dgrad or c.fp8_wgrad]
+        if self._fp8_grad_layers:
+            for c in self.convs.values():             # one scale everywhere from the start (a twin's producer reads it off a neighbour)
+                c.grad_scale = float(m.get("FP8_GRAD_SCALE", 4096.0))
+        self.fp8_delayed_scaling = bool(m.get("FP8_DELAYED_SCALING", True)) and bool(self._fp8_grad_layers) and self.device.type == "cuda"
+        # Stochastic rounding of those gradients (bd_fp8_set_stochastic_rounding): round-to-nearest e5m2 repeats the same error on the
+        # same value every step, which a repeated batch turns into a drift (the long repeated-batch runs)
+        self.fp8_stochastic_rounding = bool(m.get("FP8_STOCHASTIC_ROUNDING", True)) and bool(self._fp8_grad_layers) and self.device.type == "cuda"
+        self.fp8_amax_interval = int(m.get("FP8_AMAX_INTERVAL", 20))
+        self.fp8_amax_delay = int(m.get("FP8_AMAX_DELAY", 4))
+        self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 14.0))       # max |g| * scale lands in (2^(t-1), 2^t]; e5m2 tops out at 1.75 * 2^15 (12 and the static 4 096 diverged in the 2 020-step run, 13 - 15 did not, 16 clamps: DESIGN.md)
+        self._fp8_t, self._amax_pending, self._amax_prev = 0, None, 0.0
+        self.fp8_scale_log = []
+        if self.fp8_delayed_scaling:
+            n = len(self._fp8_grad_layers)
+            self._amax_dev = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self._amax_host = torch.zeros(n, dtype=torch.float32).pin_memory()
+            self._probe_ctl = [False]
+            for i, c in enumerate(self._fp8_grad_layers):
+                c.amax_slot, c.probe_ctl = self._amax_dev[i:i + 1], self._probe_ctl
         self._bind_params(params)
+
+    def _fp8_probe_begin(self):
+        if self.fp8_stochastic_rounding:          # this step's e5m2 quantisers: a new hash seed per step (reset at the end of backward)
+            ops.fp8_set_stochastic_rounding(((self._fp8_t + 1) * 2654435761 + 0x9E3779B9) | 1)
+        if not self.fp8_delayed_scaling:
+            self._fp8_t += 1
+            return False
+        t = self._fp8_t
+        self._fp8_t += 1
+        if self._amax_pending is None and t % self.fp8_amax_interval == 0:
+            self._amax_dev.zero_()
+            self._probe_ctl[0] = True
+            return True
+        return False
+
+    def _fp8_probe_end(self, probing):
+        if self.fp8_stochastic_rounding:
+            ops.fp8_set_stochastic_rounding(0)
+        if not self.fp8_delayed_scaling:
+            return
+        t = self._fp8_t - 1
+        if probing:
+            self._probe_ctl[0] = False
+            self._amax_host.copy_(self._amax_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._amax_pending = (ev, t)
+        elif self._amax_pending is not None and t >= self._amax_pending[1] + self.fp8_amax_delay:
+            ev, t0 = self._amax_pending
+            ev.synchronize()                      # long done: the host runs a few steps ahead of the device, not FP8_AMAX_DELAY + the queue
+            self._amax_pending = None
+            amax = float(self._amax_host.max())
+            if np.isfinite(amax) and amax > 0.0:
+                eff = max(amax, self._amax_prev)  # two-probe history: a scale never chases a single small reading
+                self._amax_prev = amax
+                scale = float(2.0 ** min(max(np.floor(self.fp8_amax_target - np.log2(eff)), -16.0), 40.0))
+                for c in self.convs.values():         # every layer: a twin's producer reads the scale off a neighbouring layer object
+                    c.grad_scale = scale
+                self.fp8_scale_log.append((t0, t, amax, scale))
 
     def _bind_params(self, params):
         """(Re)load every parameter from a reference-layout dict (name -> numpy) and refresh the packed bf16 copies."""
@@ -610,6 +675,7 @@ class FPNDetector:
 
     def backward(self, on_bucket_ready=None):
         pl = self._cur
+        probing = self._fp8_probe_begin()
         ws, cws = pl.wgrad_ws, pl.colsum_ws
         pyr = pl.pyr
         pl.g_P8_ready = False                       # set by a head whose last data gradients wrote the e5m2 twin of dL/dP
@@ -726,4 +792,5 @@ class FPNDetector:
             if on_bucket_ready and (bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]):
                 on_bucket_ready(f"layer{blk['layer']}", side)
         self._join_wgrads()
+        self._fp8_probe_end(probing)
 

@@ -125,6 +125,16 @@ def quantize_bf8(x, scale, q):
     return q
 
 
+def fp8_set_stochastic_rounding(seed):
+    """seed != 0: the e5m2 quantisers launched from now on round stochastically (hash of seed and element index); 0: to nearest."""
+    check(L().bd_fp8_set_stochastic_rounding(int(seed) & 0xFFFFFFFF), "bd_fp8_set_stochastic_rounding")
+
+
+def absmax_bf16(x, out):
+    """out[0] (fp32, device) = max(out[0], max |x|) of a bf16 tensor."""
+    check(L().bd_absmax_bf16(ptr(x), x.numel(), ptr(out), stream_ptr()), "bd_absmax_bf16")
+
+
 def weight_pack_fp8_t(w, row_scale, Cout, RS, Cin, grad_scale, wq_t, wscale_t):
     check(L().bd_weight_pack_fp8_t(ptr(w), ptr(row_scale), Cout, RS, Cin, float(grad_scale), ptr(wq_t), ptr(wscale_t), stream_ptr()),
           "bd_weight_pack_fp8_t")

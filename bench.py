@@ -648,7 +648,9 @@ def worker(args):
             "config": {"workload": f"{name} train step (fwd+bwd+allreduce+SGD), DummyLoader boxes, random-init weights, "
                                    "inputs resident in HBM",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "final_loss": round(loss, 4)},
+                       "final_loss": round(loss, 4),
+                       **({"fp8_grad_scale": [(int(a), float(c), float(d_)) for a, b_, c, d_ in (model.fp8_scale_log[:1] + model.fp8_scale_log[-2:])]}
+                          if getattr(model, "fp8_scale_log", None) else {})},
             "step_ms_p50": round(float(np.percentile(step_ms, 50)), 3), "step_ms_p95": round(float(np.percentile(step_ms, 95)), 3),
             "step_ms_note": "device time between step boundaries on rank 0's main stream (HIP events), instrumented steps included",
         }

@@ -542,6 +542,13 @@ int bd_conv_fp8_set_patch(int on);
  * dx (bf16) = epi(conv_transpose(g8, wq_t) * wscale_t [+ add]); add / mask / flags as bd_conv2d_dgrad; dx8 (may be NULL) =
  * e5m2(clamp(dx * q_scale)). */
 int bd_quantize_bf8(const void* x_bf16, int64_t n, float scale, void* q, bd_stream_t stream);
+/* seed != 0: every e5m2 quantiser launched from now on (bd_quantize_bf8, the dx8 twins of bd_conv2d_dgrad_ex / bd_conv2d_dgrad_fp8 /
+ * bd_conv1x1_fp8 mode 1) rounds stochastically -- a hash of (seed, element index) below the kept bits -- instead of to nearest; 0
+ * restores round-to-nearest.  Host-side state read at launch time. */
+int bd_fp8_set_stochastic_rounding(uint32_t seed);
+/* out[0] = max(out[0], max |x|) over a bf16 tensor (n % 8 == 0; NaNs skipped; zero out[0] first): the statistic behind the delayed scaling of
+ * the e5m2 gradients (the reference's loss-scale hook, solver/default_solver.py:66-76: GradScaler of the AMP path). */
+int bd_absmax_bf16(const void* x_bf16, int64_t n, float* out, bd_stream_t stream);
 int bd_weight_pack_fp8_t(const float* w, const float* row_scale, int Cout, int RS, int Cin, float grad_scale, void* wq_t, float* wscale_t,
                          bd_stream_t stream);
 int bd_conv2d_dgrad_fp8(const bd_conv_desc* d, const void* g8, const void* wq_t, const float* wscale_t, const void* add, const void* mask,

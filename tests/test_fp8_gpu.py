@@ -186,6 +186,9 @@ def test_retinanet_r50_fp8_backward_variants():
             cfg.MODEL.pop(k, None)
         for k, v in kw.items():
             cfg.MODEL[k] = v
+        # round-to-nearest gradients here: the variants are compared with each other value by value (stochastic rounding, the training
+        # default, is unbiased but lifts tensors that live below the e5m2 floor to the floor's noise level: its own test below)
+        cfg.MODEL.FP8_STOCHASTIC_ROUNDING = False
         m = RetinaNet(cfg, params=params)
         out = m(batch)
         m.backward()
@@ -548,3 +551,78 @@ def test_fp8_wgrad3x3_tolerance_on_random_data():
     rel = rel_l2(got, ref)
     print("fp8 wgrad rel-L2:", rel)
     assert rel < 8e-2, rel
+
+
+def test_absmax_and_delayed_gradient_scale():
+    """bd_absmax_bf16 against torch (NaNs skipped, negative extremes, accumulation into the slot), and the delayed scaling built on it:
+    on a model whose gradients are far below what the static scale resolves, the scale moves up by the probe's reading after
+    FP8_AMAX_DELAY steps and every layer agrees on it."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(1 << 16, device="cuda", generator=g) * 3e-4).to(torch.bfloat16)
+    x[1234] = -0.0731
+    x[77] = float("nan")
+    out = torch.zeros(1, dtype=torch.float32, device="cuda")
+    ops.absmax_bf16(x, out)
+    want = float(torch.nan_to_num(x.float(), nan=0.0).abs().max())
+    assert float(out) == want, (float(out), want)
+    ops.absmax_bf16((x.float() * 0.5).to(torch.bfloat16), out)          # a smaller tensor does not lower the slot
+    assert float(out) == want
+    from basedet_amd.models import RetinaNet
+    from tests.test_model_gpu import _setup
+    cfg, params, batch = _setup("resnet50", 2, (128, 160))
+    cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
+    cfg.MODEL.FP8_AMAX_INTERVAL = 3
+    cfg.MODEL.FP8_AMAX_DELAY = 1
+    m = RetinaNet(cfg, params=params)
+    assert m.fp8_delayed_scaling and all(c.grad_scale == 4096.0 for c in m.convs.values())
+    for _ in range(3):
+        m(batch); m.backward()
+    torch.cuda.synchronize()
+    assert len(m.fp8_scale_log) == 1
+    t0, t1, amax, scale = m.fp8_scale_log[0]
+    assert (t0, t1) == (0, 1) and amax > 0
+    assert 2.0 ** 13 < amax * scale <= 2.0 ** 14 and np.log2(scale) == np.floor(np.log2(scale))
+    assert all(c.grad_scale == scale for c in m.convs.values())
+    # the probe read what the fp8 data gradients consume: no larger than the largest gradient buffer of the step
+    assert amax <= float(max(t.float().abs().max() for t in m._cur.g_tower[0] + m._cur.g_tower[1] + [m._cur.g_P])) * 1.0001 + 1e-30
+
+
+def test_e5m2_stochastic_rounding():
+    """bd_fp8_set_stochastic_rounding: (1) unbiased -- the mean of the dequantised values over many seeds approaches the input where
+    round-to-nearest is off by up to an eighth; (2) every result is one of the two e5m2 neighbours of the value; (3) a function of (seed,
+    element index) only: the same bytes twice, other bytes with another seed; (4) seed 0 restores round-to-nearest exactly."""
+    ops = _ops()
+    n = 1 << 14
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = (torch.rand(n, device="cuda", generator=g) * 3 + 0.6).to(torch.bfloat16)          # (0.6, 3.6): e5m2 steps of 1/8 .. 1/2
+    q = torch.empty(n, dtype=torch.uint8, device="cuda")
+    try:
+        acc = torch.zeros(n, dtype=torch.float64, device="cuda")
+        K = 256
+        first = None
+        for s in range(1, K + 1):
+            ops.fp8_set_stochastic_rounding(s * 2654435761 | 1)
+            ops.quantize_bf8(x, 1.0, q)
+            v = q.view(torch.float8_e5m2).float()
+            lo = x.float().to(torch.float8_e5m2)          # round to nearest: one of the two neighbours
+            step = torch.where(x.float() < 1.0, 0.125, torch.where(x.float() < 2.0, 0.25, 0.5))
+            assert bool(((v - x.float()).abs() < step).all())
+            acc += v.double()
+            if s == 1:
+                first = q.clone()
+                ops.quantize_bf8(x, 1.0, q)
+                assert torch.equal(q, first)
+            if s == 2:
+                assert not torch.equal(q, first)
+        mean = (acc / K).float()
+        err_sr = float((mean - x.float()).abs().mean())
+        ops.fp8_set_stochastic_rounding(0)
+        ops.quantize_bf8(x, 1.0, q)
+        rn = q.view(torch.float8_e5m2).float()
+        assert torch.equal(q, x.float().to(torch.float8_e5m2).view(torch.uint8))
+        err_rn = float((rn - x.float()).abs().mean())
+        print(f"mean |error|: round-to-nearest {err_rn:.4f}, mean of {K} stochastic roundings {err_sr:.4f}")
+        assert err_sr < 0.2 * err_rn, (err_sr, err_rn)
+    finally:
+        ops.fp8_set_stochastic_rounding(0)
