@@ -33,11 +33,11 @@ __device__ __forceinline__ unsigned bd_mix32(unsigned x) {
 __device__ __forceinline__ unsigned bd_pack4_e5m2_sr(float a, float b, float c, float d, unsigned r) {
     a = fminf(fmaxf(a, -57344.f), 57344.f); b = fminf(fmaxf(b, -57344.f), 57344.f);
     c = fminf(fmaxf(c, -57344.f), 57344.f); d = fminf(fmaxf(d, -57344.f), 57344.f);
-    int v = 0;
+    int v = 0;                        // one hashed word per four elements, rotated by a byte per element (v_alignbit: one instruction each)
     v = __builtin_amdgcn_cvt_sr_bf8_f32(a, r, v, 0);
-    v = __builtin_amdgcn_cvt_sr_bf8_f32(b, r * 0x9e3779b1u + 0x7f4a7c15u, v, 1);
-    v = __builtin_amdgcn_cvt_sr_bf8_f32(c, (r >> 13) ^ (r << 19) ^ 0x2545f491u, v, 2);
-    v = __builtin_amdgcn_cvt_sr_bf8_f32(d, (r >> 7) * 0x85ebca6bu + 0xc2b2ae35u, v, 3);
+    v = __builtin_amdgcn_cvt_sr_bf8_f32(b, __builtin_rotateright32(r, 8), v, 1);
+    v = __builtin_amdgcn_cvt_sr_bf8_f32(c, __builtin_rotateright32(r, 16), v, 2);
+    v = __builtin_amdgcn_cvt_sr_bf8_f32(d, __builtin_rotateright32(r, 24), v, 3);
     return (unsigned)v;
 }
 

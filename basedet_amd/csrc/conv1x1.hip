@@ -76,8 +76,9 @@ __device__ __forceinline__ u32x2_t e5m2_pair(const float* v, float qs, unsigned 
     u32x2_t o8;
     if (seed) {
         const unsigned g0 = (unsigned)(idx >> 2);
-        o8[0] = bd_pack4_e5m2_sr(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, bd_mix32(seed ^ g0));
-        o8[1] = bd_pack4_e5m2_sr(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs, bd_mix32(seed ^ (g0 + 1)));
+        const unsigned r0 = bd_mix32(seed ^ g0);           // one full hash per eight elements; the second word by a multiply-add
+        o8[0] = bd_pack4_e5m2_sr(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, r0);
+        o8[1] = bd_pack4_e5m2_sr(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs, r0 * 0x9e3779b1u + 0x7f4a7c15u);
     } else {
         o8[0] = pack4_e5m2(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
         o8[1] = pack4_e5m2(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs);

@@ -383,8 +383,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
                 } else {
                     if (p.sr_seed) {
                         const unsigned g0 = (unsigned)(idx >> 2);
-                        o8[0] = bd_pack4_e5m2_sr(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale, bd_mix32(p.sr_seed ^ g0));
-                        o8[1] = bd_pack4_e5m2_sr(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale, bd_mix32(p.sr_seed ^ (g0 + 1)));
+                        const unsigned r0 = bd_mix32(p.sr_seed ^ g0);
+                        o8[0] = bd_pack4_e5m2_sr(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale, r0);
+                        o8[1] = bd_pack4_e5m2_sr(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale, r0 * 0x9e3779b1u + 0x7f4a7c15u);
                     } else {
                         o8[0] = pack4_bf8(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
                         o8[1] = pack4_bf8(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);

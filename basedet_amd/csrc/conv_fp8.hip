@@ -69,10 +69,11 @@ __global__ __launch_bounds__(256) void quantize_bf8_kernel(const bf16_raw* __res
         u32x4_t o;
         if (sr_seed) {            // element group g = index / 4: the same random word as a producing launch's twin of this element
             const unsigned g0 = (unsigned)(i * 4);
-            o[0] = bd_pack4_e5m2_sr(bf_lo(a[0]) * scale, bf_hi(a[0]) * scale, bf_lo(a[1]) * scale, bf_hi(a[1]) * scale, bd_mix32(sr_seed ^ g0));
-            o[1] = bd_pack4_e5m2_sr(bf_lo(a[2]) * scale, bf_hi(a[2]) * scale, bf_lo(a[3]) * scale, bf_hi(a[3]) * scale, bd_mix32(sr_seed ^ (g0 + 1)));
-            o[2] = bd_pack4_e5m2_sr(bf_lo(b[0]) * scale, bf_hi(b[0]) * scale, bf_lo(b[1]) * scale, bf_hi(b[1]) * scale, bd_mix32(sr_seed ^ (g0 + 2)));
-            o[3] = bd_pack4_e5m2_sr(bf_lo(b[2]) * scale, bf_hi(b[2]) * scale, bf_lo(b[3]) * scale, bf_hi(b[3]) * scale, bd_mix32(sr_seed ^ (g0 + 3)));
+            const unsigned r0 = bd_mix32(sr_seed ^ g0), r2 = bd_mix32(sr_seed ^ (g0 + 2));      // as the twin writers: one hash per eight elements
+            o[0] = bd_pack4_e5m2_sr(bf_lo(a[0]) * scale, bf_hi(a[0]) * scale, bf_lo(a[1]) * scale, bf_hi(a[1]) * scale, r0);
+            o[1] = bd_pack4_e5m2_sr(bf_lo(a[2]) * scale, bf_hi(a[2]) * scale, bf_lo(a[3]) * scale, bf_hi(a[3]) * scale, r0 * 0x9e3779b1u + 0x7f4a7c15u);
+            o[2] = bd_pack4_e5m2_sr(bf_lo(b[0]) * scale, bf_hi(b[0]) * scale, bf_lo(b[1]) * scale, bf_hi(b[1]) * scale, r2);
+            o[3] = bd_pack4_e5m2_sr(bf_lo(b[2]) * scale, bf_hi(b[2]) * scale, bf_lo(b[3]) * scale, bf_hi(b[3]) * scale, r2 * 0x9e3779b1u + 0x7f4a7c15u);
             q[i] = o;
             continue;
         }
