@@ -643,7 +643,7 @@ def worker(args):
             "metric": "images/sec training RetinaNet-R50-FPN 1333x800" if name == "retinanet_r50_800x1344" else "images/sec training " + name,
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 activations / fp8-e4m3 weights (fwd + dgrad), fp32 accumulate",
+            "vs_baseline": None, "dtype": "bf16" if not args.fp8 else ("bf16 activations / fp8-e4m3 weights (forward%s), fp32 accumulate" % (" + e5m2 data gradients" if cfg.MODEL.get("FP8_DGRAD", False) else "")),
             "data": "synthetic",
             "config": {"workload": f"{name} train step (fwd+bwd+allreduce+SGD), DummyLoader boxes, random-init weights, "
                                    "inputs resident in HBM",

@@ -198,15 +198,15 @@ def test_retinanet_r50_fp8_backward_variants():
 
     m16, l16, g16 = run()
     ma, la, ga = run(WEIGHT_DTYPE="fp8_e4m3", FP8_DGRAD=False)
-    mb, lb, gb = run(WEIGHT_DTYPE="fp8_e4m3", FP8_GRAD_TWINS=False)
-    mc, lc, gc = run(WEIGHT_DTYPE="fp8_e4m3")
+    mb, lb, gb = run(WEIGHT_DTYPE="fp8_e4m3", FP8_DGRAD=True, FP8_GRAD_TWINS=False)
+    mc, lc, gc = run(WEIGHT_DTYPE="fp8_e4m3", FP8_DGRAD=True)
     assert not any(c.fp8_dgrad for c in ma.convs.values()) and any(c.fp8_dgrad for c in mc.convs.values())
     # the bottleneck 1x1s around the fp8 3x3s run on one-byte operands too (forward and data gradient), fed by producer-written twins
     assert any(c.fp8_1x1 for c in mc.convs.values()) and any(c.fp8_1x1_dgrad for c in mc.convs.values())
     assert any(b.out8 is not None for b in mc._cur.blk) and any(b.mid8b is not None for b in mc._cur.blk)
     assert any(b.g_out8 is not None and b.g_out8_ready for b in mc._cur.blk) and any(b.g_mid8a is not None for b in mc._cur.blk)
-    md, ld, gd = run(WEIGHT_DTYPE="fp8_e4m3", FP8_1X1=False)         # (d): the 1x1 layers on bf16, as (c) otherwise
-    me, le, ge = run(WEIGHT_DTYPE="fp8_e4m3", FP8_WGRAD=2)           # (e): as (c) with the 3x3 weight gradients from the twins (opt-in)
+    md, ld, gd = run(WEIGHT_DTYPE="fp8_e4m3", FP8_DGRAD=True, FP8_1X1=False)         # (d): the 1x1 layers on bf16, as (c) otherwise
+    me, le, ge = run(WEIGHT_DTYPE="fp8_e4m3", FP8_DGRAD=True, FP8_WGRAD=2)           # (e): as (c) with the 3x3 weight gradients from the twins (opt-in)
     assert any(c.fp8_wgrad for c in me.convs.values()) and not any(c.fp8_wgrad for c in mc.convs.values())
     assert not any(c.fp8_1x1 for c in md.convs.values())
     assert mc._cur.g_P8 is not None and mb._cur.g_P8 is None
@@ -572,6 +572,7 @@ def test_absmax_and_delayed_gradient_scale():
     from tests.test_model_gpu import _setup
     cfg, params, batch = _setup("resnet50", 2, (128, 160))
     cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
+    cfg.MODEL.FP8_DGRAD = True
     cfg.MODEL.FP8_AMAX_INTERVAL = 3
     cfg.MODEL.FP8_AMAX_DELAY = 1
     m = RetinaNet(cfg, params=params)
