@@ -1,4 +1,4 @@
-"""Per-layer max |g| of the gradients the fp8 data-gradient launches consume (RetinaNet-R50, 800x1344, batch 4, one step at initialisation):
+"""Per-layer max |g| of the gradients the fp8 data-gradient launches consume (RetinaNet-R50 / argv[1] = resnet101, 800x1344, batch 4, one step at initialisation):
 how far apart are the layers that today share ONE e5m2 scale?"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -7,7 +7,8 @@ from basedet_amd.configs import RetinaNetConfig
 from basedet_amd.models import RetinaNet, params as P
 from basedet_amd.utils import DummyLoader
 B = 4
-cfg = RetinaNetConfig(); cfg.MODEL.BATCHSIZE = B; cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"; cfg.MODEL.FP8_AMAX_INTERVAL = 1; cfg.MODEL.FP8_AMAX_DELAY = 1
+BACKBONE = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
+cfg = RetinaNetConfig(); cfg.MODEL.BATCHSIZE = B; cfg.MODEL.BACKBONE.NAME = BACKBONE; cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"; cfg.MODEL.FP8_DGRAD = True; cfg.MODEL.FP8_AMAX_INTERVAL = 1; cfg.MODEL.FP8_AMAX_DELAY = 1
 params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
 m = RetinaNet(cfg, params=params)
 b = next(DummyLoader(B, (800, 1344), seed=0))
