@@ -189,7 +189,7 @@ class FPNDetector:
         self.fp8_stochastic_rounding = bool(m.get("FP8_STOCHASTIC_ROUNDING", True)) and bool(self._fp8_grad_layers) and self.device.type == "cuda"
         self.fp8_amax_interval = int(m.get("FP8_AMAX_INTERVAL", 20))
         self.fp8_amax_delay = int(m.get("FP8_AMAX_DELAY", 4))
-        self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 14.0))       # max |g| * scale lands in (2^(t-1), 2^t]; e5m2 tops out at 1.75 * 2^15 (12 and the static 4 096 diverged in the 2 020-step run, 13 - 15 did not, 16 clamps: DESIGN.md)
+        self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 15.0))       # max |g| * scale lands in (2^(t-1), 2^t]; e5m2 tops out at 1.75 * 2^15 (R50: 12 and the static 4 096 diverged in the 2 020-step run, 13 - 15 did not, 16 clamps; R101 at batch 32: 14 diverged before step 1 020, 15 did not: DESIGN.md)
         self._fp8_t, self._amax_pending, self._amax_prev = 0, None, 0.0
         self.fp8_scale_log = []
         if self.fp8_delayed_scaling:

@@ -583,7 +583,7 @@ def test_absmax_and_delayed_gradient_scale():
     assert len(m.fp8_scale_log) == 1
     t0, t1, amax, scale = m.fp8_scale_log[0]
     assert (t0, t1) == (0, 1) and amax > 0
-    assert 2.0 ** 13 < amax * scale <= 2.0 ** 14 and np.log2(scale) == np.floor(np.log2(scale))
+    assert 2.0 ** 14 < amax * scale <= 2.0 ** 15 and np.log2(scale) == np.floor(np.log2(scale))
     assert all(c.grad_scale == scale for c in m.convs.values())
     # the probe read what the fp8 data gradients consume: no larger than the largest gradient buffer of the step
     assert amax <= float(max(t.float().abs().max() for t in m._cur.g_tower[0] + m._cur.g_tower[1] + [m._cur.g_P])) * 1.0001 + 1e-30
