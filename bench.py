@@ -448,7 +448,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 16; 32 for the fp8 R101 workload)")
     ap.add_argument("--workload", default="retinanet_r50_800x1344", choices=sorted(TRAIN_GFLOP_PER_IMG))
     ap.add_argument("--fp8", action="store_true",
-                    help="fp8 (e4m3) weights for the forward / data-gradient convolutions (BASELINE config 5: retinanet_r101_800x1344)")
+                    help="fp8 (e4m3) weights and activations for the forward convolutions (BASELINE config 5: retinanet_r101_800x1344); "
+                         "--model-opt FP8_DGRAD=1 adds the e5m2 data gradients")
     ap.add_argument("--model-opt", action="append", default=[], metavar="KEY=VALUE",
                     help="ablation: set cfg.MODEL.KEY (e.g. FP8_1X1=0, FP8_DGRAD=0, FUSE_STEM_POOL=0); repeatable")
     ap.add_argument("--no-pmc", action="store_true",
