@@ -121,6 +121,9 @@ SIGNATURES = {
     "bd_det_candidates": (_I, [_I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bd_det_finalize": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "bd_sgd_momentum_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _P]),
+    "bd_clip_grad_value": (_I, [_P, _L, _F, _F, _F, _P]),
+    "bd_clip_grad_norm_workspace_bytes": (_Z, []),
+    "bd_clip_grad_norm": (_I, [_P, _L, _F, _F, _F, _P, _P, _Z, _P]),
     "bd_quantize_fp8": (_I, [_P, _L, _F, _P, _P]),
     "bd_weight_pack_fp8": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "bd_conv2d_fwd_fp8": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -111,6 +111,13 @@ class DetectionConfig(ConfigDict):
         synthetic loader of the reference's own benchmark harness (utils/dummy.py, tools/benchmark.py:173) stands in."""
         from ..utils import DummyLoader
         from .. import comm
+        if self.DATA.get("BUILDER_NAME") != "DummyLoader":
+            # a playground config names a COCO reader (DATA.TRAIN.name, AUG, NUM_WORKERS): silently training on noise instead would
+            # look like a successful run.  The caller has to opt into synthetic data explicitly.
+            raise RuntimeError(
+                f"DATA.BUILDER_NAME = {self.DATA.get('BUILDER_NAME')!r}: this build has no dataset readers (hot-path scope, DESIGN.md); "
+                "the only data source is the synthetic DummyLoader of the reference's benchmark harness.  Set DATA.BUILDER_NAME = "
+                "'DummyLoader' (basedet_train: --synthetic) to train on it, or hand your own iterable of batch dicts to DetTrainer.")
         return DummyLoader(self.MODEL.BATCHSIZE, tuple(self.DATA.get("DUMMY_SIZE", (800, 1344))), seed=comm.rank())
 
     def build_trainer(self):

@@ -154,10 +154,19 @@ int bd_comm_init(bd_comm_t* out, const void* id128_host, int rank, int world, in
     // high priority: a bucket's collective should not queue behind the backward kernels still being issued
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    BD_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi), "bd_comm_init: stream");
-    c->ev.resize(16);
-    for (auto& e : c->ev) BD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), "bd_comm_init: event");
-    BD_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming), "bd_comm_init: event");
+    c->ev.assign(16, nullptr);
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);
+    for (size_t i = 0; e == hipSuccess && i < c->ev.size(); ++i) e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+    if (e != hipSuccess) {          // release what exists: the communicator (abort: the peers may not have arrived), events, stream
+        bd_set_error("bd_comm_init: stream / event creation: %s", hipGetErrorString(e));
+        if (c->comm) g_api.CommAbort(c->comm);
+        for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+        if (c->done) (void)hipEventDestroy(c->done);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return BD_ELAUNCH;
+    }
     *out = c;
     return BD_OK;
 }
@@ -207,7 +216,7 @@ int bd_comm_destroy(bd_comm_t c) {
     if (!c) return BD_OK;
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) g_api.CommDestroy(c->comm);
-    for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -2,6 +2,7 @@
 // bf16 helpers, weight packing, column sums (bias gradients), SGD.  All use 16-byte accesses per lane.
 #include <stdarg.h>
 
+#include <cmath>
 #include "common.h"
 
 // ---- error plumbing (shared by every translation unit) -----------------------------------------------------
@@ -490,6 +491,131 @@ extern "C" int bd_colsum_bf16(const void* g, int N, int64_t pix_per_img, int64_t
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
                        COLSUM_BLOCKS, C, out, accumulate);
     BD_CHECK_LAUNCH("bd_colsum_bf16");
+    return BD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Gradient clipping over the flat gradient arena (engine/trainer.py:57-61 -> basecore clip_grad -> megengine.optimizer.clip_grad_value /
+// clip_grad_norm).  `pre_scale` is the reduce-mode factor (1 / world for MEAN) that the SGD launch otherwise applies: the reference clips
+// the already averaged gradients, so it is folded in here and the optimizer step then runs with grad_scale = 1.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void clip_value_kernel(float* __restrict__ g, long long n, float pre_scale, float lo, float hi) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i * 4;
+        if (e + 4 <= n) {
+            f32x4_t v = *reinterpret_cast<f32x4_t*>(g + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k] * pre_scale, lo), hi);
+            *reinterpret_cast<f32x4_t*>(g + e) = v;
+        } else {
+            for (long long k = e; k < n; ++k) g[k] = fminf(fmaxf(g[k] * pre_scale, lo), hi);
+        }
+    }
+}
+
+constexpr int CLIP_BLOCKS = 1024;
+// ord_mode 0: sum |g|^p (p = ord), 1: sum g^2, 2: max |g|.  Block b owns one contiguous chunk; fixed-order tree inside the block and a
+// fixed-order final pass: bitwise reproducible.  Accumulation in double (37.7 M addends).
+__global__ __launch_bounds__(256) void clip_norm_partial_kernel(const float* __restrict__ g, long long n, int ord_mode, float ord,
+                                                                double* __restrict__ partial) {
+    __shared__ double red[256];
+    const long long chunk = ((n + CLIP_BLOCKS - 1) / CLIP_BLOCKS + 3) / 4 * 4;
+    const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    double acc = 0.0;
+    for (long long e = lo + threadIdx.x * 4ll; e < hi; e += 1024) {
+        float v[4];
+        if (e + 4 <= hi) {
+            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(g + e);
+            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        } else {
+            for (int k = 0; k < 4; ++k) v[k] = e + k < hi ? g[e + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = fabsf(v[k]);
+            if (ord_mode == 2) acc = fmax(acc, (double)a);
+            else if (ord_mode == 1) acc += (double)a * (double)a;
+            else acc += (double)powf(a, ord);
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = ord_mode == 2 ? fmax(red[threadIdx.x], red[threadIdx.x + s]) : red[threadIdx.x] + red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// out[0] = norm of pre_scale * g, out[1] = the factor the arena is multiplied with: pre_scale * min(1, max_norm / (norm + 1e-6))
+__global__ __launch_bounds__(256) void clip_norm_final_kernel(const double* __restrict__ partial, int ord_mode, float ord, float pre_scale,
+                                                              float max_norm, float* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < CLIP_BLOCKS; b += 256) acc = ord_mode == 2 ? fmax(acc, partial[b]) : acc + partial[b];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = ord_mode == 2 ? fmax(red[threadIdx.x], red[threadIdx.x + s]) : red[threadIdx.x] + red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double nrm = red[0];
+        if (ord_mode == 1) nrm = sqrt(nrm);
+        else if (ord_mode == 0) nrm = pow(nrm, 1.0 / (double)ord);
+        nrm *= (double)fabsf(pre_scale);
+        const float nf = (float)nrm;
+        out[0] = nf;
+        out[1] = pre_scale * fminf(max_norm / (nf + 1e-6f), 1.f);
+    }
+}
+
+__global__ void scale_by_dev_kernel(float* __restrict__ g, long long n, const float* __restrict__ factor) {
+    const float f = factor[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i * 4;
+        if (e + 4 <= n) {
+            f32x4_t v = *reinterpret_cast<f32x4_t*>(g + e);
+            v *= f;
+            *reinterpret_cast<f32x4_t*>(g + e) = v;
+        } else {
+            for (long long k = e; k < n; ++k) g[k] *= f;
+        }
+    }
+}
+
+extern "C" int bd_clip_grad_value(float* g, int64_t n, float pre_scale, float lower, float upper, bd_stream_t stream) {
+    BD_REQUIRE(g && n >= 0, "clip_grad_value: null pointer");
+    BD_REQUIRE(lower <= upper, "clip_grad_value: lower %g > upper %g", (double)lower, (double)upper);
+    if (n == 0) return BD_OK;
+    hipLaunchKernelGGL(clip_value_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, (long long)n, pre_scale,
+                       lower, upper);
+    BD_CHECK_LAUNCH("bd_clip_grad_value");
+    return BD_OK;
+}
+
+extern "C" size_t bd_clip_grad_norm_workspace_bytes(void) { return CLIP_BLOCKS * sizeof(double) + 2 * sizeof(float); }
+
+extern "C" int bd_clip_grad_norm(float* g, int64_t n, float pre_scale, float max_norm, float ord, float* norm_out, void* ws,
+                                 size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(g && ws && n >= 0, "clip_grad_norm: null pointer");
+    BD_REQUIRE(ord > 0.f, "clip_grad_norm: ord must be positive (inf allowed), got %g", (double)ord);
+    if (ws_bytes < bd_clip_grad_norm_workspace_bytes()) {
+        bd_set_error("clip_grad_norm: workspace %zu < required %zu bytes", ws_bytes, bd_clip_grad_norm_workspace_bytes());
+        return BD_EWORKSPACE;
+    }
+    const int mode = std::isinf(ord) ? 2 : (ord == 2.f ? 1 : 0);
+    double* partial = (double*)ws;
+    float* out = (float*)(partial + CLIP_BLOCKS);
+    hipLaunchKernelGGL(clip_norm_partial_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float*)g, (long long)n,
+                       mode, ord, partial);
+    hipLaunchKernelGGL(clip_norm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)partial, mode, ord, pre_scale,
+                       max_norm, out);
+    if (n > 0)
+        hipLaunchKernelGGL(scale_by_dev_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, (long long)n,
+                           (const float*)(out + 1));
+    if (norm_out) hipMemcpyAsync(norm_out, out, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    BD_CHECK_LAUNCH("bd_clip_grad_norm");
     return BD_OK;
 }
 

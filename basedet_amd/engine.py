@@ -4,7 +4,7 @@ iteration (:98) with the LR schedule stepped before it (engine/hooks.py:218).  E
 import time
 
 from . import comm as _comm
-from .solver import WarmupMultiStepLR
+from .solver import WarmupMultiStepLR, clip_grad
 from .utils.registry import registers
 
 
@@ -29,6 +29,12 @@ class DetTrainer:
         max_iter = int(s.NUM_IMAGE_PER_EPOCH / _comm.world_size() / cfg.MODEL.BATCHSIZE)          # trainer.py:45-48
         self.progress = Progress(s.MAX_EPOCH, max_iter)
         self.lr_scheduler = WarmupMultiStepLR(solver.optimizer, cfg, _comm.world_size())
+        t = cfg.get("TRAINER", {})
+        if t.get("AMP", {}).get("ENABLE", False):                              # trainer.py:52-54
+            assert self.solver.grad_scaler is not None, "enable AMP but grad_scaler is None"
+        gc = t.get("GRAD_CLIP", {})
+        if gc.get("ENABLE", False):                                            # trainer.py:56-61
+            self.solver.grad_clip_fn = clip_grad(self.model, gc["TYPE"], **dict(gc["ARGS"]))
         self.meter = {}
         self.log_interval = cfg.GLOBAL.LOG_INTERVAL
         self._hooks = list(hooks or [])

@@ -123,8 +123,8 @@ class FCOS(FPNDetector):
         num_gt = pre["img_info"][:, 4].to(torch.int32).contiguous()
         self._assign(pl, gt, num_gt)
         c = _comm.get_comm()
-        if c is not None and c.world > 1:
-            c.allreduce(pl.stats, "avg")                               # all_reduce(mode="mean") of num_fg and sum_ctr (fcos.py:143-144)
+        if c is not None:                                              # a one-rank communicator (BD_FORCE_ALLREDUCE) goes through RCCL too: identity
+            self._allreduce_stats(c, pl.stats)                         # all_reduce(mode="mean") of num_fg and sum_ctr (fcos.py:143-144)
         pl.loss_buf.zero_()
         rows = pl.N * pl.pyr.pix_per_img
         assert m.LOSSES.IOU_LOSS_TYPE == "giou", "HIP FCOS path implements the giou ltrb loss"
@@ -135,6 +135,15 @@ class FCOS(FPNDetector):
         ops.bce_logits_fwd_bwd(pl.raw, pl.gt_ctr, pl.labels, rows, pl.stats[0:1], pl.loss_buf[2:3], pl.d_ctr, ld=8, off=4)
         cls_loss, reg_loss, ctr_loss = pl.loss_buf[0], pl.loss_buf[1], pl.loss_buf[2]
         return {"total_loss": cls_loss + reg_loss + ctr_loss, "cls_loss": cls_loss, "reg_loss": reg_loss, "ctr_loss": ctr_loss}
+
+    @staticmethod
+    def _allreduce_stats(c, stats):
+        """The two-scalar mean over the ranks on the communicator's OWN stream (after this stream's work so far; this stream then
+        waits for it): every collective of a communicator is issued on one stream, in the same order on every rank -- the bucket
+        all-reduces of the previous backward, this exchange, the buckets of this step's backward."""
+        prod = [torch.cuda.current_stream()] if stats.is_cuda else []
+        c.allreduce_async(stats, prod, "avg")
+        c.wait()
 
     def _assign(self, pl, gt, num_gt):
         """FCOS.get_ground_truth (fcos.py:222-293)."""
@@ -245,8 +254,8 @@ class OTA(FCOS):
         num_gt = pre["img_info"][:, 4].to(torch.int32).contiguous()
         self._assign(pl, gt, num_gt)
         c = _comm.get_comm()
-        if c is not None and c.world > 1:
-            c.allreduce(pl.stats, "avg")                               # all_reduce(num_foreground, mode="mean") (ota.py:200)
+        if c is not None:                                              # a one-rank communicator (BD_FORCE_ALLREDUCE) goes through RCCL too: identity
+            self._allreduce_stats(c, pl.stats)                         # all_reduce(num_foreground, mode="mean") (ota.py:200)
         pl.loss_buf.zero_()
         rows = pl.N * pl.pyr.pix_per_img
         assert m.LOSSES.IOU_LOSS_TYPE == "giou", "HIP OTA path implements the giou ltrb loss"

@@ -629,3 +629,21 @@ def fcos_offsets_bwd(raw, ld, scales, geom: Geom, strides, d_off, d_ctr, d_raw, 
 def sgd_momentum_step(w, v, g, lr, momentum, wd, grad_scale=1.0):
     check(L().bd_sgd_momentum_step(ptr(w), ptr(v), ptr(g), w.numel(), float(lr), float(momentum), float(wd),
                                    float(grad_scale), stream_ptr()), "bd_sgd_momentum_step")
+
+
+def clip_grad_value(g, lower, upper, pre_scale=1.0):
+    """megengine.optimizer.clip_grad_value over the flat gradient arena, in place (engine/trainer.py:57-61)."""
+    check(L().bd_clip_grad_value(ptr(g), g.numel(), float(pre_scale), float(lower), float(upper), stream_ptr()), "bd_clip_grad_value")
+
+
+def clip_grad_norm_workspace_bytes():
+    return int(L().bd_clip_grad_norm_workspace_bytes())
+
+
+def clip_grad_norm(g, max_norm, ord=2.0, pre_scale=1.0, norm_out=None, ws=None):
+    """megengine.optimizer.clip_grad_norm over the flat gradient arena, in place; the norm (of pre_scale * g) goes to norm_out[0]."""
+    if ws is None:
+        ws = torch.empty((clip_grad_norm_workspace_bytes(),), dtype=torch.uint8, device=g.device)
+    check(L().bd_clip_grad_norm(ptr(g), g.numel(), float(pre_scale), float(max_norm), float(ord), ptr(norm_out), ptr(ws), ws.numel(),
+                                stream_ptr()), "bd_clip_grad_norm")
+    return norm_out

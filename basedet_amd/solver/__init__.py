@@ -84,6 +84,51 @@ class GradBuckets:
         return 1.0 / self.world if (self.enabled and self.mode == "MEAN") else 1.0
 
 
+class GradClip:
+    """What basecore's `clip_grad(params, type, **args)` returns (engine/trainer.py:57-61; configs/extra_cfg.py:99-105): a callable the
+    solver invokes between the gradient all-reduce and the optimizer step.  TYPE "value" (ARGS lower, upper) =
+    megengine.optimizer.clip_grad_value, TYPE "norm" (ARGS max_norm, ord = 2) = clip_grad_norm over ALL trainable gradients -- here one
+    or three launches over the flat gradient arena (bd_clip_grad_value / bd_clip_grad_norm), no host synchronisation.  The
+    reduce-mode factor (1 / world) the SGD launch would apply is folded in (`pre_scale`): the reference clips the averaged gradients."""
+
+    def __init__(self, model, clip_type="value", **args):
+        assert clip_type in ("value", "norm"), clip_type            # basecore asserts the same two types
+        self.model, self.type, self.args = model, clip_type, dict(args)
+        if clip_type == "value":
+            self.lower, self.upper = float(args["lower"]), float(args["upper"])
+        else:
+            self.max_norm, self.ord = float(args["max_norm"]), float(args.get("ord", 2.0))
+        self.last_norm = None          # device scalar: the gradient norm of the last step (TYPE "norm")
+        self._ws = None
+
+    def __call__(self, pre_scale=1.0):
+        g = self.model.arena.g
+        if self.type == "value":
+            ops.clip_grad_value(g, self.lower, self.upper, pre_scale)
+        else:
+            if self._ws is None:
+                self._ws = torch.empty((ops.clip_grad_norm_workspace_bytes(),), dtype=torch.uint8, device=g.device)
+                self.last_norm = torch.zeros((1,), dtype=torch.float32, device=g.device)
+            ops.clip_grad_norm(g, self.max_norm, self.ord, pre_scale, self.last_norm, self._ws)
+        return 1.0
+
+
+def clip_grad(model, clip_type="value", **args):
+    """basecore.engine.clip_grad with the model in place of its parameter list (the gradients live in model.arena.g)."""
+    return GradClip(model, clip_type, **args)
+
+
+class GradScaler:
+    """Stand-in for megengine.amp.GradScaler as DetSolver builds it (solver/default_solver.py:66-76: init_scale 65536 with
+    DYNAMIC_SCALE, else 128; growth_interval 2000 / 0).  The reference needs it because its AMP is fp16; this build's mixed precision is
+    bf16 activations with fp32 accumulation and fp32 master weights, which has fp32's exponent range, so the scale factor is
+    carried for the protocol (`solver.grad_scaler is not None`, engine/trainer.py:53-54) and never applied."""
+
+    def __init__(self, init_scale=128.0, growth_interval=0):
+        self.scale_factor = float(init_scale)
+        self.growth_interval = int(growth_interval)
+
+
 class Solver:
     """basecore.engine.Solver protocol used by DetTrainer (engine/trainer.py:55-61,98)."""
 
@@ -119,7 +164,23 @@ class Solver:
     def _step(self, model, inputs):
         losses = model(inputs)
         model.backward(on_bucket_ready=self.buckets.on_ready)
+        prof = getattr(self, "comm_profile", None)        # bench.py (N > 1): [(backward done on this stream, collectives done on the comm stream)]
+        if prof is not None and self.buckets.enabled and torch.cuda.is_available():
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         scale = self.buckets.wait()
+        if prof is not None and self.buckets.enabled and torch.cuda.is_available():
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(self.buckets.comm.stream)
+            prof.append((e0, e1))
+        if self.grad_clip_fn is not None:                 # engine/trainer.py:57-61: between the all-reduce and the optimizer step
+            if isinstance(self.grad_clip_fn, GradClip):
+                scale = self.grad_clip_fn(pre_scale=scale)
+            else:                                         # a foreign callable sees the averaged gradients
+                if scale != 1.0:
+                    model.arena.g.mul_(scale)
+                self.grad_clip_fn()
+                scale = 1.0
         self.optimizer.step(grad_scale=scale)
         self.optimizer.clear_grad()
         return losses
@@ -177,7 +238,12 @@ class DetSolver:
             wd = wd * world
         extra = dict(solver_cfg.get("EXTRA_OPT_ARGS", {}))
         opt = SGD(model, lr=lr, weight_decay=wd, momentum=extra.get("momentum", 0.0))
-        return Solver(opt, GradBuckets(model, mode))
+        amp = cfg.get("TRAINER", {}).get("AMP", {}) if hasattr(cfg, "get") else {}
+        scaler = None
+        if amp.get("ENABLE", False):                      # default_solver.py:66-76
+            dyn = bool(amp.get("DYNAMIC_SCALE", False))
+            scaler = GradScaler(65536.0 if dyn else 128.0, 2000 if dyn else 0)
+        return Solver(opt, GradBuckets(model, mode), grad_scaler=scaler)
 
 
 def broadcast_parameters(model, src=0):

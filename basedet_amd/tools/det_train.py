@@ -9,6 +9,12 @@ import os
 import socket
 import subprocess
 import sys
+import time
+
+# RCCL shares buffers between the rank processes through dmabuf IPC on this driver stack; the legacy IPC mode fails with
+# `hipIpcGetMemHandle: invalid argument`.  Must be in the environment before the first HIP call of the process -- also when the ranks
+# were started by torch.distributed.run rather than by the -n launcher below.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))      # run as a script: repo root
 
@@ -18,6 +24,9 @@ def default_parser():
     p.add_argument("-f", "--file", type=str, required=True, help="training process description file (defines Cfg)")
     p.add_argument("-n", "--ngpus", type=int, default=1, help="number of GPUs (processes) on this node")
     p.add_argument("--iters", type=int, default=None, help="stop after this many iterations (smoke runs)")
+    p.add_argument("--synthetic", action="store_true",
+                   help="train on the synthetic DummyLoader batches (utils/dummy.py) -- the ONLY data source of this build: dataset "
+                        "readers are outside the hot-path scope, so without this flag (or DATA.BUILDER_NAME DummyLoader) the entry refuses to run")
     p.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE pairs merged into the config")
     return p
 
@@ -38,6 +47,8 @@ def worker(args):
     cfg = load_cfg(args.file)
     if args.opts:
         cfg.merge(args.opts)                                            # det_train.py:71
+    if args.synthetic:
+        cfg.DATA.BUILDER_NAME = "DummyLoader"
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         comm.set_comm(comm.Comm.from_env())
     else:
@@ -47,7 +58,29 @@ def worker(args):
     torch.cuda.synchronize()
     if comm.get_comm() is not None:
         comm.get_comm().barrier()
+        comm.get_comm().destroy()                                       # ncclCommDestroy before the process exits
+        comm.set_comm(None)
     return out
+
+
+def wait_ranks(procs, poll_s=0.2):
+    """Poll every rank process; when one exits non-zero, end the survivors by their exact PIDs (they would otherwise block forever in
+    an RCCL collective) and return that code."""
+    rc = 0
+    alive = set(range(len(procs)))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for o in alive:
+                    procs[o].kill()
+        if alive:
+            time.sleep(poll_s)
+    return rc
 
 
 def main():
@@ -59,10 +92,7 @@ def main():
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.ngpus), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-        rc = 0
-        for p in procs:
-            rc = p.wait() or rc
-        sys.exit(rc)
+        sys.exit(wait_ranks(procs))
     worker(args)
 
 

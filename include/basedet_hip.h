@@ -513,6 +513,18 @@ int bd_det_finalize(const float* boxes, const float* scores, const int32_t* labe
  * ------------------------------------------------------------------------------------------------------- */
 int bd_sgd_momentum_step(float* w, float* v, const float* g, int64_t n, float lr, float momentum, float wd,
                          float grad_scale, bd_stream_t stream);
+/* Gradient clipping between the all-reduce and the optimizer step (engine/trainer.py:57-61: `clip_grad(model.parameters(), TYPE,
+ * **ARGS)` -> Solver.grad_clip_fn; configs/extra_cfg.py:99-105: TYPE "value" ARGS lower/upper, TYPE "norm" ARGS max_norm/ord), over the
+ * flat fp32 gradient arena in place.  pre_scale = the reduce-mode factor (1 / world for MEAN) that has not been applied yet: the
+ * reference clips the averaged gradients, so g <- clip(pre_scale * g) and the SGD launch then runs with grad_scale 1.
+ *   value: g = min(max(pre_scale * g, lower), upper)
+ *   norm : nrm = ||pre_scale * g||_ord over ALL n elements (megengine.optimizer.clip_grad_norm: norm of the per-tensor norms = norm of
+ *          the concatenation), g *= pre_scale * min(1, max_norm / (nrm + 1e-6)); ord = INFINITY -> max |g|.  nrm also goes to
+ *          norm_out[0] (device, may be NULL).  Fixed-order double accumulation: bitwise reproducible.  No host synchronisation. */
+int bd_clip_grad_value(float* g, int64_t n, float pre_scale, float lower, float upper, bd_stream_t stream);
+size_t bd_clip_grad_norm_workspace_bytes(void);
+int bd_clip_grad_norm(float* g, int64_t n, float pre_scale, float max_norm, float ord, float* norm_out, void* ws, size_t ws_bytes,
+                      bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) forward convolutions on the block-scaled MFMA (BASELINE config 5, "fp8 weights").  The reference's

@@ -6,7 +6,7 @@ setuptools.setup(
     name="basedet_amd",
     version="0.2.0",
     description="MI355X-native training hot path behind BaseDet's operator / model / solver surface",
-    packages=setuptools.find_packages(include=["basedet_amd*", "basedet"]),
+    packages=setuptools.find_packages(include=["basedet_amd*", "basedet", "basedet.*"]),
     package_data={"basedet_amd": ["lib/*.so"]},
     entry_points={"console_scripts": ["basedet_train=basedet_amd.tools.det_train:main"]},
 )

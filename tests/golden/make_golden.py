@@ -25,7 +25,116 @@ def load_by_path(name, path):
     return mod
 
 
+def functions_by_name(path, names, env):
+    """The named top-level (pure numpy / Python) functions of a reference file that cannot be imported as a module (its import block
+    needs megengine / loguru): their definitions are compiled from the file where it lies and run in `env`.  Build container only;
+    nothing of the source is written anywhere -- only the arrays the functions return."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in picked} == set(names), (path, names)
+    ns = dict(env)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def nms_fixtures():
+    """Keep lists of the reference's own numpy NMS (layers/common/post_processing.py:106-132 py_cpu_nms) on seeded random boxes with
+    DISTINCT scores (its argsort()[::-1] is not stable, so ties have no reference answer)."""
+    (py_cpu_nms,) = functions_by_name(os.path.join(REF, "basedet/layers/common/post_processing.py"), ["py_cpu_nms"], {"np": np})
+    rng = np.random.default_rng(2024)
+    out = {}
+    cases = []
+    for i, (n, thr, spread) in enumerate([(1, 0.5, 300), (7, 0.5, 60), (64, 0.3, 200), (65, 0.7, 200), (200, 0.5, 300), (1000, 0.5, 600),
+                                          (1000, 0.6, 250), (3000, 0.5, 900)]):
+        xy = rng.uniform(0, spread, (n, 2)); wh = rng.uniform(4, 150, (n, 2))
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        if n >= 64:
+            boxes[n // 2] = boxes[3]                                   # an exact duplicate (IoU 1) and a zero-area box
+            boxes[n // 2 + 1, 2] = boxes[n // 2 + 1, 0]
+        scores = rng.permutation(n).astype(np.float32) / np.float32(n) + np.float32(0.001)     # distinct
+        dets = np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
+        keep = np.asarray(py_cpu_nms(dets, thr), np.int32)
+        out[f"boxes_{i}"], out[f"scores_{i}"], out[f"thr_{i}"], out[f"keep_{i}"] = boxes, scores, np.float32(thr), keep
+        cases.append(i)
+    out["cases"] = np.asarray(cases, np.int32)
+    np.savez(os.path.join(HERE, "reference_nms.npz"), **out)
+
+
+def checkpoint_match_fixtures():
+    """Outputs of the reference's name / shape matching (utils/checkpoint.py:13-29 get_name_matched_keys, get_shape_matched_keys;
+    :40-90 full_match + _filter_unmatched_keys) on key tables shaped like the real use: an ImageNet ResNet file (no prefix, BatchNorm
+    vectors dumped as (1, C, 1, 1)) into a RetinaNet state dict, a full detector checkpoint, ambiguous suffixes resolved by element
+    count, unused keys.  Stored as JSON (names and shapes only)."""
+    import json
+    from typing import Dict, Set, Tuple
+    names = ["get_name_matched_keys", "get_shape_matched_keys", "_filter_unmatched_keys", "full_match"]
+    gn, gs, _, fm = functions_by_name(os.path.join(REF, "basedet/utils/checkpoint.py"), names,
+                                      {"np": np, "Dict": Dict, "Set": Set, "Tuple": Tuple})
+
+    class Shaped:                       # full_match only reads .shape of the checkpoint values
+        def __init__(self, shape):
+            self.shape = tuple(shape)
+
+    model = {}
+    def conv(n, co, ci, k): model[n + ".weight"] = (co, ci, k, k)
+    def bn(n, c):
+        for t in ("weight", "bias", "running_mean", "running_var"):
+            model[f"{n}.{t}"] = (c,)
+    conv("backbone.bottom_up.conv1", 64, 3, 7); bn("backbone.bottom_up.bn1", 64)
+    for blk, (ci, ch, co) in enumerate([(64, 64, 256), (256, 64, 256)]):
+        pre = f"backbone.bottom_up.layer1.{blk}"
+        conv(pre + ".conv1", ch, ci, 1); bn(pre + ".bn1", ch); conv(pre + ".conv2", ch, ch, 3); bn(pre + ".bn2", ch)
+        conv(pre + ".conv3", co, ch, 1); bn(pre + ".bn3", co)
+        if blk == 0:
+            conv(pre + ".downsample.0", co, ci, 1); bn(pre + ".downsample.1", co)
+    for s, ci in ((3, 512), (4, 1024), (5, 2048)):
+        conv(f"backbone.fpn_lateral{s}", 256, ci, 1); model[f"backbone.fpn_lateral{s}.bias"] = (256,)
+        conv(f"backbone.fpn_output{s}", 256, 256, 3); model[f"backbone.fpn_output{s}.bias"] = (256,)
+    for t in ("cls_subnet", "bbox_subnet"):
+        for i in (0, 2, 4, 6):
+            conv(f"head.{t}.{i}", 256, 256, 3); model[f"head.{t}.{i}.bias"] = (256,)
+    conv("head.cls_score", 720, 256, 3); model["head.cls_score.bias"] = (720,)
+    conv("head.bbox_pred", 36, 256, 3); model["head.bbox_pred.bias"] = (36,)
+
+    cases = {}
+    # (a) ImageNet backbone file: bare names, BN vectors (1, C, 1, 1), an fc layer nobody wants
+    ck = {}
+    for k, v in model.items():
+        if k.startswith("backbone.bottom_up."):
+            kk = k[len("backbone.bottom_up."):]
+            ck[kk] = (1, v[0], 1, 1) if (len(v) == 1) else v
+    ck["fc.weight"] = (1000, 2048); ck["fc.bias"] = (1000,)
+    cases["imagenet_backbone"] = ck
+    # (b) a full detector checkpoint: exact names
+    cases["full_detector"] = dict(model)
+    # (c) ambiguous suffixes: "0.weight" / "0.bias" hit both towers (same element counts -> must raise), "cls_score.weight" is unique,
+    #     "conv2.weight" hits two blocks with equal shapes -> assert; "downsample.0.weight" unique
+    cases["unique_suffixes"] = {"cls_score.weight": (720, 256, 3, 3), "downsample.0.weight": (256, 64, 1, 1), "bbox_pred.bias": (36,),
+                                "fpn_lateral4.weight": (256, 1024, 1, 1), "not.there": (3,)}
+    cases["ambiguous_by_count"] = {"conv1.weight": (64, 3, 7, 7)}              # stem (9408) vs layer1.0.conv1 (4096) vs layer1.1.conv1 (16384): count decides
+    cases["ambiguous_assert"] = {"conv2.weight": (64, 64, 3, 3)}                # two blocks, same count -> AssertionError
+    out = {"model": [[k, list(v)] for k, v in model.items()], "cases": {}}
+    for name, ck in cases.items():
+        rec = {"weights": [[k, list(v)] for k, v in ck.items()]}            # a LIST: the iteration order of the checkpoint matters
+        try:
+            mapping, unused = fm({k: Shaped(v) for k, v in ck.items()}, dict(model))
+            rec["mapping"] = {k: v for k, v in mapping.items() if k is not None}
+            rec["unused"] = list(unused)
+        except AssertionError as e:
+            rec["raises"] = "AssertionError"
+        out["cases"][name] = rec
+    out["name_matched"] = {q: sorted(gn(q, model.keys())) for q in ("conv1.weight", "bn1.weight", "weight", "head.cls_score.bias", "layer1.0.conv3.weight", "x")}
+    out["shape_matched"] = {"(1,64,1,1)": sorted(gs((1, 64, 1, 1), {k: v for k, v in model.items() if k.endswith("bn1.weight")})),
+                            "(256,)": sorted(gs((256,), {k: v for k, v in model.items() if k.endswith(".bias") and "head" in k}))}
+    with open(os.path.join(HERE, "reference_checkpoint_match.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
+    nms_fixtures()
+    checkpoint_match_fixtures()
     # ---- 1. DummyLoader (basedet/utils/dummy.py:8-63) --------------------------------------
     dummy = load_by_path("ref_dummy", os.path.join(REF, "basedet/utils/dummy.py"))
     out = {}

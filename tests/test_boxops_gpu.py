@@ -170,6 +170,18 @@ def test_nms_random_matches_oracle():
     assert ops.batched_nms(_dev(np.zeros((0, 4), np.float32)), _dev(np.zeros((0,), np.float32)), None, 0.5).numel() == 0
 
 
+def test_nms_matches_reference_py_cpu_nms(golden_dir):
+    """The HIP NMS against keep lists generated by the reference's own numpy NMS (tests/golden/reference_nms.npz <- make_golden.py)."""
+    ops = _ops()
+    k = np.load(os.path.join(golden_dir, "reference_nms.npz"))
+    for i in k["cases"]:
+        boxes, scores, thr = k[f"boxes_{i}"], k[f"scores_{i}"], float(k[f"thr_{i}"])
+        got = ops.batched_nms(_dev(boxes), _dev(scores), None, thr).cpu().numpy()
+        assert got.tolist() == k[f"keep_{i}"].tolist(), int(i)
+        got = ops.batched_nms(_dev(boxes), _dev(scores), _dev(np.full(len(scores), 3, np.int32)), thr).cpu().numpy()
+        assert got.tolist() == k[f"keep_{i}"].tolist(), int(i)
+
+
 def test_focal_and_l1_losses():
     """sigmoid_focal_loss / smooth_l1_loss value and gradient vs the float64 oracle (tolerance: 2e-3 rel on the
     sum -- bf16 logits are exact inputs to both sides; gradients compared after the kernel's bf16 rounding)."""

@@ -59,3 +59,45 @@ def test_pickle_with_foreign_objects_is_refused(tmp_path):
         pickle.dump({"x": pytest}, f) if False else f.write(pickle.dumps({"x": slice(1, 2)}))
     with pytest.raises(pickle.UnpicklingError):
         load_checkpoint_file(path)
+
+
+def test_full_match_reproduces_the_reference_outputs(golden_dir):
+    """tests/golden/reference_checkpoint_match.json: outputs of the reference's own get_name_matched_keys / get_shape_matched_keys /
+    full_match (utils/checkpoint.py:13-90), generated in the build container by tests/golden/make_golden.py."""
+    import json
+    import os
+    from basedet_amd.utils.checkpoint import _name_matched
+    with open(os.path.join(golden_dir, "reference_checkpoint_match.json")) as f:
+        d = json.load(f)
+    model = {k: tuple(v) for k, v in d["model"]}
+    for q, want in d["name_matched"].items():
+        assert sorted(_name_matched(q, model.keys())) == want, q
+    for name, rec in d["cases"].items():
+        w = {k: np.zeros(tuple(v), np.float32) for k, v in rec["weights"]}
+        if rec.get("raises"):
+            with pytest.raises(AssertionError):
+                full_match(w, model)
+            continue
+        mapping, unused = full_match(w, model)
+        assert mapping == rec["mapping"], name
+        assert unused == rec["unused"], name
+    # the ImageNet-backbone case end to end: BatchNorm vectors dumped as (1, C, 1, 1) are reshaped on load (checkpoint.py:24-28, 118-121)
+    rec = d["cases"]["imagenet_backbone"]
+
+    class M:
+        def __init__(self):
+            self.p = {k: np.zeros(v, np.float32) for k, v in model.items()}
+
+        def state_dict(self):
+            return {k: v.copy() for k, v in self.p.items()}
+
+        def _bind_params(self, st):
+            self.p = st
+
+    rng = np.random.default_rng(0)
+    ck = {k: rng.normal(size=tuple(v)).astype(np.float32) for k, v in rec["weights"]}
+    m = M()
+    load_matched_weights(m, {"model": {"state_dict": ck}})
+    for mk, ckk in rec["mapping"].items():
+        assert np.array_equal(m.p[mk], ck[ckk].reshape(model[mk])), mk
+    assert not m.p["head.cls_score.weight"].any()

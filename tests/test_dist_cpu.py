@@ -90,6 +90,82 @@ def test_world2_gloo_bucketed_allreduce():
     assert phases == ["fpn", "head", "layer2", "layer3", "layer4"]
 
 
+def _worker_real_arena(rank, world, port, out):
+    """The real ParamArena (CPU tensors) reserved from RetinaNet-R18's reference parameter table; GlooComm.allreduce(.., "avg") as the
+    FCOS / OTA normaliser exchange (models/det/fcos.py:143-144); broadcast_parameters; the clip -> SGD order of Solver._step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basedet_amd import comm
+    from basedet_amd.configs import retinanet_r18_config
+    from basedet_amd.models import params as P
+    from basedet_amd.models.engine import ParamArena
+    from basedet_amd.solver import GradBuckets, broadcast_parameters
+    comm.set_comm(comm.GlooComm())
+    cfg = retinanet_r18_config()
+    params = P.init_retinanet_params(cfg, seed=rank)                 # DIFFERENT initial weights per rank: rank 0's must win
+    names = P.trainable_names(params, cfg.MODEL.BACKBONE.FREEZE_AT)
+
+    class M:
+        repacked = 0
+
+        def repack_trainable(self):
+            self.repacked += 1
+
+    model = M()
+    model.arena = ParamArena(torch.device("cpu"))
+    idx = {n: model.arena.reserve(n, params[n].shape) for n in names}
+    model.arena.allocate()
+    for n, i in idx.items():
+        model.arena.view("w", i).copy_(torch.from_numpy(params[n]))
+    w_mine = model.arena.w.clone()
+    broadcast_parameters(model)
+    gathered = [torch.empty_like(model.arena.w) for _ in range(world)]
+    dist.all_gather(gathered, model.arena.w)
+    ok_bcast = all(torch.equal(g, gathered[0]) for g in gathered) and model.repacked == 1
+    ok_bcast = ok_bcast and (rank == 0) == bool(torch.equal(model.arena.w, w_mine))
+    # every trainable parameter of the real table lands in exactly one bucket; bucketed MEAN all-reduce
+    gb = GradBuckets(model, "MEAN")
+    gen = torch.Generator().manual_seed(100 + rank)
+    model.arena.g.copy_(torch.randn(model.arena.total, generator=gen))
+    mine = model.arena.g.clone()
+    for phase in ("head", "fpn", "layer4", "layer3", "layer2"):
+        gb.on_ready(phase)
+    scale = gb.wait()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    covered = torch.zeros(model.arena.total, dtype=torch.bool)
+    for lo, hi in gb.ranges.values():
+        assert not covered[lo:hi].any()
+        covered[lo:hi] = True
+    for _, _, off, n in model.arena.entries:
+        assert covered[off:off + n].all()
+    ok_reduce = bool(torch.allclose(model.arena.g[covered] * scale, (sum(both) / world)[covered], rtol=1e-6, atol=1e-7))
+    # the two-scalar normaliser exchange: rank r holds (num_fg, sum_ctr) = (10 + 7 r, 3.5 + r)
+    stats = torch.tensor([10.0 + 7 * rank, 3.5 + rank])
+    comm.get_comm().allreduce(stats, "avg")
+    ok_stats = bool(torch.allclose(stats, torch.tensor([10.0 + 3.5 * (world - 1), 3.5 + 0.5 * (world - 1)])))
+    if rank == 0:
+        out.put((ok_bcast, ok_reduce, ok_stats, scale, len(names), model.arena.total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_real_arena_broadcast_buckets_and_stats():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real_arena, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok_bcast, ok_reduce, ok_stats, scale, n_names, total = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ok_bcast and ok_reduce and ok_stats and scale == 0.5
+    assert n_names > 40 and total > 10_000_000
+
+
 def test_lr_schedule_restates_reference_hook():
     from basedet_amd.configs import RetinaNetConfig
     from basedet_amd.solver import SGD, WarmupMultiStepLR

@@ -33,14 +33,21 @@ world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK",
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 if world > 1 or os.environ.get("BD_FORCE_ALLREDUCE") == "1":
     bdcomm.set_comm(bdcomm.Comm.from_env())
-from basedet_amd.configs import RetinaNetConfig
-from basedet_amd.models import RetinaNet, params as P
+from basedet_amd.configs import FCOSConfig, RetinaNetConfig
+from basedet_amd.models import FCOS, RetinaNet, params as P
 from basedet_amd.solver import DetSolver, broadcast_parameters
 from basedet_amd.utils import DummyLoader
 per_rank = int(os.environ["BD_TEST_BATCH"]) // world
-cfg = RetinaNetConfig(); cfg.MODEL.BATCHSIZE = per_rank
-params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
-model = RetinaNet(cfg, params=params)
+fcos = os.environ.get("BD_TEST_MODEL", "retinanet") == "fcos"
+cfg = FCOSConfig() if fcos else RetinaNetConfig()
+cfg.MODEL.BATCHSIZE = per_rank
+if fcos:
+    params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.2)
+    params["head.bbox_pred.bias"] = np.full_like(params["head.bbox_pred.bias"], 0.5)
+    model = FCOS(cfg, params=params)
+else:
+    params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
+    model = RetinaNet(cfg, params=params)
 if world > 1 and rank > 0:
     model.arena.w.add_(1.0)                      # rank 0's parameters must win (configs/detection_cfg.py:80-82)
     broadcast_parameters(model)
@@ -53,6 +60,12 @@ solver.optimizer.param_groups[0]["lr"] = 1e-3
 # the global batch: images of loaders seeded 0 and 1; a rank takes its contiguous slice (SURVEY 8e partitioning)
 parts = [next(DummyLoader(2, (320, 448), seed=s)) for s in range(int(os.environ["BD_TEST_BATCH"]) // 2)]
 full = {k: np.concatenate([np.asarray(p[k], dtype=np.float32) for p in parts], 0) for k in ("data", "gt_boxes", "im_info")}
+if fcos:
+    # the second half of the global batch (rank 1's slice when world = 2) keeps fewer gts: the ranks see DIFFERENT num_fg / sum ctr,
+    # which FCOS averages over the ranks before normalising (models/det/fcos.py:143-144) -- then the mean of the per-rank gradients
+    # equals the one-rank gradient on the concatenated batch
+    half = full["im_info"].shape[0] // 2
+    full["im_info"][half:, 4] = np.minimum(full["im_info"][half:, 4], [3, 2] * (half // 2) if half >= 2 else [3])
 lo = rank * per_rank
 batch = {k: torch.from_numpy(v[lo:lo + per_rank]).cuda() for k, v in full.items()}
 w0 = model.arena.w.clone()
@@ -74,11 +87,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(tmp, tag, world=1, force=False, batch=4):
+def _run(tmp, tag, world=1, force=False, batch=4, model="retinanet"):
     port = _free_port()
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, BD_FORCE_ALLREDUCE="1" if force else "0", HSA_ENABLE_IPC_MODE_LEGACY="0", BD_TEST_BATCH=str(batch),
+                   BD_TEST_MODEL=model,
                    RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         out = os.path.join(tmp, f"{tag}_{r}.npy")
@@ -108,6 +122,14 @@ def test_rccl_bucket_path_is_bit_identical_to_the_local_step(tmp_path):
     assert forced == plain, (forced, plain)
 
 
+def test_fcos_stats_allreduce_on_the_rccl_path_is_bit_identical_to_the_local_step(tmp_path):
+    """FCOS adds the forward-side two-scalar all-reduce (ncclAvg of num_fg / sum ctr, models/det/fcos.py:143-144) on the solver's
+    high-priority stream, interleaved with the bucket all-reduces on the communication stream of the SAME communicator."""
+    plain, _ = _run(str(tmp_path), "fplain", model="fcos")
+    forced, _ = _run(str(tmp_path), "fforced", force=True, model="fcos")
+    assert forced == plain, (forced, plain)
+
+
 def _device_count():
     import torch
     return torch.cuda.device_count()
@@ -125,4 +147,18 @@ def test_two_ranks_match_one_rank_on_the_concatenated_batch(tmp_path):
     rel = np.linalg.norm(step2 - step1) / np.linalg.norm(step1)
     # same mathematical update; the weight-gradient sums over pixels are split differently (2 + 2 images vs 4) and after the first
     # step the bf16 re-packed weights may round differently in their last bit
+    assert rel < 2e-2, rel
+
+
+def test_two_ranks_fcos_with_different_num_fg_match_one_rank(tmp_path):
+    """The FCOS step with world 2: the ranks hold different numbers of foreground points; after the two-scalar mean all-reduce the
+    averaged gradient equals the one-rank gradient on the concatenated batch."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs (one process per GPU; RCCL refuses two ranks on one device)")
+    d2, w2 = _run(str(tmp_path), "f2", world=2, batch=4, model="fcos")
+    assert d2[0] == d2[1], "the two ranks ended with different parameters"
+    _, w1 = _run(str(tmp_path), "f1", world=1, batch=4, model="fcos")
+    assert np.array_equal(w1[0][0], w2[0][0])
+    step2, step1 = w2[0][1] - w2[0][0], w1[0][1] - w1[0][0]
+    rel = np.linalg.norm(step2 - step1) / np.linalg.norm(step1)
     assert rel < 2e-2, rel

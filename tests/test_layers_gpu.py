@@ -300,7 +300,12 @@ def test_basedet_train_entry_runs_a_user_config(tmp_path):
     import subprocess
     path = tmp_path / "config.py"
     path.write_text(_USER_CFG)
-    r = subprocess.run([sys.executable, "-m", "basedet.tools.det_train", "-f", str(path), "--iters", "3", "SOLVER.WARM_ITERS", "2"],
+    base = [sys.executable, "-m", "basedet.tools.det_train", "-f", str(path), "--iters", "3"]
+    # without an explicit opt-in the entry refuses to train a COCO-reader config on synthetic noise (this build has no dataset readers)
+    r = subprocess.run(base + ["SOLVER.WARM_ITERS", "2"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode != 0 and "DummyLoader" in r.stderr, (r.returncode, r.stderr[-2000:])
+    r = subprocess.run(base + ["--synthetic", "SOLVER.WARM_ITERS", "2"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
     assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-1000:])
     lines = [l for l in r.stdout.splitlines() if "total_loss" in l]

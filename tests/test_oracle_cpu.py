@@ -24,6 +24,18 @@ def test_oracle_matches_reference_nms_kat(golden_dir):
     assert keep.tolist() == k["nms_keep"].tolist()
 
 
+def test_oracle_nms_matches_reference_py_cpu_nms(golden_dir):
+    """tests/golden/reference_nms.npz: keep lists of the reference's own numpy NMS (layers/common/post_processing.py:106-132) on seeded
+    random boxes with distinct scores, duplicates and zero-area boxes -- pins the suppression rule (IoU > thr) and the IoU form."""
+    k = np.load(os.path.join(golden_dir, "reference_nms.npz"))
+    for i in k["cases"]:
+        keep = ob.nms(k[f"boxes_{i}"], k[f"scores_{i}"], float(k[f"thr_{i}"]))
+        assert keep.tolist() == k[f"keep_{i}"].tolist(), int(i)
+        # the class-offset form with a single class is the same problem
+        keep = ob.batched_nms(k[f"boxes_{i}"], k[f"scores_{i}"], np.zeros(len(k[f"scores_{i}"]), np.int32), float(k[f"thr_{i}"]))
+        assert keep.tolist() == k[f"keep_{i}"].tolist(), int(i)
+
+
 def test_oracle_matches_reference_pad_kat(golden_dir):
     """tests/layers/test_preprocess.py:13-35: padded shapes and sum preservation."""
     k = np.load(os.path.join(golden_dir, "reference_kat.npz"))
