@@ -14,6 +14,7 @@ ARCH = "gfx950"
 # per-file extra flags: the box ops must not contract a*b+c into FMA (bit-exact parity with the numpy oracle)
 SOURCES = {
     "image_ops.hip": [],
+    "h2d.hip": [],
     "conv_igemm.hip": [],
     "conv3x3.hip": [],
     "conv3x3_pp.hip": [],

@@ -188,7 +188,8 @@ class ConvLayer:
 
     def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None, g8=None, dx8=None, q_scale=1.0,
               add_before=None, sparse=False):
-        """dx (+)= conv^T(g).  first=False accumulates onto dx (pre-mask); mask = forward activation whose
+        """dx (+)= conv^T(g); returns True when the launch also wrote the e5m2 twin dx8 (= dx * q_scale, q_scale = the CONSUMER's
+        gradient scale).  first=False accumulates onto dx (pre-mask); mask = forward activation whose
         ReLU gates dx (maskbits: the same gate bit-packed, written by the producing forward launch); add_after = tensor added
         after masking (P6: gradient that bypasses the ReLU)."""
         flags, add = 0, None
@@ -211,15 +212,18 @@ class ConvLayer:
         if self.amax_slot is not None and self.probe_ctl[0] and (self.fp8_1x1_dgrad or self.fp8_dgrad):
             ops.absmax_bf16(g, self.amax_slot)
         if self.fp8_1x1_dgrad and g8 is not None and ops.conv1x1_fp8_ok(d, 1):
-            return ops.conv1x1_fp8(d, 1, g8, self.w_q8t, self.w_scale8t, None, dx, add=add, mask=mask, maskbits=maskbits, y8=dx8,
-                                   q_scale=q_scale, flags=flags)
+            ops.conv1x1_fp8(d, 1, g8, self.w_q8t, self.w_scale8t, None, dx, add=add, mask=mask, maskbits=maskbits, y8=dx8,
+                            q_scale=q_scale, flags=flags)
+            return dx8 is not None
         if self.fp8_dgrad and maskbits is None:
             # g8: the e5m2 twin of g (g * grad_scale) when the producing launch wrote one, else a cast pass; dx8: twin of dx to write
             gq = g8 if g8 is not None else ops.quantize_bf8(g, self.grad_scale, self.q8_scratch(g.numel())[: g.numel()])
-            return ops.conv2d_dgrad_fp8(d, gq, self.w_q8t, self.w_scale8t, dx, add=add, mask=mask, flags=flags, dx8=dx8, q_scale=q_scale)
+            ops.conv2d_dgrad_fp8(d, gq, self.w_q8t, self.w_scale8t, dx, add=add, mask=mask, flags=flags, dx8=dx8, q_scale=q_scale)
+            return dx8 is not None
         if dx8 is not None and not ops.dense_1x1_bits_ok(d):
-            dx8 = None
-        return ops.conv2d_dgrad(d, g, self.w_dgrad, dx, add=add, mask=mask, flags=flags, maskbits=maskbits, dx8=dx8, q_scale=q_scale)
+            dx8 = None               # only the dense 1x1 kernel writes a twin on the bf16 path: the caller must not mark it ready
+        ops.conv2d_dgrad(d, g, self.w_dgrad, dx, add=add, mask=mask, flags=flags, maskbits=maskbits, dx8=dx8, q_scale=q_scale)
+        return dx8 is not None
 
     def dgrad_writes_twin(self, gin, gout):
         """True when dgrad(..., dx8=t) fills t: the fp8 patch kernel and the dense 1x1 kernel do, the other bf16 kernels do not."""

@@ -181,7 +181,7 @@ class FPNDetector:
         # once training has shrunk the gradients: 4 096 diverged after ~1 500 steps of the repeated-batch run, 65 536 did not.
         self._fp8_grad_layers = [c for c in self.convs.values() if c.fp8_dgrad or c.fp8_1x1_dgrad or c.fp8_wgrad]
         if self._fp8_grad_layers:
-            for c in self.convs.values():             # one scale everywhere from the start (a twin's producer reads it off a neighbour)
+            for c in self.convs.values():             # one scale everywhere at the start (a twin's producer reads it off the consumer's layer object)
                 c.grad_scale = float(m.get("FP8_GRAD_SCALE", 4096.0))
         self.fp8_delayed_scaling = bool(m.get("FP8_DELAYED_SCALING", True)) and bool(self._fp8_grad_layers) and self.device.type == "cuda"
         # Stochastic rounding of those gradients (bd_fp8_set_stochastic_rounding): round-to-nearest e5m2 repeats the same error on the
@@ -190,8 +190,18 @@ class FPNDetector:
         self.fp8_amax_interval = int(m.get("FP8_AMAX_INTERVAL", 20))
         self.fp8_amax_delay = int(m.get("FP8_AMAX_DELAY", 4))
         self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 15.0))       # max |g| * scale lands in (2^(t-1), 2^t]; e5m2 tops out at 1.75 * 2^15 (R50: 12 and the static 4 096 diverged in the 2 020-step run, 13 - 15 did not, 16 clamps; R101 at batch 32: 14 diverged before step 1 020, 15 did not: DESIGN.md)
-        self._fp8_t, self._amax_pending, self._amax_prev = 0, None, 0.0
+        # Granularity of the delayed scale (round 3).  One scale for all layers had to span the 2^9.7 spread between max |g| at the head and
+        # at the backbone's conv1 layers (scripts/exp/fp8_amax_spread.py): with the head's maximum at 2^15 the backbone's gradients sat
+        # ten binades lower and their small values flushed to zero -- R101 at the batch-32 learning rate left the finite range.  "group"
+        # (default) keeps one scale per backward phase (head / fpn / layer4 / layer3 / layer2: the all-reduce buckets), "layer" one
+        # per layer, "global" the round-2 behaviour.  Every twin is written with its CONSUMER's scale (q_scale at each hand-off) and a
+        # layer's transposed fp8 weights fold in 1 / its own scale, so any partition is consistent.
+        self.fp8_scale_groups = str(m.get("FP8_SCALE_GROUPS", "group"))
+        assert self.fp8_scale_groups in ("global", "group", "layer"), self.fp8_scale_groups
+        self._fp8_t, self._amax_pending, self._amax_prev = 0, None, {}
+        self._fp8_staged = None                  # {conv: scale} waiting for the next weight repack (optimizer step)
         self.fp8_scale_log = []
+        self.fp8_group_scales = {}
         if self.fp8_delayed_scaling:
             n = len(self._fp8_grad_layers)
             self._amax_dev = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -215,6 +225,26 @@ class FPNDetector:
             return True
         return False
 
+    def _fp8_scale_key(self, c):
+        if self.fp8_scale_groups == "global":
+            return "all"
+        if self.fp8_scale_groups == "layer":
+            return "fpn_output" if "fpn_output" in c.name else c.name      # the output convolutions all read ONE twin of dL/dP
+        n = c.name
+        if n.startswith(("head.", "rpn.", "rcnn.")):
+            return "head"
+        if "fpn_" in n or "top_block" in n:
+            return "fpn"
+        return n.split(".")[2] if n.startswith("backbone.bottom_up.") else "head"
+
+    def _fp8_apply_staged(self):
+        """New gradient scales take effect HERE, together with the weight repack that folds 1 / scale into the transposed fp8 weights
+        (repack_trainable, i.e. the optimizer step): a second backward() without a step keeps quantisers and weights consistent."""
+        st, self._fp8_staged = self._fp8_staged, None
+        if st:
+            for c, sc in st.items():
+                c.grad_scale = sc
+
     def _fp8_probe_end(self, probing):
         if self.fp8_stochastic_rounding:
             ops.fp8_set_stochastic_rounding(0)
@@ -223,6 +253,11 @@ class FPNDetector:
         t = self._fp8_t - 1
         if probing:
             self._probe_ctl[0] = False
+            from .. import comm as _comm
+            cm = _comm.get_comm()
+            if cm is not None and cm.world > 1:       # every rank quantises with the same scales: max |g| over the ranks
+                cm.allreduce_async(self._amax_dev, [torch.cuda.current_stream()], "max")
+                cm.wait()
             self._amax_host.copy_(self._amax_dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -231,14 +266,28 @@ class FPNDetector:
             ev, t0 = self._amax_pending
             ev.synchronize()                      # long done: the host runs a few steps ahead of the device, not FP8_AMAX_DELAY + the queue
             self._amax_pending = None
-            amax = float(self._amax_host.max())
-            if np.isfinite(amax) and amax > 0.0:
-                eff = max(amax, self._amax_prev)  # two-probe history: a scale never chases a single small reading
-                self._amax_prev = amax
-                scale = float(2.0 ** min(max(np.floor(self.fp8_amax_target - np.log2(eff)), -16.0), 40.0))
-                for c in self.convs.values():         # every layer: a twin's producer reads the scale off a neighbouring layer object
-                    c.grad_scale = scale
-                self.fp8_scale_log.append((t0, t, amax, scale))
+            am = self._amax_host.numpy().astype(np.float64)
+            keys = {}
+            for i, c in enumerate(self._fp8_grad_layers):
+                k = self._fp8_scale_key(c)
+                if np.isfinite(am[i]):
+                    keys[k] = max(keys.get(k, 0.0), float(am[i]))
+            scales = {}
+            for k, amax in keys.items():
+                if amax > 0.0:
+                    eff = max(amax, self._amax_prev.get(k, 0.0))      # two-probe history: a scale never chases a single small reading
+                    self._amax_prev[k] = amax
+                    scales[k] = float(2.0 ** min(max(np.floor(self.fp8_amax_target - np.log2(eff)), -16.0), 40.0))
+            if scales:
+                staged = {}
+                for c in self.convs.values():         # every layer of a group (a twin's producer reads the scale off its CONSUMER's layer object)
+                    k = self._fp8_scale_key(c)
+                    if k in scales:
+                        staged[c] = scales[k]
+                self._fp8_staged = staged
+                self.fp8_group_scales.update(scales)
+                top = max(keys.values())
+                self.fp8_scale_log.append((t0, t, top, min(scales.values())))
 
     def _bind_params(self, params):
         """(Re)load every parameter from a reference-layout dict (name -> numpy) and refresh the packed bf16 copies."""
@@ -278,6 +327,7 @@ class FPNDetector:
     def repack_trainable(self):
         """All trainable convs in ONE launch (bd_weight_pack_multi); the table holds raw pointers into the arena and the packed
         tensors, which never move after _build_layers."""
+        self._fp8_apply_staged()
         if getattr(self, "_pack_table", None) is None:
             ent = [(c.w, c.row_scale, c.w_fwd, c.w_dgrad, c.cout, c.k * c.k, c.cin) for c in self.convs.values() if c.trainable]
             self._pack_table = ops.build_pack_table(ent, self.device)
@@ -508,9 +558,7 @@ class FPNDetector:
     def pre_process(self, inputs):
         """RetinaNet.pre_process (retinanet.py:90-107): H2D copy + pad to x32 + normalise (fused kernel)."""
         image = inputs["data"] if isinstance(inputs, dict) else inputs
-        if not torch.is_tensor(image):
-            image = torch.as_tensor(np.asarray(image))
-        if not image.is_cuda:
+        if not (torch.is_tensor(image) and image.is_cuda):
             image = self._host_to_device(image)
         image = image.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
         N, _, H, W = image.shape
@@ -534,20 +582,20 @@ class FPNDetector:
         return out
 
     def _host_to_device(self, image):
-        """data_to_input's `Tensor(image)` (layers/common/pre_processing.py:13): a host batch of any float dtype (the loaders yield
-        float64 / uint8-valued float32) becomes fp32 in a pinned staging buffer -- the conversion is torch's multi-threaded host copy
-        -- and goes to HBM with one asynchronous DMA on the current stream.  (Converting and sending image by image, to overlap the
-        two, measured slower: 251 vs 299-352 img/s in bench.py's reference-protocol leg.)  The staging buffer is reused: the next call
-        first waits for the previous transfer's event."""
-        st = getattr(self, "_stage", None)
-        if st is None or st[0].shape != image.shape:
-            st = self._stage = [torch.empty(image.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event()]
-        else:
-            st[1].synchronize()
-        st[0].copy_(image)
-        dev = st[0].to(self.device, non_blocking=True)
-        st[1].record()
-        return dev
+        """data_to_input's `Tensor(image)` (layers/common/pre_processing.py:13): a host batch (the loaders yield float64 / float32 /
+        uint8 numpy arrays) becomes the fp32 device tensor through bd_h2d_submit -- the library's worker threads convert it chunk by
+        chunk into pinned memory and every chunk leaves with its own DMA as soon as it is converted (conversion under transfer).
+        Round 2 converted the whole batch with one host copy first: 13-20 ms of the reference-protocol step."""
+        arr = image.numpy() if torch.is_tensor(image) else np.asarray(image)
+        st = getattr(self, "_stager", None)
+        if st is None:
+            st = self._stager = ops.HostStager(self.device, int(self.cfg.MODEL.get("H2D_THREADS", 0)))
+        if not st.supports(arr):
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+        dst = getattr(self, "_h2d_dst", None)
+        if dst is None or dst.shape != arr.shape:
+            dst = self._h2d_dst = torch.empty(arr.shape, dtype=torch.float32, device=self.device)
+        return st.submit(arr, dst, int(self.cfg.MODEL.get("H2D_CHUNK_ELEMS", 0)))
 
     def _block_forward(self, blk, b, x, x8=None):
         """x8: the e4m3 twin of the block input when the previous block's conv3 wrote one (fp8 mode)."""
@@ -762,9 +810,9 @@ class FPNDetector:
                     nxt = getattr(b, "g_mid8", None) if ci == 2 else getattr(b, "g_mid8a", None)
                 if nxt is not None and not convs[ci].dgrad_writes_twin(geos[ci], geos[ci + 1]):
                     nxt = None
-                convs[ci].dgrad(g, geos[ci], geos[ci + 1], b.g_mids[ci - 1], mask=b.mids[ci - 1], g8=g8, dx8=nxt,
-                                q_scale=convs[ci - 1].grad_scale)
-                g, g8 = b.g_mids[ci - 1], nxt
+                wrote = convs[ci].dgrad(g, geos[ci], geos[ci + 1], b.g_mids[ci - 1], mask=b.mids[ci - 1], g8=g8, dx8=nxt,
+                                        q_scale=convs[ci - 1].grad_scale)
+                g, g8 = b.g_mids[ci - 1], (nxt if wrote else None)
             self._wgrad(convs[0], xin, g, geos[0], geos[1], ws)
             if prev_tr:
                 gx = pl.blk[bi - 1].g_out
@@ -775,24 +823,25 @@ class FPNDetector:
                 # twin (fp8 mode) for the previous block's conv3
                 pb = pl.blk[bi - 1]
                 gx8 = getattr(pb, "g_out8", None)
-                kw = dict(mask=xin, maskbits=xbits, g8=g8, dx8=gx8, q_scale=convs[0].grad_scale)
+                # ... written with the scale of its consumer, the previous block's conv3 (another scale group at a layer boundary)
+                kw = dict(mask=xin, maskbits=xbits, g8=g8, dx8=gx8, q_scale=self.blocks[bi - 1]["convs"][-1].grad_scale)
                 if blk["ds"] is not None and gx8 is None and self.sparse_shortcut_grad:
                     # conv1 first (writes every pixel, gated), then the stride-2 shortcut adds its gradient IN PLACE at the quarter of
                     # the pixels it reaches ((a m + b) m = (a + b) m for a 0 / 1 gate m): instead of a full-resolution tensor that is
                     # three quarters zeros being written, read back and summed
-                    convs[0].dgrad(g, geos[0], geos[1], gx, first=not tapped, **kw)
+                    wrote = convs[0].dgrad(g, geos[0], geos[1], gx, first=not tapped, **kw)
                     blk["ds"].dgrad(G, b.gin, b.gout, gx, first=False, mask=xin, sparse=True)
                 elif blk["ds"] is not None:         # (the last writer must be the launch that can write the e5m2 twin)
                     blk["ds"].dgrad(G, b.gin, b.gout, gx, first=not tapped)
-                    convs[0].dgrad(g, geos[0], geos[1], gx, first=False, **kw)
+                    wrote = convs[0].dgrad(g, geos[0], geos[1], gx, first=False, **kw)
                 else:
                     if tapped:
                         ops.add_bf16(gx, G, gx)
-                        convs[0].dgrad(g, geos[0], geos[1], gx, first=False, **kw)
+                        wrote = convs[0].dgrad(g, geos[0], geos[1], gx, first=False, **kw)
                     else:
                         # identity skip: gx = (dgrad + G) * mask
-                        convs[0].dgrad(g, geos[0], geos[1], gx, add_before=G, **kw)
-                pb.g_out8_ready = gx8 is not None and (convs[0].fp8_1x1_dgrad and g8 is not None or convs[0].dgrad_writes_twin(geos[0], geos[1]))
+                        wrote = convs[0].dgrad(g, geos[0], geos[1], gx, add_before=G, **kw)
+                pb.g_out8_ready = gx8 is not None and bool(wrote)     # what the launch actually did (a bf16 fallback drops the twin)
             if on_bucket_ready and (bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]):
                 on_bucket_ready(f"layer{blk['layer']}", side)
         self._join_wgrads()

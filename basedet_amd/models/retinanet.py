@@ -148,7 +148,8 @@ class RetinaNet(FPNDetector):
             gs = tower[n - 1].grad_scale
             self._wgrad(pred, acts[-1], dpred, pyr, pyr, ws, cws)
             tw = g8[n - 1] if pred.dgrad_writes_twin(pyr, pyr) else None       # None also when twins are off (g8 holds no buffers)
-            pred.dgrad(dpred, pyr, pyr, gbuf[n - 1], mask=acts[-1], dx8=tw, q_scale=gs)
+            if not pred.dgrad(dpred, pyr, pyr, gbuf[n - 1], mask=acts[-1], dx8=tw, q_scale=gs):
+                tw = None
             act8 = pl.cls_act8 if ti == 0 else pl.box_act8
             for i in range(n - 1, -1, -1):
                 x = acts[i - 1] if i > 0 else pl.P
@@ -157,13 +158,15 @@ class RetinaNet(FPNDetector):
                 self._wgrad(tower[i], x, gbuf[i], pyr, pyr, ws, cws, x8=x8, g8=tw)
                 if i > 0:
                     nxt = g8[i - 1] if tower[i].dgrad_writes_twin(pyr, pyr) else None
-                    tower[i].dgrad(gbuf[i], pyr, pyr, gbuf[i - 1], mask=acts[i - 1], g8=tw, dx8=nxt, q_scale=gs)
-                    tw = nxt
+                    wrote = tower[i].dgrad(gbuf[i], pyr, pyr, gbuf[i - 1], mask=acts[i - 1], g8=tw, dx8=nxt, q_scale=tower[i - 1].grad_scale)
+                    tw = nxt if wrote else None
                 else:
-                    tower[i].dgrad(gbuf[i], pyr, pyr, pl.g_P, first=(ti == 0), g8=tw,
-                                   dx8=pl.g_P8 if tower[i].dgrad_writes_twin(pyr, pyr) else None, q_scale=gs)
+                    # dL/dP's twin goes to the FPN output convolutions: THEIR scale (another scale group)
+                    wrote_p = tower[i].dgrad(gbuf[i], pyr, pyr, pl.g_P, first=(ti == 0), g8=tw,
+                                             dx8=pl.g_P8 if tower[i].dgrad_writes_twin(pyr, pyr) else None,
+                                             q_scale=self.output[self.fpn_stages[0]].grad_scale)
         # the box tower's launch wrote the twin of the FINAL dL/dP (it accumulates onto the class tower's contribution)
-        pl.g_P8_ready = pl.g_P8 is not None
+        pl.g_P8_ready = pl.g_P8 is not None and bool(wrote_p)
 
     def _debug_head(self, pl, out, lvl):
         for i in range(pl.pyr.nlev):

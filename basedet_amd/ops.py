@@ -647,3 +647,39 @@ def clip_grad_norm(g, max_norm, ord=2.0, pre_scale=1.0, norm_out=None, ws=None):
     check(L().bd_clip_grad_norm(ptr(g), g.numel(), float(pre_scale), float(max_norm), float(ord), ptr(norm_out), ptr(ws), ws.numel(),
                                 stream_ptr()), "bd_clip_grad_norm")
     return norm_out
+
+
+class HostStager:
+    """bd_h2d_*: host batch (numpy float64 / float32 / uint8, C-contiguous) -> fp32 device tensor through the library's pinned staging
+    buffer, converted by its worker threads and sent chunk by chunk (data_to_input's `Tensor(image)`, pre_processing.py:13)."""
+
+    _DT = {"float64": 0, "float32": 1, "uint8": 2}
+
+    def __init__(self, device, threads=0):
+        self._h = C.c_void_p()
+        self.device = torch.device(device)
+        check(L().bd_h2d_create(C.byref(self._h), self.device.index or 0, int(threads)), "bd_h2d_create")
+        self.threads = int(L().bd_h2d_threads(self._h))
+
+    def supports(self, arr):
+        return hasattr(arr, "dtype") and str(arr.dtype) in self._DT and getattr(arr, "flags", None) is not None and arr.flags["C_CONTIGUOUS"]
+
+    def submit(self, arr, out=None, chunk_elems=0):
+        """arr: numpy array; returns the fp32 device tensor of the same shape (valid in the current stream's order)."""
+        if out is None:
+            out = torch.empty(arr.shape, dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.numel() == arr.size and out.dtype == torch.float32
+        check(L().bd_h2d_submit(self._h, C.c_void_p(arr.ctypes.data), self._DT[str(arr.dtype)], arr.size, ptr(out), int(chunk_elems),
+                                stream_ptr()), "bd_h2d_submit")
+        return out
+
+    def close(self):
+        if self._h:
+            L().bd_h2d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # noqa: BLE001 (interpreter shutdown)
+            pass

@@ -182,6 +182,22 @@ int bd_colsum_bf16(const void* g, int N, int64_t pix_per_img, int64_t off, int64
  * out: bf16 [N][Hp+6][Wp+8][4] with a zero halo of 3 rows / 4 columns and channel 3 = 0 (stem layout). */
 int bd_pad_normalize(const float* in, int N, int H, int W, int Hp, int Wp, const float* mean3,
                      const float* std3, void* out, bd_stream_t stream);
+/* layers/common/pre_processing.py:13 `Tensor(image)`: the host batch the loader hands over (float64 from utils/dummy.py:60, float32 or
+ * uint8 from a reader) becomes the fp32 device tensor bd_pad_normalize reads.  Host-side transport, no arithmetic beyond the exact
+ * widening / narrowing cast (float64 -> fp32 rounds to nearest, as numpy's astype does): `threads` workers (0 = a default from the
+ * core count) convert `chunk_elems`-element chunks (0 = 1 Mi) into a pinned staging buffer owned by the handle, and every chunk leaves
+ * with its own hipMemcpyAsync on `stream` as soon as it is converted -- conversion of chunk k + 1 under the DMA of chunk k.  submit
+ * returns when every chunk has been ENQUEUED; dst_dev is valid in stream order.  A second submit first waits until the previous one's
+ * copies have drained the staging buffer.  One handle per process / device; not re-entrant for one handle. */
+typedef struct bd_h2d* bd_h2d_t;
+#define BD_HOST_F64 0
+#define BD_HOST_F32 1
+#define BD_HOST_U8 2
+int bd_h2d_create(bd_h2d_t* out, int device, int threads);
+int bd_h2d_threads(bd_h2d_t h);
+int bd_h2d_submit(bd_h2d_t h, const void* src_host, int src_dtype, int64_t n, float* dst_dev, int64_t chunk_elems, bd_stream_t stream);
+int bd_h2d_destroy(bd_h2d_t h);
+
 /* same arithmetic, fp32 NCHW output [N][3][Hp][Wp] (parity checks of the reference semantics). */
 int bd_pad_normalize_nchw(const float* in, int N, int H, int W, int Hp, int Wp, const float* mean3,
                           const float* std3, float* out, bd_stream_t stream);

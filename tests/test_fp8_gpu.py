@@ -575,18 +575,40 @@ def test_absmax_and_delayed_gradient_scale():
     cfg.MODEL.FP8_DGRAD = True
     cfg.MODEL.FP8_AMAX_INTERVAL = 3
     cfg.MODEL.FP8_AMAX_DELAY = 1
-    m = RetinaNet(cfg, params=params)
-    assert m.fp8_delayed_scaling and all(c.grad_scale == 4096.0 for c in m.convs.values())
-    for _ in range(3):
-        m(batch); m.backward()
-    torch.cuda.synchronize()
-    assert len(m.fp8_scale_log) == 1
-    t0, t1, amax, scale = m.fp8_scale_log[0]
-    assert (t0, t1) == (0, 1) and amax > 0
-    assert 2.0 ** 14 < amax * scale <= 2.0 ** 15 and np.log2(scale) == np.floor(np.log2(scale))
-    assert all(c.grad_scale == scale for c in m.convs.values())
-    # the probe read what the fp8 data gradients consume: no larger than the largest gradient buffer of the step
-    assert amax <= float(max(t.float().abs().max() for t in m._cur.g_tower[0] + m._cur.g_tower[1] + [m._cur.g_P])) * 1.0001 + 1e-30
+    for mode in ("global", "group", "layer"):
+        cfg.MODEL.FP8_SCALE_GROUPS = mode
+        m = RetinaNet(cfg, params=params)
+        assert m.fp8_delayed_scaling and all(c.grad_scale == 4096.0 for c in m.convs.values())
+        for k in range(3):
+            m(batch); m.backward()
+            if k == 1:                                   # staged by the backward of step 1, NOT applied before the weight repack
+                assert m._fp8_staged and all(c.grad_scale == 4096.0 for c in m.convs.values())
+            m.repack_trainable()                         # what optimizer.step() does after the SGD launch
+        torch.cuda.synchronize()
+        assert len(m.fp8_scale_log) == 1 and m._fp8_staged is None
+        t0, t1, amax, scale = m.fp8_scale_log[0]
+        assert (t0, t1) == (0, 1) and amax > 0
+        am = m._amax_host.numpy()
+        keys = {}
+        for i, c in enumerate(m._fp8_grad_layers):
+            keys[m._fp8_scale_key(c)] = max(keys.get(m._fp8_scale_key(c), 0.0), float(am[i]))
+        assert (len(keys) == 1) == (mode == "global") and (mode != "group" or set(keys) <= {"head", "fpn", "layer4", "layer3", "layer2"})
+        for c in m._fp8_grad_layers:
+            a = keys[m._fp8_scale_key(c)]
+            if a > 0:                                    # every group's largest gradient lands in (2^14, 2^15] of e5m2's range
+                assert 2.0 ** 14 < a * c.grad_scale <= 2.0 ** 15 and np.log2(c.grad_scale) == np.floor(np.log2(c.grad_scale)), (mode, c.name)
+        assert len({c.grad_scale for c in m.output.values()}) == 1        # the FPN output convolutions read ONE twin of dL/dP
+        if mode == "global":
+            assert all(c.grad_scale == scale for c in m.convs.values())
+        else:
+            assert len({c.grad_scale for c in m._fp8_grad_layers}) > 1    # the backbone's gradients are binades below the head's
+        # the probe read what the fp8 data gradients consume: no larger than the largest gradient buffer of the step
+        assert amax <= float(max(t.float().abs().max() for t in m._cur.g_tower[0] + m._cur.g_tower[1] + [m._cur.g_P])) * 1.0001 + 1e-30
+        # a step with the new scales: finite gradients, cosine with the bf16-data-gradient run of the same forward
+        m(batch); m.backward(); torch.cuda.synchronize()
+        g = m.reference_grads()
+        assert all(bool(torch.isfinite(v).all()) for v in g.values()), mode
+    cfg.MODEL.pop("FP8_SCALE_GROUPS")
 
 
 def test_e5m2_stochastic_rounding():

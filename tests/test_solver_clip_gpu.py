@@ -75,4 +75,7 @@ def test_trainer_installs_and_solver_applies_grad_clip(ctype, args):
     lr, wd = solver.optimizer.param_groups[0]["lr"], solver.optimizer.param_groups[0]["weight_decay"]
     w_want = w0 - lr * (g_want + wd * w0)
     got = model.arena.w.double().cpu().numpy()
-    assert np.allclose(got - w0, w_want - w0, rtol=1e-4, atol=1e-9)
+    # w is fp32: the update (lr * g ~ 1e-6) is resolved to half an ulp of w
+    assert np.allclose(got - w0, w_want - w0, rtol=1e-4, atol=1.2e-7 * np.abs(w0).max())
+    big = np.abs(w_want - w0) > 1e-6 * np.abs(w0).max()              # where the update is well above w's rounding: relative check
+    assert big.any() and np.allclose((got - w0)[big], (w_want - w0)[big], rtol=0.2)
