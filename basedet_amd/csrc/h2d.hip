@@ -132,9 +132,10 @@ int bd_h2d_create(bd_h2d_t* out, int device, int threads) {
 int bd_h2d_threads(bd_h2d_t h) { return h ? (int)h->workers.size() + 1 : 0; }
 
 int bd_h2d_submit(bd_h2d_t h, const void* src_host, int src_dtype, int64_t n, float* dst_dev, int64_t chunk_elems, bd_stream_t stream) {
-    BD_REQUIRE(h && src_host && dst_dev && n >= 0, "bd_h2d_submit: null argument");
+    BD_REQUIRE(h != nullptr && n >= 0, "bd_h2d_submit: null handle or negative count");
     BD_REQUIRE(src_dtype == BD_HOST_F64 || src_dtype == BD_HOST_F32 || src_dtype == BD_HOST_U8, "bd_h2d_submit: dtype %d", src_dtype);
-    if (n == 0) return BD_OK;
+    if (n == 0) return BD_OK;             // an empty batch: nothing to move (its pointers may be null)
+    BD_REQUIRE(src_host && dst_dev, "bd_h2d_submit: null buffer");
     if (h->pending) {                 // the previous batch's copies still read the staging buffer
         if (hipEventSynchronize(h->drained) != hipSuccess) {
             bd_set_error("bd_h2d_submit: waiting for the previous transfer failed");

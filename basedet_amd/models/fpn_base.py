@@ -189,6 +189,7 @@ class FPNDetector:
         self.fp8_stochastic_rounding = bool(m.get("FP8_STOCHASTIC_ROUNDING", True)) and bool(self._fp8_grad_layers) and self.device.type == "cuda"
         self.fp8_amax_interval = int(m.get("FP8_AMAX_INTERVAL", 20))
         self.fp8_amax_delay = int(m.get("FP8_AMAX_DELAY", 4))
+        self.fp8_amax_history = max(1, int(m.get("FP8_AMAX_HISTORY", 2)))         # probes whose maximum sets the scale
         self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 15.0))       # max |g| * scale lands in (2^(t-1), 2^t]; e5m2 tops out at 1.75 * 2^15 (R50: 12 and the static 4 096 diverged in the 2 020-step run, 13 - 15 did not, 16 clamps; R101 at batch 32: 14 diverged before step 1 020, 15 did not: DESIGN.md)
         # Granularity of the delayed scale (round 3).  One scale for all layers had to span the 2^9.7 spread between max |g| at the head and
         # at the backbone's conv1 layers (scripts/exp/fp8_amax_spread.py): with the head's maximum at 2^15 the backbone's gradients sat
@@ -273,10 +274,15 @@ class FPNDetector:
                 if np.isfinite(am[i]):
                     keys[k] = max(keys.get(k, 0.0), float(am[i]))
             scales = {}
+            # diagnostic: where the probe's largest value sat in e5m2's range under the scale it was quantised with (> 57 344: clamped)
+            cur = {self._fp8_scale_key(c): c.grad_scale for c in self._fp8_grad_layers}
+            self.fp8_last_fill = {k: a * cur[k] for k, a in keys.items()}
             for k, amax in keys.items():
                 if amax > 0.0:
-                    eff = max(amax, self._amax_prev.get(k, 0.0))      # two-probe history: a scale never chases a single small reading
-                    self._amax_prev[k] = amax
+                    hist = self._amax_prev.setdefault(k, [])          # probe history: a scale never chases a single small reading
+                    hist.append(amax)
+                    del hist[:-self.fp8_amax_history]
+                    eff = max(hist)
                     scales[k] = float(2.0 ** min(max(np.floor(self.fp8_amax_target - np.log2(eff)), -16.0), 40.0))
             if scales:
                 staged = {}

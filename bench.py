@@ -463,6 +463,8 @@ def main():
                          "instrumented step keeps the weight gradients on the main stream: ~2.7 ms per instrumented step; the headline "
                          "stays within ~1 %% of an uninstrumented run)")
     ap.add_argument("--dump-convs", action="store_true", help="per-shape kernel timing table on stderr")
+    ap.add_argument("--log-every", type=int, default=0,
+                    help="long repeated-batch runs: print the loss (and the fp8 gradient-scale state) to stderr every n timed steps (a host sync each)")
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight-gradient kernels on the main stream for the whole run (what the instrumented steps do): "
                          "use it under rocprofv3 so that per-kernel durations are not inflated by concurrent kernels")
@@ -599,6 +601,12 @@ def worker(args):
             model.async_wgrad = False
         marks[k].record()
         last = solver.minimize(model, batch)
+        if args.log_every and (k + 1) % args.log_every == 0 and rank == 0:
+            extra = ""
+            if getattr(model, "fp8_group_scales", None):
+                extra = " scales " + " ".join(f"{kk}:2^{int(np.log2(v))}" for kk, v in sorted(model.fp8_group_scales.items())[:8]) + \
+                        " top(amax*scale) " + " ".join(f"{kk}:{v:.0f}" for kk, v in sorted(getattr(model, "fp8_last_fill", {}).items())[:8])
+            print(f"# step {k + 1} loss {float(last['total_loss']):.4f}{extra}", file=sys.stderr, flush=True)
     marks[args.steps].record()
     sync()
     elapsed = time.perf_counter() - t0

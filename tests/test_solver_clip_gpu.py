@@ -53,6 +53,7 @@ def test_trainer_installs_and_solver_applies_grad_clip(ctype, args):
     model = RetinaNet(cfg, params=params)
     solver = DetSolver.build(cfg, model)
     assert solver.grad_scaler is not None and solver.grad_scaler.scale_factor == 128.0      # default_solver.py:66-76 (static scale)
+    solver.optimizer.param_groups[0]["lr"] = 0.1         # updates well above the fp32 resolution of the weights
     trainer = DetTrainer(cfg, model, iter([batch]), solver)
     assert isinstance(solver.grad_clip_fn, GradClip)
     # reference run without clipping: same forward / backward, gradients kept
