@@ -135,10 +135,11 @@ class FPNDetector:
         self.fuse_stem_pool = bool(m.get("FUSE_STEM_POOL", True))
         self.sparse_shortcut_grad = bool(m.get("SPARSE_SHORTCUT_GRAD", True))   # False: the shortcut's data gradient as a full-resolution pass (A/B)
         self.weight_dtype = m.get("WEIGHT_DTYPE", "bf16")
-        # FP8_DGRAD (default False since the end of round 2): e5m2 gradients x e4m3 weights for the data gradients of the fp8 layers.  +3 % on
-        # the step and, with delayed scaling + stochastic rounding, as stable as bf16 on R50 (2 000 repeated-batch steps), but R101 at the
-        # batch-32 learning rate left the finite range between steps 620 and 1 020 where bf16 and the fp8 FORWARD alone did not
-        # (DESIGN.md): "fp8 weights" (BASELINE config 5) therefore means the forward by default, the gradients stay bf16.
+        # FP8_DGRAD (default True again since round 3): e5m2 gradients x e4m3 weights for the data gradients of the fp8 layers, +2.5-3.5 % on
+        # the step.  Round 2 had to make it opt-in: with ONE delayed scale for all layers R101 at the batch-32 learning rate left the
+        # finite range between steps 620 and 1 020 of the repeated-batch run.  Round 3: one scale per backward phase (FP8_SCALE_GROUPS)
+        # with two binades of headroom below e5m2's maximum and a four-probe history -- see _fp8_probe_end and DESIGN.md (a21).
+        fp8_dgrad_default = True
         self._q8 = {}
         # e5m2 twins of gradients written by the producing launch (False: every fp8 data gradient casts its input in a pass; a test knob)
         self.fp8_grad_twins = bool(m.get("FP8_GRAD_TWINS", True))
@@ -152,13 +153,13 @@ class FPNDetector:
                         and ((c.stride == 1 and c.cout > 128) or id(c) in side)):
                     key = "side" if id(c) in side else "main"          # P6 / P7 run on a side stream: their own scratch
                     c.enable_fp8(lambda n, key=key: self._q8_buf(key, n), m.get("FP8_ACT_SCALE", 1.0),
-                                 dgrad=bool(m.get("FP8_DGRAD", False)), grad_scale=m.get("FP8_GRAD_SCALE", 4096.0),
+                                 dgrad=bool(m.get("FP8_DGRAD", fp8_dgrad_default)), grad_scale=m.get("FP8_GRAD_SCALE", 4096.0),
                                  # FP8_WGRAD (default 0 = bf16 weight gradients): 1 = the one-byte kernel (bd_conv2d_wgrad_fp8) for the
                                  # bias-free layers (backbone conv2), 2 = also the towers.  Exact and 1.1 - 1.45x its bf16 launch in
                                  # isolation, but not faster in the step: R101 batch 32, same box, 469.5 / 470.8 img/s at 0, 466.3 /
                                  # 468.6 at 1, 468.0 / 467.5 at 2 (bound by its transposing LDS reads, one 8-wave workgroup per CU next
                                  # to the main stream's kernels, and the towers' bias gradient becomes a separate column-sum pass)
-                                 wgrad=(int(m.get("FP8_WGRAD", 0)) >= (2 if c.has_bias else 1)) and bool(m.get("FP8_DGRAD", False)))
+                                 wgrad=(int(m.get("FP8_WGRAD", 0)) >= (2 if c.has_bias else 1)) and bool(m.get("FP8_DGRAD", fp8_dgrad_default)))
             # the bottleneck 1x1s around an fp8 3x3 (res4 / res5 blocks after the first) on one-byte operands.  In isolation the reducing
             # direction (conv1 forward, conv3's data gradient: the input is most of the bytes) is 1.5 - 1.6x faster than its bf16 launch
             # and the expanding one about even; in the step the extra twins the neighbouring launches must write take most of it back:
@@ -168,7 +169,7 @@ class FPNDetector:
                     if blk["kind"] == "bottleneck" and blk["convs"][1].fp8 and blk["convs"][1].stride == 1:
                         for c in (blk["convs"][0], blk["convs"][2]):
                             if c.cin % 32 == 0 and c.cout % 32 == 0:
-                                c.enable_fp8_1x1(m.get("FP8_ACT_SCALE", 1.0), dgrad=bool(m.get("FP8_DGRAD", False)),
+                                c.enable_fp8_1x1(m.get("FP8_ACT_SCALE", 1.0), dgrad=bool(m.get("FP8_DGRAD", fp8_dgrad_default)),
                                                  grad_scale=m.get("FP8_GRAD_SCALE", 4096.0),
                                                  expanding=bool(m.get("FP8_1X1_EXPANDING", True)))
         else:
@@ -187,10 +188,16 @@ class FPNDetector:
         # Stochastic rounding of those gradients (bd_fp8_set_stochastic_rounding): round-to-nearest e5m2 repeats the same error on the
         # same value every step, which a repeated batch turns into a drift (the long repeated-batch runs)
         self.fp8_stochastic_rounding = bool(m.get("FP8_STOCHASTIC_ROUNDING", True)) and bool(self._fp8_grad_layers) and self.device.type == "cuda"
-        self.fp8_amax_interval = int(m.get("FP8_AMAX_INTERVAL", 20))
+        self.fp8_amax_interval = int(m.get("FP8_AMAX_INTERVAL", 10))
         self.fp8_amax_delay = int(m.get("FP8_AMAX_DELAY", 4))
-        self.fp8_amax_history = max(1, int(m.get("FP8_AMAX_HISTORY", 2)))         # probes whose maximum sets the scale
-        self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 15.0))       # max |g| * scale lands in (2^(t-1), 2^t]; e5m2 tops out at 1.75 * 2^15 (R50: 12 and the static 4 096 diverged in the 2 020-step run, 13 - 15 did not, 16 clamps; R101 at batch 32: 14 diverged before step 1 020, 15 did not: DESIGN.md)
+        self.fp8_amax_history = max(1, int(m.get("FP8_AMAX_HISTORY", 4)))         # probes whose maximum sets the scale
+        # max |g| * scale lands in (2^(t-1), 2^t]; e5m2 tops out at 1.75 * 2^15 and everything above is CLAMPED.  One global scale: t = 15 (R50:
+        # 12 and the static 4 096 diverged in the 2 020-step run, 13 - 15 did not; R101 at batch 32: 14 diverged before step 1 020): only
+        # the head sits at the top of the range, every other layer has binades of headroom.  Per-group scales put EVERY group at the top,
+        # and a group whose gradients grow between two probes then saturates: R101 batch 32 at t = 15 had layer3 at 92 672 = 1.6 x the
+        # maximum at step 100 and left the finite range before step 400, while t = 12 (0.3035 after 1 500 steps) and an eight-probe
+        # history at t = 15 (0.3306) both ran through (profiles/r03_fp8_scale_groups.txt) -- default t = 13 with a four-probe history.
+        self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 15.0 if str(m.get("FP8_SCALE_GROUPS", "group")) == "global" else 13.0))
         # Granularity of the delayed scale (round 3).  One scale for all layers had to span the 2^9.7 spread between max |g| at the head and
         # at the backbone's conv1 layers (scripts/exp/fp8_amax_spread.py): with the head's maximum at 2^15 the backbone's gradients sat
         # ten binades lower and their small values flushed to zero -- R101 at the batch-32 learning rate left the finite range.  "group"

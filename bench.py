@@ -449,7 +449,7 @@ def main():
     ap.add_argument("--workload", default="retinanet_r50_800x1344", choices=sorted(TRAIN_GFLOP_PER_IMG))
     ap.add_argument("--fp8", action="store_true",
                     help="fp8 (e4m3) weights and activations for the forward convolutions (BASELINE config 5: retinanet_r101_800x1344); "
-                         "--model-opt FP8_DGRAD=1 adds the e5m2 data gradients")
+                         "e5m2 data gradients under per-group delayed scales are on by default (--model-opt FP8_DGRAD=0: forward only)")
     ap.add_argument("--model-opt", action="append", default=[], metavar="KEY=VALUE",
                     help="ablation: set cfg.MODEL.KEY (e.g. FP8_1X1=0, FP8_DGRAD=0, FUSE_STEM_POOL=0); repeatable")
     ap.add_argument("--no-pmc", action="store_true",
@@ -654,7 +654,7 @@ def worker(args):
             "metric": "images/sec training RetinaNet-R50-FPN 1333x800" if name == "retinanet_r50_800x1344" else "images/sec training " + name,
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if not args.fp8 else ("bf16 activations / fp8-e4m3 weights (forward%s), fp32 accumulate" % (" + e5m2 data gradients" if cfg.MODEL.get("FP8_DGRAD", False) else "")),
+            "vs_baseline": None, "dtype": "bf16" if not args.fp8 else ("bf16 activations / fp8-e4m3 weights (forward%s), fp32 accumulate" % (" + e5m2 data gradients, per-group delayed scales" if cfg.MODEL.get("FP8_DGRAD", True) else "")),
             "data": "synthetic",
             "config": {"workload": f"{name} train step (fwd+bwd+allreduce+SGD), DummyLoader boxes, random-init weights, "
                                    "inputs resident in HBM",

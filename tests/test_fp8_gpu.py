@@ -147,6 +147,7 @@ def test_retinanet_fp8_step_tolerance():
     m16.backward()
     g16 = m16.reference_grads()
     cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
+    cfg.MODEL.FP8_DGRAD = False                   # the forward-only mode (the e5m2 data gradients: test_retinanet_r50_fp8_backward_variants)
     m8 = RetinaNet(cfg, params=params)
     assert any(c.fp8 for c in m8.convs.values()) and not all(c.fp8 for c in m8.convs.values())
     out8 = m8(batch)
@@ -575,6 +576,7 @@ def test_absmax_and_delayed_gradient_scale():
     cfg.MODEL.FP8_DGRAD = True
     cfg.MODEL.FP8_AMAX_INTERVAL = 3
     cfg.MODEL.FP8_AMAX_DELAY = 1
+    cfg.MODEL.FP8_AMAX_HISTORY = 1
     for mode in ("global", "group", "layer"):
         cfg.MODEL.FP8_SCALE_GROUPS = mode
         m = RetinaNet(cfg, params=params)
@@ -596,7 +598,9 @@ def test_absmax_and_delayed_gradient_scale():
         for c in m._fp8_grad_layers:
             a = keys[m._fp8_scale_key(c)]
             if a > 0:                                    # every group's largest gradient lands in (2^14, 2^15] of e5m2's range
-                assert 2.0 ** 14 < a * c.grad_scale <= 2.0 ** 15 and np.log2(c.grad_scale) == np.floor(np.log2(c.grad_scale)), (mode, c.name)
+                t = m.fp8_amax_target                    # 15 for one global scale, 13 (two binades of headroom) per group / layer
+                assert t == (15.0 if mode == "global" else 13.0)
+                assert 2.0 ** (t - 1) < a * c.grad_scale <= 2.0 ** t and np.log2(c.grad_scale) == np.floor(np.log2(c.grad_scale)), (mode, c.name)
         assert len({c.grad_scale for c in m.output.values()}) == 1        # the FPN output convolutions read ONE twin of dL/dP
         if mode == "global":
             assert all(c.grad_scale == scale for c in m.convs.values())
