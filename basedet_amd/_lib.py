@@ -62,6 +62,8 @@ SIGNATURES = {
     "bd_colsum_workspace_bytes": (_Z, [_I]),
     "bd_colsum_bf16": (_I, [_P, _I, _L, _L, _L, _I, _P, _I, _P, _Z, _P]),
     "bd_pad_normalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "bd_bottleneck_fwd_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "bd_bottleneck_fwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bd_h2d_create": (_I, [C.POINTER(C.c_void_p), _I, _I]),
     "bd_h2d_threads": (_I, [_P]),
     "bd_h2d_submit": (_I, [_P, _P, _I, _L, _P, _L, _P]),

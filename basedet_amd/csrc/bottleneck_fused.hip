@@ -1,0 +1,359 @@
+// A FROZEN ResNet bottleneck block in ONE launch (models/cls/resnet.py:70-113 Bottleneck.forward; stem + layer1 are frozen under
+// BACKBONE.FREEZE_AT = 2, solver/default_solver.py:83-94, so nothing ever reads their mid tensors again):
+//     y = relu( bn3(conv3_1x1( relu(bn2(conv2_3x3( relu(bn1(conv1_1x1(x))) ))) )) + (x | bn_d(conv_d_1x1(x))) )
+// The three-launch form moves 16 (block 0: 18) units of M x 64 x 2 bytes per block through HBM -- conv1 writes a mid tensor conv2 reads,
+// conv2 writes one conv3 reads, conv3 re-reads the block input as its residual -- where input once + output once is 8 (5) units.  Here a
+// persistent workgroup of FOUR waves (one per SIMD, 512 registers each: the weights below and two staging sets do not fit in 256) walks
+// 8 x 16 output patches:
+//   phase 1  conv1 on the patch WITH its one-pixel halo (10 x 18 pixels, the halo is recomputed: 1.41 x conv1's work, which is cheap) in
+//            64-channel K chunks staged through registers into a two-buffer LDS image (the next chunks' loads are in flight under the
+//            MFMAs); the result (+ shift, ReLU, ZERO outside the image: conv2 pads conv1's OUTPUT) goes to LDS as bf16 -- bit for bit what
+//            the separate launch stores;
+//   phase 2  conv2 = nine taps = nine shifted reads of that LDS image (row pitch 18 pixels: a tap is an address immediate);
+//   phase 3  conv3 (+ the 1x1 downsample of block 0 from the staged input patch) + shifts + residual (blocks 1, 2: the input rows just read,
+//            out of L2) + ReLU, 16-byte stores of 128 contiguous bytes per pixel and wave.
+// conv1's and conv2's weight slices live in REGISTERS for the whole kernel (104 VGPRs: the matrix A operand; every wave owns 16 mid
+// channels), conv3's / the downsample's in LDS.  The kernel is HBM-bound by a factor ~3 over its matrix work (1.1 GB against 150 GFLOP per
+// block at batch 16), so the design spends registers and LDS on bytes in flight, not on MFMA scheduling.
+#include "common.h"
+
+namespace {
+
+constexpr int PH = 8, PW = 16;                 // output patch
+constexpr int HH = PH + 2, HW = PW + 2;        // input / mid-1 patch with halo: 10 x 18
+constexpr int NHALO = HH * HW;                 // 180
+constexpr int NHP = 192;                       // padded to 12 pixel blocks of 16
+constexpr int PITCH = 144;                     // bytes per pixel row of 64 channels (+ 16: conflict-free 16-byte fragment reads)
+constexpr int XB_BYTES = NHP * PITCH;          // 27 648
+constexpr int W3_BYTES = 256 * PITCH;          // 36 864
+constexpr int CMID = 64, COUT = 256;
+constexpr unsigned X_NONE = 0x80000000u;
+
+struct BP {
+    const bf16_raw *x, *w1, *w2, *w3, *wd;
+    const float *b1, *b2, *b3, *bd;
+    bf16_raw* y;
+    int N, H, W;
+    int tiles_x, tiles_per_img, total_tiles, per_xcd;
+    unsigned x_bytes;
+};
+
+__device__ __forceinline__ bf16x8_t ld_frag_lds(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+template <int CIN, bool HAS_DS>
+__global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
+    static_assert(CIN == 64 || CIN == 256, "layer1 shapes");
+    constexpr int NCH = CIN / 64;                       // K chunks of conv1
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const XB = smem;                     // two staged input chunks
+    unsigned char* const M1 = smem + 2 * XB_BYTES;      // mid-1 image (192 rows); later mid-2 (128 rows)
+    unsigned char* const W3L = M1 + XB_BYTES;
+    unsigned char* const WDL = W3L + W3_BYTES;          // HAS_DS only
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, q = lane >> 4;
+    const int cb = wave;                                // phases 1 / 2: this wave's 16 mid channels; phase 3: its 64 output channels
+
+    // ---- one-time: weights ---------------------------------------------------------------------------------------------------------
+    bf16x8_t w1r[2 * NCH], w2r[18];
+    {
+        const bf16_raw* r1 = p.w1 + (long long)(cb * 16 + px) * CIN + q * 8;
+#pragma unroll
+        for (int s = 0; s < 2 * NCH; ++s) w1r[s] = *reinterpret_cast<const bf16x8_t*>(r1 + s * 32);
+        const bf16_raw* r2 = p.w2 + (long long)(cb * 16 + px) * 576 + q * 8;
+#pragma unroll
+        for (int s = 0; s < 18; ++s) w2r[s] = *reinterpret_cast<const bf16x8_t*>(r2 + s * 32);      // s = tap * 2 + k half
+    }
+    // conv3 / downsample rows into LDS in the permuted order of the other 1x1 kernels: LDS row (c64 * 64 + t * 16 + rho) holds output
+    // channel c64 * 64 + 32 (t >> 1) + 8 (rho >> 2) + 4 (t & 1) + (rho & 3), so that after the MFMAs lane group q owns 8 CONSECUTIVE
+    // channels of each 32-channel half (16-byte stores)
+    for (int u = tid; u < 256 * 8; u += 256) {
+        const int row = u >> 3, part = u & 7;
+        const int t = (row >> 4) & 3, rho = row & 15;
+        const int ch = (row & ~63) + 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
+        *reinterpret_cast<u32x4_t*>(W3L + row * PITCH + part * 16) = *reinterpret_cast<const u32x4_t*>(p.w3 + (long long)ch * CMID + part * 8);
+        if constexpr (HAS_DS)
+            *reinterpret_cast<u32x4_t*>(WDL + row * PITCH + part * 16) = *reinterpret_cast<const u32x4_t*>(p.wd + (long long)ch * CIN + part * 8);
+    }
+    f32x4_t b1v = *reinterpret_cast<const f32x4_t*>(p.b1 + cb * 16 + 4 * q);
+    f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(p.b2 + cb * 16 + 4 * q);
+
+    // ---- lane-constant geometry of the staging loads (NST x 16 bytes per thread and chunk) and of the phase-1 pixels ----------------------
+    constexpr int NST = 6;
+    int s_hy[NST], s_hx[NST];
+    unsigned s_lds[NST];
+    bool s_ok[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int u = tid + 256 * i, h = u >> 3, part = u & 7;
+        s_hy[i] = h / HW; s_hx[i] = h - s_hy[i] * HW;
+        s_ok[i] = h < NHALO;
+        s_lds[i] = (unsigned)(h * PITCH + part * 16);
+    }
+    int e_hy[12], e_hx[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int h = j * 16 + px;
+        e_hy[j] = h / HW; e_hx[j] = h - e_hy[j] * HW;       // h >= 180: hy = 10 -> never inside the image test below (row 10 of a 10-row patch is unused)
+    }
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
+
+    // ---- persistent tile walk: XCD k (= blockIdx & 7) owns the contiguous tile range [k * per_xcd, (k + 1) * per_xcd) -----------------------
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, stride = gridDim.x >> 3;
+    const int t_end = min((xcd + 1) * p.per_xcd, p.total_tiles);
+    int tile = xcd * p.per_xcd + slot;
+
+    unsigned voff[NST];
+    int n_img = 0, ty0 = 0, tx0 = 0;
+    auto decode = [&](int t, unsigned (&vo)[NST], int& n, int& y0, int& x0) {
+        n = t / p.tiles_per_img;
+        const int r = t - n * p.tiles_per_img;
+        const int ty = r / p.tiles_x;
+        y0 = ty * PH; x0 = (r - ty * p.tiles_x) * PW;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int gy = y0 - 1 + s_hy[i], gx = x0 - 1 + s_hx[i];
+            const bool ok = s_ok[i] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            vo[i] = ok ? (unsigned)((((long long)n * p.H + gy) * p.W + gx) * CIN + (tid & 7) * 8) * 2u : X_NONE;     // (256 i is a multiple of 8)
+        }
+    };
+    u32x4_t st[2][NST];                                 // two staging sets: chunks g + 1 and g + 2 in flight
+    auto stage_load = [&](u32x4_t (&r)[NST], const unsigned (&vo)[NST], int c) {
+        int so = c * 128;
+        asm volatile("" : "+s"(so));
+#pragma unroll
+        for (int i = 0; i < NST; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo[i], so, 0);
+    };
+    auto stage_write = [&](int buf, const u32x4_t (&r)[NST]) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) *reinterpret_cast<u32x4_t*>(XB + buf * XB_BYTES + s_lds[i]) = r[i];
+    };
+
+    if (tile >= t_end) return;                          // (after the LDS fill: no barrier is pending)
+    // chunk stream: global chunk index g; chunk g lives in staging set g & 1 and goes to LDS buffer g & 1
+    unsigned nvoff[NST];
+    int nn = 0, ny0 = 0, nx0 = 0;
+    decode(tile, voff, n_img, ty0, tx0);
+    stage_load(st[0], voff, 0);
+    int next_tile = tile + stride;
+    bool have_next = next_tile < t_end;
+    if (have_next) decode(next_tile, nvoff, nn, ny0, nx0);
+    if (NCH > 1) stage_load(st[1], voff, 1);
+    else if (have_next) stage_load(st[1], nvoff, 0);
+    __syncthreads();                                    // W3L / WDL visible
+    int g = 0;                                          // parity of the current tile's first chunk (NCH = 1: alternates per tile)
+
+    for (;;) {
+        // ================= phase 1: conv1 over the halo patch ==============================================================================
+        f32x4_t acc1[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc1[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int buf = (NCH == 1) ? (g & 1) : (c & 1);
+            // set `buf` holds this chunk (requested two chunks ago)
+            if (buf == 0) stage_write(0, st[0]); else stage_write(1, st[1]);
+            // refill the set with the chunk two ahead: same tile, or the next tile's
+            {
+                const int c2 = c + 2;
+                if (NCH > 1 && c2 < NCH) { if (buf == 0) stage_load(st[0], voff, c2); else stage_load(st[1], voff, c2); }
+                else if (have_next) {
+                    const int cn = (NCH == 1) ? 0 : c2 - NCH;
+                    // NCH = 1: the set that is free now receives tile + 2's only chunk -- decoded below, after this tile's addresses are dead
+                    if (NCH > 1) { if (buf == 0) stage_load(st[0], nvoff, cn); else stage_load(st[1], nvoff, cn); }
+                }
+            }
+            __syncthreads();
+            const unsigned char* xb = XB + buf * XB_BYTES + px * PITCH + q * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 12; ++j)
+                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[c * 2 + ks], ld_frag_lds(xb + j * 16 * PITCH + ks * 64), acc1[j], 0, 0, 0);
+        }
+        // mid-1 = relu(acc + shift), zero outside the image, bf16, into M1 (its previous readers -- the last tile's phase 3 -- are behind
+        // at least one barrier of the chunk loop above)
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int gy = ty0 - 1 + e_hy[j], gx = tx0 - 1 + e_hx[j];
+            const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            u32x2_t o;
+            o[0] = in ? pack_bf2(fmaxf(acc1[j][0] + b1v[0], 0.f), fmaxf(acc1[j][1] + b1v[1], 0.f)) : 0u;
+            o[1] = in ? pack_bf2(fmaxf(acc1[j][2] + b1v[2], 0.f), fmaxf(acc1[j][3] + b1v[3], 0.f)) : 0u;
+            *reinterpret_cast<u32x2_t*>(M1 + (j * 16 + px) * PITCH + cb * 32 + q * 8) = o;
+        }
+        __syncthreads();
+
+        // ================= phase 2: conv2 (3x3) from the mid-1 image ========================================================================
+        f32x4_t acc2[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc2[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        {
+            const unsigned char* mb = M1 + px * PITCH + q * 16;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        acc2[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            w2r[t * 2 + kh], ld_frag_lds(mb + ((r + t / 3) * HW + t % 3) * PITCH + kh * 64), acc2[r], 0, 0, 0);
+        }
+        __syncthreads();                                // every wave has read mid-1: its memory becomes mid-2 [128 pixels][64]
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            u32x2_t o;
+            o[0] = pack_bf2(fmaxf(acc2[r][0] + b2v[0], 0.f), fmaxf(acc2[r][1] + b2v[1], 0.f));
+            o[1] = pack_bf2(fmaxf(acc2[r][2] + b2v[2], 0.f), fmaxf(acc2[r][3] + b2v[3], 0.f));
+            *reinterpret_cast<u32x2_t*>(M1 + (r * 16 + px) * PITCH + cb * 32 + q * 8) = o;
+        }
+        __syncthreads();
+
+        // ================= phase 3: conv3 (+ downsample) + residual + ReLU =================================================================
+        // this wave: output channels cb * 64 .. + 63, all eight patch rows in two groups of four (hf); lane: pixel column px, channels
+        // 32 half + 8 q .. + 7
+        const int xbuf = g & 1;                         // HAS_DS (NCH = 1): the input patch of THIS tile
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int cbase = cb * 64 + 32 * half + 8 * q;
+            u32x4_t res[4];
+            if constexpr (!HAS_DS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = ty0 + hf * 4 + r, gx = tx0 + px;
+                    const bool ok = gy < p.H && gx < p.W;
+                    res[r] = (u32x4_t){0u, 0u, 0u, 0u};
+                    if (ok) res[r] = *reinterpret_cast<const u32x4_t*>(p.x + (((long long)n_img * p.H + gy) * p.W + gx) * CIN + cbase);
+                }
+            }
+            f32x4_t bv0 = *reinterpret_cast<const f32x4_t*>(p.b3 + cbase);
+            f32x4_t bv1 = *reinterpret_cast<const f32x4_t*>(p.b3 + cbase + 4);
+            if constexpr (HAS_DS) {
+                bv0 += *reinterpret_cast<const f32x4_t*>(p.bd + cbase);
+                bv1 += *reinterpret_cast<const f32x4_t*>(p.bd + cbase + 4);
+            }
+            f32x4_t acc3[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc3[t][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t a[2], b[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a[t] = ld_frag_lds(W3L + (cb * 64 + (2 * half + t) * 16 + px) * PITCH + ks * 64 + q * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = ld_frag_lds(M1 + ((hf * 4 + r) * 16 + px) * PITCH + ks * 64 + q * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc3[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[r], acc3[t][r], 0, 0, 0);
+                if constexpr (HAS_DS) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) a[t] = ld_frag_lds(WDL + (cb * 64 + (2 * half + t) * 16 + px) * PITCH + ks * 64 + q * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        b[r] = ld_frag_lds(XB + xbuf * XB_BYTES + ((hf * 4 + r + 1) * HW + 1 + px) * PITCH + ks * 64 + q * 16);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc3[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[r], acc3[t][r], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gy = ty0 + hf * 4 + r, gx = tx0 + px;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] = acc3[0][r][k] + bv0[k]; v[4 + k] = acc3[1][r][k] + bv1[k]; }
+                if constexpr (!HAS_DS) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(res[r][k]); v[2 * k + 1] += bf_hi(res[r][k]); }
+                }
+                u32x4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = pack_bf2(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
+                if (gy < p.H && gx < p.W)
+                    *reinterpret_cast<u32x4_t*>(p.y + (((long long)n_img * p.H + gy) * p.W + gx) * COUT + cbase) = o;
+            }
+        }
+
+        // ================= next tile ==========================================================================================================
+        if (!have_next) break;
+        tile = next_tile;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) voff[i] = nvoff[i];
+        n_img = nn; ty0 = ny0; tx0 = nx0;
+        next_tile = tile + stride;
+        have_next = next_tile < t_end;
+        if (have_next) decode(next_tile, nvoff, nn, ny0, nx0);
+        if constexpr (NCH == 1) {
+            // the set this tile's chunk came from (g & 1) is free: request the chunk of the tile after next
+            if (have_next) { if ((g & 1) == 0) stage_load(st[0], nvoff, 0); else stage_load(st[1], nvoff, 0); }
+            g ^= 1;
+        }
+        // (phase 3 of this tile read mid-2 and, for block 0, the staged input of buffer xbuf: the next writes to either come after at least
+        // one barrier of the next tile's chunk loop -- its own first stage_write goes to the OTHER input buffer)
+    }
+}
+
+}  // namespace
+
+extern "C" int bd_bottleneck_fwd_supported(int N, int H, int W, int Cin, int Cmid, int Cout, int has_ds) {
+    if (N < 1 || H < 1 || W < 1) return 0;
+    if (Cmid != CMID || Cout != COUT) return 0;
+    if (!((Cin == 64 && has_ds) || (Cin == 256 && !has_ds))) return 0;
+    const long long bytes_in = (long long)N * H * W * Cin * 2, bytes_out = (long long)N * H * W * Cout * 2;
+    return bytes_in < 0x7fffffffll && bytes_out < (1ll << 40);
+}
+
+extern "C" int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cout, const void* x, const void* w1, const float* b1,
+                                 const void* w2, const float* b2, const void* w3, const float* b3, const void* wd, const float* bd,
+                                 void* y, bd_stream_t stream) {
+    BD_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && y, "bottleneck_fwd: null pointer");
+    BD_REQUIRE(bd_bottleneck_fwd_supported(N, H, W, Cin, Cmid, Cout, wd != nullptr), "bottleneck_fwd: unsupported shape N=%d %dx%d %d->%d->%d ds=%d",
+               N, H, W, Cin, Cmid, Cout, wd != nullptr);
+    BD_REQUIRE(wd == nullptr || bd != nullptr, "bottleneck_fwd: downsample weights without their shift");
+    BP p{};
+    p.x = (const bf16_raw*)x; p.w1 = (const bf16_raw*)w1; p.w2 = (const bf16_raw*)w2; p.w3 = (const bf16_raw*)w3; p.wd = (const bf16_raw*)wd;
+    p.b1 = b1; p.b2 = b2; p.b3 = b3; p.bd = bd; p.y = (bf16_raw*)y;
+    p.N = N; p.H = H; p.W = W;
+    p.tiles_x = cdiv(W, PW);
+    p.tiles_per_img = p.tiles_x * cdiv(H, PH);
+    p.total_tiles = p.tiles_per_img * N;
+    p.per_xcd = cdiv(p.total_tiles, 8);
+    p.x_bytes = (unsigned)((long long)N * H * W * Cin * 2);
+    int cus = 256;
+    {
+        static int cached = 0;
+        if (!cached) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cached = prop.multiProcessorCount;
+            else
+                cached = 256;
+        }
+        cus = cached;
+    }
+    int grid = (cus / 8) * 8;                           // one persistent four-wave workgroup per CU, a multiple of the 8 XCDs
+    if (grid < 8) grid = 8;
+    const int need = p.per_xcd * 8;
+    if (grid > need) grid = need;                       // (per_xcd >= 1: at least 8 workgroups; the surplus ones exit at once)
+    const size_t lds = 2 * XB_BYTES + XB_BYTES + W3_BYTES + (wd ? W3_BYTES : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_fused_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * XB_BYTES + 2 * W3_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_fused_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * XB_BYTES + W3_BYTES);
+        attr_set = true;
+    }
+    if (wd) hipLaunchKernelGGL((bottleneck_fused_kernel<64, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((bottleneck_fused_kernel<256, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    BD_CHECK_LAUNCH("bd_bottleneck_fwd");
+    return BD_OK;
+}

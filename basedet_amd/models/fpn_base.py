@@ -133,6 +133,9 @@ class FPNDetector:
         # BASELINE config 5: fp8-e4m3 weights (one scale per output channel) for the forward of the 3x3 convolutions -- where a
         # quantised copy of the input is read nine times; the HBM-bound 1x1 layers and the whole backward pass stay bf16
         self.fuse_stem_pool = bool(m.get("FUSE_STEM_POOL", True))
+        # frozen bottleneck blocks (layer1 under FREEZE_AT = 2) in one launch each: the two mid tensors and the residual re-read never
+        # reach HBM (bd_bottleneck_fwd; False: the three / four bd_conv2d_fwd launches, kept as the parity reference)
+        self.fuse_frozen_blocks = bool(m.get("FUSE_FROZEN_BLOCKS", True))
         self.sparse_shortcut_grad = bool(m.get("SPARSE_SHORTCUT_GRAD", True))   # False: the shortcut's data gradient as a full-resolution pass (A/B)
         self.weight_dtype = m.get("WEIGHT_DTYPE", "bf16")
         # FP8_DGRAD (default True again since round 3): e5m2 gradients x e4m3 weights for the data gradients of the fp8 layers, +2.5-3.5 % on
@@ -467,13 +470,19 @@ class FPNDetector:
             b = _Plan()
             b.gin = gin
             b.gout = gin.conv_out(1, blk["stride"], 0) if blk["stride"] == 2 else gin
-            if blk["kind"] == "bottleneck":
+            b.fused = (self.fuse_frozen_blocks and not blk["trainable"] and blk["kind"] == "bottleneck" and blk["stride"] == 1
+                       and gin.nlev == 1
+                       and ops.bottleneck_fwd_supported(N, gin.H[0], gin.W[0], blk["cin"], blk["ch"], blk["cout"], blk["has_ds"]))
+            if b.fused:                                   # one launch: no mid tensors, no materialised shortcut
+                b.mid_geo = [gin, b.gout]
+                b.mids = []
+            elif blk["kind"] == "bottleneck":
                 b.mid_geo = [gin, b.gout]
                 b.mids = [act(gin, blk["ch"]), act(b.gout, blk["ch"])]
             else:
                 b.mid_geo = [b.gout]
                 b.mids = [act(b.gout, blk["ch"])]
-            b.idt = act(b.gout, blk["cout"]) if blk["has_ds"] else None
+            b.idt = act(b.gout, blk["cout"]) if (blk["has_ds"] and not b.fused) else None
             b.out = act(b.gout, blk["cout"])
             # e4m3 twin of conv1's output, written by the dense 1x1 launch for the fp8 conv2 that follows
             b.mid8 = None
@@ -613,6 +622,11 @@ class FPNDetector:
     def _block_forward(self, blk, b, x, x8=None):
         """x8: the e4m3 twin of the block input when the previous block's conv3 wrote one (fp8 mode)."""
         convs = blk["convs"]
+        if getattr(b, "fused", False):
+            ds = blk["ds"]
+            return ops.bottleneck_fwd(b.gin.N, b.gin.H[0], b.gin.W[0], blk["cin"], blk["ch"], blk["cout"], x, convs[0].w_fwd, convs[0].b,
+                                      convs[1].w_fwd, convs[1].b, convs[2].w_fwd, convs[2].b, ds.w_fwd if ds is not None else None,
+                                      ds.b if ds is not None else None, b.out)
         idt = x
         if blk["ds"] is not None:
             blk["ds"].forward(x, b.gin, b.gout, b.idt)

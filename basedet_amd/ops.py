@@ -683,3 +683,14 @@ class HostStager:
             self.close()
         except Exception:            # noqa: BLE001 (interpreter shutdown)
             pass
+
+
+def bottleneck_fwd_supported(N, H, W, cin, cmid, cout, has_ds):
+    return bool(L().bd_bottleneck_fwd_supported(int(N), int(H), int(W), int(cin), int(cmid), int(cout), int(bool(has_ds))))
+
+
+def bottleneck_fwd(N, H, W, cin, cmid, cout, x, w1, b1, w2, b2, w3, b3, wd, bd, y):
+    """A frozen Bottleneck block (models/cls/resnet.py:70-113) in one launch: bd_bottleneck_fwd."""
+    check(L().bd_bottleneck_fwd(int(N), int(H), int(W), int(cin), int(cmid), int(cout), ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                ptr(w3), ptr(b3), ptr(wd), ptr(bd), ptr(y), stream_ptr()), "bd_bottleneck_fwd")
+    return y

@@ -173,6 +173,17 @@ size_t bd_colsum_workspace_bytes(int C);
 int bd_colsum_bf16(const void* g, int N, int64_t pix_per_img, int64_t off, int64_t cnt, int C, float* out,
                    int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
+/* A FROZEN bottleneck block in one launch (models/cls/resnet.py:70-113 Bottleneck.forward; frozen = stem + layer1 under
+ * BACKBONE.FREEZE_AT = 2, solver/default_solver.py:83-94: forward only, nobody reads the mid tensors again):
+ *   y = relu( conv3(relu(conv2_3x3(relu(conv1(x) + b1)) + b2)) + b3 + (wd ? conv_d(x) + bd : x) )
+ * x: bf16 NHWC [N][H][W][Cin] (one dense level), y: bf16 [N][H][W][Cout]; weights as written by bd_weight_pack (bf16 [Cout][RS][Cin],
+ * FrozenBN scale folded in), shifts fp32.  Supported: stride 1, Cmid = 64, Cout = 256, and Cin = 64 with a 1x1 downsample (layer1.0)
+ * or Cin = 256 with the identity skip (layer1.1, layer1.2) -- bd_bottleneck_fwd_supported says so; other shapes take the three
+ * bd_conv2d_fwd launches.  The mid tensors are rounded to bf16 exactly as those launches store them. */
+int bd_bottleneck_fwd_supported(int N, int H, int W, int Cin, int Cmid, int Cout, int has_downsample);
+int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cout, const void* x, const void* w1, const float* b1, const void* w2,
+                      const float* b2, const void* w3, const float* b3, const void* wd, const float* bd, void* y, bd_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Memory-bound image ops.
  * ------------------------------------------------------------------------------------------------------- */
