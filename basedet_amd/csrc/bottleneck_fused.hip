@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
         if (!have_next) break;
         tile = next_tile;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) voff[i] = nvoff[i];
+        for (int i = 0; i < NST; ++i) voff[i] = nvoff[i];
         n_img = nn; ty0 = ny0; tx0 = nx0;
         next_tile = tile + stride;
         have_next = next_tile < t_end;

@@ -237,6 +237,10 @@ class KernelTimer:
         # e4m3 cast of a convolution's input: 2 B read + 1 B written per element
         wrap_stream("quantize_fp8", "quantize_fp8_kernel", lambda k: k["x"].numel() * 3.0)
         wrap_stream("quantize_bf8", "quantize_bf8_kernel", lambda k: k["x"].numel() * 3.0)
+        # fused frozen bottleneck: block input once + block output once (+ the weights)
+        wrap_stream("bottleneck_fwd", "bottleneck_fused_kernel",
+                    lambda k: k["N"] * k["H"] * k["W"] * (k["cin"] + k["cout"]) * 2.0
+                    + 2.0 * (k["cin"] * k["cmid"] + 9 * k["cmid"] * k["cmid"] + k["cmid"] * k["cout"] + (k["cin"] * k["cout"] if k["wd"] is not None else 0)))
         wrap_stream("pad_normalize", "pad_normalize_kernel",
                     lambda k: k["x"].numel() * 4.0 + k["x"].shape[0] * (k["Hp"] + 6) * (k["Wp"] + 8) * 8.0)
 
