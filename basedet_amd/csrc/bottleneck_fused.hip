@@ -185,6 +185,22 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
         }
         __syncthreads();
 
+        // the residual rows of this tile (blocks 1, 2: the input pixels just staged, out of L2) are requested a phase ahead of their use: with
+        // one wave per SIMD nothing else hides their latency (rows 0-3 here, under conv2; rows 4-7 at the start of phase 3, under rows 0-3)
+        u32x4_t res_all[2][2][4];
+        auto res_load = [&](int hfq) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = ty0 + hfq * 4 + r, gx = tx0 + px;
+                    const bool ok = gy < p.H && gx < p.W;
+                    const unsigned vo = ok ? (unsigned)((((long long)n_img * p.H + gy) * p.W + gx) * CIN + cb * 64 + 32 * half + 8 * q) * 2u : X_NONE;
+                    res_all[hfq][half][r] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo, 0, 0);
+                }
+        };
+        if constexpr (!HAS_DS) res_load(0);
+
         // ================= phase 2: conv2 (3x3) from the mid-1 image ========================================================================
         f32x4_t acc2[8];
 #pragma unroll
@@ -214,21 +230,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
         // this wave: output channels cb * 64 .. + 63, all eight patch rows in two groups of four (hf); lane: pixel column px, channels
         // 32 half + 8 q .. + 7
         const int xbuf = g & 1;                         // HAS_DS (NCH = 1): the input patch of THIS tile
+        if constexpr (!HAS_DS) res_load(1);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int cbase = cb * 64 + 32 * half + 8 * q;
-            u32x4_t res[4];
-            if constexpr (!HAS_DS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gy = ty0 + hf * 4 + r, gx = tx0 + px;
-                    const bool ok = gy < p.H && gx < p.W;
-                    res[r] = (u32x4_t){0u, 0u, 0u, 0u};
-                    if (ok) res[r] = *reinterpret_cast<const u32x4_t*>(p.x + (((long long)n_img * p.H + gy) * p.W + gx) * CIN + cbase);
-                }
-            }
             f32x4_t bv0 = *reinterpret_cast<const f32x4_t*>(p.b3 + cbase);
             f32x4_t bv1 = *reinterpret_cast<const f32x4_t*>(p.b3 + cbase + 4);
             if constexpr (HAS_DS) {
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
                 for (int k = 0; k < 4; ++k) { v[k] = acc3[0][r][k] + bv0[k]; v[4 + k] = acc3[1][r][k] + bv1[k]; }
                 if constexpr (!HAS_DS) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(res[r][k]); v[2 * k + 1] += bf_hi(res[r][k]); }
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(res_all[hf][half][r][k]); v[2 * k + 1] += bf_hi(res_all[hf][half][r][k]); }
                 }
                 u32x4_t o;
 #pragma unroll
