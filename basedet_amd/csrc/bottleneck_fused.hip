@@ -29,18 +29,45 @@ constexpr int W3_BYTES = 256 * PITCH;          // 36 864
 constexpr int CMID = 64, COUT = 256;
 constexpr unsigned X_NONE = 0x80000000u;
 
+#ifdef BD_BN_STAMP        // diagnostic build only (scripts/exp/bneck_stamp.py): phase time stamps (s_memtime) of workgroup 0's second tile
+__device__ unsigned long long g_bn_stamp[16];
+#define BN_STAMP(i) do { if (blockIdx.x == 0 && tid == 0 && tile_seq == 1) g_bn_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BN_STAMP(i) do { } while (0)
+#endif
+
 struct BP {
     const bf16_raw *x, *w1, *w2, *w3, *wd;
     const float *b1, *b2, *b3, *bd;
     bf16_raw* y;
     int N, H, W;
     int tiles_x, tiles_per_img, total_tiles, per_xcd;
-    unsigned x_bytes;
+    unsigned x_bytes, y_bytes;
 };
 
 __device__ __forceinline__ bf16x8_t ld_frag_lds(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
-template <int CIN, bool HAS_DS>
+typedef __attribute__((ext_vector_type(2))) float f32x2_bn_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_bn_t;
+typedef __attribute__((ext_vector_type(2))) short s16x2_bn_t;
+// two fp32 values -> ReLU -> one packed bf16 pair in two instructions (v_cvt_pk_bf16_f32, v_pk_max_i16 against 0: a bf16 is negative exactly
+// when its bit pattern is a negative int16; round-to-nearest and ReLU commute).  With one wave per SIMD every vector instruction of an
+// epilogue is 4 issue cycles nothing else fills: the first build spent 1 150 of them per tile in phase 3 alone.
+__device__ __forceinline__ unsigned relu_pack2(float a, float b) {
+    const f32x2_bn_t v = {a, b};
+    s16x2_bn_t h = __builtin_bit_cast(s16x2_bn_t, __builtin_convertvector(v, bf16x2_bn_t));
+    h = __builtin_elementwise_max(h, (s16x2_bn_t){0, 0});
+    return __builtin_bit_cast(unsigned, h);
+}
+typedef __attribute__((address_space(3))) void lds_void_bn_t;
+// 16 bytes per lane straight into LDS (no destination registers).  Used here only to pull lines into L2 ahead of the real loads.
+__device__ __forceinline__ void dma16_bn(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_bn_t*)lds, 16, voff, soff, 0, 0);
+}
+constexpr int PAD_BYTES = 4 * 1024;            // one 1-KiB landing pad per wave for the L2 warm-up DMAs (never read)
+constexpr int BIAS_BYTES = 1024;               // conv3's (+ the downsample's) 256 shifts, read back through LDS (lgkmcnt, not vmcnt)
+
+template <int CIN, bool HAS_DS, bool WARM = true>
 __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
     static_assert(CIN == 64 || CIN == 256, "layer1 shapes");
     constexpr int NCH = CIN / 64;                       // K chunks of conv1
@@ -49,6 +76,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
     unsigned char* const M1 = smem + 2 * XB_BYTES;      // mid-1 image (192 rows); later mid-2 (128 rows)
     unsigned char* const W3L = M1 + XB_BYTES;
     unsigned char* const WDL = W3L + W3_BYTES;          // HAS_DS only
+    float* const B3L = reinterpret_cast<float*>(smem + 3 * XB_BYTES + W3_BYTES + (HAS_DS ? W3_BYTES : 0));
+    unsigned char* const PAD = reinterpret_cast<unsigned char*>(B3L) + BIAS_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,6 +105,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
         if constexpr (HAS_DS)
             *reinterpret_cast<u32x4_t*>(WDL + row * PITCH + part * 16) = *reinterpret_cast<const u32x4_t*>(p.wd + (long long)ch * CIN + part * 8);
     }
+    B3L[tid] = p.b3[tid] + (HAS_DS ? p.bd[tid] : 0.f);      // 256 threads, 256 output channels
     f32x4_t b1v = *reinterpret_cast<const f32x4_t*>(p.b1 + cb * 16 + 4 * q);
     f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(p.b2 + cb * 16 + 4 * q);
 
@@ -98,6 +128,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
         e_hy[j] = h / HW; e_hx[j] = h - e_hy[j] * HW;       // h >= 180: hy = 10 -> never inside the image test below (row 10 of a 10-row patch is unused)
     }
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
 
     // ---- persistent tile walk: XCD k (= blockIdx & 7) owns the contiguous tile range [k * per_xcd, (k + 1) * per_xcd) -----------------------
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, stride = gridDim.x >> 3;
@@ -143,8 +174,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
     else if (have_next) stage_load(st[1], nvoff, 0);
     __syncthreads();                                    // W3L / WDL visible
     int g = 0;                                          // parity of the current tile's first chunk (NCH = 1: alternates per tile)
+    [[maybe_unused]] int tile_seq = 0;
 
     for (;;) {
+        BN_STAMP(0);
         // ================= phase 1: conv1 over the halo patch ==============================================================================
         f32x4_t acc1[12];
 #pragma unroll
@@ -172,6 +205,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
                 for (int j = 0; j < 12; ++j)
                     acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[c * 2 + ks], ld_frag_lds(xb + j * 16 * PITCH + ks * 64), acc1[j], 0, 0, 0);
         }
+        BN_STAMP(1);
         // mid-1 = relu(acc + shift), zero outside the image, bf16, into M1 (its previous readers -- the last tile's phase 3 -- are behind
         // at least one barrier of the chunk loop above)
 #pragma unroll
@@ -179,12 +213,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
             const int gy = ty0 - 1 + e_hy[j], gx = tx0 - 1 + e_hx[j];
             const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             u32x2_t o;
-            o[0] = in ? pack_bf2(fmaxf(acc1[j][0] + b1v[0], 0.f), fmaxf(acc1[j][1] + b1v[1], 0.f)) : 0u;
-            o[1] = in ? pack_bf2(fmaxf(acc1[j][2] + b1v[2], 0.f), fmaxf(acc1[j][3] + b1v[3], 0.f)) : 0u;
+            const f32x4_t v = acc1[j] + b1v;          // shift AFTER the accumulation, as the separate launch adds it: the same fp32 roundings
+            o[0] = in ? relu_pack2(v[0], v[1]) : 0u;
+            o[1] = in ? relu_pack2(v[2], v[3]) : 0u;
             *reinterpret_cast<u32x2_t*>(M1 + (j * 16 + px) * PITCH + cb * 32 + q * 8) = o;
         }
         __syncthreads();
 
+        BN_STAMP(2);
         // the residual rows of this tile (blocks 1, 2: the input pixels just staged, out of L2) are requested a phase ahead of their use: with
         // one wave per SIMD nothing else hides their latency (rows 0-3 here, under conv2; rows 4-7 at the start of phase 3, under rows 0-3)
         u32x4_t res_all[2][2][4];
@@ -200,6 +236,21 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
                 }
         };
         if constexpr (!HAS_DS) res_load(0);
+        // L2 warm-up: the staging sets hold the next tile's chunks 0 and 1; its chunks 2 and 3 are requested only while those are being
+        // consumed -- two chunk times (~1 us) before their use, less than HBM's latency under load.  Request them NOW by LDS-DMA into a
+        // landing pad nobody reads (no destination registers): they cross HBM -> L2 under conv2, the real loads then find them in L2.
+        if constexpr (NCH > 2 && WARM) {
+            if (have_next) {
+                const int uw = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+                for (int c = 2; c < NCH; ++c) {
+                    int so = c * 128;
+                    asm volatile("" : "+s"(so));
+#pragma unroll
+                    for (int i = 0; i < NST; ++i) dma16_bn(x_rsrc, PAD + uw * 1024, nvoff[i], so);
+                }
+            }
+        }
 
         // ================= phase 2: conv2 (3x3) from the mid-1 image ========================================================================
         f32x4_t acc2[8];
@@ -216,37 +267,57 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
                         acc2[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             w2r[t * 2 + kh], ld_frag_lds(mb + ((r + t / 3) * HW + t % 3) * PITCH + kh * 64), acc2[r], 0, 0, 0);
         }
+        BN_STAMP(3);
         __syncthreads();                                // every wave has read mid-1: its memory becomes mid-2 [128 pixels][64]
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             u32x2_t o;
-            o[0] = pack_bf2(fmaxf(acc2[r][0] + b2v[0], 0.f), fmaxf(acc2[r][1] + b2v[1], 0.f));
-            o[1] = pack_bf2(fmaxf(acc2[r][2] + b2v[2], 0.f), fmaxf(acc2[r][3] + b2v[3], 0.f));
+            const f32x4_t v = acc2[r] + b2v;
+            o[0] = relu_pack2(v[0], v[1]);
+            o[1] = relu_pack2(v[2], v[3]);
             *reinterpret_cast<u32x2_t*>(M1 + (r * 16 + px) * PITCH + cb * 32 + q * 8) = o;
         }
         __syncthreads();
 
+        BN_STAMP(4);
         // ================= phase 3: conv3 (+ downsample) + residual + ReLU =================================================================
         // this wave: output channels cb * 64 .. + 63, all eight patch rows in two groups of four (hf); lane: pixel column px, channels
         // 32 half + 8 q .. + 7
         const int xbuf = g & 1;                         // HAS_DS (NCH = 1): the input patch of THIS tile
         if constexpr (!HAS_DS) res_load(1);
+        unsigned yoff[8];                               // this lane's 16-byte unit of each of the eight patch rows (half 0; half 1 = + 64 bytes)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int gy = ty0 + r, gx = tx0 + px;
+            yoff[r] = (gy < p.H && gx < p.W) ? (unsigned)((((long long)n_img * p.H + gy) * p.W + gx) * COUT + cb * 64 + 8 * q) * 2u : X_NONE;
+        }
+        // One vmcnt for loads AND stores: a load result first touched after a store makes the compiler wait for that store too (the first
+        // build waited for the previous store's completion before each of the 16 stores of a tile: phase 3 took 11 700 of a tile's 31 200
+        // cycles).  So everything that is still in flight -- the residual rows and the next tile's two staged chunks -- is awaited HERE, once,
+        // before the first store; after it the stores of a tile are issued back to back and nothing waits on them until two chunks into the
+        // next tile.
+        if constexpr (!HAS_DS) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(res_all[a][b][r]));
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < NST; ++i) asm volatile("" : "+v"(st[a][i]));
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int cbase = cb * 64 + 32 * half + 8 * q;
-            f32x4_t bv0 = *reinterpret_cast<const f32x4_t*>(p.b3 + cbase);
-            f32x4_t bv1 = *reinterpret_cast<const f32x4_t*>(p.b3 + cbase + 4);
-            if constexpr (HAS_DS) {
-                bv0 += *reinterpret_cast<const f32x4_t*>(p.bd + cbase);
-                bv1 += *reinterpret_cast<const f32x4_t*>(p.bd + cbase + 4);
-            }
+            const f32x4_t bv0 = *reinterpret_cast<const f32x4_t*>(B3L + cbase);
+            const f32x4_t bv1 = *reinterpret_cast<const f32x4_t*>(B3L + cbase + 4);
             f32x4_t acc3[2][4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc3[t][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) { acc3[0][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc3[1][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t a[2], b[4];
@@ -272,23 +343,27 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gy = ty0 + hf * 4 + r, gx = tx0 + px;
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { v[k] = acc3[0][r][k] + bv0[k]; v[4 + k] = acc3[1][r][k] + bv1[k]; }
-                if constexpr (!HAS_DS) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(res_all[hf][half][r][k]); v[2 * k + 1] += bf_hi(res_all[hf][half][r][k]); }
-                }
                 u32x4_t o;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = pack_bf2(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
-                if (gy < p.H && gx < p.W)
-                    *reinterpret_cast<u32x4_t*>(p.y + (((long long)n_img * p.H + gy) * p.W + gx) * COUT + cbase) = o;
+                for (int k = 0; k < 4; ++k) {
+                    // output word k = channels 2k, 2k + 1 of the lane's eight: accumulator block k >> 1, elements 2 (k & 1), + 1
+                    const f32x4_t bk = (k >> 1) ? bv1 : bv0;
+                    f32x2_bn_t v = {acc3[k >> 1][r][2 * (k & 1)], acc3[k >> 1][r][2 * (k & 1) + 1]};
+                    v += (f32x2_bn_t){bk[2 * (k & 1)], bk[2 * (k & 1) + 1]};       // shift, then residual: the separate launch's order
+                    if constexpr (!HAS_DS) {
+                        const unsigned w = res_all[hf][half][r][k];
+                        v += (f32x2_bn_t){bf_lo(w), bf_hi(w)};
+                    }
+                    o[k] = relu_pack2(v[0], v[1]);
+                }
+                // rows / columns outside the image carry the offset X_NONE: the buffer store drops them
+                __builtin_amdgcn_raw_buffer_store_b128(o, y_rsrc, yoff[hf * 4 + r], 64 * half, 0);
             }
         }
 
+        BN_STAMP(5);
         // ================= next tile ==========================================================================================================
+        ++tile_seq;
         if (!have_next) break;
         tile = next_tile;
 #pragma unroll
@@ -309,12 +384,18 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
 
 }  // namespace
 
+#ifdef BD_BN_STAMP
+extern "C" int bd_debug_bn_stamp(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bn_stamp), sizeof(g_bn_stamp)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int bd_bottleneck_fwd_supported(int N, int H, int W, int Cin, int Cmid, int Cout, int has_ds) {
     if (N < 1 || H < 1 || W < 1) return 0;
     if (Cmid != CMID || Cout != COUT) return 0;
     if (!((Cin == 64 && has_ds) || (Cin == 256 && !has_ds))) return 0;
     const long long bytes_in = (long long)N * H * W * Cin * 2, bytes_out = (long long)N * H * W * Cout * 2;
-    return bytes_in < 0x7fffffffll && bytes_out < (1ll << 40);
+    return bytes_in < 0x7fffffffll && bytes_out < 0x7fffffffll;      // 32-bit buffer offsets on both sides
 }
 
 extern "C" int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cout, const void* x, const void* w1, const float* b1,
@@ -333,6 +414,7 @@ extern "C" int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cou
     p.total_tiles = p.tiles_per_img * N;
     p.per_xcd = cdiv(p.total_tiles, 8);
     p.x_bytes = (unsigned)((long long)N * H * W * Cin * 2);
+    p.y_bytes = (unsigned)((long long)N * H * W * Cout * 2);
     int cus = 256;
     {
         static int cached = 0;
@@ -350,13 +432,13 @@ extern "C" int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cou
     if (grid < 8) grid = 8;
     const int need = p.per_xcd * 8;
     if (grid > need) grid = need;                       // (per_xcd >= 1: at least 8 workgroups; the surplus ones exit at once)
-    const size_t lds = 2 * XB_BYTES + XB_BYTES + W3_BYTES + (wd ? W3_BYTES : 0);
+    const size_t lds = 2 * XB_BYTES + XB_BYTES + W3_BYTES + (wd ? W3_BYTES : 0) + BIAS_BYTES + PAD_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_fused_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  3 * XB_BYTES + 2 * W3_BYTES);
+                                  3 * XB_BYTES + 2 * W3_BYTES + BIAS_BYTES + PAD_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_fused_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  3 * XB_BYTES + W3_BYTES);
+                                  3 * XB_BYTES + W3_BYTES + BIAS_BYTES + PAD_BYTES);
         attr_set = true;
     }
     if (wd) hipLaunchKernelGGL((bottleneck_fused_kernel<64, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
