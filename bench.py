@@ -375,10 +375,21 @@ def measure_traffic(args, timeout_s=120):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + tail, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
-            if r.returncode != 0:
-                return {}, f"rocprofv3 --pmc {counter} exited with {r.returncode}: traffic not measured"
+            # own process group: on a timeout the profiler AND the profiled child (which holds the GPU) are ended together, by that exact group id
+            proc = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + tail, cwd="/tmp", env=env,
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                raise
+            if rc != 0:
+                return {}, f"rocprofv3 --pmc {counter} exited with {rc}: traffic not measured"
             res[counter] = pmc_traffic.load(d, counter)
     except subprocess.TimeoutExpired:
         return {}, f"a rocprofv3 --pmc pass exceeded {timeout_s} s: traffic not measured"

@@ -57,12 +57,13 @@ class _Inject(torch.autograd.Function):
 class Oracle:
     """Functional model over a parameter dict.  ``trainable`` names get requires_grad."""
 
-    def __init__(self, params, arch, trainable=(), sim_bf16=False, inject=None):
+    def __init__(self, params, arch, trainable=(), sim_bf16=False, inject=None, record=None):
         """sim_bf16: round weights (after folding the FrozenBN scale) and every stored activation to bf16 with a
         straight-through gradient -- the rounding points of the HIP path -- while all arithmetic stays fp32.
         With it the ReLU masks of both sides coincide, which makes the gradient comparison tight."""
         self.sim_bf16 = sim_bf16
         self.inject = inject      # dict key -> NCHW tensor: stored activations of the HIP run (see _act)
+        self.record = record      # optional dict: key -> (norm, squared error against `inject`-style reference, count); see _act
         self.arch = dict(arch)
         self.p = {}
         tset = set(trainable)
@@ -78,7 +79,13 @@ class Oracle:
         """Every tensor the HIP path stores goes through here: (ReLU), bf16 rounding, optional injection."""
         if self.inject is not None and key in self.inject:
             return _Inject.apply(x, self.inject[key], relu)
-        return self._q(TF.relu(x) if relu else x)
+        y = self._q(TF.relu(x) if relu else x)
+        if self.record is not None and isinstance(self.record.get("_compare"), dict) and key in self.record["_compare"]:
+            # per-layer forward comparison (tests): rel-L2 of the other side's stored activation against this fp32 value
+            ref = y.detach().double()
+            got = self.record["_compare"][key].double()
+            self.record[key] = float((got - ref).norm() / (ref.norm() + 1e-30))
+        return y
 
     def _q(self, x):
         if not self.sim_bf16:

@@ -4,7 +4,8 @@
    playground/examples/retinanet/res50_coco_800size_1x/config.py is imported BY PATH against the alias -- `from basedet.configs import
    RetinaNetConfig` resolves to this repo -- and its `Cfg()` instantiates; the names the training entry resolves from it
    (registers.models / registers.solvers / registers.trainers, tools/det_train.py:111, configs/detection_cfg.py:55-63) exist.
-   `megfile` (a path-joining helper the config imports; not installed here) is stood in by os.path.join for the duration of the test.
+   `megfile` (a path-joining helper the config imports; not installed here) is stood in by os.path.join inside the child process the
+   config is executed in.
 2. Everywhere: the alias exposes the operator surface under the reference's module paths and names."""
 import importlib.util
 import os
@@ -23,30 +24,54 @@ def _load_by_path(path):
     return mod
 
 
+_CHILD = r"""
+import importlib.util, json, os, sys, types
+root, path, rel = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, root)
+import basedet  # noqa: F401  (the alias package at the repo root)
+if "megfile" not in sys.modules:          # a path-joining helper the configs import; not installed here
+    stub = types.ModuleType("megfile")
+    stub.smart_path_join = lambda *a: os.path.join(*a)
+    sys.modules["megfile"] = stub
+spec = importlib.util.spec_from_file_location("playground_cfg_under_test", path)
+mod = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mod)
+cfg = mod.Cfg()
+from basedet.configs import DetectionConfig
+from basedet.utils import registers
+import basedet.models, basedet.solver, basedet.engine  # noqa: F401,E401
+model_cls = registers.models.get(cfg.MODEL.NAME)
+solver_builder = registers.solvers.get(cfg.SOLVER.BUILDER_NAME)
+trainer_cls = registers.trainers.get(cfg.TRAINER.NAME)
+print("RESULT " + json.dumps(dict(
+    is_cfg=isinstance(cfg, DetectionConfig), out_dir=cfg.GLOBAL.OUTPUT_DIR,
+    resolved=bool(callable(model_cls) and hasattr(solver_builder, "build") and hasattr(trainer_cls, "train")),
+    builders=all(hasattr(cfg, n) for n in ("build_model", "build_solver", "build_trainer")),
+    reduce=cfg.SOLVER.REDUCE_MODE, freeze=cfg.MODEL.BACKBONE.FREEZE_AT, classes=cfg.DATA.NUM_CLASSES)))
+"""
+
+
 @pytest.mark.skipif(not os.path.exists(REF_CFG), reason="the reference tree is only present in the build container")
 @pytest.mark.parametrize("rel", ["retinanet/res50_coco_800size_1x", "fcos", "faster_rcnn/res50_coco_800size_1x", "atss", "freeanchor", "ota"])
-def test_reference_playground_config_loads_against_the_alias(rel, monkeypatch):
+def test_reference_playground_config_loads_against_the_alias(rel):
+    """The reference's config file is untrusted content: it is executed in a CHILD process (no GPU, nothing of this test process's state),
+    which reports what the training entry would resolve from it."""
+    import json
+    import subprocess
     path = os.path.join("/root/reference/playground/examples", rel, "config.py")
     if not os.path.exists(path):
         pytest.skip(path + " absent")
-    import basedet  # noqa: F401  (the alias package at the repo root)
-    if "megfile" not in sys.modules:
-        stub = types.ModuleType("megfile")
-        stub.smart_path_join = lambda *a: os.path.join(*a)
-        monkeypatch.setitem(sys.modules, "megfile", stub)
-    cfg = _load_by_path(path).Cfg()
-    from basedet.configs import DetectionConfig
-    from basedet.utils import registers
-    import basedet.models, basedet.solver, basedet.engine  # noqa: F401,E401
-    assert isinstance(cfg, DetectionConfig)
-    assert cfg.GLOBAL.OUTPUT_DIR.endswith(os.path.join("examples", rel))
-    model_cls = registers.models.get(cfg.MODEL.NAME)
-    solver_builder = registers.solvers.get(cfg.SOLVER.BUILDER_NAME)
-    trainer_cls = registers.trainers.get(cfg.TRAINER.NAME)
-    assert callable(model_cls) and hasattr(solver_builder, "build") and hasattr(trainer_cls, "train")
-    assert hasattr(cfg, "build_model") and hasattr(cfg, "build_solver") and hasattr(cfg, "build_trainer")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CHILD, root, path, rel], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stdout[-1000:]
+    res = json.loads(line[-1][7:])
+    assert res["is_cfg"] and res["resolved"] and res["builders"]
+    assert res["out_dir"].endswith(os.path.join("examples", rel))
     # the values the hot path reads are the reference's (configs/det_model/*.py, configs/extra_cfg.py)
-    assert cfg.SOLVER.REDUCE_MODE == "MEAN" and cfg.MODEL.BACKBONE.FREEZE_AT == 2 and cfg.DATA.NUM_CLASSES == 80
+    assert res["reduce"] == "MEAN" and res["freeze"] == 2 and res["classes"] == 80
 
 
 def test_alias_exposes_the_operator_surface():
