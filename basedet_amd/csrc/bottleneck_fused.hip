@@ -41,11 +41,19 @@ struct BP {
     const float *b1, *b2, *b3, *bd;
     bf16_raw* y;
     int N, H, W;
-    int tiles_x, tiles_per_img, total_tiles, per_xcd;
+    int tiles_x, tiles_y, tiles_per_img, total_tiles, per_xcd, run;
     unsigned x_bytes, y_bytes;
 };
 
 __device__ __forceinline__ bf16x8_t ld_frag_lds(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+// Bank layout of every LDS image of this kernel (144-byte rows; the same fix as conv3x3.hip): ds_read_b128 serves lanes {0-3, 12-15, 20-27}
+// in one LDS cycle, i.e. fragment rows 0-3, 12-15 at K chunk c together with rows 4-11 at chunk c + 1 -- with plain rows those two sets
+// collide on 7 of 8 slots (the first build: SQ_LDS_BANK_CONFLICT = 14.5 % of the kernel's wave cycles).  So MFMA column / row f lives at
+// LDS row colperm(f) (even / odd rows for the two sets) and the 16-byte chunks of a 64-byte K half are stored in the order 0 2 1 3.
+__device__ __forceinline__ int colperm(int f) { return f < 4 ? 2 * f : (f < 12 ? 2 * (f - 4) + 1 : 2 * (f - 8)); }
+__device__ __forceinline__ int colperm_inv(int r) { return (r & 1) ? (r >> 1) + 4 : (r < 8 ? (r >> 1) : (r >> 1) + 8); }
+__device__ __forceinline__ int xpos(int chunk) { return (chunk >> 2) * 64 + ((((chunk & 1) << 1) | ((chunk >> 1) & 1)) << 4); }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_bn_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_bn_t;
@@ -82,7 +90,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, q = lane >> 4;
+    const int pxc = colperm(px);                        // the pixel column (of a 16-pixel block) this lane's MFMA column stands for
+    const int xq0 = xpos(q), xq1 = xpos(q + 4);         // this lane's 16-byte chunk of the first / second K half of a 64-channel row
     const int cb = wave;                                // phases 1 / 2: this wave's 16 mid channels; phase 3: its 64 output channels
+    const int wq = xpos(cb * 2 + (q >> 1)) + (q & 1) * 8;      // where this lane's four mid channels (cb * 16 + 4 q ..) go in a row
 
     // ---- one-time: weights ---------------------------------------------------------------------------------------------------------
     bf16x8_t w1r[2 * NCH], w2r[18];
@@ -99,11 +110,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
     // channels of each 32-channel half (16-byte stores)
     for (int u = tid; u < 256 * 8; u += 256) {
         const int row = u >> 3, part = u & 7;
-        const int t = (row >> 4) & 3, rho = row & 15;
+        const int t = (row >> 4) & 3, rho = colperm_inv(row & 15);       // LDS row position r' is read by MFMA row rho = colperm^-1(r')
         const int ch = (row & ~63) + 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
-        *reinterpret_cast<u32x4_t*>(W3L + row * PITCH + part * 16) = *reinterpret_cast<const u32x4_t*>(p.w3 + (long long)ch * CMID + part * 8);
+        *reinterpret_cast<u32x4_t*>(W3L + row * PITCH + xpos(part)) = *reinterpret_cast<const u32x4_t*>(p.w3 + (long long)ch * CMID + part * 8);
         if constexpr (HAS_DS)
-            *reinterpret_cast<u32x4_t*>(WDL + row * PITCH + part * 16) = *reinterpret_cast<const u32x4_t*>(p.wd + (long long)ch * CIN + part * 8);
+            *reinterpret_cast<u32x4_t*>(WDL + row * PITCH + xpos(part)) = *reinterpret_cast<const u32x4_t*>(p.wd + (long long)ch * CIN + part * 8);
     }
     B3L[tid] = p.b3[tid] + (HAS_DS ? p.bd[tid] : 0.f);      // 256 threads, 256 output channels
     f32x4_t b1v = *reinterpret_cast<const f32x4_t*>(p.b1 + cb * 16 + 4 * q);
@@ -119,29 +130,34 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
         const int u = tid + 256 * i, h = u >> 3, part = u & 7;
         s_hy[i] = h / HW; s_hx[i] = h - s_hy[i] * HW;
         s_ok[i] = h < NHALO;
-        s_lds[i] = (unsigned)(h * PITCH + part * 16);
+        s_lds[i] = (unsigned)(h * PITCH + xpos(part));
     }
     int e_hy[12], e_hx[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-        const int h = j * 16 + px;
+        const int h = j * 16 + pxc;
         e_hy[j] = h / HW; e_hx[j] = h - e_hy[j] * HW;       // h >= 180: hy = 10 -> never inside the image test below (row 10 of a 10-row patch is unused)
     }
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
 
-    // ---- persistent tile walk: XCD k (= blockIdx & 7) owns the contiguous tile range [k * per_xcd, (k + 1) * per_xcd) -----------------------
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, stride = gridDim.x >> 3;
-    const int t_end = min((xcd + 1) * p.per_xcd, p.total_tiles);
-    int tile = xcd * p.per_xcd + slot;
+    // ---- persistent tile walk.  Tiles are numbered COLUMN-major inside an image (a workgroup walks DOWN a column of patches: the bottom
+    // halo rows of one tile are the top rows of its next -- 20 % of a tile's input, re-read out of L2 instead of HBM; with the row-major,
+    // strided walk of the first build the PMC traffic was 1.30 GB per launch against 0.96 GB algorithmic: no halo ever hit L2).  XCD k
+    // (= blockIdx & 7) owns the contiguous tile range [k * per_xcd, (k + 1) * per_xcd), split into contiguous runs of `run` tiles per
+    // workgroup: neighbouring columns are walked by neighbouring workgroups of the same XCD at the same time.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int t_end = min(min((xcd + 1) * p.per_xcd, p.total_tiles), xcd * p.per_xcd + (slot + 1) * p.run);
+    int tile = xcd * p.per_xcd + slot * p.run;
+    constexpr int stride = 1;
 
     unsigned voff[NST];
     int n_img = 0, ty0 = 0, tx0 = 0;
     auto decode = [&](int t, unsigned (&vo)[NST], int& n, int& y0, int& x0) {
         n = t / p.tiles_per_img;
         const int r = t - n * p.tiles_per_img;
-        const int ty = r / p.tiles_x;
-        y0 = ty * PH; x0 = (r - ty * p.tiles_x) * PW;
+        const int tx = r / p.tiles_y;                 // column-major inside the image
+        y0 = (r - tx * p.tiles_y) * PH; x0 = tx * PW;
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int gy = y0 - 1 + s_hy[i], gx = x0 - 1 + s_hx[i];
@@ -198,12 +214,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
                 }
             }
             __syncthreads();
-            const unsigned char* xb = XB + buf * XB_BYTES + px * PITCH + q * 16;
+            const unsigned char* xb = XB + buf * XB_BYTES + pxc * PITCH;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int j = 0; j < 12; ++j)
-                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[c * 2 + ks], ld_frag_lds(xb + j * 16 * PITCH + ks * 64), acc1[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[c * 2 + ks], ld_frag_lds(xb + j * 16 * PITCH + (ks ? xq1 : xq0)), acc1[j], 0, 0, 0);
         }
         BN_STAMP(1);
         // mid-1 = relu(acc + shift), zero outside the image, bf16, into M1 (its previous readers -- the last tile's phase 3 -- are behind
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
             const f32x4_t v = acc1[j] + b1v;          // shift AFTER the accumulation, as the separate launch adds it: the same fp32 roundings
             o[0] = in ? relu_pack2(v[0], v[1]) : 0u;
             o[1] = in ? relu_pack2(v[2], v[3]) : 0u;
-            *reinterpret_cast<u32x2_t*>(M1 + (j * 16 + px) * PITCH + cb * 32 + q * 8) = o;
+            *reinterpret_cast<u32x2_t*>(M1 + (j * 16 + pxc) * PITCH + wq) = o;
         }
         __syncthreads();
 
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
             for (int half = 0; half < 2; ++half)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int gy = ty0 + hfq * 4 + r, gx = tx0 + px;
+                    const int gy = ty0 + hfq * 4 + r, gx = tx0 + pxc;
                     const bool ok = gy < p.H && gx < p.W;
                     const unsigned vo = ok ? (unsigned)((((long long)n_img * p.H + gy) * p.W + gx) * CIN + cb * 64 + 32 * half + 8 * q) * 2u : X_NONE;
                     res_all[hfq][half][r] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo, 0, 0);
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) acc2[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         {
-            const unsigned char* mb = M1 + px * PITCH + q * 16;
+            const unsigned char* mb = M1 + pxc * PITCH;
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r)
                         acc2[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            w2r[t * 2 + kh], ld_frag_lds(mb + ((r + t / 3) * HW + t % 3) * PITCH + kh * 64), acc2[r], 0, 0, 0);
+                            w2r[t * 2 + kh], ld_frag_lds(mb + ((r + t / 3) * HW + t % 3) * PITCH + (kh ? xq1 : xq0)), acc2[r], 0, 0, 0);
         }
         BN_STAMP(3);
         __syncthreads();                                // every wave has read mid-1: its memory becomes mid-2 [128 pixels][64]
@@ -275,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
             const f32x4_t v = acc2[r] + b2v;
             o[0] = relu_pack2(v[0], v[1]);
             o[1] = relu_pack2(v[2], v[3]);
-            *reinterpret_cast<u32x2_t*>(M1 + (r * 16 + px) * PITCH + cb * 32 + q * 8) = o;
+            *reinterpret_cast<u32x2_t*>(M1 + (r * 16 + pxc) * PITCH + wq) = o;
         }
         __syncthreads();
 
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
         unsigned yoff[8];                               // this lane's 16-byte unit of each of the eight patch rows (half 0; half 1 = + 64 bytes)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int gy = ty0 + r, gx = tx0 + px;
+            const int gy = ty0 + r, gx = tx0 + pxc;
             yoff[r] = (gy < p.H && gx < p.W) ? (unsigned)((((long long)n_img * p.H + gy) * p.W + gx) * COUT + cb * 64 + 8 * q) * 2u : X_NONE;
         }
         // One vmcnt for loads AND stores: a load result first touched after a store makes the compiler wait for that store too (the first
@@ -322,19 +338,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t a[2], b[4];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) a[t] = ld_frag_lds(W3L + (cb * 64 + (2 * half + t) * 16 + px) * PITCH + ks * 64 + q * 16);
+                for (int t = 0; t < 2; ++t) a[t] = ld_frag_lds(W3L + (cb * 64 + (2 * half + t) * 16 + pxc) * PITCH + (ks ? xq1 : xq0));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = ld_frag_lds(M1 + ((hf * 4 + r) * 16 + px) * PITCH + ks * 64 + q * 16);
+                for (int r = 0; r < 4; ++r) b[r] = ld_frag_lds(M1 + ((hf * 4 + r) * 16 + pxc) * PITCH + (ks ? xq1 : xq0));
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc3[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[r], acc3[t][r], 0, 0, 0);
                 if constexpr (HAS_DS) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) a[t] = ld_frag_lds(WDL + (cb * 64 + (2 * half + t) * 16 + px) * PITCH + ks * 64 + q * 16);
+                    for (int t = 0; t < 2; ++t) a[t] = ld_frag_lds(WDL + (cb * 64 + (2 * half + t) * 16 + pxc) * PITCH + (ks ? xq1 : xq0));
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        b[r] = ld_frag_lds(XB + xbuf * XB_BYTES + ((hf * 4 + r + 1) * HW + 1 + px) * PITCH + ks * 64 + q * 16);
+                        b[r] = ld_frag_lds(XB + xbuf * XB_BYTES + ((hf * 4 + r + 1) * HW + 1 + pxc) * PITCH + (ks ? xq1 : xq0));
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -410,7 +426,8 @@ extern "C" int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cou
     p.b1 = b1; p.b2 = b2; p.b3 = b3; p.bd = bd; p.y = (bf16_raw*)y;
     p.N = N; p.H = H; p.W = W;
     p.tiles_x = cdiv(W, PW);
-    p.tiles_per_img = p.tiles_x * cdiv(H, PH);
+    p.tiles_y = cdiv(H, PH);
+    p.tiles_per_img = p.tiles_x * p.tiles_y;
     p.total_tiles = p.tiles_per_img * N;
     p.per_xcd = cdiv(p.total_tiles, 8);
     p.x_bytes = (unsigned)((long long)N * H * W * Cin * 2);
@@ -432,6 +449,7 @@ extern "C" int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cou
     if (grid < 8) grid = 8;
     const int need = p.per_xcd * 8;
     if (grid > need) grid = need;                       // (per_xcd >= 1: at least 8 workgroups; the surplus ones exit at once)
+    p.run = cdiv(p.per_xcd, grid / 8);                  // tiles per workgroup: one contiguous run
     const size_t lds = 2 * XB_BYTES + XB_BYTES + W3_BYTES + (wd ? W3_BYTES : 0) + BIAS_BYTES + PAD_BYTES;
     static bool attr_set = false;
     if (!attr_set) {

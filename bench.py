@@ -19,7 +19,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                   are HIP events on the launch stream during the timed steps, `traffic` the PMC-measured HBM bytes per launch:
                   at N = 1 measured IN the run (after the timed region rank 0 starts `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
                   child processes around three steps of the same workload: measure_traffic; --no-pmc skips them), else read from
-                  profiles/r02_pmc_traffic.json (refused -- null -- when that was collected on a different build of the kernels)
+                  profiles/r03_pmc_traffic.json (refused -- null -- when that was collected on a different build of the kernels)
   cpu_baseline -- the CPU oracle's (oracle/model.py, torch-CPU fp32) training step on the host cores, bounded sample.
 """
 import argparse
@@ -702,7 +702,7 @@ def worker(args):
             # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the bench): valid for the
             # workload / batch AND the kernel build they were collected on (source digest recorded by scripts/pmc_traffic.py)
             pmc, pmc_note = {}, None
-            pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
             if world == 1 and not args.no_pmc:
                 pmc, pmc_note = measure_traffic(args)
             if pmc:
@@ -714,7 +714,7 @@ def worker(args):
                 if rec.get("build_digest") == _b._digest():
                     pmc = rec.get("kernels", {})
                 else:
-                    pmc_note = "profiles/r02_pmc_traffic.json was collected on a different build of csrc/: traffic refused (null)"
+                    pmc_note = "profiles/r03_pmc_traffic.json was collected on a different build of csrc/: traffic refused (null)"
             for kern in timer.records:
                 sm = timer.summary(kern)
                 tf = sm["flops"] / (sm["ms"] * 1e-3) / 1e12

@@ -17,13 +17,13 @@ for r in csv.DictReader(open(f)):
 out = {}
 for k, c in sorted(tot.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
     wc = c.get("SQ_WAVE_CYCLES", 0.0)
-    if not wc or "conv" not in k:
+    if not wc or not ("conv" in k or "bottleneck" in k):
         continue
     gui = c.get("GRBM_GUI_ACTIVE", 0.0)
     out[k] = {"launches": launches[k],
               "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0) / wc, 3), "wait_inst_any_frac": round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
               "active_inst_any_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
-              "lds_bank_conflict_cycles": int(c.get("SQ_LDS_BANK_CONFLICT", 0)),
+              "lds_bank_conflict_cycles": int(c.get("SQ_LDS_BANK_CONFLICT", 0)), "lds_bank_conflict_frac": round(c.get("SQ_LDS_BANK_CONFLICT", 0) / wc, 4),
               "mfma_busy_frac_of_simd_cycles": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui / 8 * 1024), 3) if gui else None,
               "valu_insts_per_mfma_inst": round(c.get("SQ_INSTS_VALU", 0) / c["SQ_INSTS_MFMA"], 2) if c.get("SQ_INSTS_MFMA") else None}
 src = ("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT "
