@@ -359,17 +359,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
             drow[j] = p.dst + e;
             mrow[j] = p.mask + e;
         }
+        // ALL of the tile's gate operands are requested before its first store (round 3).  gfx950 has one vmcnt for loads and stores: with
+        // the loads of channel group h + 1 issued after the stores of group h, the compiler's wait for those loads was vmcnt(0) -- it also
+        // waited for the stores' acknowledgements, four serialised round trips per tile in a kernel that has one workgroup per CU (seen in
+        // the ISA; the same pattern cost bottleneck_fused.hip a third of its tile time).  The K loop's fragments and staging registers are
+        // dead here, so the 16 operands (64 VGPRs) fit beside the accumulators.
+        u32x4_t mv[4][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const bool okh = cbase + 32 * h < p.CO;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mv[h][j] = (u32x4_t){0u, 0u, 0u, 0u};
+                if (do_mask && okh && okj[j]) mv[h][j] = *reinterpret_cast<const u32x4_t*>(mrow[j] + 32 * h);
+            }
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const bool okh = cbase + 32 * h < p.CO;
             const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h);
             const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h + 4);
-            u32x4_t mv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mv[j] = (u32x4_t){0u, 0u, 0u, 0u};
-                if (do_mask && okh && okj[j]) mv[j] = *reinterpret_cast<const u32x4_t*>(mrow[j] + 32 * h);
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x4_t o;
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                         // read the first mask register for every k -- caught by test_patch_instances_agree_bitwise; op_sel_hi:[0,1]: both halves shift
                         // by the low half of the inline constant, whose high half is 0)
                         unsigned gate;
-                        asm("v_pk_sub_i16 %0, 0, %1 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(gate) : "v"(mv[j][k]));
+                        asm("v_pk_sub_i16 %0, 0, %1 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(gate) : "v"(mv[h][j][k]));
                         w &= __builtin_bit_cast(i16x2_e, gate);
                     }
                     w = __builtin_elementwise_max(w, relu_floor);
@@ -396,50 +405,69 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
         }
         return;
     }
+    // General path (a residual / accumulate operand): the operands of TWO channel groups (eight 16-byte units: up to 64 VGPRs of residuals +
+    // gates) are requested together, then consumed and stored -- two round trips per tile instead of one per unit (the plain loop compiled to
+    // load -> s_waitcnt vmcnt(0) -> use -> store for each of the 16 units, each wait also covering the previous unit's store).
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        if (cbase + 32 * h >= p.CO) continue;
-        float bias[8];
-        {
-            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h);
-            const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h + 4);
+    for (int hp = 0; hp < 2; ++hp) {
+        u32x4_t av[2][4], mv[2][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { bias[k] = b0[k]; bias[4 + k] = b1[k]; }
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * hp + hh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int oy = oy0 + j;
+                const bool ok = cbase + 32 * h < p.CO && oy < H && ox < W;
+                const long long idx = (long long)(dbase + oy * W + ox) * p.CO + cbase + 32 * h;
+                av[hh][j] = (u32x4_t){0u, 0u, 0u, 0u}; mv[hh][j] = (u32x4_t){0u, 0u, 0u, 0u};
+                if (ok && (add_before || add_after)) av[hh][j] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                if (ok && do_mask) mv[hh][j] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int oy = oy0 + j;
-            if (oy >= H || ox >= W) continue;
-            const long long idx = (long long)(dbase + oy * W + ox) * p.CO + cbase + 32 * h;
-            float v[8];
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * hp + hh;
+            if (cbase + 32 * h >= p.CO) continue;
+            float bias[8];
+            {
+                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h);
+                const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h + 4);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = acc[2 * h + (k >> 2)][j][k & 3] + bias[k];
-            if (add_before) {
-                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
+                for (int k = 0; k < 4; ++k) { bias[k] = b0[k]; bias[4 + k] = b1[k]; }
             }
-            if (do_relu) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-            }
-            if (do_mask) {
-                const u32x4_t mv = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+            for (int j = 0; j < 4; ++j) {
+                const int oy = oy0 + j;
+                if (oy >= H || ox >= W) continue;
+                const long long idx = (long long)(dbase + oy * W + ox) * p.CO + cbase + 32 * h;
+                float v[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (!(bf_lo(mv[k]) > 0.f)) v[2 * k] = 0.f;
-                    if (!(bf_hi(mv[k]) > 0.f)) v[2 * k + 1] = 0.f;
+                for (int k = 0; k < 8; ++k) v[k] = acc[2 * h + (k >> 2)][j][k & 3] + bias[k];
+                const u32x4_t a4 = av[hh][j], m4 = mv[hh][j];
+                if (add_before) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(a4[k]); v[2 * k + 1] += bf_hi(a4[k]); }
                 }
-            }
-            if (add_after) {
-                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+                if (do_relu) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
-            }
-            u32x4_t o;
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
+                if (do_mask) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
-            *reinterpret_cast<u32x4_t*>(p.dst + idx) = o;
+                    for (int k = 0; k < 4; ++k) {
+                        if (!(bf_lo(m4[k]) > 0.f)) v[2 * k] = 0.f;
+                        if (!(bf_hi(m4[k]) > 0.f)) v[2 * k + 1] = 0.f;
+                    }
+                }
+                if (add_after) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(a4[k]); v[2 * k + 1] += bf_hi(a4[k]); }
+                }
+                u32x4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+                *reinterpret_cast<u32x4_t*>(p.dst + idx) = o;
+            }
         }
     }
 #ifdef BD_PP_STAMP

@@ -132,3 +132,65 @@ def test_test_time_compose_im_info():
     train = build_transform(mode="train", rng=np.random.default_rng(1))
     o, b, c = train((img, np.array([[10, 10, 100, 100]], dtype=np.float32), np.array([2])))
     assert o.shape[0] == 3 and min(o.shape[1:]) in (640, 672, 704, 736, 768, 800)
+
+
+def _textbook_ap(gts, dts, thr):
+    """An independent restatement of box AP at one IoU threshold for ONE category without crowds / area ranges, written from the
+    definition (not from bbox_eval's code): detections of all images by descending score; each takes the unmatched ground truth of
+    its image with the highest IoU >= thr; precision envelope sampled at recall 0, 0.01, ..., 1."""
+    def iou(a, b):
+        ax2, ay2, bx2, by2 = a[0] + a[2], a[1] + a[3], b[0] + b[2], b[1] + b[3]
+        iw, ih = min(ax2, bx2) - max(a[0], b[0]), min(ay2, by2) - max(a[1], b[1])
+        inter = max(iw, 0.0) * max(ih, 0.0)
+        return inter / (a[2] * a[3] + b[2] * b[3] - inter)
+    order = sorted(range(len(dts)), key=lambda i: (-dts[i]["score"], i))
+    used = set()
+    tp = []
+    for i in order:
+        d = dts[i]
+        best, arg = thr, None
+        for j, g in enumerate(gts):
+            if g["image_id"] != d["image_id"] or j in used:
+                continue
+            v = iou(d["bbox"], g["bbox"])
+            if v >= best:
+                best, arg = v, j
+        if arg is not None:
+            used.add(arg)
+        tp.append(arg is not None)
+    tp = np.asarray(tp, dtype=np.float64)
+    ctp, cfp = np.cumsum(tp), np.cumsum(1 - tp)
+    rec, prec = ctp / len(gts), ctp / np.maximum(ctp + cfp, 1e-300)
+    ap = 0.0
+    for r in np.linspace(0, 1, 101):
+        m = prec[rec >= r - 1e-12]
+        ap += (m.max() if m.size else 0.0) / 101
+    return ap
+
+
+def test_bbox_eval_agrees_with_an_independent_textbook_ap():
+    """Random detection sets (several images, one category, jittered copies of the ground truth + clutter, distinct scores): the AP at
+    every IoU threshold of bbox_eval equals an AP written independently from the definition -- pycocotools itself is not available here,
+    so this is the strongest pin the evaluator can get in this container."""
+    rng = np.random.default_rng(12)
+    for trial in range(6):
+        gts, dts, k = [], [], 0
+        for img in range(1, 5):
+            for _ in range(rng.integers(1, 6)):
+                x, y, w, h = rng.uniform(0, 300), rng.uniform(0, 300), rng.uniform(120, 200), rng.uniform(120, 200)   # all "large": one area cell
+                k += 1
+                gts.append(_gt(k, img, 1, (x, y, w, h)))
+                for _ in range(rng.integers(0, 3)):
+                    j = rng.normal(0, 12, 4)
+                    dts.append(_dt(img, 1, (x + j[0], y + j[1], max(w + j[2], 5), max(h + j[3], 5)), 0.0))
+            for _ in range(rng.integers(0, 4)):
+                dts.append(_dt(img, 1, (rng.uniform(0, 400), rng.uniform(0, 400), rng.uniform(100, 180), rng.uniform(100, 180)), 0.0))
+        for d, s in zip(dts, rng.permutation(len(dts))):
+            d["score"] = 0.05 + 0.9 * (s + 1) / (len(dts) + 1)
+        r = bbox_eval(gts, dts)
+        P = r["precision"]                                   # (T, R, K, A, M)
+        for ti, thr in enumerate(np.linspace(0.5, 0.95, 10)):
+            want = _textbook_ap(gts, dts, thr)
+            got = float(P[ti, :, 0, 0, 2].mean())
+            assert got == pytest.approx(want, abs=1e-9), (trial, thr, got, want)
+        assert r["stats"][0] == pytest.approx(np.mean([_textbook_ap(gts, dts, t) for t in np.linspace(0.5, 0.95, 10)]), abs=1e-9)
