@@ -73,7 +73,7 @@ __device__ __forceinline__ void dma16_bn(__amdgpu_buffer_rsrc_t rsrc, unsigned c
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_bn_t*)lds, 16, voff, soff, 0, 0);
 }
 constexpr int PAD_BYTES = 4 * 1024;            // one 1-KiB landing pad per wave for the L2 warm-up DMAs (never read)
-constexpr int BIAS_BYTES = 1024;               // conv3's (+ the downsample's) 256 shifts, read back through LDS (lgkmcnt, not vmcnt)
+constexpr int BIAS_BYTES = 2048;               // conv3's (+ the downsample's) 256 shifts, read back through LDS (lgkmcnt, not vmcnt)
 
 template <int CIN, bool HAS_DS, bool WARM = true>
 __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
         if constexpr (HAS_DS)
             *reinterpret_cast<u32x4_t*>(WDL + row * PITCH + xpos(part)) = *reinterpret_cast<const u32x4_t*>(p.wd + (long long)ch * CIN + part * 8);
     }
-    B3L[tid] = p.b3[tid] + (HAS_DS ? p.bd[tid] : 0.f);      // 256 threads, 256 output channels
+    B3L[tid] = p.b3[tid];                                   // 256 threads, 256 output channels
+    if constexpr (HAS_DS) B3L[256 + tid] = p.bd[tid];
     f32x4_t b1v = *reinterpret_cast<const f32x4_t*>(p.b1 + cb * 16 + 4 * q);
     f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(p.b2 + cb * 16 + 4 * q);
 
@@ -331,9 +332,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
             const int cbase = cb * 64 + 32 * half + 8 * q;
             const f32x4_t bv0 = *reinterpret_cast<const f32x4_t*>(B3L + cbase);
             const f32x4_t bv1 = *reinterpret_cast<const f32x4_t*>(B3L + cbase + 4);
-            f32x4_t acc3[2][4];
+            f32x4_t acc3[2][4], accd[2][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { acc3[0][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc3[1][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+            for (int r = 0; r < 4; ++r) {
+                acc3[0][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc3[1][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                accd[0][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; accd[1][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t a[2], b[4];
@@ -354,8 +358,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc3[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[r], acc3[t][r], 0, 0, 0);
+                        for (int r = 0; r < 4; ++r) accd[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[r], accd[t][r], 0, 0, 0);
                 }
+            }
+            [[maybe_unused]] f32x4_t dv0, dv1;
+            if constexpr (HAS_DS) {
+                dv0 = *reinterpret_cast<const f32x4_t*>(B3L + 256 + cbase);
+                dv1 = *reinterpret_cast<const f32x4_t*>(B3L + 256 + cbase + 4);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -368,6 +377,15 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
                     v += (f32x2_bn_t){bk[2 * (k & 1)], bk[2 * (k & 1) + 1]};       // shift, then residual: the separate launch's order
                     if constexpr (!HAS_DS) {
                         const unsigned w = res_all[hf][half][r][k];
+                        v += (f32x2_bn_t){bf_lo(w), bf_hi(w)};
+                    } else {
+                        // the shortcut exactly as its own launch leaves it: + shift, rounded to bf16 (no ReLU), then added as the residual --
+                        // kept in fp32 it differs by half a bf16 ulp per element, and the repeated-batch run at batch 16 took another
+                        // trajectory with it (non-finite by step 500, where the three-launch form reaches 0.36 at step 1 500)
+                        const f32x4_t dk = (k >> 1) ? dv1 : dv0;
+                        f32x2_bn_t d = {accd[k >> 1][r][2 * (k & 1)], accd[k >> 1][r][2 * (k & 1) + 1]};
+                        d += (f32x2_bn_t){dk[2 * (k & 1)], dk[2 * (k & 1) + 1]};
+                        const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2_bn_t));
                         v += (f32x2_bn_t){bf_lo(w), bf_hi(w)};
                     }
                     o[k] = relu_pack2(v[0], v[1]);
