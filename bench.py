@@ -478,6 +478,8 @@ def main():
                          "instrumented step keeps the weight gradients on the main stream: ~2.7 ms per instrumented step; the headline "
                          "stays within ~1 %% of an uninstrumented run)")
     ap.add_argument("--dump-convs", action="store_true", help="per-shape kernel timing table on stderr")
+    ap.add_argument("--seed", type=int, default=0, help="seed of the random-init weights (long-run stability studies)")
+    ap.add_argument("--lr-scale", type=float, default=1.0, help="multiplies SOLVER.BASIC_LR (long-run stability studies)")
     ap.add_argument("--log-every", type=int, default=0,
                     help="long repeated-batch runs: print the loss (and the fp8 gradient-scale state) to stderr every n timed steps (a host sync each)")
     ap.add_argument("--serial-wgrad", action="store_true",
@@ -547,6 +549,8 @@ def worker(args):
     else:
         cfg, size = retinanet_r18_config(), (512, 512)
     cfg.MODEL.BATCHSIZE = args.batch
+    if args.lr_scale != 1.0:
+        cfg.SOLVER.BASIC_LR = cfg.SOLVER.BASIC_LR * args.lr_scale
     if args.fp8:
         cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
     for kv in args.model_opt:
@@ -555,13 +559,13 @@ def worker(args):
     # random-init weights of the named architecture; the last FrozenBN gamma of every residual branch is 0.2
     # (stand-in for ImageNet statistics: identity BN overflows a random ResNet-50; same FLOPs and bytes)
     if cfg.MODEL.NAME in ("FCOS", "ATSS", "OTA"):
-        params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.2)
+        params = P.init_fcos_params(cfg, seed=args.seed, residual_gamma=0.2)
         model = {"FCOS": FCOS, "ATSS": ATSS, "OTA": OTA}[cfg.MODEL.NAME](cfg, params=params)
     elif cfg.MODEL.NAME == "FasterRCNN":
-        params = P.init_faster_rcnn_params(cfg, seed=0, residual_gamma=0.2)
+        params = P.init_faster_rcnn_params(cfg, seed=args.seed, residual_gamma=0.2)
         model = FasterRCNN(cfg, params=params)
     else:
-        params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
+        params = P.init_retinanet_params(cfg, seed=args.seed, residual_gamma=0.2)
         model = (FreeAnchor if cfg.MODEL.NAME == "FreeAnchor" else RetinaNet)(cfg, params=params)
     broadcast_parameters(model)
     solver = DetSolver.build(cfg, model)
