@@ -689,7 +689,15 @@ def worker(args):
         if comm is not None:
             # how much of the gradient exchange the backward pass did NOT hide: time from "backward (data + weight gradients) done on the
             # main stream" to "last bucket's all-reduce done on the communication stream", per timed step (<= 0: fully hidden)
-            ex = np.array([e0.elapsed_time(e1) for e0, e1 in solver.comm_profile[:args.steps]] or [0.0])
+            def _gap(a, b):
+                try:
+                    return a.elapsed_time(b)
+                except RuntimeError:            # (a runtime that refuses stop-before-start pairs: the collectives finished first)
+                    try:
+                        return -b.elapsed_time(a)
+                    except RuntimeError:
+                        return 0.0
+            ex = np.array([_gap(e0, e1) for e0, e1 in solver.comm_profile[:args.steps]] or [0.0])
             out["comm"] = {"rccl_ranks": world, "transport": "bd_comm_* (RCCL ncclAllReduce, one communicator, one high-priority stream)",
                            "buckets_bytes": {k: int((hi - lo) * 4) for k, (lo, hi) in sorted(solver.buckets.ranges.items(), key=lambda kv: -kv[1][0])},
                            "allreduce_exposed_ms": round(float(np.maximum(ex, 0.0).mean()), 3),
