@@ -41,7 +41,7 @@ struct BP {
     const float *b1, *b2, *b3, *bd;
     bf16_raw* y;
     int N, H, W;
-    int tiles_x, tiles_y, tiles_per_img, total_tiles, per_xcd, run;
+    int tiles_x, tiles_y, tiles_per_img, total_tiles, per_xcd;
     unsigned x_bytes, y_bytes;
 };
 
@@ -142,23 +142,21 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused_kernel(const BP p) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
 
-    // ---- persistent tile walk.  Tiles are numbered COLUMN-major inside an image (a workgroup walks DOWN a column of patches: the bottom
-    // halo rows of one tile are the top rows of its next -- 20 % of a tile's input, re-read out of L2 instead of HBM; with the row-major,
-    // strided walk of the first build the PMC traffic was 1.30 GB per launch against 0.96 GB algorithmic: no halo ever hit L2).  XCD k
-    // (= blockIdx & 7) owns the contiguous tile range [k * per_xcd, (k + 1) * per_xcd), split into contiguous runs of `run` tiles per
-    // workgroup: neighbouring columns are walked by neighbouring workgroups of the same XCD at the same time.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int t_end = min(min((xcd + 1) * p.per_xcd, p.total_tiles), xcd * p.per_xcd + (slot + 1) * p.run);
-    int tile = xcd * p.per_xcd + slot * p.run;
-    constexpr int stride = 1;
+    // ---- persistent tile walk: XCD k (= blockIdx & 7) owns the contiguous (row-major) tile range [k * per_xcd, (k + 1) * per_xcd); its
+    // workgroups take the tiles of that range round-robin, so at any moment an XCD works on ~1.5 consecutive rows of patches.  (A
+    // column-major walk in contiguous runs per workgroup -- the bottom halo of one tile is the top of its next -- was built and measured:
+    // same launch time, MORE traffic: 1.46 against 1.30 GB per launch.)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, stride = gridDim.x >> 3;
+    const int t_end = min((xcd + 1) * p.per_xcd, p.total_tiles);
+    int tile = xcd * p.per_xcd + slot;
 
     unsigned voff[NST];
     int n_img = 0, ty0 = 0, tx0 = 0;
     auto decode = [&](int t, unsigned (&vo)[NST], int& n, int& y0, int& x0) {
         n = t / p.tiles_per_img;
         const int r = t - n * p.tiles_per_img;
-        const int tx = r / p.tiles_y;                 // column-major inside the image
-        y0 = (r - tx * p.tiles_y) * PH; x0 = tx * PW;
+        const int ty = r / p.tiles_x;
+        y0 = ty * PH; x0 = (r - ty * p.tiles_x) * PW;
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int gy = y0 - 1 + s_hy[i], gx = x0 - 1 + s_hx[i];
@@ -467,7 +465,6 @@ extern "C" int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cou
     if (grid < 8) grid = 8;
     const int need = p.per_xcd * 8;
     if (grid > need) grid = need;                       // (per_xcd >= 1: at least 8 workgroups; the surplus ones exit at once)
-    p.run = cdiv(p.per_xcd, grid / 8);                  // tiles per workgroup: one contiguous run
     const size_t lds = 2 * XB_BYTES + XB_BYTES + W3_BYTES + (wd ? W3_BYTES : 0) + BIAS_BYTES + PAD_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
