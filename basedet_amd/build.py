@@ -48,7 +48,8 @@ def _digest():
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode())
             h.update(f.read())
-    h.update(repr(sorted(SOURCES.items())).encode() + repr(COMMON).encode())
+    flags = [f for f in COMMON if not os.path.isabs(f)]        # (the include directory is an absolute path: not part of the build's identity)
+    h.update(repr(sorted(SOURCES.items())).encode() + repr(flags).encode())
     return h.hexdigest()
 
 
