@@ -95,7 +95,7 @@ def build_driver(verbose=False):
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
         return out
     cmd = [HIPCC, "-O2", "-std=c++17", "-x", "hip", f"--offload-arch={ARCH}", "-I", os.path.join(HERE, "..", "include"), src,
-           "-o", out, "-L", OUT_DIR, "-l:" + os.path.basename(LIB), "-Wl,-rpath,$ORIGIN", "-Wno-unused-result"]
+           "-o", out, "-L", OUT_DIR, "-l:" + os.path.basename(LIB), "-Wl,-rpath,$ORIGIN", "-Wno-unused-result", "-Wno-unused-value"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
