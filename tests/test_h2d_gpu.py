@@ -47,3 +47,29 @@ def test_model_preprocess_takes_host_batches_of_every_dtype():
             ref = x
         assert torch.equal(x, ref)
     assert float(ref.float().abs().sum()) > 0
+
+
+def test_h2d_pool_survives_many_submits_of_changing_sizes():
+    """The worker pool is woken once per submit (generation counter + condition variable): 120 back-to-back submits of changing sizes,
+    dtypes and chunkings, each checked -- a lost wake-up would hang (pytest-timeout), a stale job descriptor would copy the wrong range."""
+    from basedet_amd import ops
+    st = ops.HostStager("cuda:0", 8)
+    rng = np.random.default_rng(5)
+    pending = []
+    for it in range(120):
+        n = int(rng.integers(1, 400_000))
+        arr = (rng.random(n) * 255) if it % 3 else rng.integers(0, 256, n, dtype=np.uint8)
+        if it % 3 == 2:
+            arr = arr.astype(np.float32)
+        out = torch.empty((n,), dtype=torch.float32, device="cuda")
+        st.submit(arr, out, chunk_elems=int(rng.choice([0, 777, 4096, 100_000])))
+        pending.append((arr, out))
+        if len(pending) == 8:
+            torch.cuda.synchronize()
+            for a, o in pending:
+                assert np.array_equal(o.cpu().numpy(), a.astype(np.float32))
+            pending = []
+    torch.cuda.synchronize()
+    for a, o in pending:
+        assert np.array_equal(o.cpu().numpy(), a.astype(np.float32))
+    st.close()
