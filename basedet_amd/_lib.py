@@ -159,6 +159,7 @@ SIGNATURES = {
     "bd_comm_bcast": (_I, [_P, _P, _Z, _I, _I, _P]),
     "bd_comm_allreduce": (_I, [_P, _P, _Z, _I, _I, _P]),
     "bd_comm_allreduce_async": (_I, [_P, _P, _Z, _I, _I, C.POINTER(C.c_void_p), _I]),
+    "bd_comm_allreduce_async_bf16": (_I, [_P, _P, _P, _Z, _I, C.POINTER(C.c_void_p), _I]),
     "bd_comm_wait": (_I, [_P, _P]),
     "bd_comm_destroy": (_I, [_P]),
     "bd_wgrad_set_transpose_read": (_I, [_I]),

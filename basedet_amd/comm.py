@@ -102,6 +102,13 @@ class Comm:
         check(self._lib.bd_comm_allreduce_async(self._h, ptr(t), t.numel(), _DTYPES[t.dtype], _OPS[op], arr, len(producers)),
               "bd_comm_allreduce_async")
 
+    def allreduce_async_bf16(self, t, tmp, producers, op="sum"):
+        """As allreduce_async, with the fp32 tensor compressed to bf16 on the wire (tmp: bf16 scratch of t.numel() elements)."""
+        assert t.dtype == torch.float32 and tmp.dtype == torch.bfloat16 and tmp.numel() >= t.numel()
+        arr = (C.c_void_p * len(producers))(*[s.cuda_stream for s in producers])
+        check(self._lib.bd_comm_allreduce_async_bf16(self._h, ptr(t), ptr(tmp), t.numel(), _OPS[op], arr, len(producers)),
+              "bd_comm_allreduce_async_bf16")
+
     def wait(self, stream=None):
         check(self._lib.bd_comm_wait(self._h, self._sp(stream)), "bd_comm_wait")
 
@@ -139,6 +146,14 @@ class GlooComm:
 
     def allreduce_async(self, t, producers, op="sum"):
         self.allreduce(t, op)
+
+    def allreduce_async_bf16(self, t, tmp, producers, op="sum"):
+        """CPU stand-in of the compressed exchange: every rank rounds its contribution to bf16, the sum is rounded to bf16 again."""
+        tmp = tmp[: t.numel()].view_as(t)
+        tmp.copy_(t)                                     # fp32 -> bf16 (round to nearest even)
+        r = tmp.float()
+        self.allreduce(r, op)
+        t.copy_(r.to(torch.bfloat16).float())
 
     def wait(self, stream=None):
         pass

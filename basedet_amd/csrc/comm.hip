@@ -205,6 +205,35 @@ int bd_comm_allreduce_async(bd_comm_t c, void* buf, size_t count, int dtype, int
     return bd_comm_allreduce(c, buf, count, dtype, op, (bd_stream_t)c->stream);
 }
 
+namespace {
+__global__ void comm_f32_to_bf16_kernel(const float* __restrict__ src, bf16_raw* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
+}
+__global__ void comm_bf16_to_f32_kernel(const bf16_raw* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = bf2f(src[i]);
+}
+}  // namespace
+
+int bd_comm_allreduce_async_bf16(bd_comm_t c, float* buf, void* tmp_bf16, size_t count, int op, const bd_stream_t* producers,
+                                 int n_producers) {
+    BD_REQUIRE(c && buf && tmp_bf16, "bd_comm_allreduce_async_bf16: null argument");
+    BD_REQUIRE(n_producers >= 0 && n_producers <= 8, "bd_comm_allreduce_async_bf16: %d producer streams", n_producers);
+    BD_REQUIRE(op == BD_COMM_SUM || op == BD_COMM_AVG, "bd_comm_allreduce_async_bf16: op %d", op);
+    for (int i = 0; i < n_producers; ++i) {
+        hipEvent_t e = c->ev[c->ev_next++ % c->ev.size()];
+        BD_HIP(hipEventRecord(e, (hipStream_t)producers[i]), "bd_comm_allreduce_async_bf16: record");
+        BD_HIP(hipStreamWaitEvent(c->stream, e, 0), "bd_comm_allreduce_async_bf16: wait");
+    }
+    if (count == 0) return BD_OK;
+    const unsigned grid = (unsigned)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
+    hipLaunchKernelGGL(comm_f32_to_bf16_kernel, dim3(grid), dim3(256), 0, c->stream, (const float*)buf, (bf16_raw*)tmp_bf16, (long long)count);
+    const int rc = bd_comm_allreduce(c, tmp_bf16, count, BD_COMM_BF16, op, (bd_stream_t)c->stream);
+    if (rc != BD_OK) return rc;
+    hipLaunchKernelGGL(comm_bf16_to_f32_kernel, dim3(grid), dim3(256), 0, c->stream, (const bf16_raw*)tmp_bf16, buf, (long long)count);
+    BD_CHECK_LAUNCH("bd_comm_allreduce_async_bf16");
+    return BD_OK;
+}
+
 int bd_comm_wait(bd_comm_t c, bd_stream_t consumer) {
     BD_REQUIRE(c != nullptr, "bd_comm_wait: null communicator");
     BD_HIP(hipEventRecord(c->done, c->stream), "bd_comm_wait: record");

@@ -677,6 +677,12 @@ int bd_comm_allreduce(bd_comm_t comm, void* buf, size_t count, int dtype, int op
 int bd_comm_allreduce_async(bd_comm_t comm, void* buf, size_t count, int dtype, int op, const bd_stream_t* producers_host,
                             int n_producers);
 /* `consumer` waits (stream-side) for every collective enqueued so far on the communication stream. */
+/* The same with the bucket compressed to bf16 on the wire (SOLVER.ALLREDUCE_DTYPE = "bf16", opt-in; the reference's all-reduce callback
+ * keeps the gradient dtype, solver/default_solver.py:58-63): on the communication stream, after the producers' events, buf (fp32) is rounded
+ * into tmp_bf16 (count elements, caller-owned), all-reduced as ncclBfloat16, and widened back into buf.  Half the bytes per xGMI link;
+ * every rank ends with the same values (the rounded sums), each within bf16 resolution (2^-9 relative) of the fp32 result. */
+int bd_comm_allreduce_async_bf16(bd_comm_t comm, float* buf, void* tmp_bf16, size_t count, int op, const bd_stream_t* producers_host,
+                                 int n_producers);
 int bd_comm_wait(bd_comm_t comm, bd_stream_t consumer);
 int bd_comm_destroy(bd_comm_t comm);
 
