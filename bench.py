@@ -486,7 +486,8 @@ def main():
                     help="keep the weight-gradient kernels on the main stream for the whole run (what the instrumented steps do): "
                          "use it under rocprofv3 so that per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--main-priority", type=int, default=None,
-                    help="ablation: 0 = run the step's main chain on the caller's stream instead of the solver's high-priority stream")
+                    help="ablation: -1 = run the step's main chain on a high-priority stream owned by the solver (round 2's default); "
+                         "0 / unset = the caller's stream")
     ap.add_argument("--roi-bwd-pk", action="store_true",
                     help="Faster R-CNN: packed-bf16 atomic RoIAlign backward (running bf16 sums; default is the fp32 scatter)")
     ap.add_argument("--dense1x1", type=int, default=None, help="ablation: bd_conv_set_dense1x1 (0 = generic kernel for the dense 1x1 launches)")
