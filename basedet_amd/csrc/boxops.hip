@@ -221,8 +221,28 @@ __global__ __launch_bounds__(256) void fcos_assign_kernel(const float* __restric
         if (lab > 0) { fgf = 1.f; ctr_fg = ctr; }
     }
     fgf = wave_sum(fgf);
-    ctr_fg = wave_sum(ctr_fg);
-    if ((threadIdx.x & 63) == 0 && fgf > 0.f) { atomicAdd(stats, fgf); atomicAdd(stats + 1, ctr_fg); }
+    (void)ctr_fg;
+    // num_fg: a sum of ones, exact in fp32 whatever the order of the atomics.  The sum of centre-ness (the regression loss's normaliser,
+    // fcos.py:139-144) is left to ctr_sum_kernel below: float atomics would make it -- and with it every gradient of the step -- differ in
+    // the last bits from run to run.
+    if ((threadIdx.x & 63) == 0 && fgf > 0.f) atomicAdd(stats, fgf);
+}
+
+// stats[1] = sum of ctrness over the foreground points, in a FIXED order (one workgroup: strided per-thread partial sums in index order,
+// then a tree): bitwise reproducible.  N * P is a few 100 K elements: ~10 us.
+__global__ __launch_bounds__(1024) void ctr_sum_kernel(const int* __restrict__ labels, const float* __restrict__ ctrness, long long n,
+                                                       float* __restrict__ stats) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024)
+        if (labels[i] > 0) s += ctrness[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stats[1] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -334,8 +354,9 @@ __global__ __launch_bounds__(256) void atss_finalize_kernel(const float* __restr
         if (lab > 0) { fgf = 1.f; ctr_fg = ctr; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { fgf += __shfl_xor(fgf, o, 64); ctr_fg += __shfl_xor(ctr_fg, o, 64); }
-    if ((threadIdx.x & 63) == 0 && fgf > 0.f) { atomicAdd(stats, fgf); atomicAdd(stats + 1, ctr_fg); }
+    for (int o = 32; o > 0; o >>= 1) fgf += __shfl_xor(fgf, o, 64);
+    (void)ctr_fg;
+    if ((threadIdx.x & 63) == 0 && fgf > 0.f) atomicAdd(stats, fgf);          // (the centre-ness sum: ctr_sum_kernel, fixed order)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -534,6 +555,7 @@ extern "C" int bd_fcos_assign(const float* points, int P, const int32_t* lvl_sta
     (void)hipMemsetAsync(stats, 0, 2 * sizeof(float), st);
     hipLaunchKernelGGL(fcos_assign_kernel, dim3(cdiv(P, 256), N), dim3(256), 0, st, points, P, lv, radius > 0.f ? 1 : 0,
                        gt_boxes, num_gt, Gmax, labels, offsets, ctrness, stats);
+    hipLaunchKernelGGL(ctr_sum_kernel, dim3(1), dim3(1024), 0, st, (const int*)labels, (const float*)ctrness, (long long)N * P, stats);
     BD_CHECK_LAUNCH("bd_fcos_assign");
     return BD_OK;
 }
@@ -560,6 +582,7 @@ extern "C" int bd_atss_assign(const float* points, int P, const int32_t* lvl_sta
                        (unsigned long long*)ws);
     hipLaunchKernelGGL(atss_finalize_kernel, dim3(cdiv(P, 256), N), dim3(256), 0, st, points, P, gt_boxes, num_gt, Gmax,
                        (const unsigned long long*)ws, labels, offsets, ctrness, stats);
+    hipLaunchKernelGGL(ctr_sum_kernel, dim3(1), dim3(1024), 0, st, (const int*)labels, (const float*)ctrness, (long long)N * P, stats);
     BD_CHECK_LAUNCH("bd_atss_assign");
     return BD_OK;
 }

@@ -66,6 +66,33 @@ def test_training_step_is_bitwise_reproducible_full_size():
     assert abs(outs[0][0] - outs[1][0]) <= 1e-4 * abs(outs[0][0])
 
 
+def test_fcos_training_step_is_bitwise_reproducible_full_size():
+    """FCOS normalises its regression loss by the sum of centre-ness over the foreground points (models/det/fcos.py:139-144); that sum is
+    taken in a fixed order (ctr_sum_kernel), GroupNorm's statistics in two fixed-order stages: two runs give bit-identical gradients."""
+    from basedet_amd.configs import FCOSConfig
+    from basedet_amd.models import FCOS, params as P
+    from basedet_amd.utils import DummyLoader
+    cfg = FCOSConfig()
+    cfg.MODEL.BATCHSIZE = 2
+    params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.2)
+    params["head.bbox_pred.bias"] = np.full_like(params["head.bbox_pred.bias"], 0.5)
+    b = next(DummyLoader(2, (800, 1344), seed=0))
+    batch = {"data": torch.from_numpy(b["data"].astype(np.float32)).cuda(), "gt_boxes": torch.from_numpy(b["gt_boxes"]).cuda(),
+             "im_info": torch.from_numpy(b["im_info"]).cuda()}
+    outs = []
+    for _ in range(2):
+        model = FCOS(cfg, params=params)
+        model(batch)
+        model.backward()
+        torch.cuda.synchronize()
+        pl = model._cur
+        assert float(pl.stats[0]) > 0 and float(pl.stats[1]) > 0
+        outs.append((pl.stats.clone(), model.arena.g.clone(), pl.labels.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])          # num_fg and the centre-ness sum, bit for bit
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][1], outs[1][1])          # every gradient of the arena, bit for bit
+
+
 def test_anchor_grid_invariants_full_size():
     from basedet_amd import ops
     from oracle import box_ops
