@@ -9,6 +9,7 @@ import math
 
 import numpy as np
 import torch
+from contextlib import nullcontext as _nullcontext
 
 from .. import ops
 from ..utils.registry import registers
@@ -117,15 +118,23 @@ class RetinaNet(FPNDetector):
         pre = self.pre_process(inputs)
         pl = pre["plan"]
         self._cur = pl
-        self.network_forward(pl)
         m = self.cfg.MODEL
         gt = pre["gt_boxes"]
         num_gt = pre["img_info"][:, 4].to(torch.int32).contiguous()
         N, Gmax = gt.shape[0], gt.shape[1]
         ws = pl.wgrad_ws[: N * Gmax]
         thr = m.MATCHER.THRESHOLDS
-        ops.retina_assign_encode(pl.anchors, gt, num_gt, thr[0], thr[1], m.MATCHER.ALLOW_LOW_QUALITY, m.BOX_REG.MEAN,
-                                 m.BOX_REG.STD, pl.labels, pl.match_idx, pl.gt_offsets, pl.num_fg, ws)
+        # The target assignment depends on the anchors and the gt boxes only (retinanet.py:211-232), not on the network's output: its two
+        # launches (~0.12 ms at 16 x 201 600 anchors) run on a side stream under the forward pass instead of between forward and losses.
+        side = self._tstream if (self.async_wgrad and self._tstream is not None and m.get("ASSIGN_ON_SIDE_STREAM", True)) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side) if side is not None else _nullcontext():
+            ops.retina_assign_encode(pl.anchors, gt, num_gt, thr[0], thr[1], m.MATCHER.ALLOW_LOW_QUALITY, m.BOX_REG.MEAN,
+                                     m.BOX_REG.STD, pl.labels, pl.match_idx, pl.gt_offsets, pl.num_fg, ws)
+        self.network_forward(pl)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         pl.loss_buf.zero_()
         rows = N * pl.A_total
         ops.focal_loss_fwd_bwd(pl.logits, pl.labels, rows, self.num_classes, m.LOSSES.FOCAL_LOSS_ALPHA,
