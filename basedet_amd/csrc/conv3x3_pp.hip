@@ -16,7 +16,7 @@
 //     re-synchronise for that swap).
 // Used for Cout > 128 and Cin % 8 == 0 (heads incl. the 720- and 40-channel gradients, FPN outputs, res4/res5) when its grid fills the
 // chip; the rest stays on conv3x3.hip.
-#include "common.h"
+#include "conv3x3_pp128_body.h"
 
 namespace {
 
@@ -32,6 +32,7 @@ constexpr int NSLOT = 3;
 constexpr int W_BYTES = NSLOT * W_SLOT;        // 98304
 constexpr int LDS_BYTES = W_BYTES + X_BYTES + TILE_CO * 4;   // 161536
 constexpr int MAX_SEG = BD_MAX_SEGS;
+constexpr int TAIL_CO = 64;                   // channel tile of the tail workgroups
 
 struct PSeg { int patch_start, H, W, pw, src_off, dst_off; float inv_pw; };
 
@@ -46,6 +47,8 @@ struct PParams {
     int src_ppi, dst_ppi;
     unsigned src_bytes;
     int patches_per_img, total_patches, n_tiles;
+    int main_grid;           // workgroups [0, main_grid) run this kernel's 256-channel tiles over patches [0, total_patches); the rest of
+    int tail_end;            // the grid runs the 64-channel tile of conv3x3_pp128_body.h over patches [total_patches, tail_end)
     float inv_ppi;           // 1 / patches_per_img (the patch indices are < 2^24: exact quotients by a float multiply and one correction)
     PSeg seg[MAX_SEG];
 };
@@ -75,6 +78,11 @@ __device__ unsigned long long g_pp_stamp[8];
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= p.main_grid) {       // tail tiles of a grid of 256 k + r pixel tiles (see bd_conv3x3_pp_launch): 4 r short workgroups
+        pp128::body<MODE, TAIL_CO>(p, smem, (int)blockIdx.x - p.main_grid, (int)gridDim.x - p.main_grid, p.total_patches, p.tail_end,
+                                   (p.CO + TAIL_CO - 1) / TAIL_CO);
+        return;
+    }
     unsigned char* wbuf = smem;                                   // [3][W_SLOT]
     unsigned char* xbuf = smem + W_BYTES;                         // [X_BYTES]
     float* sbias = reinterpret_cast<float*>(smem + W_BYTES + X_BYTES);      // [256]
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     const int wm = wave >> 2, wp = wave & 3;          // channel half (= stagger group), patch
     int bid = blockIdx.x;
     {
-        const int nwg = gridDim.x;
+        const int nwg = p.main_grid;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
@@ -483,6 +491,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
 }  // namespace
 
 // 0 = launched, 1 = shape not handled here (caller falls back to conv3x3.hip)
+int g_pp_tail_split = 1;     // bd_conv_set_patch3x3 bit 13 clears it
 extern int g_patch_pp;       // 0 = never, 1 = where the makespan estimate favours it, 2 = wherever the shape allows (default)
 int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                          const void* mask, void* dst, int flags, hipStream_t stream) {
@@ -511,7 +520,28 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     p.total_patches = ps * d->N;
     if (p.total_patches >= (1 << 24)) return 1;
     p.n_tiles = cdiv(p.CO, TILE_CO);
-    const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
+    int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
+    // Tail split (round 3).  One workgroup per CU: a grid of 256 k + r tiles with a small r pays a whole extra round for r tiles (res4's
+    // 3x3 at 16 x 50x84: 312 tiles = 2 rounds, 56 CUs busy in the second).  The last r pixel tiles go to the 64- / 128-channel instance
+    // of conv3x3_pp128.hip instead (same accumulation order: the same bits): the LAST 4 r workgroups of this launch's grid run that body
+    // (~0.4 of a 256-channel tile's time each), one launch, and they start as soon as the first CUs come free.
+    int tail_wgs = 0;
+    p.main_grid = grid;
+    p.tail_end = p.total_patches;
+    static int num_cus = 0;
+    if (!num_cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            num_cus <= 0) num_cus = 256;
+    }
+    if (g_pp_tail_split && p.n_tiles == 1 && grid > num_cus) {
+        const int r = grid % num_cus;
+        if (r > 0 && r * (TILE_CO / TAIL_CO) <= num_cus) {
+            p.main_grid = grid - r;
+            p.total_patches = p.main_grid * NPATCH;
+            tail_wgs = cdiv(p.tail_end - p.total_patches, NPATCH) * cdiv(p.CO, TAIL_CO);
+        }
+    }
     {
         // A workgroup here does the work of two 128-channel workgroups of conv3x3.hip in ~1.5x their time, but small grids quantise
         // worse (one workgroup per CU, 256 CUs).  Mode 1 takes the instance with the shorter estimated makespan; the default takes
@@ -525,8 +555,8 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<0>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((conv3x3_pp_kernel<1>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<0>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((conv3x3_pp_kernel<1>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
     return 0;
 }
 

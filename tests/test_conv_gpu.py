@@ -492,3 +492,46 @@ def test_strided_dgrad_sparse_accumulate(R):
         pv, kv = poison.view(N, H, W, Cin), keep.view(N, H, W, Cin)
         assert torch.equal(pv[:, 1::2], kv[:, 1::2]) and torch.equal(pv[:, :, 1::2], kv[:, :, 1::2])
         assert torch.equal(pv[:, ::2, ::2], sparse.view(N, H, W, Cin)[:, ::2, ::2])
+
+
+@pytest.mark.parametrize("shape,knob", [((16, 50, 84, 256, 256), 3), ((15, 100, 168, 256, 256), 3), ((16, 50, 84, 192, 200), 3)])
+def test_pp_tail_split_same_bits(shape, knob):
+    """conv3x3_pp.hip runs the last (grid mod CUs) pixel tiles of a launch on the 64-channel tile, in the last workgroups of the same grid
+    (one workgroup per CU: a small remainder otherwise costs a whole round; res4's 3x3 at 16 x 50x84 = 312 tiles = 256 + 56; 15 x 100x168 =
+    1032 = 4 x 256 + 8 with a ragged last tile; 200 channels: a ragged last channel tile).  Same accumulation order: the split launch must
+    give the bits of the unsplit one, forward and data gradient, plain and fused epilogues."""
+    ops = _ops()
+    N, H, W, Cin, Cout = shape
+    gin = ops.single(N, H, W)
+    d = ops.conv_desc(gin, gin, Cin, Cout, 3, 3, 1, 1)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, 9, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    wt = (torch.randn(Cin, 9, Cout, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    res = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    gy = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    gate = torch.relu(torch.randn(gin.pixels, Cin, device="cuda", generator=g)).to(torch.bfloat16)
+    outs = []
+    for kb in (knob | 8192, knob):
+        ops.L().bd_conv_set_patch3x3(kb)
+        y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
+        y2 = torch.full_like(y, 3.0)
+        dx = torch.full((gin.pixels, Cin), 3.0, device="cuda", dtype=torch.bfloat16)
+        dx2 = torch.full_like(dx, 3.0)
+        ops.conv2d_fwd(d, x, w, b, y, add=res, flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE)
+        ops.conv2d_fwd(d, x, w, b, y2, flags=ops.EPI_RELU)
+        ops.conv2d_dgrad(d, gy, wt, dx, mask=gate, flags=ops.EPI_MASK)
+        ops.conv2d_dgrad(d, gy, wt, dx2)
+        torch.cuda.synchronize()
+        outs.append((y, y2, dx, dx2))
+    ops.L().bd_conv_set_patch3x3(3)
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+    # and against fp32 on a strip that lies in the tail tiles (the last image)
+    import torch.nn.functional as F
+    xi = x.view(N, H, W, Cin)[-1:].permute(0, 3, 1, 2).float()
+    wf = w.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).float()
+    ref = torch.relu(F.conv2d(xi, wf, b, padding=1)).permute(0, 2, 3, 1).reshape(-1, Cout)
+    got = outs[1][1].view(N, H * W, Cout)[-1].float()
+    assert float((got - ref).norm() / ref.norm()) < 1e-2
