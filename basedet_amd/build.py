@@ -90,7 +90,8 @@ def build(force=False, verbose=True):
 def build_driver(verbose=False):
     """tools/abi_driver.cpp: a C++ caller of the C ABI with no Python / torch in the process (links the in-tree library by rpath)."""
     src = os.path.join(HERE, "..", "tools", "abi_driver.cpp")
-    out = os.path.join(OUT_DIR, "abi_driver")
+    name = os.path.basename(LIB)
+    out = os.path.join(OUT_DIR, "abi_driver" if name == "libbasedet_hip.so" else "abi_driver." + name)      # (diagnostic builds keep their own)
     lib = build(force=False, verbose=verbose)
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
         return out

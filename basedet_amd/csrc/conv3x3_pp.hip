@@ -30,7 +30,9 @@ constexpr int TILE_CO = 256;
 constexpr int W_SLOT = TILE_CO * 128;          // 32768: one tap's 256 x 64 weight tile
 constexpr int NSLOT = 3;
 constexpr int W_BYTES = NSLOT * W_SLOT;        // 98304
-constexpr int LDS_BYTES = W_BYTES + X_BYTES + TILE_CO * 4;   // 161536
+constexpr int GTAB_TILES = 16;                 // patch geometry of this workgroup's next 16 tiles (8 ints per patch), rebuilt by wave 0
+constexpr int GTAB_BYTES = GTAB_TILES * NPATCH * 32;          // 2048
+constexpr int LDS_BYTES = W_BYTES + X_BYTES + TILE_CO * 4 + GTAB_BYTES;   // 163584 of 163840
 constexpr int MAX_SEG = BD_MAX_SEGS;
 constexpr int TAIL_CO = 64;                   // channel tile of the tail workgroups
 
@@ -47,8 +49,9 @@ struct PParams {
     int src_ppi, dst_ppi;
     unsigned src_bytes;
     int patches_per_img, total_patches, n_tiles;
-    int main_grid;           // workgroups [0, main_grid) run this kernel's 256-channel tiles over patches [0, total_patches); the rest of
-    int tail_end;            // the grid runs the 64-channel tile of conv3x3_pp128_body.h over patches [total_patches, tail_end)
+    int main_grid;           // workgroups [0, main_grid) are PERSISTENT: each runs the 256-channel tiles pt = b / n_tiles + k * (main_grid / n_tiles)
+    int px_tiles;            // (k = 0, 1, ...; pt < px_tiles) of channel tile b % n_tiles over patches [0, total_patches); the rest of the grid runs
+    int tail_end;            // the 64-channel tile of conv3x3_pp128_body.h over patches [total_patches, tail_end)
     float inv_ppi;           // 1 / patches_per_img (the patch indices are < 2^24: exact quotients by a float multiply and one correction)
     PSeg seg[MAX_SEG];
 };
@@ -70,7 +73,8 @@ __device__ __forceinline__ int colperm(int f) { return f < 4 ? 2 * f : (f < 12 ?
 __device__ __forceinline__ int xpos(int chunk) { return (chunk >> 2) * 64 + ((((chunk & 1) << 1) | ((chunk >> 1) & 1)) << 4); }
 
 #ifdef BD_PP_STAMP        // diagnostic build only (scripts/exp/pp_clock.py): in-kernel clock of workgroup 0 = d(s_memtime) / d(s_memrealtime) x 100 MHz
-__device__ unsigned long long g_pp_stamp[8];
+__device__ unsigned long long g_pp_stamp[64];
+__device__ unsigned long long g_pp_span[2048];      // [2 b], [2 b + 1]: s_memrealtime (100 MHz, chip-wide) at the start / end of workgroup b
 #endif
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
@@ -88,7 +92,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     float* sbias = reinterpret_cast<float*>(smem + W_BYTES + X_BYTES);      // [256]
 
 #ifdef BD_PP_STAMP
-    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    int st_n = 0;
+    const bool st_on = blockIdx.x == 100 % gridDim.x && threadIdx.x == 0;
+#define PP_STAMP() do { if (st_on && st_n < 62) g_pp_stamp[st_n] = __builtin_amdgcn_s_memtime(); ++st_n; } while (0)
+    PP_STAMP();                    // 0: kernel start
+    if (st_on) g_pp_stamp[62] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_pp_span[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PP_STAMP() do { } while (0)
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wp = wave & 3;          // channel half (= stagger group), patch
@@ -98,19 +109,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int pt = bid / p.n_tiles;          // (n_tiles is 1 .. 3: the compiler's division by a uniform value stays on the scalar path)
-    const int ct = bid - pt * p.n_tiles;
+    // Persistent workgroups (round 3): workgroup b keeps its channel tile (so its weight-DMA addresses and bias vector) and walks the pixel
+    // tiles b / n_tiles + k * pt_step.  The NEXT tile's patch decode, its first activation image and its first two weight taps are requested
+    // inside the current tile's last K block, exactly as a K-block swap would request them -- no extra registers -- and land under that
+    // block's MFMAs and the epilogue: the 9 400-cycle prologue (two memory round trips in front of the first MFMA, ~10 % of a tile) is paid
+    // once per workgroup instead of once per tile.
+    const int ct = bid % p.n_tiles;          // (n_tiles is 1 .. 3: the compiler's division by a uniform value stays on the scalar path)
+    int pt = bid / p.n_tiles;
+    const int pt_step = p.main_grid / p.n_tiles;
     const int co0 = ct * TILE_CO;
 
-    // ---- geometry of the four patches (workgroup-uniform) ----
-    // Lane k of every wave decodes patch k (the four decodes side by side instead of a four-times-longer serial chain in front of the
-    // first load), then the results are broadcast into scalar registers, where they live through the MFMA loop.
-    int py0[NPATCH], px0[NPATCH], pH[NPATCH], pWd[NPATCH];
-    int psrc[NPATCH], pdst[NPATCH];
-    {
-        const int pid = pt * NPATCH + (lane & (NPATCH - 1));
+    // ---- activation staging: chunk id c = tid + 512 k -> LDS row (tid >> 3) + 64 k, 16-byte chunk tid & 7 ----
+    // buffer loads: 32-bit per-lane byte offset + scalar K-block offset, and an offset past the end of the tensor (X_NONE) returns
+    // zeros: halo / out-of-image rows need no predication and no 64-bit per-lane addresses
+    constexpr unsigned X_NONE = 0x80000000u;          // >= num_records (the host checks that the tensor is < 2 GB)
+    const int x_lds0 = (tid >> 3) * X_PITCH + xpos(tid & 7);
+    unsigned x_off[XPASSES];
+
+    // ---- patch geometry ----
+    // The level search and the two divisions of a patch decode (~250 instructions over a 60-register level table) run ONCE per workgroup:
+    // wave 0 decodes the 64 patches of this workgroup's (at most 16: the host sizes the grid for that) tiles side by side, one per lane,
+    // into a table in LDS.  What a tile change costs inside the K loop is then two LDS reads, 24 lane reads and the seven staging offsets.
+    int* gtab = reinterpret_cast<int*>(smem + W_BYTES + X_BYTES + TILE_CO * 4);
+    const int pt_first = pt;
+    auto build_table = [&](int k0) {
+        const int k = k0 + (lane >> 2);
+        const int ptile = pt_first + k * pt_step;
+        const int pid = ptile * NPATCH + (lane & (NPATCH - 1));
         int vH = 0, vW = 0, vy = 0, vx = 0, vs = 0, vd = 0;
-        if (pid < p.total_patches) {
+        if (ptile < p.px_tiles && pid < p.total_patches) {
             const int n = pp_div(pid, p.patches_per_img, p.inv_ppi);
             const int rem = pid - n * p.patches_per_img;
             // level search as selects over the (scalar) level table: no per-lane table fetch
@@ -130,38 +157,59 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
             vs = n * p.src_ppi + g_src;
             vd = n * p.dst_ppi + g_dst;
         }
+        typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+        i32x4_t* e = reinterpret_cast<i32x4_t*>(gtab + ((k & (GTAB_TILES - 1)) * NPATCH + (lane & (NPATCH - 1))) * 8);
+        e[0] = (i32x4_t){vy, vx, vH, vW};
+        e[1] = (i32x4_t){vs, vd, 0, 0};
+    };
+    // tile k of this workgroup -> x_off[] and this wave's epilogue geometry
+    auto decode = [&](int k, int& e_oy0, int& e_px0, int& e_H, int& e_W, int& e_dst) {
+        int py0[NPATCH], px0[NPATCH], pH[NPATCH], pWd[NPATCH];
+        int psrc[NPATCH], pdst[NPATCH];
+        // (an opaque copy of the thread index: the per-thread row / column constants below are recomputed per tile -- ~40 instructions --
+        // instead of being hoisted out of the tile loop and kept, i.e. spilled, across the MFMA loop)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        {
+            typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+            const i32x4_t* e = reinterpret_cast<const i32x4_t*>(gtab + ((k & (GTAB_TILES - 1)) * NPATCH + (tq & (NPATCH - 1))) * 8);
+            const i32x4_t e0 = e[0], e1 = e[1];
 #pragma unroll
-        for (int k = 0; k < NPATCH; ++k) {
-            py0[k] = __builtin_amdgcn_readlane(vy, k); px0[k] = __builtin_amdgcn_readlane(vx, k);
-            pH[k] = __builtin_amdgcn_readlane(vH, k); pWd[k] = __builtin_amdgcn_readlane(vW, k);
-            psrc[k] = __builtin_amdgcn_readlane(vs, k); pdst[k] = __builtin_amdgcn_readlane(vd, k);
+            for (int q = 0; q < NPATCH; ++q) {
+                py0[q] = __builtin_amdgcn_readlane(e0[0], q); px0[q] = __builtin_amdgcn_readlane(e0[1], q);
+                pH[q] = __builtin_amdgcn_readlane(e0[2], q); pWd[q] = __builtin_amdgcn_readlane(e0[3], q);
+                psrc[q] = __builtin_amdgcn_readlane(e1[0], q); pdst[q] = __builtin_amdgcn_readlane(e1[1], q);
+            }
         }
-    }
-
-    // ---- activation staging: chunk id c = tid + 512 k -> LDS row (tid >> 3) + 64 k, 16-byte chunk tid & 7 ----
-    // buffer loads: 32-bit per-lane byte offset + scalar K-block offset, and an offset past the end of the tensor (X_NONE) returns
-    // zeros: halo / out-of-image rows need no predication and no 64-bit per-lane addresses
-    constexpr unsigned X_NONE = 0x80000000u;          // >= num_records (the host checks that the tensor is < 2 GB)
-    const int x_lds0 = (tid >> 3) * X_PITCH + xpos(tid & 7);
-    unsigned x_off[XPASSES];
 #pragma unroll
-    for (int k = 0; k < XPASSES; ++k) {
-        const int row = (tid >> 3) + 64 * k;
-        unsigned off = X_NONE;
-        if (row < XROWS) {
-            // the 64 rows of pass k straddle at most two patches, both known at compile time: selects between scalar registers
-            const int lo = (64 * k) / (IH * IW), hi = (64 * k + 63) / (IH * IW) < NPATCH ? (64 * k + 63) / (IH * IW) : NPATCH - 1;
-            const bool up = row >= hi * (IH * IW);
-            const int pk = up ? hi : lo;
-            const int rr = row - pk * (IH * IW);
-            const int iy = rr / IW, ix = rr - iy * IW;
-            const int qy = up ? py0[hi] : py0[lo], qx = up ? px0[hi] : px0[lo], H = up ? pH[hi] : pH[lo];
-            const int W = up ? pWd[hi] : pWd[lo], qs = up ? psrc[hi] : psrc[lo];
-            const int y = qy - 1 + iy, x = qx - 1 + ix;
-            if (y >= 0 && x >= 0 && y < H && x < W) off = (unsigned)((qs + y * W + x) * p.CK + (tid & 7) * 8) * 2u;
+        for (int k = 0; k < XPASSES; ++k) {
+            const int row = (tq >> 3) + 64 * k;
+            unsigned off = X_NONE;
+            if (row < XROWS) {
+                // the 64 rows of pass k straddle at most two patches, both known at compile time: selects between scalar registers
+                const int lo = (64 * k) / (IH * IW), hi = (64 * k + 63) / (IH * IW) < NPATCH ? (64 * k + 63) / (IH * IW) : NPATCH - 1;
+                const bool up = row >= hi * (IH * IW);
+                const int pk = up ? hi : lo;
+                const int rr = row - pk * (IH * IW);
+                const int iy = rr / IW, ix = rr - iy * IW;
+                const int qy = up ? py0[hi] : py0[lo], qx = up ? px0[hi] : px0[lo], H = up ? pH[hi] : pH[lo];
+                const int W = up ? pWd[hi] : pWd[lo], qs = up ? psrc[hi] : psrc[lo];
+                const int y = qy - 1 + iy, x = qx - 1 + ix;
+                if (y >= 0 && x >= 0 && y < H && x < W) off = (unsigned)((qs + y * W + x) * p.CK + (tq & 7) * 8) * 2u;
+            }
+            x_off[k] = off;
         }
-        x_off[k] = off;
-    }
+        e_oy0 = py0[0]; e_px0 = px0[0]; e_H = pH[0]; e_W = pWd[0]; e_dst = pdst[0];
+#pragma unroll
+        for (int q = 1; q < NPATCH; ++q)
+            if (wp == q) { e_oy0 = py0[q]; e_px0 = px0[q]; e_H = pH[q]; e_W = pWd[q]; e_dst = pdst[q]; }
+    };
+    int c_oy0, c_px0, c_H, c_W, c_dst;          // this wave's patch of the tile in flight (wave-uniform)
+    int kt = 0;                                 // index of that tile in this workgroup's sequence
+    if (wave == 0) build_table(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    decode(0, c_oy0, c_px0, c_H, c_W, c_dst);
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.src), 0, p.src_bytes, 0x00020000);
     u32x4_t rx[XPASSES];
@@ -206,10 +254,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     };
 
     f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment addressing ----
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -249,26 +293,42 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
 
     const int kblocks = (p.CK + 63) >> 6;
 
-#ifdef BD_PP_STAMP
-    const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- prologue: activation image of K block 0, taps 0 and 1 ----
+    PP_STAMP();                    // 1: first decode done
+    // ---- prologue: activation image of K block 0, taps 0, 1 and 2 (the whole ring) ----
     if (tid < TILE_CO) sbias[tid] = (p.bias && co0 + tid < p.CO) ? p.bias[co0 + tid] : 0.f;
     load_x(0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) dma_piece(0, 0, 0, k);
 #pragma unroll
     for (int k = 0; k < 4; ++k) dma_piece(1, 0, 1, k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_piece(2, 0, 2, k);
     write_x();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     PP_BARRIER();
     PP_FENCE();
 
-#ifdef BD_PP_STAMP
-    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    PP_STAMP();                    // 2: prologue done = K loop of tile 0 starts; then per tile: last K block (+ decode) starts, K loop done, epilogue issued, next K loop starts
+    // Every tile enters its K loop with taps 0 and 1 of K block 0 complete in the ring and tap 2 requested (the prologue; for a following
+    // tile: tap 1 is completed in phase (8, 1) of the previous tile's K loop and awaited in front of that tile's first store, tap 2 -- its
+    // slot is tap 8's -- is requested at the head of the epilogue): phase (0, 1) awaits nothing, and the first counted wait, in phase (1, 1),
+    // comes ~3 500 cycles after the epilogue's stores.  Loads and stores share one vmcnt: a counted wait for a load that is younger than the
+    // stores waits for the stores' acknowledgements too, with the matrix pipe idle.
+    for (;;) {
+    const int pt_next = pt + pt_step;
+    const bool more = pt_next < p.px_tiles;
+    int n_oy0 = 0, n_px0 = 0, n_H = 0, n_W = 0, n_dst = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     for (int cb = 0; cb < kblocks; ++cb) {
         const bool last_kb = cb + 1 == kblocks;
+        const bool cont = !last_kb || more;        // something follows this K block: the next one, or the first one of the next tile
+        const int nb = last_kb ? 0 : cb + 1;       // its K block index
+        // the next tile's patches: x_off[] was last read by the loads of THIS K block (issued in the previous one / the prologue)
+        if (last_kb) PP_STAMP();
+        if (last_kb && more) decode(kt + 1, n_oy0, n_px0, n_H, n_W, n_dst);
         if (wm == 1) PP_BARRIER();                 // stagger: the second channel half runs one barrier behind
         PP_FENCE();
 #pragma unroll
@@ -287,9 +347,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 PP_FENCE();
                 if (kk == 1) {
                     // retire the pieces of tap t+1 (the last of them was issued in phase (t, 0)); piece 0 of tap t+2 stays in flight
-                    if (last_kb && t >= 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                    if (t == 6 && !last_kb) load_x(cb + 1);        // consumed by the swap after tap 8
+                    if (!cont && t >= 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (t >= 1 || cb > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    if (t == 6) {
+                        if (cont) load_x(nb);                      // consumed by the swap after tap 8
+                        else {                                     // (nothing follows: tell the allocator that the staging registers hold nothing
+#pragma unroll
+                            for (int k = 0; k < XPASSES; ++k) asm volatile("" : "=v"(rx[k]));      // from here on -- no instruction)
+                        }
+                    }
                     PP_FENCE();
                 }
                 // weight DMA, two pieces per phase: (t, 0) issues the last piece of tap t+1 and the first of tap t+2, (t, 1) pieces 1 and 2 of
@@ -297,16 +363,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 // group's (t, 0) -- by the other group, whose reads were issued before that barrier and return within ~100 cycles; the DMA
                 // data needs a memory round trip to arrive
                 if (kk == 0) {
-                    if (t + 1 < 9) { if (t > 0 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
-                    else if (!last_kb) dma_piece(0, cb + 1, 0, 3);
-                    if (t + 2 < 9) dma_piece(t + 2, cb, (t + 2) % 3, 0);
-                    else if (!last_kb) dma_piece(t - 7, cb + 1, (t + 2) % 3, 0);
+                    if (t + 1 < 9) { if (t > 1 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
+                    else if (cont) dma_piece(0, nb, 0, 3);
+                    if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, 0); }
+                    else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, 0);
                 } else {
 #pragma unroll
                     for (int pc = 1; pc < 3; ++pc) {
-                        if (t + 2 < 9) dma_piece(t + 2, cb, (t + 2) % 3, pc);
-                        else if (!last_kb) dma_piece(t - 7, cb + 1, (t + 2) % 3, pc);
+                        if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, pc); }
+                        else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, pc);
                     }
+                    if (t == 8 && last_kb && more) dma_piece(1, 0, 1, 3);      // the next tile's tap 1 complete: see the head of the tile loop
                 }
                 PP_FENCE();
                 PP_BARRIER();
@@ -323,30 +390,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
         }
         if (wm == 0) PP_BARRIER();                 // un-stagger: every wave has passed the same number of barriers, all reads retired
         PP_FENCE();
-        if (!last_kb) {
+        if (cont) {
             write_x();
+            // (last K block: this publishes the NEXT tile's image, in front of this tile's epilogue, where the waves are still in step --
+            // behind the epilogue every wave would wait here for the slowest one's stores to issue; now a wave that is done walks into the
+            // next tile's first load segment and meets the others at that phase's barrier)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BARRIER();
             PP_FENCE();
         }
     }
 
-#ifdef BD_PP_STAMP
-    const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();
-    if (blockIdx.x == 300 % gridDim.x && tid == 0) { g_pp_stamp[0] = st_t2 - st_c0; g_pp_stamp[1] = __builtin_amdgcn_s_memrealtime() - st_r0; g_pp_stamp[2] = st_c0 - st_t0; g_pp_stamp[5] = st_t1 - st_t0; }
-#endif
+    PP_STAMP();                    // K loop done
     // ---- epilogue ----
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the inline-asm MFMAs are opaque to the hazard recogniser: let the last ones retire
-    const int cg = lane >> 4;
+    int lq = lane;                            // (opaque copy: the epilogue's per-lane constants are not kept across the MFMA loop)
+    asm volatile("" : "+v"(lq));
+    const int cg = lq >> 4, erow = lq & 15;
     const bool do_relu = p.flags & BD_EPI_RELU;
     const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
     const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
     const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
     const int cbase = co0 + wm * 128 + 8 * cg;          // + 32 h
-    int oy0 = py0[0], ox = px0[0] + colperm(frow), H = pH[0], W = pWd[0], dbase = pdst[0];
-#pragma unroll
-    for (int q = 1; q < NPATCH; ++q)
-        if (wp == q) { oy0 = py0[q]; ox = px0[q] + colperm(frow); H = pH[q]; W = pWd[q]; dbase = pdst[q]; }
+    const int oy0 = c_oy0, ox = c_px0 + colperm(erow), H = c_H, W = c_W, dbase = c_dst;
     // Fast paths (no residual operand): the epilogue of a one-workgroup-per-CU kernel is pure issue time -- the general loop below, with
     // its run-time flag branches, 64-bit index arithmetic and per-element selects, took 8 100 cycles per tile (stamped), a sixth of the
     // 256-channel head launch's K loop.  Here: one address per patch row, packed adds / converts, ReLU and the gate as packed 16-bit
@@ -382,40 +448,74 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 if (do_mask && okh && okj[j]) mv[h][j] = *reinterpret_cast<const u32x4_t*>(mrow[j] + 32 * h);
             }
         }
+        PP_FENCE();
+        if (more) {            // the next tile's tap 2 (its slot was tap 8's): the four youngest requests in front of the first store
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dma_piece(2, 0, 2, k);
+        }
+        PP_FENCE();
+        auto unit = [&](int h, int j, const f32x4_t b0, const f32x4_t b1) {
+            u32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4_t a = acc[2 * h + (k >> 1)][j];
+                const f32x4_t bb = (k >> 1) ? b1 : b0;
+                f32x2_e v = {a[2 * (k & 1)], a[2 * (k & 1) + 1]};
+                v += (f32x2_e){bb[2 * (k & 1)], bb[2 * (k & 1) + 1]};
+                i16x2_e w = __builtin_bit_cast(i16x2_e, __builtin_convertvector(v, bf16x2_e));
+                if (do_mask) {          // keep where the stored activation is > 0: sat(0 - m) >> 15 is all ones exactly for m > 0 (-0.0 = 0x8000 saturates to 32767)
+                    // (written as the two packed instructions: the vector-builtin form of this gate was compiled into selects that
+                    // read the first mask register for every k -- caught by test_patch_instances_agree_bitwise; op_sel_hi:[0,1]: both halves shift
+                    // by the low half of the inline constant, whose high half is 0)
+                    unsigned gate;
+                    asm("v_pk_sub_i16 %0, 0, %1 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(gate) : "v"(mv[h][j][k]));
+                    w &= __builtin_bit_cast(i16x2_e, gate);
+                }
+                w = __builtin_elementwise_max(w, relu_floor);
+                o[k] = __builtin_bit_cast(unsigned, w);
+            }
+            return o;
+        };
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const bool okh = cbase + 32 * h < p.CO;
             const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h);
             const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sbias + wm * 128 + 8 * cg + 32 * h + 4);
+            if (h == 0) {
+                // the first channel group is converted BEFORE the wait that precedes the first store: everything requested before the next
+                // tile's tap 2 -- the gates, that tile's tap 1 and activation image -- must have landed before a store is in flight (loads
+                // return in order: with no store outstanding the count is exact)
+                u32x4_t o0[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32x4_t o;
+                for (int j = 0; j < 4; ++j) o0[j] = unit(0, j, b0, b1);
+                PP_FENCE();
+                PP_STAMP();            // first channel group converted
+                if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PP_STAMP();            // ... and everything older than the next tile's tap 2 has landed
+                PP_FENCE();
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x4_t a = acc[2 * h + (k >> 1)][j];
-                    const f32x4_t bb = (k >> 1) ? b1 : b0;
-                    f32x2_e v = {a[2 * (k & 1)], a[2 * (k & 1) + 1]};
-                    v += (f32x2_e){bb[2 * (k & 1)], bb[2 * (k & 1) + 1]};
-                    i16x2_e w = __builtin_bit_cast(i16x2_e, __builtin_convertvector(v, bf16x2_e));
-                    if (do_mask) {          // keep where the stored activation is > 0: sat(0 - m) >> 15 is all ones exactly for m > 0 (-0.0 = 0x8000 saturates to 32767)
-                        // (written as the two packed instructions: the vector-builtin form of this gate was compiled into selects that
-                        // read the first mask register for every k -- caught by test_patch_instances_agree_bitwise; op_sel_hi:[0,1]: both halves shift
-                        // by the low half of the inline constant, whose high half is 0)
-                        unsigned gate;
-                        asm("v_pk_sub_i16 %0, 0, %1 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(gate) : "v"(mv[h][j][k]));
-                        w &= __builtin_bit_cast(i16x2_e, gate);
-                    }
-                    w = __builtin_elementwise_max(w, relu_floor);
-                    o[k] = __builtin_bit_cast(unsigned, w);
+                for (int j = 0; j < 4; ++j)
+                    if (okh && okj[j]) *reinterpret_cast<u32x4_t*>(drow[j]) = o0[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4_t o = unit(h, j, b0, b1);
+                    if (okh && okj[j]) *reinterpret_cast<u32x4_t*>(drow[j] + 32 * h) = o;
                 }
-                if (okh && okj[j]) *reinterpret_cast<u32x4_t*>(drow[j] + 32 * h) = o;
             }
         }
-        return;
-    }
+    } else {
     // General path (a residual / accumulate operand): the operands of TWO channel groups (eight 16-byte units: up to 64 VGPRs of residuals +
     // gates) are requested together, then consumed and stored -- two round trips per tile instead of one per unit (the plain loop compiled to
     // load -> s_waitcnt vmcnt(0) -> use -> store for each of the 16 units, each wait also covering the previous unit's store).
+    if (more) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dma_piece(2, 0, 2, k);
+    }
+    long long erow_off[4];          // element offset of this lane's 8-channel group in patch row j (+ 32 h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) erow_off[j] = (long long)(dbase + (oy0 + j) * W + ox) * p.CO + cbase;
 #pragma unroll
     for (int hp = 0; hp < 2; ++hp) {
         u32x4_t av[2][4], mv[2][4];
@@ -426,12 +526,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int oy = oy0 + j;
                 const bool ok = cbase + 32 * h < p.CO && oy < H && ox < W;
-                const long long idx = (long long)(dbase + oy * W + ox) * p.CO + cbase + 32 * h;
+                const long long idx = erow_off[j] + 32 * h;
                 av[hh][j] = (u32x4_t){0u, 0u, 0u, 0u}; mv[hh][j] = (u32x4_t){0u, 0u, 0u, 0u};
                 if (ok && (add_before || add_after)) av[hh][j] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
                 if (ok && do_mask) mv[hh][j] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
             }
         }
+        if (hp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (before the first store: see the fast path)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int h = 2 * hp + hh;
@@ -447,7 +548,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int oy = oy0 + j;
                 if (oy >= H || ox >= W) continue;
-                const long long idx = (long long)(dbase + oy * W + ox) * p.CO + cbase + 32 * h;
+                const long long idx = erow_off[j] + 32 * h;
                 float v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = acc[2 * h + (k >> 2)][j][k & 3] + bias[k];
@@ -478,13 +579,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
             }
         }
     }
-#ifdef BD_PP_STAMP
-    {
-        const unsigned long long st_t3 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long st_t4 = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 300 % gridDim.x && tid == 0) { g_pp_stamp[3] = st_t3 - st_t2; g_pp_stamp[4] = st_t4 - st_t3; }
     }
+    PP_STAMP();                    // epilogue issued
+    // ---- next tile: its image and first two taps are in LDS (written above / by DMA), its first loads were retired in the K loop ----
+    if (!more) break;
+    ++kt;
+    pt = pt_next;
+    c_oy0 = n_oy0; c_px0 = n_px0; c_H = n_H; c_W = n_W; c_dst = n_dst;
+    PP_FENCE();
+    PP_STAMP();                    // next K loop starts
+    }
+#ifdef BD_PP_STAMP
+    if (st_on) { g_pp_stamp[63] = __builtin_amdgcn_s_memrealtime(); g_pp_stamp[61] = __builtin_amdgcn_s_memtime(); }
+    if (threadIdx.x == 0 && blockIdx.x < 1024) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_pp_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 }
 
@@ -492,6 +599,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
 
 // 0 = launched, 1 = shape not handled here (caller falls back to conv3x3.hip)
 int g_pp_tail_split = 1;     // bd_conv_set_patch3x3 bit 13 clears it
+int g_pp_persistent = 1;     // bit 14 clears it: one workgroup per tile
 extern int g_patch_pp;       // 0 = never, 1 = where the makespan estimate favours it, 2 = wherever the shape allows (default)
 int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                          const void* mask, void* dst, int flags, hipStream_t stream) {
@@ -526,7 +634,7 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     // of conv3x3_pp128.hip instead (same accumulation order: the same bits): the LAST 4 r workgroups of this launch's grid run that body
     // (~0.4 of a 256-channel tile's time each), one launch, and they start as soon as the first CUs come free.
     int tail_wgs = 0;
-    p.main_grid = grid;
+    int px_tiles = cdiv(p.total_patches, NPATCH);
     p.tail_end = p.total_patches;
     static int num_cus = 0;
     if (!num_cus) {
@@ -534,13 +642,22 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             num_cus <= 0) num_cus = 256;
     }
-    if (g_pp_tail_split && p.n_tiles == 1 && grid > num_cus) {
-        const int r = grid % num_cus;
+    if (g_pp_tail_split && p.n_tiles == 1 && px_tiles > num_cus) {
+        const int r = px_tiles % num_cus;
         if (r > 0 && r * (TILE_CO / TAIL_CO) <= num_cus) {
-            p.main_grid = grid - r;
-            p.total_patches = p.main_grid * NPATCH;
+            px_tiles -= r;
+            p.total_patches = px_tiles * NPATCH;
             tail_wgs = cdiv(p.tail_end - p.total_patches, NPATCH) * cdiv(p.CO, TAIL_CO);
         }
+    }
+    // persistent workgroups: one per CU (a multiple of the channel tiles, so that a workgroup keeps its channel tile), fewer if the tiles run out
+    p.px_tiles = px_tiles;
+    // ... and at most GTAB_TILES tiles per workgroup (the kernel's geometry table): larger launches get a whole multiple of that grid
+    p.main_grid = px_tiles * p.n_tiles;
+    if (g_pp_persistent) {
+        const int g1 = (num_cus / p.n_tiles) * p.n_tiles;
+        const int rounds = cdiv(px_tiles * p.n_tiles, g1 * GTAB_TILES);
+        if (g1 * rounds < p.main_grid) p.main_grid = g1 * rounds;
     }
     {
         // A workgroup here does the work of two 128-channel workgroups of conv3x3.hip in ~1.5x their time, but small grids quantise
@@ -562,6 +679,9 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
 
 #ifdef BD_PP_STAMP
 extern "C" int bd_debug_pp_stamp(unsigned long long* out2) {
-    return hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_pp_stamp), 64) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_pp_stamp), 512) == hipSuccess ? 0 : 1;
+}
+extern "C" int bd_debug_pp_span(unsigned long long* out2048) {
+    return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_pp_span), 2048 * 8) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -460,6 +460,7 @@ extern int g_patch_pp;
 extern int g_patch_pp128;
 extern int g_conv1x1_s2;
 extern int g_pp_tail_split;
+extern int g_pp_persistent;
 extern "C" int bd_conv_set_patch3x3(int enable) {
     g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1;
     g_patch_dma = ((enable >> 3) & 1) ^ 1;
@@ -470,6 +471,7 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_igemm_buf = ((enable >> 11) & 1) ^ 1;
     g_conv1x1_s2 = ((enable >> 12) & 1) ^ 1;
     g_pp_tail_split = ((enable >> 13) & 1) ^ 1;
+    g_pp_persistent = ((enable >> 14) & 1) ^ 1;
     return BD_OK;
 }
 
