@@ -43,15 +43,35 @@ __device__ __forceinline__ void focal_elem(float x, bool t, float alpha, float g
 // gamma == 2 (the configured value, retinanet_cfg.py:30): with z = x for a negative target and -x for the positive one, q = sigmoid(z)
 // is the probability of the WRONG answer and  ce = log(1 + e^-|x|) + max(z, 0),  loss = a * ce * q^2,
 // d loss / dx = s * a * q^2 * (q + 2 ce (1 - q))  (s = +1 / -1, a = 1 - alpha / alpha): ~15 vector instructions + exp, log, rcp.
+// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp): `__expf`, `__logf` and `__frcp_rn` compiled to their denormal-safe and
+// correctly rounded forms -- range scaling with compares, selects and ldexp around exp / log, the ten-instruction IEEE division sequence for
+// the reciprocal -- ~60 vector instructions per logit for a result that is rounded to bf16 (gradient) or summed over 2.6e8 terms (loss).
+// The arguments here are harmless: e^-|x| underflows to 0 for |x| > 87 (q = 0 or 1, ce = max(z, 0): the right limits), 1 <= 1 + e <= 2.
 __device__ __forceinline__ void focal_g2(float x, float z, float a_signed, float a_abs, float& loss, float& grad) {
-    const float e = __expf(-fabsf(x));
+    const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.4426950408889634f);
     const float t1 = 1.f + e;
-    const float inv = __frcp_rn(t1);
+    const float inv = __builtin_amdgcn_rcpf(t1);
     const float q = z >= 0.f ? inv : e * inv;
-    const float ce = __logf(t1) + fmaxf(z, 0.f);
+    const float ce = __builtin_amdgcn_logf(t1) * 0.6931471805599453f + fmaxf(z, 0.f);
     const float q2 = q * q;
     loss = a_abs * ce * q2;
     grad = a_signed * q2 * (q + 2.f * ce * (1.f - q));
+}
+
+// two negatives at once (z = x, a_signed = a_abs = a): the arithmetic around the six transcendentals as packed fp32 instructions
+typedef __attribute__((ext_vector_type(2))) float f32x2_l;
+__device__ __forceinline__ void focal_g2_neg2(float x0, float x1, float a, f32x2_l& loss, f32x2_l& grad) {
+    const f32x2_l e = {__builtin_amdgcn_exp2f(-fabsf(x0) * 1.4426950408889634f), __builtin_amdgcn_exp2f(-fabsf(x1) * 1.4426950408889634f)};
+    const f32x2_l t1 = e + 1.f;
+    const f32x2_l inv = {__builtin_amdgcn_rcpf(t1[0]), __builtin_amdgcn_rcpf(t1[1])};
+    const f32x2_l einv = e * inv;
+    const f32x2_l q = {x0 >= 0.f ? inv[0] : einv[0], x1 >= 0.f ? inv[1] : einv[1]};
+    const f32x2_l l2 = {__builtin_amdgcn_logf(t1[0]), __builtin_amdgcn_logf(t1[1])};
+    const f32x2_l mz = {fmaxf(x0, 0.f), fmaxf(x1, 0.f)};
+    const f32x2_l ce = l2 * 0.6931471805599453f + mz;
+    const f32x2_l aq2 = q * q * a;
+    loss = aq2 * ce;
+    grad = aq2 * ((ce + ce) * (1.f - q) + q);
 }
 
 // The 8 logits of a vector are treated as negatives; the (at most one) positive among them is recomputed in a rare branch.
@@ -92,13 +112,15 @@ __global__ __launch_bounds__(256) void focal_g2_kernel(const bf16_raw* __restric
             u32x4_t o = {0u, 0u, 0u, 0u};
             if (lab[u] >= 0) {
                 float g[8];
+                f32x2_l lsum = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float l0, l1;
-                    focal_g2(bf_lo(v[u][k]), bf_lo(v[u][k]), a_neg, a_neg, l0, g[2 * k]);
-                    focal_g2(bf_hi(v[u][k]), bf_hi(v[u][k]), a_neg, a_neg, l1, g[2 * k + 1]);
-                    acc += l0 + l1;
+                    f32x2_l l2, g2;
+                    focal_g2_neg2(bf_lo(v[u][k]), bf_hi(v[u][k]), a_neg, l2, g2);
+                    g[2 * k] = g2[0]; g[2 * k + 1] = g2[1];
+                    lsum += l2;
                 }
+                acc += lsum[0] + lsum[1];
                 const int pos = lab[u] - 1 - c0[u];
                 if (pos >= 0 && pos < 8) {                      // this vector holds the row's positive class: redo that one element
                     const unsigned w = v[u][pos >> 1];
