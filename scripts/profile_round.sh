@@ -22,10 +22,10 @@ done
 python3 bench.py --workload faster_rcnn_r50_800x1344 --roi-bwd-pk --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('faster_rcnn pk', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 python3 bench.py --workload retinanet_r101_800x1344 --fp8 --steps 20 --warmup 5 --no-cpu-baseline --ref-protocol-steps 0 > $O/r03_bench_r101_fp8.json 2>/dev/null
 python3 bench.py --workload retinanet_r101_800x1344 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline --ref-protocol-steps 0 > $O/r03_bench_r101_bf16_b32.json 2>/dev/null
-for a in "--batch 16" "--batch 32" "--batch 16 --fp8" "--batch 32 --fp8" "--batch 32 --fp8 --model-opt FP8_DGRAD=0" "--batch 16 --model-opt FUSE_FROZEN_BLOCKS=0"; do
+for a in "--batch 16" "--batch 32" "--batch 16 --fp8" "--batch 32 --fp8" "--batch 32 --fp8 --model-opt FP8_DGRAD=0" "--batch 16 --model-opt FUSE_FROZEN_BLOCKS=0" "--batch 16 --conv-knob 24579" "--batch 16"; do
   python3 bench.py $a --steps 30 --warmup 8 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r50 $a', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 done
-for a in "--batch 32 --fp8 --model-opt FP8_DGRAD=0" "--batch 32 --fp8 --model-opt FP8_SCALE_GROUPS=global" "--batch 16"; do
+for a in "--batch 32 --fp8 --model-opt FP8_DGRAD=0" "--batch 32 --fp8 --model-opt FP8_SCALE_GROUPS=global" "--batch 16" "--batch 16 --conv-knob 24579"; do
   python3 bench.py --workload retinanet_r101_800x1344 $a --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r101 $a', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 done
 BD_FORCE_ALLREDUCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>$O/torchrun.err | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('torchrun world1 forced allreduce', d['value'], d['ms_per_step'])" >> $O/workloads.txt
