@@ -131,7 +131,9 @@ int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const void* g, co
  * with BD_EPI_SPARSE) stay on the generic kernel instead of the dense 1x1 kernel with strided rows;
  * bit 13 = no tail split in conv3x3_pp.hip (by default a launch of 256 k + r pixel tiles with 0 < r <= CUs / 4 runs its last r tiles on
  * the 64-channel tile of conv3x3_pp128_body.h, in 4 r short workgroups at the end of the same grid, instead of paying a whole round of
- * 256-channel workgroups for r tiles; same bits). */
+ * 256-channel workgroups for r tiles; same bits);
+ * bit 14 = one workgroup per tile in conv3x3_pp.hip instead of the persistent grid (by default one workgroup per CU walks up to 16 tiles
+ * and requests the next tile's operands inside the current tile's last K block; same bits). */
 int bd_conv_set_patch3x3(int enable);
 
 /* debug/measurement knob: 1 (default) = operand transposes through ds_read_b64_tr_b16, 0 = scalar 16-bit LDS reads

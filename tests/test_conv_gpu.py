@@ -494,12 +494,15 @@ def test_strided_dgrad_sparse_accumulate(R):
         assert torch.equal(pv[:, ::2, ::2], sparse.view(N, H, W, Cin)[:, ::2, ::2])
 
 
-@pytest.mark.parametrize("shape,knob", [((16, 50, 84, 256, 256), 3), ((15, 100, 168, 256, 256), 3), ((16, 50, 84, 192, 200), 3)])
+@pytest.mark.parametrize("shape,knob", [((16, 50, 84, 256, 256), 3), ((15, 100, 168, 256, 256), 3), ((16, 50, 84, 192, 200), 3),
+                                        ((16, 200, 336, 64, 256), 3), ((3, 100, 168, 64, 720), 3)])
 def test_pp_tail_split_same_bits(shape, knob):
     """conv3x3_pp.hip runs the last (grid mod CUs) pixel tiles of a launch on the 64-channel tile, in the last workgroups of the same grid
     (one workgroup per CU: a small remainder otherwise costs a whole round; res4's 3x3 at 16 x 50x84 = 312 tiles = 256 + 56; 15 x 100x168 =
-    1032 = 4 x 256 + 8 with a ragged last tile; 200 channels: a ragged last channel tile).  Same accumulation order: the split launch must
-    give the bits of the unsplit one, forward and data gradient, plain and fused epilogues."""
+    1032 = 4 x 256 + 8 with a ragged last tile; 200 channels: a ragged last channel tile), and the main tiles by PERSISTENT workgroups that
+    walk up to 16 tiles each (16 x 200x336: 4 200 tiles = two workgroups per CU; 720 channels: three channel tiles, 255 workgroups).
+    Same accumulation order: the launch must give the bits of the one-workgroup-per-tile, unsplit form (knob bits 13 + 14), forward and
+    data gradient, plain and fused epilogues."""
     ops = _ops()
     N, H, W, Cin, Cout = shape
     gin = ops.single(N, H, W)
@@ -513,7 +516,7 @@ def test_pp_tail_split_same_bits(shape, knob):
     gy = torch.randn(gin.pixels, Cout, device="cuda", generator=g).to(torch.bfloat16)
     gate = torch.relu(torch.randn(gin.pixels, Cin, device="cuda", generator=g)).to(torch.bfloat16)
     outs = []
-    for kb in (knob | 8192, knob):
+    for kb in (knob | 8192 | 16384, knob):
         ops.L().bd_conv_set_patch3x3(kb)
         y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
         y2 = torch.full_like(y, 3.0)
