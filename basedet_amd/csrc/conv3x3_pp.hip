@@ -13,7 +13,10 @@
 //     wave is in its MFMA segment while its partner is in its load segment: the matrix pipe never waits for LDS;
 //   * weights: ring of three 32 KB tap slots filled by LDS-DMA two taps ahead (counted vmcnt, raw s_barrier: the pieces stay
 //     in flight across barriers); activations: one padded image, re-staged through registers once per K block (the groups
-//     re-synchronise for that swap).
+//     re-synchronise for that swap);
+//   * round 3: the grid is one PERSISTENT workgroup per CU walking up to 16 tiles (the next tile's image, first weight taps and patch
+//     decode are requested inside the current tile's last K block), and the last r tiles of a 256 k + r grid run as 4 r workgroups of
+//     the 64-channel tile (conv3x3_pp128_body.h) at the end of the same launch.
 // Used for Cout > 128 and Cin % 8 == 0 (heads incl. the 720- and 40-channel gradients, FPN outputs, res4/res5) when its grid fills the
 // chip; the rest stays on conv3x3.hip.
 #include "conv3x3_pp128_body.h"
