@@ -538,3 +538,36 @@ def test_pp_tail_split_same_bits(shape, knob):
     ref = torch.relu(F.conv2d(xi, wf, b, padding=1)).permute(0, 2, 3, 1).reshape(-1, Cout)
     got = outs[1][1].view(N, H * W, Cout)[-1].float()
     assert float((got - ref).norm() / ref.norm()) < 1e-2
+
+
+def test_pp_persistent_launches_on_two_streams_same_bits():
+    """Two streams launch the persistent 3x3 kernel (one workgroup per CU each, 161 KB of LDS: they cannot share a CU) against each other, with
+    different shapes, twenty times: every result equals the single-stream one (no state outside a workgroup; the tail workgroups of one
+    launch and the persistent ones of the other interleave on the CUs)."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(23)
+    cases = []
+    for (N, H, W, Cin, Cout) in [(16, 50, 84, 256, 256), (6, 100, 168, 256, 256)]:
+        gin = ops.single(N, H, W)
+        d = ops.conv_desc(gin, gin, Cin, Cout, 3, 3, 1, 1)
+        x = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(Cout, 9, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn(Cout, device="cuda", generator=g)
+        ref = torch.empty((gin.pixels, Cout), device="cuda", dtype=torch.bfloat16)
+        ops.conv2d_fwd(d, x, w, b, ref, flags=ops.EPI_RELU)
+        cases.append((d, x, w, b, ref, gin.pixels, Cout))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(20):
+        for k, st in enumerate(streams):
+            d, x, w, b, ref, pix, Cout = cases[k]
+            with torch.cuda.stream(st):
+                y = torch.full((pix, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
+                ops.conv2d_fwd(d, x, w, b, y, flags=ops.EPI_RELU)
+                outs[k].append(y)
+    for st in streams:
+        st.synchronize()
+    for k in range(2):
+        for y in outs[k]:
+            assert torch.equal(y, cases[k][4])
