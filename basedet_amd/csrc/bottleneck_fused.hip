@@ -448,32 +448,17 @@ extern "C" int bd_bottleneck_fwd(int N, int H, int W, int Cin, int Cmid, int Cou
     p.per_xcd = cdiv(p.total_tiles, 8);
     p.x_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     p.y_bytes = (unsigned)((long long)N * H * W * Cout * 2);
-    int cus = 256;
-    {
-        static int cached = 0;
-        if (!cached) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                cached = prop.multiProcessorCount;
-            else
-                cached = 256;
-        }
-        cus = cached;
-    }
+    const int cus = bd_num_cus();
     int grid = (cus / 8) * 8;                           // one persistent four-wave workgroup per CU, a multiple of the 8 XCDs
     if (grid < 8) grid = 8;
     const int need = p.per_xcd * 8;
     if (grid > need) grid = need;                       // (per_xcd >= 1: at least 8 workgroups; the surplus ones exit at once)
     const size_t lds = 2 * XB_BYTES + XB_BYTES + W3_BYTES + (wd ? W3_BYTES : 0) + BIAS_BYTES + PAD_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_fused_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   3 * XB_BYTES + 2 * W3_BYTES + BIAS_BYTES + PAD_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_fused_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  3 * XB_BYTES + W3_BYTES + BIAS_BYTES + PAD_BYTES);
-        attr_set = true;
-    }
+                                  3 * XB_BYTES + W3_BYTES + BIAS_BYTES + PAD_BYTES));
     if (wd) hipLaunchKernelGGL((bottleneck_fused_kernel<64, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((bottleneck_fused_kernel<256, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     BD_CHECK_LAUNCH("bd_bottleneck_fwd");

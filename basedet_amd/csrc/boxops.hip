@@ -614,12 +614,9 @@ extern "C" int bd_batched_nms(const float* boxes, const float* scores, const int
     unsigned long long* mask = (unsigned long long*)p;
     const int npow2 = next_pow2(n);
     const size_t lds = (size_t)npow2 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  NMS_MAX * 8);
-        attr_set = true;
-    }
+                                  NMS_MAX * 8));
     hipLaunchKernelGGL(nms_prepare_kernel, dim3(1), dim3(1024), lds, st, boxes, scores, idxs, n, npow2, sboxes, order);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(n, words), dim3(64), 0, st, (const float*)sboxes, (const int*)order, n,
                        iou_thresh, mask, words);

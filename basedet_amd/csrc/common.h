@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 
 #include "../../include/basedet_hip.h"
@@ -75,3 +76,30 @@ void bd_set_error(const char* fmt, ...);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- per-device launch state -------------------------------------------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are properties of a DEVICE: a process-wide `static bool` set them for the
+// first device only, and two threads racing through the first call could launch before the attribute was in place.
+//   BD_ONCE_PER_DEVICE(stmts): runs stmts once per (call site, current device), under a lock the later callers of that site also take
+//   bd_num_cus(): multiProcessorCount of the current device (256 if the query fails)
+struct BdDeviceOnce {
+    std::mutex mu;
+    unsigned long long done[4] = {0, 0, 0, 0};      // 256 device ordinals
+    struct Guard {
+        BdDeviceOnce& o; int dev = 0; bool first_;
+        explicit Guard(BdDeviceOnce& o_) : o(o_) {
+            o.mu.lock();
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 255) dev = 0;
+            first_ = !((o.done[dev >> 6] >> (dev & 63)) & 1ull);
+        }
+        bool first() const { return first_; }
+        ~Guard() { if (first_) o.done[dev >> 6] |= 1ull << (dev & 63); o.mu.unlock(); }
+    };
+};
+#define BD_ONCE_PER_DEVICE(...)                 \
+    do {                                        \
+        static BdDeviceOnce once__;             \
+        BdDeviceOnce::Guard guard__(once__);    \
+        if (guard__.first()) { __VA_ARGS__; }   \
+    } while (0)
+int bd_num_cus();

@@ -863,11 +863,8 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
         const int mt = (int)cdiv64(M, BG_T), nt = cdiv(CO, BG_T);
         const bool legal = CK % BG_BK == 0 && CO >= BG_T && g_conv1x1_depth != 3;
         if (legal && g_conv1x1_depth == 2) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS);
-                attr_set = true;
-            }
+            BD_ONCE_PER_DEVICE(
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS));
             p.m_tiles = mt; p.n_tiles = nt;
             const long long tiles = (long long)mt * nt;
             hipLaunchKernelGGL(conv1x1_big_kernel, dim3((int)(tiles < 256 ? tiles : 256)), dim3(512), BG_LDS, stream, p);
@@ -876,11 +873,8 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     }
     if (g_conv1x1_depth == 4 && CK % BK == 0 && CO >= 256 && CK >= g_conv1x1_wide_min_k) {
         constexpr int WIDE_LDS = 3 * (256 * 64 + TILE_BYTES);          // 72 KB: two eight-wave workgroups per CU
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dense_kernel<1, 4, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
-            attr_set = true;
-        }
+        BD_ONCE_PER_DEVICE(
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dense_kernel<1, 4, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
         p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, 256);
         hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, true, 4>), dim3(p.m_tiles * p.n_tiles), dim3(512), WIDE_LDS, stream, p);
         return 0;
@@ -959,12 +953,9 @@ extern "C" int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, c
     p.x_bytes = (unsigned)(M * CK); p.w_bytes = (unsigned)((long long)CO * CK);
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
     const int grid = p.m_tiles * p.n_tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fp8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * F8_TILE);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * F8_TILE);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * F8_TILE));
     if (mode == 0) hipLaunchKernelGGL((conv1x1_fp8_kernel<0>), dim3(grid), dim3(256), 4 * F8_TILE, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv1x1_fp8_kernel<1>), dim3(grid), dim3(256), 4 * F8_TILE, (hipStream_t)stream, p);
     BD_CHECK_LAUNCH("bd_conv1x1_fp8");

@@ -432,14 +432,11 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
     p.n_tiles = cdiv(p.CO, TILE_CO);
     const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
     const size_t lds = X_BYTES + 2 * W_BYTES + TILE_CO * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const bool dma = g_patch_dma && p.CK % 64 == 0;
     if (dma && mode == 0) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 0>), dim3(grid), dim3(512), lds, stream, p);
     else if (dma) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 1>), dim3(grid), dim3(512), lds, stream, p);

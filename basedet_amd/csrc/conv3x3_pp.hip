@@ -639,12 +639,7 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     int tail_wgs = 0;
     int px_tiles = cdiv(p.total_patches, NPATCH);
     p.tail_end = p.total_patches;
-    static int num_cus = 0;
-    if (!num_cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            num_cus <= 0) num_cus = 256;
-    }
+    const int num_cus = bd_num_cus();
     if (g_pp_tail_split && p.n_tiles == 1 && px_tiles > num_cus) {
         const int r = px_tiles % num_cus;
         if (r > 0 && r * (TILE_CO / TAIL_CO) <= num_cus) {
@@ -669,12 +664,9 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
         const int grid128 = cdiv(p.total_patches, NPATCH) * cdiv(p.CO, 128);
         if (g_patch_pp < 2 && 3 * cdiv(grid, 256) >= 2 * cdiv(grid128, 256)) return 1;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     if (mode == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<0>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
     else hipLaunchKernelGGL((conv3x3_pp_kernel<1>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
     return 0;

@@ -71,14 +71,11 @@ int bd_conv3x3_pp128_launch_range(const bd_conv_desc* d, int mode, const void* s
     p.n_tiles = cdiv(p.CO, small ? 64 : 128);
     const int grid = cdiv(p.total_patches - p.patch_begin, NPATCH) * p.n_tiles;
     if (grid <= 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<128>::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<128>::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<64>::LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<64>::LDS_BYTES);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<64>::LDS_BYTES));
     if (small) {
         if (mode == 0) hipLaunchKernelGGL((conv3x3_pp128_kernel<0, 64>), dim3(grid), dim3(512), Tile<64>::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv3x3_pp128_kernel<1, 64>), dim3(grid), dim3(512), Tile<64>::LDS_BYTES, stream, p);

@@ -430,12 +430,9 @@ int bd_conv3x3_pp8_launch(const bd_conv_desc* d, int mode, const void* xq, const
     p.total_patches = ps * d->N;
     p.n_tiles = cdiv(p.CO, TILE_CO);
     const int grid = cdiv(p.total_patches, NPATCH) * p.n_tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     if (mode == 0) hipLaunchKernelGGL((conv3x3_pp8_kernel<0>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
     else hipLaunchKernelGGL((conv3x3_pp8_kernel<1>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
     return 0;

@@ -484,11 +484,8 @@ int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, 
     p.src_bytes = (unsigned)sb; p.w_bytes = (unsigned)wb;
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     const size_t lds = 4 * TILE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    BD_ONCE_PER_DEVICE(
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(conv_fp8_kernel, dim3(p.m_tiles * p.n_tiles), dim3(256), lds, (hipStream_t)stream, fp);
     BD_CHECK_LAUNCH("bd_conv2d_fwd_fp8");
     return BD_OK;

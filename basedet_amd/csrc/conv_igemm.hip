@@ -390,8 +390,7 @@ template <int BK>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
     using C = Cfg<BK>;
     const size_t lds = 4 * C::TILE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, true, false>),
@@ -399,9 +398,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = p.m_tiles * p.n_tiles;
     const bool epi_ops = ((p.flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER)) && p.add) || ((p.flags & BD_EPI_MASK) && p.mask);
     const int ksteps = (p.CK + BK - 1) / BK * p.R * p.S;

@@ -437,14 +437,11 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
     }
     const int grid = pl.splits * d->R * d->S * pl.ci_tiles * pl.co_tiles;
     const size_t lds = 4 * BKP_DEFAULT * ROW_PITCH;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BKP_DEFAULT, true>),
+    BD_ONCE_PER_DEVICE(
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BKP_DEFAULT, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BKP_DEFAULT, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BKP_DEFAULT, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (g_wgrad_use_tr)
         hipLaunchKernelGGL((conv_wgrad_kernel<BKP_DEFAULT, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     else

@@ -260,12 +260,9 @@ template <int TCI, int TCO, int BKP, bool BUF>
 void launch_w1(const W1Params& p, int grid, hipStream_t stream) {
     constexpr size_t lds = 2 * (size_t)BKP * ((TCI * 2 + 32) + (TCO * 2 + 32));
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1x1_kernel<TCI, TCO, BKP, BUF>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((conv_wgrad1x1_kernel<TCI, TCO, BKP, BUF>), dim3(grid), dim3(512), lds, stream, p);
 }
 

@@ -390,14 +390,11 @@ int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, floa
         sg.in_off = d->in_off[s]; sg.out_off = d->out_off[s]; sg.Hi = d->Hi[s]; sg.Wi = d->Wi[s];
         ps += cdiv(d->Ho[s], ph) * sg.pw;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * XImg<1>::BUF_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * XImg<2>::BUF_BYTES);
-        attr_set = true;
-    }
+                                  2 * XImg<2>::BUF_BYTES));
     const int grid = splits * p.ci_tiles * p.co_tiles;
     if (d->stride == 1) hipLaunchKernelGGL(conv_wgrad3x3_kernel<1>, dim3(grid), dim3(256), 2 * XImg<1>::BUF_BYTES, stream, p);
     else hipLaunchKernelGGL(conv_wgrad3x3_kernel<2>, dim3(grid), dim3(256), 2 * XImg<2>::BUF_BYTES, stream, p);

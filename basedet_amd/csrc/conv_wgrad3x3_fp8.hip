@@ -310,11 +310,8 @@ extern "C" int bd_conv2d_wgrad_fp8(const bd_conv_desc* d, const void* x8, const 
         sg.in_off = d->in_off[s]; sg.out_off = d->out_off[s];
         ps += cdiv(d->Ho[s], F8_PH) * sg.pw;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F8_BUF);
-        attr_set = true;
-    }
+    BD_ONCE_PER_DEVICE(
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F8_BUF));
     const int grid = splits * p.ci_tiles * p.co_tiles;
     hipLaunchKernelGGL(conv_wgrad3x3_fp8_kernel, dim3(grid), dim3(256), 2 * F8_BUF, (hipStream_t)stream, p);
     BD_CHECK_LAUNCH("bd_conv2d_wgrad_fp8");

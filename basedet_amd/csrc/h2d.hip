@@ -112,8 +112,17 @@ int bd_h2d_create(bd_h2d_t* out, int device, int threads) {
         threads = (int)(hw >= 32 ? 16 : (hw >= 8 ? hw / 2 : 2));
     }
     BD_REQUIRE(threads <= 256, "bd_h2d_create: %d threads", threads);
-    if (hipSetDevice(device) != hipSuccess) {
+    // The caller's current device is left alone (a rank with LOCAL_RANK > 0 must not find itself on device 0 afterwards): the event
+    // is created under a save / restore, and only the worker threads bind themselves to `device`.
+    int ndev = 0, prev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipGetDevice(&prev) != hipSuccess) {
+        bd_set_error("bd_h2d_create: device %d not available (%d devices)", device, ndev);
+        return BD_ELAUNCH;
+    }
+    struct Restore { int prev, dev; ~Restore() { if (prev != dev) (void)hipSetDevice(prev); } } restore{prev, device};
+    if (prev != device && hipSetDevice(device) != hipSuccess) {
         bd_set_error("bd_h2d_create: hipSetDevice(%d) failed", device);
+        restore.dev = prev;
         return BD_ELAUNCH;
     }
     bd_h2d* h = new bd_h2d();
@@ -136,6 +145,11 @@ int bd_h2d_submit(bd_h2d_t h, const void* src_host, int src_dtype, int64_t n, fl
     BD_REQUIRE(src_dtype == BD_HOST_F64 || src_dtype == BD_HOST_F32 || src_dtype == BD_HOST_U8, "bd_h2d_submit: dtype %d", src_dtype);
     if (n == 0) return BD_OK;             // an empty batch: nothing to move (its pointers may be null)
     BD_REQUIRE(src_host && dst_dev, "bd_h2d_submit: null buffer");
+    {   // the submitting thread issues copies too: it must sit on the handle's device (stream and destination belong to it)
+        int cur = -1;
+        BD_REQUIRE(hipGetDevice(&cur) == hipSuccess && cur == h->device, "bd_h2d_submit: current device %d is not the handle's device %d", cur,
+                   h->device);
+    }
     if (h->pending) {                 // the previous batch's copies still read the staging buffer
         if (hipEventSynchronize(h->drained) != hipSuccess) {
             bd_set_error("bd_h2d_submit: waiting for the previous transfer failed");

@@ -7,6 +7,20 @@
 
 // ---- error plumbing (shared by every translation unit) -----------------------------------------------------
 static thread_local std::string g_bd_error = "";
+// multiProcessorCount of the CURRENT device, cached per device ordinal (common.h)
+int bd_num_cus() {
+    static std::mutex mu;
+    static int cached[256] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 255) return 256;
+    std::lock_guard<std::mutex> g(mu);
+    if (!cached[dev]) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 void bd_set_error(const char* fmt, ...) {
     char buf[512];
     va_list ap;

@@ -1123,11 +1123,8 @@ int nmsb_run(const float* boxes, const float* scores, const int32_t* idxs, int B
     int* nvalid = (int*)(ws + l.nvalid);
     unsigned long long* mask = (unsigned long long*)(ws + l.mask);
     const int npow2 = next_pow2_i(C);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)nmsb_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMSB_MAX * 8);
-        attr_set = true;
-    }
+    BD_ONCE_PER_DEVICE(
+        (void)hipFuncSetAttribute((const void*)nmsb_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMSB_MAX * 8));
     hipLaunchKernelGGL(nmsb_prepare_kernel, dim3(B), dim3(1024), (size_t)npow2 * 8, st, boxes, scores, idxs, C, npow2, sboxes,
                        order, nvalid);
     const int tiles = (C + 63) / 64;
@@ -1331,7 +1328,7 @@ extern "C" int bd_roi_align_bwd(const void* gout, int64_t pix_per_img, int C, in
     RoiLevels lv{};
     BD_REQUIRE(fill_roi_levels(lv, L, lvl_pix_off_host, lvl_h_host, lvl_w_host, strides_host) == 0, "roi_align_bwd: strides must be powers of two");
     static const int use_sep = getenv("BD_ROI_BWD_SEP") ? atoi(getenv("BD_ROI_BWD_SEP")) : 1;       // 0: the per-bin scatter (A/B)
-    if (use_sep && PH == 7 && PW == 7)
+    if (use_sep && PH == 7 && PW == 7 && 7 * sample_points <= 64)      // the separable kernel builds its row / column tables with 7 * S threads each
         hipLaunchKernelGGL(roi_align_bwd_sep_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
                            C, lv, rois, labels, rois_per_img, sample_points, gfeat);
     else

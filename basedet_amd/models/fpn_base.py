@@ -199,8 +199,10 @@ class FPNDetector:
         # the head sits at the top of the range, every other layer has binades of headroom.  Per-group scales put EVERY group at the top,
         # and a group whose gradients grow between two probes then saturates: R101 batch 32 at t = 15 had layer3 at 92 672 = 1.6 x the
         # maximum at step 100 and left the finite range before step 400, while t = 12 (0.3035 after 1 500 steps) and an eight-probe
-        # history at t = 15 (0.3306) both ran through (profiles/r03_fp8_scale_groups.txt) -- default t = 13 with a four-probe history.
-        self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 15.0 if str(m.get("FP8_SCALE_GROUPS", "group")) == "global" else 13.0))
+        # history at t = 15 (0.3306) both ran through (profiles/r03_fp8_scale_groups.txt).  Round 3 shipped t = 13 with a four-probe
+        # history, a combination that had NOT run through (seed 0 diverged on it, same file, section 2): the default is t = 12 with the
+        # four-probe history, the combination that did; the round-4 seed matrix is profiles/r04_fp8_stability.txt.
+        self.fp8_amax_target = float(m.get("FP8_AMAX_TARGET_LOG2", 15.0 if str(m.get("FP8_SCALE_GROUPS", "group")) == "global" else 12.0))
         # Granularity of the delayed scale (round 3).  One scale for all layers had to span the 2^9.7 spread between max |g| at the head and
         # at the backbone's conv1 layers (scripts/exp/fp8_amax_spread.py): with the head's maximum at 2^15 the backbone's gradients sat
         # ten binades lower and their small values flushed to zero -- R101 at the batch-32 learning rate left the finite range.  "group"

@@ -658,7 +658,10 @@ class HostStager:
     def __init__(self, device, threads=0):
         self._h = C.c_void_p()
         self.device = torch.device(device)
-        check(L().bd_h2d_create(C.byref(self._h), self.device.index or 0, int(threads)), "bd_h2d_create")
+        # torch.device("cuda") carries no index: the rank's CURRENT device is meant (one process per GPU), never device 0
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        check(L().bd_h2d_create(C.byref(self._h), int(index), int(threads)), "bd_h2d_create")
         self.threads = int(L().bd_h2d_threads(self._h))
 
     def supports(self, arr):

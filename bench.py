@@ -411,18 +411,21 @@ def _free_port():
     return p
 
 
-def launch_ranks(n):
+def launch_ranks(n, argv=None, script=None, exit=True, poll_s=0.2):
     """The parent of a `python bench.py --gpus N` run: N fresh rank processes (one per GPU), started before this process has
     imported torch or made any HIP call; relays rank 0's result line; non-zero exit if any rank fails.  The children are ended by
-    their exact PIDs if one of them dies."""
+    their exact PIDs if one of them dies (the survivors would wait in a collective forever).
+    `argv` / `script` / `exit=False` (returns (rc, pids) instead of leaving): tests/test_dist_cpu.py drives it with a stand-in script."""
     port = _free_port()
     procs = []
+    argv = sys.argv[1:] if argv is None else list(argv)
+    script = os.path.abspath(__file__) if script is None else script
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         # as torch.distributed.run does: N ranks with a full-size OpenMP pool each would oversubscribe the host's cores
         env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // n))))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
     line = None
     import threading
@@ -446,12 +449,16 @@ def launch_ranks(n):
                     rc = rc or code
                     for o in alive:          # one rank failed: the others would wait in a collective forever
                         procs[o].kill()
-        time.sleep(0.2)
+        time.sleep(poll_s)
+    for p in procs:
+        p.wait()
     t.join(5)
     if line:
         print(line, flush=True)
     if rc == 0 and not line:
         rc = 1
+    if not exit:
+        return rc, [p.pid for p in procs]
     sys.exit(rc)
 
 
@@ -756,9 +763,11 @@ def worker(args):
         _print_result(saved_stdout, json.dumps(out))
     if comm is not None:
         comm.barrier()
-        # every rank is past its last collective: leave without tearing the communicator down
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        torch.cuda.synchronize()
+        # every rank is past its last collective and its queue is empty: tear the communicator down in order (ncclCommDestroy +
+        # store shutdown; round 3 left through os._exit here, which skipped both)
+        comm.destroy()
+        bdcomm.set_comm(None)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,199 @@
+"""Parity at the benchmark's OWN per-GPU batch (BASELINE configs C2 / C3 / C4: 16 images of 800 x 1344; C5: 32 with fp8 weights).
+
+Every other model-level parity test runs batch 2 (the oracle's 20-30 s of host time per step).  The grids the bench launches -- 16 x
+22 400 locations through the 1x1 / weight-gradient / fused-block / focal / assignment kernels -- are checked here WITHOUT the oracle,
+through a property the reference's own benchmark input has: `DummyLoader` repeats a fixed two-image annotation pattern over the batch
+(utils/dummy.py:51-57, `np.repeat`: images 0 .. B/2-1 carry pattern 0, the rest pattern 1; tools/benchmark.py:173).  With the IMAGES
+repeated the same way, image k of the big batch is image k // (B/2) of the batch-2 run, which the oracle tests pin:
+
+  * targets (labels, matched boxes) of image k  ==  image k // (B/2) of the batch-2 run, bit for bit;
+  * forward outputs (logits, box offsets) of image k  ==  image k // (B/2), bit for bit (a pixel's K loop does not depend on where
+    its tile sits in the grid);
+  * the loss normalisers (num_fg; FCOS: sum of centre-ness; Faster R-CNN: sample counts) grow by B / 2, a power of two, so every data
+    gradient is the batch-2 one scaled exactly and the parameter gradient -- a sum over B / 2 copies of the same two images divided by
+    B / 2 times the normaliser -- equals the batch-2 gradient up to the order of fp32 sums: rel-L2 <= 1e-3 per parameter;
+  * two runs at batch B give bit-identical gradient arenas where every reduction is fixed-order (RetinaNet, FCOS).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SIZE = (800, 1344)
+
+
+def _tile(batch2, B):
+    assert B % 2 == 0
+    out = {}
+    for k, v in batch2.items():
+        if isinstance(v, dict):
+            out[k] = {kk: np.repeat(vv, B // 2, axis=0) for kk, vv in v.items()}
+        else:
+            out[k] = np.repeat(v, B // 2, axis=0)
+    return out
+
+
+def _dev(batch):
+    out = {}
+    for k, v in batch.items():
+        out[k] = {kk: torch.from_numpy(vv).cuda() for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    return out
+
+
+def _rel(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _run(make_model, batch, outputs):
+    """One forward + backward; returns ({name: tensor copy} of the requested plan tensors, gradient dict, arena gradient copy, losses)."""
+    model = make_model()
+    loss = model(_dev(batch))
+    model.backward()
+    torch.cuda.synchronize()
+    pl = model._cur
+    got = {n: getattr(pl, n).clone() for n in outputs}
+    grads = {k: v.clone() for k, v in model.reference_grads().items()}
+    arena = model.arena.g.clone()
+    losses = {k: float(v) for k, v in loss.items()}
+    del model
+    torch.cuda.empty_cache()
+    return got, grads, arena, losses
+
+
+def _per_image(t, N):
+    return t.reshape(N, -1)
+
+
+def _check_tiled(small, big, B, names, exact=True):
+    for n in names:
+        s, b = _per_image(small[n], 2), _per_image(big[n], B)
+        assert b.shape[1] == s.shape[1], (n, b.shape, s.shape)
+        for k in range(B):
+            ref = s[k // (B // 2)]
+            if exact:
+                assert torch.equal(b[k], ref), (n, k, int((b[k] != ref).sum()))
+            else:
+                assert _rel(b[k].float(), ref.float()) < 3e-3, (n, k)
+
+
+def _check_grads(g_small, g_big, tag, bound=1e-3):
+    worst = ("", 0.0)
+    for n, g in g_small.items():
+        r = _rel(g_big[n], g)
+        worst = (n, r) if r > worst[1] else worst
+    print(f"[{tag}] worst per-parameter gradient rel-L2, bench batch vs batch 2: {worst}")
+    assert worst[1] < bound, worst
+
+
+def _retinanet_case(backbone, B, fp8):
+    from basedet_amd.models import RetinaNet
+    if backbone == "resnet101":
+        from tests.test_r101_gpu import _setup as setup101
+        cfg, params, batch2 = setup101()
+    else:
+        from tests.test_model_gpu import _setup
+        cfg, params, batch2 = _setup(backbone, 2, SIZE)
+
+    def make(n):
+        def f():
+            cfg.MODEL.BATCHSIZE = n
+            if fp8:
+                cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
+                # the e5m2 quantiser's stochastic-rounding word is a hash of the ELEMENT INDEX, which moves with the batch position:
+                # round to nearest here, so that image k and its batch-2 twin quantise alike
+                cfg.MODEL.FP8_STOCHASTIC_ROUNDING = False
+            try:
+                return RetinaNet(cfg, params=params)
+            finally:
+                for k in ("WEIGHT_DTYPE", "FP8_STOCHASTIC_ROUNDING"):
+                    cfg.MODEL.pop(k, None)
+        return f
+    return make, batch2
+
+
+@pytest.mark.parametrize("backbone,B,fp8", [("resnet50", 16, False), ("resnet101", 32, True)], ids=["C2-r50-b16", "C5-r101-fp8-b32"])
+def test_retinanet_bench_batch_equals_tiled_batch2(backbone, B, fp8):
+    make, batch2 = _retinanet_case(backbone, B, fp8)
+    outs = ("labels", "logits", "offsets")
+    small, g2, _, l2 = _run(make(2), batch2, outs)
+    big, gB, arena_a, lB = _run(make(B), _tile(batch2, B), outs)
+    assert big["labels"].shape == (B, 201600)
+    _check_tiled(small, big, B, outs)
+    for k in l2:
+        assert abs(lB[k] - l2[k]) <= 1e-4 * abs(l2[k]), (k, lB[k], l2[k])
+    _check_grads(g2, gB, f"RetinaNet {backbone} b{B}{' fp8' if fp8 else ''}")
+    _, _, arena_b, _ = _run(make(B), _tile(batch2, B), ())
+    assert torch.equal(arena_a, arena_b)          # every gradient of the arena, bit for bit, at the bench's own grid sizes
+
+
+def test_fcos_bench_batch_equals_tiled_batch2():
+    from basedet_amd.configs import FCOSConfig
+    from basedet_amd.models import FCOS, params as P
+    from basedet_amd.utils import DummyLoader
+    B = 16
+    cfg = FCOSConfig()
+    params = P.init_fcos_params(cfg, seed=0, residual_gamma=0.25)
+    rng = np.random.default_rng(7)
+    for k in list(params):
+        if k.startswith("head.") and k.rsplit(".", 2)[-2] in ("1", "4", "7", "10") and k.endswith(".weight"):
+            params[k] = rng.uniform(0.7, 1.3, params[k].shape).astype(np.float32)       # GroupNorm gamma
+        if k == "head.scales":
+            params[k] = rng.uniform(0.8, 1.2, params[k].shape).astype(np.float32)
+        if k == "head.bbox_pred.bias":
+            params[k] = np.full_like(params[k], 0.5)
+    batch2 = next(DummyLoader(2, SIZE, seed=0))
+    batch2["data"] = (batch2["data"] * 255).astype(np.float32)
+
+    def make(n):
+        def f():
+            cfg.MODEL.BATCHSIZE = n
+            return FCOS(cfg, params=params)
+        return f
+    outs = ("labels", "gt_offsets", "logits", "offsets")
+    small, g2, _, l2 = _run(make(2), batch2, outs)
+    big, gB, arena_a, lB = _run(make(B), _tile(batch2, B), outs)
+    assert big["labels"].numel() == B * 22400
+    _check_tiled(small, big, B, outs)
+    for k in l2:
+        assert abs(lB[k] - l2[k]) <= 1e-4 * abs(l2[k]), (k, lB[k], l2[k])
+    _check_grads(g2, gB, "FCOS-R50 b16")
+    _, _, arena_b, _ = _run(make(B), _tile(batch2, B), ())
+    assert torch.equal(arena_a, arena_b)
+
+
+def test_faster_rcnn_bench_batch_equals_tiled_batch2():
+    """C4: the sampling keys are tiled with the images, so image k draws the samples of image k // (B/2).  RoIAlign's backward scatters with
+    float atomics (order differs run to run): gradients are compared within tolerance, not bitwise."""
+    from basedet_amd.configs import FasterRCNNConfig
+    from basedet_amd.models import FasterRCNN, params as P
+    from basedet_amd.utils import DummyLoader
+    B = 16
+    cfg = FasterRCNNConfig()
+    params = P.init_faster_rcnn_params(cfg, 0, residual_gamma=0.25)
+    for k in ("rpn.rpn_cls_score.weight", "rpn.rpn_bbox_offsets.weight", "rcnn.pred_cls.weight", "rcnn.pred_delta.weight",
+              "rcnn.fc1.weight", "rcnn.fc2.weight", "rpn.rpn_conv.weight"):
+        params[k] = (params[k] * 3).astype(np.float32)
+    batch2 = next(DummyLoader(2, SIZE, seed=0))
+    batch2["data"] = (batch2["data"] * 255).astype(np.float32)
+    Gmax = batch2["gt_boxes"].shape[1]
+    A_total, R = 268569, cfg.MODEL.RPN.TRAIN_POST_NMS_TOPK
+    rng = np.random.default_rng(5)
+    batch2["sample_keys"] = dict(rpn_pos=rng.random((2, A_total), dtype=np.float32), rpn_neg=rng.random((2, A_total), dtype=np.float32),
+                                 rcnn_fg=rng.random((2, R + Gmax), dtype=np.float32), rcnn_bg=rng.random((2, R + Gmax), dtype=np.float32))
+
+    def make(n):
+        def f():
+            cfg.MODEL.BATCHSIZE = n
+            return FasterRCNN(cfg, params=params)
+        return f
+    outs = ("rpn_labels", "rois", "num_rois", "s_labels", "s_rois", "s_targets")
+    small, g2, _, l2 = _run(make(2), batch2, outs)
+    big, gB, _, lB = _run(make(B), _tile(batch2, B), outs)
+    assert big["rpn_labels"].shape == (B, A_total)
+    _check_tiled(small, big, B, outs)
+    for k in l2:
+        assert abs(lB[k] - l2[k]) <= 1e-3 * abs(l2[k]), (k, lB[k], l2[k])
+    # (the packed-bf16 RoIAlign backward keeps running bf16 sums whose roundings depend on the atomics' order: 6e-3 per level, see
+    # test_rcnn_ops_gpu.py; the default fp32 scatter is order-dependent at the 1e-6 level only)
+    _check_grads(g2, gB, "Faster R-CNN R50 b16", bound=2e-3)

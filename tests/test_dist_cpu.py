@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -196,3 +197,41 @@ def test_lr_schedule_restates_reference_hook():
     assert np.isclose(s2.lr_at(0), 0.01 * 0.001) and np.isclose(s2.lr_at(250), 0.01 * (0.001 + 0.999 * 0.5)) and np.isclose(s2.lr_at(500), 0.01)
     cfg.SOLVER.WARMUP_MODE = "constant"
     assert np.isclose(WarmupMultiStepLR(opt, cfg, world_size=1).lr_at(499), 0.01 * 0.001)
+
+
+def test_launch_ranks_kills_survivors_and_fails_when_one_rank_exits_nonzero(tmp_path):
+    """bench.py's parent process (`python bench.py --gpus N`): when one rank dies the others would sit in a collective forever, so the
+    parent ends them by their exact PIDs and returns the failing rank's code.  Driven here with a stand-in rank script (no GPU)."""
+    import importlib.util
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)                     # stdlib imports only at module level: no torch, no HIP in the parent
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "r = int(os.environ['RANK'])\n"
+        "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "assert os.environ['LOCAL_RANK'] == os.environ['RANK']\n"
+        "if r == 1:\n"
+        "    time.sleep(0.5); sys.exit(3)\n"
+        "if r == 0:\n"
+        "    print('{\"rank0\": \"line\"}', flush=True)\n"
+        "time.sleep(120)\n")
+    t0 = time.time()
+    rc, pids = bench.launch_ranks(3, argv=[], script=str(script), exit=False, poll_s=0.05)
+    assert rc == 3
+    assert time.time() - t0 < 30                       # the survivors did not run out their 120 s
+    for pid in pids:
+        with pytest.raises(ProcessLookupError):        # reaped: the PID is gone (or belongs to nobody we may signal)
+            os.kill(pid, 0)
+    # all ranks succeed but rank 0 prints no result line: still a failure
+    ok = tmp_path / "ok.py"
+    ok.write_text("import sys\nsys.exit(0)\n")
+    rc, _ = bench.launch_ranks(2, argv=[], script=str(ok), exit=False, poll_s=0.05)
+    assert rc == 1
+    good = tmp_path / "good.py"
+    good.write_text("import os\nif os.environ['RANK'] == '0':\n    print('{\"ok\": 1}', flush=True)\n")
+    rc, _ = bench.launch_ranks(2, argv=[], script=str(good), exit=False, poll_s=0.05)
+    assert rc == 0

@@ -70,11 +70,18 @@ if fcos:
     full["im_info"][half:, 4] = np.minimum(full["im_info"][half:, 4], [3, 2] * (half // 2) if half >= 2 else [3])
 lo = rank * per_rank
 batch = {k: torch.from_numpy(v[lo:lo + per_rank]).cuda() for k, v in full.items()}
+if os.environ.get("BD_TEST_HOST_BATCH") == "1":
+    # the loaders' form (DummyLoader / the collator yield numpy): the images go through bd_h2d_submit's staging threads, which must
+    # bind to THIS rank's device and leave the process's current device alone (round-3 ADVICE: every rank staged to device 0)
+    batch = dict(batch, data=np.ascontiguousarray(full["data"][lo:lo + per_rank]).astype(np.float64))
 w0 = model.arena.w.clone()
 for _ in range(3):
     out = solver.minimize(model, batch)
 torch.cuda.synchronize()
 assert np.isfinite(float(out["total_loss"]))
+assert torch.cuda.current_device() == int(os.environ.get("LOCAL_RANK", "0"))
+if os.environ.get("BD_TEST_HOST_BATCH") == "1":
+    assert model._stager.device.index == torch.cuda.current_device() and model._h2d_dst.device.index == torch.cuda.current_device()
 w = model.arena.w.cpu().numpy()
 np.save(out_path, np.stack([w0.cpu().numpy(), w]))
 sys.stderr.write("DIGEST " + hashlib.sha256(w.tobytes()).hexdigest() + " " + repr(float(np.abs(w).sum())) + "\n")
@@ -89,12 +96,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(tmp, tag, world=1, force=False, batch=4, model="retinanet", wire=""):
+def _run(tmp, tag, world=1, force=False, batch=4, model="retinanet", wire="", host_batch=False):
     port = _free_port()
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, BD_FORCE_ALLREDUCE="1" if force else "0", HSA_ENABLE_IPC_MODE_LEGACY="0", BD_TEST_BATCH=str(batch),
-                   BD_TEST_MODEL=model, BD_TEST_WIRE=wire,
+                   BD_TEST_MODEL=model, BD_TEST_WIRE=wire, BD_TEST_HOST_BATCH="1" if host_batch else "0",
                    RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         out = os.path.join(tmp, f"{tag}_{r}.npy")
@@ -176,3 +183,21 @@ def test_two_ranks_fcos_with_different_num_fg_match_one_rank(tmp_path):
     step2, step1 = w2[0][1] - w2[0][0], w1[0][1] - w1[0][0]
     rel = np.linalg.norm(step2 - step1) / np.linalg.norm(step1)
     assert rel < 2e-2, rel
+
+
+def test_host_numpy_batch_takes_the_same_step_as_a_device_batch(tmp_path):
+    """float64 host images through bd_h2d_submit (data_to_input's `Tensor(image)`): bit-identical parameters to the device-batch run --
+    the float64 -> float32 conversion is the same rounding on both paths -- and the current device is untouched."""
+    dev, _ = _run(str(tmp_path), "hdev")
+    host, _ = _run(str(tmp_path), "hhost", host_batch=True)
+    assert host == dev, (host, dev)
+
+
+def test_two_ranks_with_host_numpy_batches(tmp_path):
+    """Round-3 ADVICE (high): with `torch.device("cuda")` every rank passed device 0 to bd_h2d_create and the staging threads of rank 1
+    copied into device 0.  Two ranks fed host batches must end with the parameters of the two-rank device-batch run."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs (one process per GPU; RCCL refuses two ranks on one device)")
+    d_dev, _ = _run(str(tmp_path), "h2dev", world=2, batch=4)
+    d_host, _ = _run(str(tmp_path), "h2host", world=2, batch=4, host_batch=True)
+    assert d_host[0] == d_host[1] and d_host == d_dev, (d_host, d_dev)

@@ -194,3 +194,79 @@ def test_bbox_eval_agrees_with_an_independent_textbook_ap():
             got = float(P[ti, :, 0, 0, 2].mean())
             assert got == pytest.approx(want, abs=1e-9), (trial, thr, got, want)
         assert r["stats"][0] == pytest.approx(np.mean([_textbook_ap(gts, dts, t) for t in np.linspace(0.5, 0.95, 10)]), abs=1e-9)
+
+
+# ---- hand-computed cells for the cases pycocotools' protocol is known for ------------------------------------
+# Every expected number below is worked out in the comment from COCOeval's published rules (evaluateImg / accumulate), not read off the
+# implementation: a change of the matching or interpolation rule moves them.
+
+def test_crowd_region_is_rematched_and_uses_detection_area_iou():
+    """g1 normal, g2 crowd [20, 40) x [0, 10).  By score: d1, d2 lie inside the crowd (plain IoU 100 / 200 = 0.5 would fail every threshold
+    above 0.50; the crowd rule inter / det-area gives 1.0), d3 is g1 exactly.  d1 matches the crowd -> ignored; d2 matches the SAME crowd
+    again -> ignored (matched once only it would be a false positive in front of the true positive: precision 1/2); d3 is the one true
+    positive of one countable ground truth: tp = [0, 0, 1], fp = [0, 0, 0] -> precision 1 at every recall point and IoU threshold."""
+    gts = [_gt(1, 1, 1, (0, 0, 10, 10)), _gt(2, 1, 1, (20, 0, 20, 10), crowd=1)]
+    dts = [_dt(1, 1, (20, 0, 10, 10), 0.9), _dt(1, 1, (30, 0, 10, 10), 0.8), _dt(1, 1, (0, 0, 10, 10), 0.7)]
+    r = bbox_eval(gts, dts)
+    assert np.all(r["precision"][:, :, 0, 0, 2] == pytest.approx(1.0))
+    assert r["stats"][0] == pytest.approx(1.0) and r["stats"][2] == pytest.approx(1.0) and r["stats"][8] == pytest.approx(1.0)
+    # the same detections against a NON-crowd g2: d1 takes it at IoU 0.5 (threshold 0.50 only), d2 is a false positive:
+    #   t = 0.50: npig 2, by score tp [1, 1, 2], fp [0, 1, 1] -> rc [.5, .5, 1], pr [1, .5, 2/3] -> envelope [1, 2/3, 2/3]:
+    #             51 recall points (<= .5) at 1, 50 at 2/3
+    #   t > 0.50: d1, d2 false positives: tp [0, 0, 1], fp [1, 2, 2] -> rc [0, 0, .5], pr 1/3 up to recall .5 (51 points), 0 beyond
+    gts[1]["iscrowd"] = 0
+    P = bbox_eval(gts, dts)["precision"][:, :, 0, 0, 2]
+    assert P[0].mean() == pytest.approx((51 + 50 * 2 / 3) / 101, abs=1e-12)
+    for ti in range(1, 10):
+        assert P[ti].mean() == pytest.approx(51 / 3 / 101, abs=1e-12)
+
+
+def test_area_range_ignores_ground_truth_and_unmatched_detections():
+    """g1 20 x 20 (area 400: small), g2 50 x 50 (2 500: medium).  By score: d3 (30 x 30 = 900, matches nothing), d1 = g1, d2 = g2,
+    d4 (50 x 50, matches nothing).
+      all:    FP TP TP FP -> tp [0,1,2,2], fp [1,1,1,2], rc [0,.5,1,1], pr [0,1/2,2/3,1/2] -> envelope 2/3 everywhere: AP 2/3
+      small:  g2 ignored; d3 FP (in range), d1 TP, d2 matches the ignored g2 -> ignored, d4 unmatched and out of range -> ignored:
+              tp [0,1,1,1], fp [1,1,1,1], one countable gt -> pr envelope 1/2 at every recall point: AP 1/2
+      medium: g1 ignored; d3 unmatched, out of range -> ignored; d1 matches the ignored g1 -> ignored; d2 TP; d4 FP (in range):
+              tp [0,0,1,1], fp [0,0,0,1] -> pr [0,0,1,1/2] -> envelope [1,1,1,1/2]; recall reaches 1 at index 2: AP 1
+      large:  no ground truth in range: -1"""
+    gts = [_gt(1, 1, 1, (0, 0, 20, 20)), _gt(2, 1, 1, (100, 100, 50, 50))]
+    dts = [_dt(1, 1, (300, 300, 30, 30), 0.95), _dt(1, 1, (0, 0, 20, 20), 0.9), _dt(1, 1, (100, 100, 50, 50), 0.8),
+           _dt(1, 1, (400, 400, 50, 50), 0.6)]
+    st = bbox_eval(gts, dts)["stats"]
+    assert st[0] == pytest.approx(2 / 3, abs=1e-12)
+    assert st[3] == pytest.approx(0.5, abs=1e-12)
+    assert st[4] == pytest.approx(1.0, abs=1e-12)
+    assert st[5] == -1.0
+    assert st[9] == pytest.approx(1.0) and st[10] == pytest.approx(1.0) and st[11] == -1.0          # ARs, ARm, ARl
+
+
+def test_max_dets_is_applied_per_image_before_pooling():
+    """Image 1: d1 (0.9, matches nothing), d2 (0.8) = g1.  Image 2: d3 (0.7) = g2.
+      maxDets 1:   image 1 keeps d1 only (its true positive is cut off PER IMAGE, although d2 outscores image 2's d3): pooled FP, TP ->
+                   tp [0,1], fp [1,1], npig 2 -> rc [0,.5], pr envelope [.5,.5]: 51 recall points at 1/2, recall .5
+      maxDets 100: FP TP TP -> tp [0,1,2], fp [1,1,1] -> pr [0,1/2,2/3] -> envelope 2/3 at all 101 points, recall 1"""
+    gts = [_gt(1, 1, 1, (0, 0, 40, 40)), _gt(2, 2, 1, (0, 0, 40, 40))]
+    dts = [_dt(1, 1, (200, 200, 40, 40), 0.9), _dt(1, 1, (0, 0, 40, 40), 0.8), _dt(2, 1, (0, 0, 40, 40), 0.7)]
+    r = bbox_eval(gts, dts)
+    assert r["precision"][0, :, 0, 0, 0].mean() == pytest.approx(51 * 0.5 / 101, abs=1e-12)
+    assert r["recall"][0, 0, 0, 0] == pytest.approx(0.5) and r["stats"][6] == pytest.approx(0.5)
+    assert r["stats"][0] == pytest.approx(2 / 3, abs=1e-12)
+    assert r["stats"][7] == pytest.approx(1.0) and r["stats"][8] == pytest.approx(1.0)
+
+
+def test_score_ties_keep_image_order_and_iou_equal_to_threshold_matches():
+    """Pooled detections are sorted by score with a STABLE sort: equal scores keep the order of the image ids.  Image 1 holds a true
+    positive, image 2 a false positive and an unmatched ground truth, both detections at score 0.5:
+      image 1 first: tp [1,1], fp [0,1], npig 2 -> rc [.5,.5], pr [1,.5]: recall points 0 ... 0.50 (51 of 101) read precision 1 -> 51/101
+      ids swapped:   tp [0,1], fp [1,1] -> pr envelope [.5,.5] -> 25.5/101
+    recThrs[50] must compare equal to the recall 1/2 (searchsorted side = left)."""
+    def case(tp_img, fp_img):
+        gts = [_gt(1, tp_img, 1, (0, 0, 40, 40)), _gt(2, fp_img, 1, (0, 0, 40, 40))]
+        dts = [_dt(tp_img, 1, (0, 0, 40, 40), 0.5), _dt(fp_img, 1, (200, 200, 40, 40), 0.5)]
+        return bbox_eval(gts, dts)["stats"][0]
+    assert case(1, 2) == pytest.approx(51 / 101, abs=1e-12)
+    assert case(2, 1) == pytest.approx(25.5 / 101, abs=1e-12)
+    # IoU exactly 0.5 (100 / 200) matches at the 0.50 threshold (the rule is "iou < threshold: no match") and at no other: AP = 1 / 10
+    st = bbox_eval([_gt(1, 1, 1, (0, 0, 10, 10))], [_dt(1, 1, (0, 0, 10, 20), 0.9)])["stats"]
+    assert st[1] == pytest.approx(1.0) and st[2] == pytest.approx(0.0) and st[0] == pytest.approx(0.1)

@@ -351,7 +351,7 @@ def test_roi_align_bwd_pk_full_size():
         sl = slice(o, o + h * w)
         ref_l = refg[l].reshape(N, h * w, C)
         # a running bf16 sum of n terms: ~sqrt(n) * 2^-9 relative (tests at toy size: 0.2-0.4 %)
-        assert np.linalg.norm(gk[:, sl] - ref_l) <= 8e-3 * np.linalg.norm(ref_l), l
+        assert np.linalg.norm(gk[:, sl] - ref_l) <= 6e-3 * np.linalg.norm(ref_l), l
         tot = ref_l + b[:, sl]
         # on top of a base of comparable size every add also rounds the BASE to bf16 again: measured 0.6-0.9 % per level
         assert np.linalg.norm(gk2[:, sl] - tot) <= 1.5e-2 * np.linalg.norm(tot), l
@@ -412,8 +412,10 @@ def test_roi_align_fwd_bwd():
         # rel-L2 0.2-0.4 % here (a running bf16 sum of n terms: ~sqrt(n) x 2^-9; storing an exact fp32 sum as bf16 costs 0.11 %)
         # (the order of the atomics differs from run to run, and with it every running sum's roundings: the per-element bound below failed
         # once in ~10 full-suite runs at rtol 2^-5 / atol 0.03 -- the rel-L2 bound is the statement, the element bound a sanity net)
-        assert np.linalg.norm(got_l - ref_l) <= 8e-3 * np.linalg.norm(ref_l), l
-        np.testing.assert_allclose(got_l, ref_l, rtol=2 ** -4, atol=0.06)
+        assert np.linalg.norm(got_l - ref_l) <= 6e-3 * np.linalg.norm(ref_l), l
+        # per element the statement is statistical: a handful of running sums may round unluckily, the bulk may not
+        bad = np.abs(got_l - ref_l) > 2 ** -5 * np.abs(ref_l) + 0.03
+        assert bad.mean() <= 1e-4, (l, float(bad.mean()))
         o += h * w
     assert np.all(gk[:, o:] == 0)
     # deterministic gather variant: bf16 output over the whole pyramid, bitwise reproducible
