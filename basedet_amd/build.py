@@ -25,6 +25,7 @@ SOURCES = {
     "conv3x3_pp8.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad3x3.hip": [],
+    "conv_wgrad3x3_ring.hip": [],
     "conv_wgrad3x3_fp8.hip": [],
     "conv_wgrad1x1.hip": [],
     "stem.hip": [],

@@ -245,6 +245,7 @@ struct Plan { int ci_tiles, co_tiles, splits, steps_per_split, total_steps; long
 constexpr int BKP_DEFAULT = 64;
 int g_wgrad_use_tr = 1;
 int g_wgrad_use_3x3 = 1;
+int g_wgrad_use_ring = 1;       // conv_wgrad3x3_ring.hip for the wide stride-1 3x3 layers (bd_wgrad_set_transpose_read bit 2 set = off)
 
 // 3x3 / pad 1 with stride 1 or 2: served by the nine-tap patch kernel (conv_wgrad3x3.hip)
 bool is_3x3s1(const bd_conv_desc* d) {
@@ -281,12 +282,19 @@ int bd_wgrad1x1_splits(const bd_conv_desc* d);
 int bd_wgrad1x1_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream);
 int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patches_per_img_out);
 int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, float* csum, int* splits_out, hipStream_t stream);
+bool bd_wgrad3x3r_eligible(const bd_conv_desc* d);
+size_t bd_wgrad3x3r_slab_bytes(const bd_conv_desc* d, int* splits_out);
+int bd_wgrad3x3r_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, float* csum, int* splits_out, hipStream_t stream);
+void bd_wgrad3x3r_reduce(const bd_conv_desc* d, const float* slab, int splits, const float* row_scale, float* dw, int accumulate,
+                         hipStream_t stream);
 
 // use_tr: 1 = transposing LDS reads (default), 0 = scalar-read reference path of the generic kernel.
-// bit 1 (value 2) additionally disables the nine-tap 3x3 kernel (forces the generic per-tap kernel).
+// bit 1 (value 2) additionally disables the nine-tap 3x3 kernels (forces the generic per-tap kernel);
+// bit 2 (value 4) disables the ring-staged nine-tap kernel only (conv_wgrad3x3_ring.hip; its shapes then take conv_wgrad3x3.hip).
 extern "C" int bd_wgrad_set_transpose_read(int use_tr) {
     g_wgrad_use_tr = use_tr & 1;
     g_wgrad_use_3x3 = (use_tr & 2) ? 0 : 1;
+    g_wgrad_use_ring = (use_tr & 4) ? 0 : 1;
     if (!(use_tr & 1)) g_wgrad_use_3x3 = 0;
     return BD_OK;
 }
@@ -310,7 +318,12 @@ extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
         const size_t s1 = (size_t)bd_wgrad1x1_splits(d);
         if (s1 > splits) splits = s1;
     }
-    return splits * d->Cout * d->R * d->S * d->Cin * sizeof(float);
+    size_t bytes = splits * d->Cout * d->R * d->S * d->Cin * sizeof(float);
+    if (bd_wgrad3x3r_eligible(d)) {                 // register-row slabs of whole (padded) tiles
+        const size_t r = bd_wgrad3x3r_slab_bytes(d, nullptr);
+        if (r > bytes) bytes = r;
+    }
+    return bytes;
 }
 
 namespace {
@@ -346,6 +359,12 @@ extern "C" size_t bd_conv2d_wgrad_bias_workspace_bytes(const bd_conv_desc* d) {
     size_t extra = bd_colsum_workspace_bytes(d->Cout);
     if (is_3x3s1(d)) {
         const size_t s3 = (size_t)bd_wgrad3x3_splits(d, nullptr, nullptr) * d->Cout * sizeof(float);
+        if (s3 > extra) extra = s3;
+    }
+    if (bd_wgrad3x3r_eligible(d)) {
+        int sr = 1;
+        (void)bd_wgrad3x3r_slab_bytes(d, &sr);
+        const size_t s3 = (size_t)sr * d->Cout * sizeof(float);
         if (s3 > extra) extra = s3;
     }
     return align256(w) + extra;
@@ -396,6 +415,17 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
         }
         return BD_OK;
     };
+    if (g_wgrad_use_3x3 && g_wgrad_use_ring && bd_wgrad3x3r_eligible(d)) {
+        int splitsr = 1;
+        bd_wgrad3x3r_launch(d, x, g, (float*)ws, dbias ? (float*)extra : nullptr, &splitsr, (hipStream_t)stream);
+        BD_CHECK_LAUNCH("bd_conv2d_wgrad(3x3 ring)");
+        bd_wgrad3x3r_reduce(d, (const float*)ws, splitsr, row_scale, dw, accumulate, (hipStream_t)stream);
+        if (dbias)
+            hipLaunchKernelGGL(csum_reduce_kernel, dim3(cdiv(d->Cout, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)extra, splitsr,
+                               d->Cout, dbias, accumulate);
+        BD_CHECK_LAUNCH("bd_conv2d_wgrad(ring reduce)");
+        return BD_OK;
+    }
     if (g_wgrad_use_3x3 && is_3x3s1(d)) {
         int splits3 = 1;
         bd_wgrad3x3_launch(d, x, g, (float*)ws, dbias ? (float*)extra : nullptr, &splits3, (hipStream_t)stream);

@@ -12,7 +12,33 @@ import torch
 
 from .coco_eval import COCOEvaluator
 
-__all__ = ["batch_annotations", "evaluate_batch", "overfit"]
+__all__ = ["batch_annotations", "evaluate_batch", "overfit", "painted_batch"]
+
+
+def painted_batch(size=(320, 416), seed=0):
+    """Two synthetic images in the collator's contract (data (2,3,H,W) float32 0..255, gt_boxes (2,G,5) zero-padded, im_info (2,5)): uniform
+    noise with one filled rectangle per annotation, colour = a function of the class.  Unlike `DummyLoader`'s pattern (whose image 0 holds
+    two class-52 boxes of IoU 0.63 -- NMS at 0.5 can never return both -- a 38 x 24 px box and 5 : 1 slivers) every box here can be matched
+    by an anchor at IoU >= 0.5 and no two boxes overlap by more than 0.2: a detector that has learnt the batch can reach AP ~ 1, so a low
+    AP means a broken stage, not an unreachable target.  `im_info` declares an ORIGINAL size different from the padded one, so the
+    rescale of post_processing.py:93-101 is part of what is checked."""
+    H, W = size
+    rng = np.random.default_rng(seed)
+    # (x1, y1, x2, y2) as fractions of (W, H), class (1-based)
+    spec = [[(0.05, 0.08, 0.30, 0.45, 3), (0.40, 0.10, 0.62, 0.38, 17), (0.70, 0.05, 0.95, 0.50, 41), (0.08, 0.58, 0.40, 0.92, 58),
+             (0.50, 0.55, 0.68, 0.90, 66), (0.74, 0.62, 0.93, 0.88, 80)],
+            [(0.10, 0.10, 0.45, 0.55, 17), (0.55, 0.12, 0.90, 0.42, 3), (0.15, 0.65, 0.38, 0.93, 25), (0.52, 0.55, 0.88, 0.92, 72)]]
+    G = max(len(v) for v in spec)
+    data = rng.random((2, 3, H, W)) * 64.0 + 96.0                     # noise around mid-grey
+    gt = np.zeros((2, G, 5), np.float32)
+    for i, boxes in enumerate(spec):
+        for k, (fx1, fy1, fx2, fy2, c) in enumerate(boxes):
+            x1, y1, x2, y2 = round(fx1 * W), round(fy1 * H), round(fx2 * W), round(fy2 * H)
+            col = np.array([(37 * c) % 256, (91 * c + 60) % 256, (53 * c + 130) % 256], np.float64)
+            data[i, :, y1:y2, x1:x2] = col[:, None, None] + rng.random((3, y2 - y1, x2 - x1)) * 16.0
+            gt[i, k] = (x1, y1, x2, y2, c)
+    info = np.array([[H, W, 0.75 * H, 0.75 * W, len(spec[0])], [H, W, 1.25 * H, 1.25 * W, len(spec[1])]], np.float32)
+    return {"data": data.astype(np.float32), "gt_boxes": gt, "im_info": info}
 
 
 def batch_annotations(host_batch):

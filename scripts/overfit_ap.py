@@ -23,6 +23,11 @@ if len(a) > 6:
     cfg.SOLVER.WARM_ITERS = int(a[6])
 params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
 model = RetinaNet(cfg, params=params)
-hb = next(DummyLoader(B, (H, W), seed=0))
-hb["data"] = (hb["data"] * 255).astype(np.float32)        # pixel range 0..255 (DummyLoader draws [0, 1): next to the dataset mean that is a constant image)
+if os.environ.get("BD_PAINTED") == "1":          # the asserted test's batch (evaluators/selfcheck.painted_batch): two images
+    from basedet_amd.evaluators.selfcheck import painted_batch
+    assert B == 2
+    hb = painted_batch((H, W))
+else:
+    hb = next(DummyLoader(B, (H, W), seed=0))
+    hb["data"] = (hb["data"] * 255).astype(np.float32)        # pixel range 0..255 (DummyLoader draws [0, 1): next to the dataset mean that is a constant image)
 overfit(cfg, model, hb, steps, eval_every=max(steps // 6, 1), log=lambda s: print(s, flush=True))

@@ -338,7 +338,8 @@ def test_patch_instances_agree_bitwise(shape):
         assert torch.equal(outs[1][4], torch.where(gate.float() > 0, outs[1][5], torch.zeros_like(outs[1][5])))
 
 
-@pytest.mark.parametrize("case", [(2, 64, 72, 19, 27, 3, 1, 1), (2, 128, 64, 22, 30, 3, 2, 1), (3, 64, 136, 9, 14, 1, 1, 0)])
+@pytest.mark.parametrize("case", [(2, 64, 72, 19, 27, 3, 1, 1), (2, 128, 64, 22, 30, 3, 2, 1), (3, 64, 136, 9, 14, 1, 1, 0),
+                                  (2, 128, 136, 19, 27, 3, 1, 1), (1, 72, 264, 21, 9, 3, 1, 1)])      # the last two: the ring-staged kernel
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_wgrad_bias_entry_point(case, accumulate):
     """bd_conv2d_wgrad_bias: weight gradient + bias gradient (column sums of g) in one call -- fused into the nine-tap kernel for the
@@ -364,10 +365,11 @@ def test_wgrad_bias_entry_point(case, accumulate):
     assert rel_l2(db.cpu() - base_b, br.grad) < 1e-4
 
 
-def test_wgrad_bias_multilevel():
+@pytest.mark.parametrize("chans", [(64, 72), (64, 200)])          # (64, 200): the ring-staged kernel (ones-row MFMA column sums)
+def test_wgrad_bias_multilevel(chans):
     """Five pyramid levels in one descriptor: the fused column sums cover every level's pixels exactly once (ragged patches)."""
     ops = _ops()
-    N, C, Cout = 2, 64, 72
+    N, (C, Cout) = 2, chans
     Hs, Ws = [12, 6, 3, 2, 1], [20, 10, 5, 3, 2]
     gen = torch.Generator().manual_seed(11)
     geo = ops.Geom(N, Hs, Ws)
@@ -571,3 +573,30 @@ def test_pp_persistent_launches_on_two_streams_same_bits():
     for k in range(2):
         for y in outs[k]:
             assert torch.equal(y, cases[k][4])
+
+
+@pytest.mark.parametrize("case", [(2, 256, 256, 50, 84), (1, 128, 720, 37, 41), (3, 200, 136, 11, 19), (2, 64, 96, 8, 8), (1, 64, 128, 3, 5)])
+def test_wgrad_ring_kernel_agrees_with_the_register_staged_kernel(case):
+    """conv_wgrad3x3_ring.hip (LDS-DMA ring, 64 ci x 128 co tile, persistent workgroups) against conv_wgrad3x3.hip (bit 2 of
+    bd_wgrad_set_transpose_read routes its shapes back there): the same products summed in another order -> fp32 rounding only; the
+    bias column sums likewise; and two launches of the ring kernel are bit-identical (fixed-order reduce)."""
+    ops = _ops()
+    N, Cin, Cout, H, W = case
+    gen = torch.Generator().manual_seed(5 + Cin + Cout)
+    geo = ops.single(N, H, W)
+    d = ops.conv_desc(geo, geo, Cin, Cout, 3, 3, 1, 1)
+    x = bf16_round(torch.randn(geo.pixels, Cin, generator=gen)).to(torch.bfloat16).cuda()
+    gy = bf16_round(torch.randn(geo.pixels, Cout, generator=gen)).to(torch.bfloat16).cuda()
+    ws = torch.empty((ops.conv2d_wgrad_bias_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
+    outs = []
+    for knob in (1, 5, 1):
+        ops.L().bd_wgrad_set_transpose_read(knob)
+        dw = torch.full((Cout, 3, 3, Cin), 3.0, dtype=torch.float32, device="cuda")
+        db = torch.full((Cout,), 3.0, dtype=torch.float32, device="cuda")
+        ops.conv2d_wgrad_bias(d, x, gy, dw, db, ws)
+        torch.cuda.synchronize()
+        outs.append((dw.cpu(), db.cpu()))
+    ops.L().bd_wgrad_set_transpose_read(1)
+    assert rel_l2(outs[0][0], outs[1][0]) < 2e-6 and rel_l2(outs[0][1], outs[1][1]) < 2e-6
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert rel_l2(outs[0][1], gy.float().sum(0).cpu()) < 1e-4

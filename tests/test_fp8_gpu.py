@@ -598,8 +598,8 @@ def test_absmax_and_delayed_gradient_scale():
         for c in m._fp8_grad_layers:
             a = keys[m._fp8_scale_key(c)]
             if a > 0:                                    # every group's largest gradient lands in (2^14, 2^15] of e5m2's range
-                t = m.fp8_amax_target                    # 15 for one global scale, 13 (two binades of headroom) per group / layer
-                assert t == (15.0 if mode == "global" else 13.0)
+                t = m.fp8_amax_target                    # 15 for one global scale, 12 (three binades of headroom) per group / layer
+                assert t == (15.0 if mode == "global" else 12.0)
                 assert 2.0 ** (t - 1) < a * c.grad_scale <= 2.0 ** t and np.log2(c.grad_scale) == np.floor(np.log2(c.grad_scale)), (mode, c.name)
         assert len({c.grad_scale for c in m.output.values()}) == 1        # the FPN output convolutions read ONE twin of dL/dP
         if mode == "global":

@@ -1,37 +1,53 @@
-"""SURVEY row f2 under test: train -> inference -> COCO box-AP produced by a `-m gpu` test.
+"""SURVEY row f2 under test: train -> inference -> COCO box-AP produced by `-m gpu` tests.
 
-RetinaNet-R18-FPN is trained on ONE repeated DummyLoader batch (the benchmark's synthetic boxes, utils/dummy.py:13-45, on uniform-noise
-images) and must then find those boxes again: every image goes through `model.inference` (retinanet.py:172-201) and the detections are
-scored by `COCOEvaluator` (evaluators/coco_eval.py:72-172) against the batch's own annotations, in original-image coordinates.  An
-overfitted batch says nothing about COCO accuracy; it checks that class indices, box decoding, NMS, the rescale to the original size and
-the evaluator's matching agree with each other -- a 1-off class id, a swapped axis in the rescale or an xyxy / xywh slip gives AP ~ 0."""
+RetinaNet-R18-FPN is trained on ONE repeated two-image batch and must then find that batch's boxes again: every image goes through
+`model.inference` (retinanet.py:172-201) and the detections are scored by `COCOEvaluator` (evaluators/coco_eval.py:72-172) against the
+batch's own annotations, in original-image coordinates.  An overfitted batch says nothing about COCO accuracy; it checks that class
+indices, box decoding, NMS, the rescale to the original size and the evaluator's matching agree with each other -- a 1-off class id, a
+swapped axis in the rescale or an xyxy / xywh slip gives AP ~ 0.
+
+Two batches:
+  * `painted_batch` (evaluators/selfcheck.py): ten well-separated, anchor-matchable boxes painted into noise images, original sizes 0.75x
+    and 1.25x the padded one -> AP50 >= 0.9 is reachable and asserted (observed 1.000 / AP 1.000 after 800 steps);
+  * the benchmark's own DummyLoader pattern (utils/dummy.py:13-45) on pure-noise images: its ceiling is below 1 by construction -- image 0
+    holds two class-52 boxes of IoU 0.63, which NMS at 0.5 cannot both return, a 15 x 10 px box at this scale and 5 : 1 slivers no
+    anchor matches above 0.5 -- so the bar there is AP50 >= 0.6 (observed 0.70-0.80)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-STEPS, SIZE, B = 600, (320, 416), 2
+SIZE, B = (320, 416), 2
 
 
-def test_overfitted_batch_is_found_again_by_inference_and_evaluator():
+def _train_and_score(hb, steps, lr_per_image):
     from basedet_amd.configs import retinanet_r18_config
     from basedet_amd.evaluators.selfcheck import batch_annotations, overfit
     from basedet_amd.models import RetinaNet, params as P
-    from basedet_amd.utils import DummyLoader
     cfg = retinanet_r18_config()
     cfg.MODEL.BATCHSIZE = B
-    cfg.SOLVER.BASIC_LR = 0.01 / B            # 0.01 for the batch of two (the reference's 0.000625 per image is tuned for 18 epochs of COCO)
-    cfg.SOLVER.WARM_ITERS = 50
-    params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
-    model = RetinaNet(cfg, params=params)
+    cfg.SOLVER.BASIC_LR = lr_per_image        # (the reference's 0.000625 per image is tuned for 18 epochs of COCO, not for 10^3 steps on one batch)
+    cfg.SOLVER.WARM_ITERS = 100
+    model = RetinaNet(cfg, params=P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2))
+    n_gt = len(batch_annotations(hb)["annotations"])
+    hist = overfit(cfg, model, hb, steps, eval_every=steps // 3, log=print)
+    step, loss, st, ndet = hist[-1]
+    assert step == steps and np.isfinite(loss) and loss < hist[0][1]
+    assert ndet >= n_gt
+    return st, n_gt
+
+
+def test_painted_batch_is_found_again_by_inference_and_evaluator():
+    from basedet_amd.evaluators.selfcheck import painted_batch
+    st, n_gt = _train_and_score(painted_batch(SIZE), 900, 0.0025)
+    assert n_gt == 10
+    assert st["AP50"] >= 0.9 and st["AP"] >= 0.8 and st["AR100"] >= 0.9, st
+
+
+def test_dummyloader_batch_reaches_its_ceiling_band():
+    from basedet_amd.utils import DummyLoader
     hb = next(DummyLoader(B, SIZE, seed=0))
     hb["data"] = (hb["data"] * 255).astype(np.float32)        # pixel range 0..255 (DummyLoader draws [0, 1): next to the dataset mean that is a constant image)
-    n_gt = len(batch_annotations(hb)["annotations"])
-    assert n_gt == 15                          # 10 + 5 boxes of the two-image pattern
-    hist = overfit(cfg, model, hb, STEPS, eval_every=STEPS // 3, log=print)
-    step, loss, st, ndet = hist[-1]
-    assert step == STEPS and np.isfinite(loss) and loss < hist[0][1]
-    assert ndet >= n_gt
-    assert st["AP50"] >= 0.9, st
-    assert st["AP"] >= 0.6, st
-    assert st["AR100"] >= 0.7, st
+    st, n_gt = _train_and_score(hb, 1200, 0.00125)            # (0.0025 per image leaves the finite range after ~900 steps on this batch: scripts/exp/nan_hunt.py)
+    assert n_gt == 15
+    assert st["AP50"] >= 0.6 and st["AR100"] >= 0.6, st

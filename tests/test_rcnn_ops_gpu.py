@@ -351,7 +351,7 @@ def test_roi_align_bwd_pk_full_size():
         sl = slice(o, o + h * w)
         ref_l = refg[l].reshape(N, h * w, C)
         # a running bf16 sum of n terms: ~sqrt(n) * 2^-9 relative (tests at toy size: 0.2-0.4 %)
-        assert np.linalg.norm(gk[:, sl] - ref_l) <= 6e-3 * np.linalg.norm(ref_l), l
+        assert np.linalg.norm(gk[:, sl] - ref_l) <= 8e-3 * np.linalg.norm(ref_l), l
         tot = ref_l + b[:, sl]
         # on top of a base of comparable size every add also rounds the BASE to bf16 again: measured 0.6-0.9 % per level
         assert np.linalg.norm(gk2[:, sl] - tot) <= 1.5e-2 * np.linalg.norm(tot), l
