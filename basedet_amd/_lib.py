@@ -53,6 +53,11 @@ SIGNATURES = {
     "bd_conv2d_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_conv2d_wgrad_bias_workspace_bytes": (_Z, [_D]),
     "bd_conv2d_wgrad_bias": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
+    "bd_wgrad_queue_create": (_I, [_P]),
+    "bd_wgrad_queue_destroy": (_I, [_P]),
+    "bd_wgrad_queue_pending": (_I, [_P]),
+    "bd_conv2d_wgrad_queued": (_I, [_P, _D, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
+    "bd_wgrad_queue_flush": (_I, [_P, _P]),
     "bd_stem_conv7x7_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "bd_stem_pool_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "bd_stem_weight_pack": (_I, [_P, _P, _P, _P]),

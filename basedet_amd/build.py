@@ -28,6 +28,7 @@ SOURCES = {
     "conv_wgrad3x3_ring.hip": [],
     "conv_wgrad3x3_fp8.hip": [],
     "conv_wgrad1x1.hip": [],
+    "conv_wgrad1x1_ring.hip": [],
     "stem.hip": [],
     "boxops.hip": ["-ffp-contract=off"],
     "rcnn_ops.hip": ["-ffp-contract=off"],

@@ -16,6 +16,7 @@
 // Split over pixels: grid = splits x taps x ci-tiles x co-tiles; every workgroup writes its own fp32 slab,
 // a second kernel sums the slabs in a fixed order (bitwise reproducible), applies the FrozenBN row scale and
 // stores / accumulates into the fp32 gradient.
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -209,35 +210,102 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
-// slab reduce: block = 64 element-vectors x 4 split lanes; lane y sums splits y, y+4, ... (fixed order), then the four
-// partial sums are added in lane order -> bitwise reproducible, and short chains even for 256 splits.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long long n, int row_len,
-                                                           const float* __restrict__ row_scale, float* __restrict__ dw,
-                                                           int accumulate) {
+// ---- fixed-order reduce of the per-split partial sums, BATCHED over layers ---------------------------------------------------------------
+// One launch sums the slabs of up to BD_RED_MAX entries (a layer's weight gradient; its bias column sums are an entry of their own).
+// Block = 64 f32x4 elements x 4 split chains: chain y sums splits y, y + 4, ... in order, the four partial sums are added in chain order ->
+// bitwise reproducible whatever the grid looks like.  Rounds 1-3 launched one such kernel per layer (60 launches per RetinaNet-R50 step).
+// kind 0: slab[split][n] floats in the result's own order (generic / register-staged kernels; bias column sums with row_len = 1, no scale);
+// kind 1 / 2: the register-row slabs of conv_wgrad3x3_ring.hip / conv_wgrad1x1_ring.hip (slab[split][tile][wave][reg][lane] f32x4), un-permuted here.
+}  // namespace
+#include "wgrad_reduce.h"
+namespace {
+
+__global__ __launch_bounds__(256) void wgrad_batch_reduce_kernel(const BdRedBatch b) {
     __shared__ f32x4_t red[4][64];
+    int ei = 0;
+#pragma unroll 1
+    for (int k = 1; k < b.count; ++k)
+        if ((int)blockIdx.x >= b.e[k].block_begin) ei = k;
+    const BdRedEntry& en = b.e[ei];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const long long i = ((long long)blockIdx.x * 64 + tx) * 4;
+    const long long e = (long long)((int)blockIdx.x - en.block_begin) * 64 + tx;        // f32x4 element inside one split
+    const long long n4 = en.n4;
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    if (i < n) {
+    if (e < n4) {
+        const long long stride = n4 * 4;
+        const float* src = en.slab + e * 4;
+        const int splits = en.splits;
         int k = ty;
         for (; k + 12 < splits; k += 16) {
-            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(slab + (long long)k * n + i);
-            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(slab + (long long)(k + 4) * n + i);
-            const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(slab + (long long)(k + 8) * n + i);
-            const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(slab + (long long)(k + 12) * n + i);
+            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + (long long)k * stride);
+            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 4) * stride);
+            const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 8) * stride);
+            const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 12) * stride);
             s += v0; s += v1; s += v2; s += v3;
         }
-        for (; k < splits; k += 4) s += *reinterpret_cast<const f32x4_t*>(slab + (long long)k * n + i);
+        for (; k < splits; k += 4) s += *reinterpret_cast<const f32x4_t*>(src + (long long)k * stride);
     }
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && i < n) {
-        f32x4_t t = red[0][tx];
-        t += red[1][tx]; t += red[2][tx]; t += red[3][tx];
-        if (row_scale) t *= row_scale[i / row_len];
-        if (accumulate) t += *reinterpret_cast<const f32x4_t*>(dw + i);
-        *reinterpret_cast<f32x4_t*>(dw + i) = t;
+    if (ty != 0 || e >= n4) return;
+    f32x4_t t = red[0][tx];
+    t += red[1][tx]; t += red[2][tx]; t += red[3][tx];
+    long long idx;          // float index into dw
+    int row;                // output channel (row scale)
+    if (en.kind == 0) {
+        idx = e * 4;
+        row = (int)(idx / en.row_len);
+    } else {
+        const int regs = en.regs;                                     // f32x4 registers per lane: 36 (3x3: tap * 4 + j) / fi * fj (1x1: i * fj + j)
+        const long long per_tile = 8ll * regs * 64;
+        const int tile = (int)(e / per_tile);
+        int r = (int)(e - tile * per_tile);
+        const int wave = r / (regs * 64);
+        r -= wave * (regs * 64);
+        const int reg = r >> 6, lane = r & 63;
+        const int ci_tile = tile / en.co_tiles, co_tile = tile - ci_tile * en.co_tiles;
+        int co, ci, tap = 0, taps = 1;
+        if (en.kind == 1) {                                           // wave = (16-ci group wave & 3, 64-co group wave >> 2), reg = tap * 4 + j
+            tap = reg >> 2; taps = 9;
+            co = co_tile * en.tco + (wave >> 2) * 64 + (reg & 3) * 16 + (lane & 15);
+            ci = ci_tile * en.tci + (wave & 3) * 16 + (lane >> 4) * 4;
+        } else {                                                      // wave = (wci, wco), reg = i * fj + j
+            const int i = reg / en.fj, j = reg - i * en.fj;
+            const int wco_n = en.tco / (16 * en.fj);
+            const int wci = wave / wco_n, wco = wave - wci * wco_n;
+            co = co_tile * en.tco + (wco * en.fj + j) * 16 + (lane & 15);
+            ci = ci_tile * en.tci + (wci * en.fi + i) * 16 + (lane >> 4) * 4;
+        }
+        if (co >= en.Cout || ci >= en.Cin) return;                    // Cin % 4 == 0
+        idx = ((long long)co * taps + tap) * en.Cin + ci;
+        row = co;
     }
+    float* d = en.dw + idx;
+    if (en.row_scale) t *= en.row_scale[row];
+    if (en.accumulate) t += *reinterpret_cast<const f32x4_t*>(d);
+    *reinterpret_cast<f32x4_t*>(d) = t;
+}
+
+int launch_batch(const BdRedEntry* entries, int count, hipStream_t stream) {
+    for (int base = 0; base < count; base += BD_RED_MAX) {
+        BdRedBatch b{};
+        b.count = count - base < BD_RED_MAX ? count - base : BD_RED_MAX;
+        int blocks = 0;
+        for (int k = 0; k < b.count; ++k) {
+            b.e[k] = entries[base + k];
+            b.e[k].block_begin = blocks;
+            blocks += (int)cdiv64(b.e[k].n4, 64);
+        }
+        if (blocks > 0) hipLaunchKernelGGL(wgrad_batch_reduce_kernel, dim3(blocks), dim3(256), 0, stream, b);
+    }
+    return 0;
+}
+
+BdRedEntry plain_entry(const float* slab, int splits, long long n, int row_len, const float* row_scale, float* dw, int accumulate) {
+    BdRedEntry e{};
+    e.slab = slab; e.dw = dw; e.row_scale = row_scale; e.kind = 0; e.splits = splits; e.accumulate = accumulate;
+    e.n4 = (int)(n / 4); e.row_len = row_len;
+    return e;
 }
 
 struct Plan { int ci_tiles, co_tiles, splits, steps_per_split, total_steps; long long M; };
@@ -285,12 +353,16 @@ int bd_wgrad3x3_launch(const bd_conv_desc* d, const void* x, const void* g, floa
 bool bd_wgrad3x3r_eligible(const bd_conv_desc* d);
 size_t bd_wgrad3x3r_slab_bytes(const bd_conv_desc* d, int* splits_out);
 int bd_wgrad3x3r_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, float* csum, int* splits_out, hipStream_t stream);
-void bd_wgrad3x3r_reduce(const bd_conv_desc* d, const float* slab, int splits, const float* row_scale, float* dw, int accumulate,
-                         hipStream_t stream);
+void bd_wgrad3x3r_entry(const bd_conv_desc* d, BdRedEntry* e);
+bool bd_wgrad1x1r_eligible(const bd_conv_desc* d);
+size_t bd_wgrad1x1r_slab_bytes(const bd_conv_desc* d, int* splits_out);
+int bd_wgrad1x1r_launch(const bd_conv_desc* d, const void* x, const void* g, float* slab, int* splits_out, hipStream_t stream);
+void bd_wgrad1x1r_entry(const bd_conv_desc* d, BdRedEntry* e);
 
 // use_tr: 1 = transposing LDS reads (default), 0 = scalar-read reference path of the generic kernel.
 // bit 1 (value 2) additionally disables the nine-tap 3x3 kernels (forces the generic per-tap kernel);
-// bit 2 (value 4) disables the ring-staged nine-tap kernel only (conv_wgrad3x3_ring.hip; its shapes then take conv_wgrad3x3.hip).
+// bit 2 (value 4) disables the ring-staged kernels only (conv_wgrad3x3_ring.hip, conv_wgrad1x1_ring.hip; their shapes then take
+// conv_wgrad3x3.hip / conv_wgrad1x1.hip).
 extern "C" int bd_wgrad_set_transpose_read(int use_tr) {
     g_wgrad_use_tr = use_tr & 1;
     g_wgrad_use_3x3 = (use_tr & 2) ? 0 : 1;
@@ -302,8 +374,8 @@ extern "C" int bd_wgrad_set_transpose_read(int use_tr) {
 // the fixed-order slab reduce for the other translation units (conv_wgrad3x3_fp8.hip)
 void bd_wgrad_reduce_launch(const float* slab, int splits, long long n, int row_len, const float* row_scale, float* dw, int accumulate,
                             hipStream_t stream) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n / 4, 64)), dim3(256), 0, stream, slab, splits, n, row_len, row_scale, dw,
-                       accumulate);
+    const BdRedEntry e = plain_entry(slab, splits, n, row_len, row_scale, dw, accumulate);
+    launch_batch(&e, 1, stream);
 }
 
 extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
@@ -323,35 +395,23 @@ extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
         const size_t r = bd_wgrad3x3r_slab_bytes(d, nullptr);
         if (r > bytes) bytes = r;
     }
+    if (bd_wgrad1x1r_eligible(d)) {
+        const size_t r = bd_wgrad1x1r_slab_bytes(d, nullptr);
+        if (r > bytes) bytes = r;
+    }
     return bytes;
 }
 
 namespace {
-// bias gradient from the per-split partial column sums the nine-tap kernel leaves behind: fixed-order sum over the splits
-__global__ __launch_bounds__(256) void csum_reduce_kernel(const float* __restrict__ part, int splits, int C, float* __restrict__ out,
-                                                          int accumulate) {
-    __shared__ float red[256];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;      // 32 columns x 8 interleaved split chains
-    float s = 0.f;
-    if (c < C)
-        for (int k = q; k < splits; k += 8) s += part[(long long)k * C + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (q == 0 && c < C) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t += red[j * 32 + threadIdx.x];
-        out[c] = accumulate ? out[c] + t : t;
-    }
-}
 size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 }  // namespace
 
 extern "C" size_t bd_colsum_workspace_bytes(int C);
 extern "C" int bd_colsum_bf16(const void* g, int N, int64_t pix_per_img, int64_t off, int64_t cnt, int C, float* out, int accumulate,
                               void* ws, size_t ws_bytes, bd_stream_t stream);
+struct bd_wgrad_queue { std::vector<BdRedEntry> entries; };
 static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw, float* dbias,
-                      int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
+                      int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream, bd_wgrad_queue* q);
 
 extern "C" size_t bd_conv2d_wgrad_bias_workspace_bytes(const bd_conv_desc* d) {
     const size_t w = bd_conv2d_wgrad_workspace_bytes(d);
@@ -379,16 +439,49 @@ extern "C" int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const 
         bd_set_error("conv2d_wgrad_bias: workspace %zu < required %zu bytes", ws_bytes, need);
         return BD_EWORKSPACE;
     }
-    return wgrad_impl(d, x, g, row_scale, dw, dbias, accumulate, ws, ws_bytes, stream);
+    return wgrad_impl(d, x, g, row_scale, dw, dbias, accumulate, ws, ws_bytes, stream, nullptr);
 }
 
 extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale,
                                float* dw, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
-    return wgrad_impl(d, x, g, row_scale, dw, nullptr, accumulate, ws, ws_bytes, stream);
+    return wgrad_impl(d, x, g, row_scale, dw, nullptr, accumulate, ws, ws_bytes, stream, nullptr);
+}
+
+// ---- deferred reduces: the partial-sum kernels of several layers run back to back, ONE launch reduces them all ---------------------------
+extern "C" int bd_wgrad_queue_create(bd_wgrad_queue_t* out) {
+    BD_REQUIRE(out != nullptr, "bd_wgrad_queue_create: null argument");
+    *out = new bd_wgrad_queue();
+    return BD_OK;
+}
+extern "C" int bd_wgrad_queue_destroy(bd_wgrad_queue_t q) {
+    delete q;
+    return BD_OK;
+}
+extern "C" int bd_wgrad_queue_pending(bd_wgrad_queue_t q) { return q ? (int)q->entries.size() : 0; }
+extern "C" int bd_conv2d_wgrad_queued(bd_wgrad_queue_t q, const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
+                                      float* dbias, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_REQUIRE(q != nullptr, "bd_conv2d_wgrad_queued: null queue");
+    if (dbias) {
+        BD_REQUIRE(d && d->Cout <= 2048, "conv2d_wgrad_queued: Cout must be <= 2048");
+        const size_t need = bd_conv2d_wgrad_bias_workspace_bytes(d);
+        if (ws_bytes < need) {
+            bd_set_error("conv2d_wgrad_queued: workspace %zu < required %zu bytes", ws_bytes, need);
+            return BD_EWORKSPACE;
+        }
+    }
+    return wgrad_impl(d, x, g, row_scale, dw, dbias, accumulate, ws, ws_bytes, stream, q);
+}
+extern "C" int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream) {
+    BD_REQUIRE(q != nullptr, "bd_wgrad_queue_flush: null queue");
+    if (q->entries.empty()) return BD_OK;
+    launch_batch(q->entries.data(), (int)q->entries.size(), (hipStream_t)stream);
+    q->entries.clear();
+    BD_CHECK_LAUNCH("bd_wgrad_queue_flush");
+    return BD_OK;
 }
 
 static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw, float* dbias,
-                      int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+                      int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream, bd_wgrad_queue* q) {
     BD_REQUIRE(d && x && g && dw && ws, "conv2d_wgrad: null pointer");
     BD_REQUIRE(d->nseg >= 1 && d->nseg <= BD_MAX_SEGS, "conv2d_wgrad: nseg out of range");
     BD_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, "conv2d_wgrad: Cin=%d / Cout=%d must be multiples of 8", d->Cin, d->Cout);
@@ -415,39 +508,49 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
         }
         return BD_OK;
     };
+    // the reduce of this layer: its weight slabs and, where the kernel left per-split column sums of g behind (fused_csum), the bias
+    // gradient -- launched at once, or handed to the queue (bd_conv2d_wgrad_queued) for the next bd_wgrad_queue_flush
+    auto finish = [&](const BdRedEntry& we, int splits, bool fused_csum) -> int {
+        BdRedEntry es[2] = {we, {}};
+        int n = 1;
+        if (dbias && fused_csum) es[n++] = plain_entry((const float*)extra, splits, d->Cout, 1, nullptr, dbias, accumulate);
+        if (q) {
+            for (int k = 0; k < n; ++k) q->entries.push_back(es[k]);
+        } else {
+            launch_batch(es, n, (hipStream_t)stream);
+            BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
+        }
+        return (dbias && !fused_csum) ? bias_fallback() : BD_OK;
+    };
     if (g_wgrad_use_3x3 && g_wgrad_use_ring && bd_wgrad3x3r_eligible(d)) {
         int splitsr = 1;
         bd_wgrad3x3r_launch(d, x, g, (float*)ws, dbias ? (float*)extra : nullptr, &splitsr, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(3x3 ring)");
-        bd_wgrad3x3r_reduce(d, (const float*)ws, splitsr, row_scale, dw, accumulate, (hipStream_t)stream);
-        if (dbias)
-            hipLaunchKernelGGL(csum_reduce_kernel, dim3(cdiv(d->Cout, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)extra, splitsr,
-                               d->Cout, dbias, accumulate);
-        BD_CHECK_LAUNCH("bd_conv2d_wgrad(ring reduce)");
-        return BD_OK;
+        BdRedEntry e{};
+        bd_wgrad3x3r_entry(d, &e);
+        e.slab = (const float*)ws; e.splits = splitsr; e.row_scale = row_scale; e.dw = dw; e.accumulate = accumulate;
+        return finish(e, splitsr, true);
     }
     if (g_wgrad_use_3x3 && is_3x3s1(d)) {
         int splits3 = 1;
         bd_wgrad3x3_launch(d, x, g, (float*)ws, dbias ? (float*)extra : nullptr, &splits3, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(3x3)");
-        const long long n3 = (long long)d->Cout * 9 * d->Cin;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n3 / 4, 64)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)ws, splits3, n3, 9 * d->Cin, row_scale, dw, accumulate);
-        if (dbias)
-            hipLaunchKernelGGL(csum_reduce_kernel, dim3(cdiv(d->Cout, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)extra, splits3,
-                               d->Cout, dbias, accumulate);
-        BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
-        return BD_OK;
+        return finish(plain_entry((const float*)ws, splits3, (long long)d->Cout * 9 * d->Cin, 9 * d->Cin, row_scale, dw, accumulate), splits3, true);
+    }
+    if (g_wgrad_use_3x3 && g_wgrad_use_ring && bd_wgrad1x1r_eligible(d)) {
+        int splitsr = 1;
+        bd_wgrad1x1r_launch(d, x, g, (float*)ws, &splitsr, (hipStream_t)stream);
+        BD_CHECK_LAUNCH("bd_conv2d_wgrad(1x1 ring)");
+        BdRedEntry e{};
+        bd_wgrad1x1r_entry(d, &e);
+        e.slab = (const float*)ws; e.splits = splitsr; e.row_scale = row_scale; e.dw = dw; e.accumulate = accumulate;
+        return finish(e, splitsr, false);
     }
     if (g_wgrad_use_3x3 && d->R == 1 && d->S == 1 && d->pad == 0) {
         int splits1 = 1;
         bd_wgrad1x1_launch(d, x, g, (float*)ws, &splits1, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(1x1)");
-        const long long n1 = (long long)d->Cout * d->Cin;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)cdiv64(n1 / 4, 64)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)ws, splits1, n1, d->Cin, row_scale, dw, accumulate);
-        BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
-        return dbias ? bias_fallback() : BD_OK;
+        return finish(plain_entry((const float*)ws, splits1, (long long)d->Cout * d->Cin, d->Cin, row_scale, dw, accumulate), splits1, false);
     }
     WgradParams p{};
     p.x = (const bf16_raw*)x; p.g = (const bf16_raw*)g; p.slab = (float*)ws;
@@ -478,9 +581,5 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
         hipLaunchKernelGGL((conv_wgrad_kernel<BKP_DEFAULT, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     BD_CHECK_LAUNCH("bd_conv2d_wgrad");
     const long long n = (long long)d->Cout * d->R * d->S * d->Cin;
-    const int rblocks = (int)cdiv64(n / 4, 64);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
-                       pl.splits, n, d->R * d->S * d->Cin, row_scale, dw, accumulate);
-    BD_CHECK_LAUNCH("bd_conv2d_wgrad(reduce)");
-    return dbias ? bias_fallback() : BD_OK;
+    return finish(plain_entry((const float*)ws, pl.splits, n, d->R * d->S * d->Cin, row_scale, dw, accumulate), pl.splits, false);
 }

@@ -19,6 +19,7 @@
 //     share a co group: no pass over G, no VALU work.
 #include <stdlib.h>
 #include "common.h"
+#include "wgrad_reduce.h"
 
 namespace {
 
@@ -349,53 +350,6 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
     }
 }
 
-// Fixed-order sum over the splits of the register-row slabs, un-permuted into dW[co][tap][ci]: thread = one f32x4 of one (tile, wave, reg,
-// lane); four interleaved split chains per element (as wgrad_reduce_kernel), combined in lane order -> bitwise reproducible.
-__global__ __launch_bounds__(256) void wgrad_ring_reduce_kernel(const float* __restrict__ slab, int splits, int tiles, int ci_tiles, int co_tiles,
-                                                                int Cin, int Cout, const float* __restrict__ row_scale, float* __restrict__ dw,
-                                                                int accumulate) {
-    __shared__ f32x4_t red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const long long per_tile = 8ll * REGS * 64;                       // f32x4 elements per tile
-    const long long e = (long long)blockIdx.x * 64 + tx;              // element inside one split
-    const long long n = per_tile * tiles;
-    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    if (e < n) {
-        const long long stride = n * 4;                               // floats per split
-        const float* src = slab + e * 4;
-        int k = ty;
-        for (; k + 12 < splits; k += 16) {
-            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + (long long)k * stride);
-            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 4) * stride);
-            const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 8) * stride);
-            const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 12) * stride);
-            s += v0; s += v1; s += v2; s += v3;
-        }
-        for (; k < splits; k += 4) s += *reinterpret_cast<const f32x4_t*>(src + (long long)k * stride);
-    }
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && e < n) {
-        f32x4_t t = red[0][tx];
-        t += red[1][tx]; t += red[2][tx]; t += red[3][tx];
-        const int tile = (int)(e / per_tile);
-        int r = (int)(e - tile * per_tile);
-        const int wave = r / (REGS * 64);
-        r -= wave * (REGS * 64);
-        const int reg = r >> 6, lane = r & 63;
-        const int tap = reg >> 2, j = reg & 3;
-        const int ci_tile = tile / co_tiles, co_tile = tile - ci_tile * co_tiles;
-        const int co = co_tile * RK_CO + (wave >> 2) * 64 + j * 16 + (lane & 15);
-        const int ci = ci_tile * RK_CI + (wave & 3) * 16 + (lane >> 4) * 4;
-        if (co < Cout && ci < Cin) {                                  // Cin % 4 == 0
-            float* d = dw + ((long long)co * 9 + tap) * Cin + ci;
-            if (row_scale) t *= row_scale[co];
-            if (accumulate) t += *reinterpret_cast<const f32x4_t*>(d);
-            *reinterpret_cast<f32x4_t*>(d) = t;
-        }
-    }
-}
-
 struct RPlan { int ci_tiles, co_tiles, tiles, splits, total, ppi, per; };
 
 RPlan ring_plan(const bd_conv_desc* d) {
@@ -467,10 +421,9 @@ int bd_wgrad3x3r_launch(const bd_conv_desc* d, const void* x, const void* g, flo
     return 0;
 }
 
-void bd_wgrad3x3r_reduce(const bd_conv_desc* d, const float* slab, int splits, const float* row_scale, float* dw, int accumulate,
-                         hipStream_t stream) {
+// the layout half of this layer's reduce descriptor (conv_wgrad.hip fills in pointers and launches / queues it)
+void bd_wgrad3x3r_entry(const bd_conv_desc* d, BdRedEntry* e) {
     const RPlan pl = ring_plan(d);
-    const long long n = 8ll * REGS * 64 * pl.tiles;
-    hipLaunchKernelGGL(wgrad_ring_reduce_kernel, dim3((int)cdiv64(n, 64)), dim3(256), 0, stream, slab, splits, pl.tiles, pl.ci_tiles,
-                       pl.co_tiles, d->Cin, d->Cout, row_scale, dw, accumulate);
+    e->kind = 1; e->regs = REGS; e->co_tiles = pl.co_tiles; e->tci = RK_CI; e->tco = RK_CO; e->fi = 0; e->fj = 0;
+    e->Cin = d->Cin; e->Cout = d->Cout; e->n4 = 8 * REGS * 64 * pl.tiles; e->row_len = 0;
 }

@@ -229,7 +229,7 @@ class ConvLayer:
         """True when dgrad(..., dx8=t) fills t: the fp8 patch kernel and the dense 1x1 kernel do, the other bf16 kernels do not."""
         return self.fp8_dgrad or ops.dense_1x1_bits_ok(self.desc(gin, gout))
 
-    def wgrad(self, x, g, gin, gout, ws, colsum_ws=None, x8=None, g8=None):
+    def wgrad(self, x, g, gin, gout, ws, colsum_ws=None, x8=None, g8=None, queue=None):
         """x8 / g8: the e4m3 twin of x (x * act_scale) and the e5m2 twin of g (g * grad_scale) when their producers wrote them: the
         weight gradient then runs on the one-byte kernel (the bias gradient stays a column sum of the bf16 g)."""
         d = self.desc(gin, gout)
@@ -238,7 +238,9 @@ class ConvLayer:
             if self.gb is not None:
                 ops.colsum_bf16(g, g.shape[0], self.cout, self.gb, colsum_ws)
             return
-        if self.gb is not None:      # weight + bias gradient in one entry point (fused in the 3x3 patch kernel; colsum_ws is unused)
+        if queue is not None:        # ops.WgradQueue: the reduce waits for the caller's flush (ws stays untouched until then)
+            queue.wgrad(d, x, g, self.gw, self.gb, ws, row_scale=self.row_scale)
+        elif self.gb is not None:    # weight + bias gradient in one entry point (fused in the 3x3 patch kernel; colsum_ws is unused)
             ops.conv2d_wgrad_bias(d, x, g, self.gw, self.gb, ws, row_scale=self.row_scale)
         else:
             ops.conv2d_wgrad(d, x, g, self.gw, ws, row_scale=self.row_scale)

@@ -73,6 +73,12 @@ class FPNDetector:
         # weight-gradient kernels run on a side stream, concurrently with the dgrad chain they do not feed: tails and
         # barrier bubbles of one kernel are filled by the other (set False to serialise, e.g. for per-kernel timing)
         self.async_wgrad = True
+        # WGRAD_QUEUE: "bucket" (default) = the weight-gradient reduces of a gradient bucket (head / fpn / layer4 / layer3 / layer2) in ONE
+        # launch (bd_wgrad_queue_*: 5 reduce launches per step instead of 60); an integer = additionally flush whenever that many bytes of
+        # partial sums are pending; "layer" = one reduce per layer right behind its kernel (rounds 1-3)
+        self.wgrad_queue_mode = m.get("WGRAD_QUEUE", "bucket")
+        self._wq = None
+        self._wq_need = {}                  # (layer name, geometry) -> workspace bytes
         self.use_mask_bits = True          # bit-packed ReLU gates for the wide 1x1 data gradients (False: bf16 activations as masks)
         self._wstream = torch.cuda.Stream() if (torch.cuda.is_available() and self.device.type == "cuda") else None
         self._tstream = torch.cuda.Stream() if self._wstream is not None else None      # P6/P7 top-block dgrads
@@ -749,19 +755,60 @@ class FPNDetector:
         """conv.wgrad on the side stream: it only needs x and g as they are NOW (everything enqueued so far on the main
         stream), and nothing on the main stream reads its outputs before `_join_wgrads`.  Callers must not overwrite g/x
         later in the same backward pass (the heads keep one gradient buffer per layer for that reason)."""
+        q = None
+        pl = self._cur
+        if self.wgrad_queue_mode != "layer" and self.device.type == "cuda" and not (conv.fp8_wgrad and x8 is not None and g8 is not None):
+            # deferred reduce: this layer's partial sums get their own slice of the plan's arena, untouched until the bucket's flush.  The
+            # arena is sized by the first backward pass of a plan, which runs un-queued and records what every layer needs.
+            key = (conv.name, gin.pixels, gout.pixels)
+            need = self._wq_need.get(key)
+            if need is None:
+                need = self._wq_need[key] = (conv.wgrad_ws_bytes(gin, gout) + 255) // 256 * 256
+            arena = getattr(pl, "wq_arena", None)
+            if arena is None:
+                pl.wq_total = getattr(pl, "wq_total", 0) + need
+            else:
+                off = pl.wq_off
+                assert off + need <= arena.numel() * 4, "weight-gradient arena too small for this backward pass"
+                ws = arena[off // 4: (off + need) // 4]
+                pl.wq_off = off + need
+                pl.wq_pending += need
+                if self._wq is None:
+                    self._wq = ops.WgradQueue()
+                q = self._wq
         if not (self.async_wgrad and self._wstream is not None):
-            return conv.wgrad(x, g, gin, gout, ws, cws, x8=x8, g8=g8)
-        self._wstream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._wstream):
-            conv.wgrad(x, g, gin, gout, ws, cws, x8=x8, g8=g8)
+            conv.wgrad(x, g, gin, gout, ws, cws, x8=x8, g8=g8, queue=q)
+        else:
+            self._wstream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._wstream):
+                conv.wgrad(x, g, gin, gout, ws, cws, x8=x8, g8=g8, queue=q)
+        if q is not None and isinstance(self.wgrad_queue_mode, int) and pl.wq_pending >= self.wgrad_queue_mode:
+            self._flush_wgrads()
+
+    def _flush_wgrads(self):
+        """One launch reduces every weight gradient queued since the last flush (on the stream the partial sums were computed on)."""
+        q = self._wq
+        if q is None or not q.pending():
+            return
+        self._cur.wq_pending = 0
+        if self.async_wgrad and self._wstream is not None:
+            with torch.cuda.stream(self._wstream):
+                q.flush()
+        else:
+            q.flush()
 
     def _join_wgrads(self):
+        self._flush_wgrads()
+        pl = self._cur
+        if getattr(pl, "wq_arena", None) is None and getattr(pl, "wq_total", 0) > 0 and self.wgrad_queue_mode != "layer":
+            pl.wq_arena = torch.empty((pl.wq_total // 4 + 64,), dtype=torch.float32, device=self.device)      # sized by this first pass
         if self.async_wgrad and self._wstream is not None:
             torch.cuda.current_stream().wait_stream(self._wstream)
 
     def backward(self, on_bucket_ready=None):
         pl = self._cur
         probing = self._fp8_probe_begin()
+        pl.wq_off, pl.wq_pending = 0, 0
         ws, cws = pl.wgrad_ws, pl.colsum_ws
         pyr = pl.pyr
         pl.g_P8_ready = False                       # set by a head whose last data gradients wrote the e5m2 twin of dL/dP
@@ -769,6 +816,7 @@ class FPNDetector:
             b.g_out8_ready = False
         self.head_backward(pl, ws, cws)
         side = (self._wstream,) if (self.async_wgrad and self._wstream is not None) else ()
+        self._flush_wgrads()
         if on_bucket_ready:
             on_bucket_ready("head", side)
         # ---- FPN
@@ -811,6 +859,7 @@ class FPNDetector:
                 self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=pool_top, mask=b.out, maskbits=b.out_bits)
             else:
                 self.lateral[s].dgrad(pl.g_lat[s], b.gout, b.gout, b.g_out, first=True)
+        self._flush_wgrads()
         if on_bucket_ready:
             on_bucket_ready("fpn", side)
         # ---- backbone, last block first.  g_out of a block holds the masked gradient once all consumers are done:
@@ -876,8 +925,10 @@ class FPNDetector:
                         # identity skip: gx = (dgrad + G) * mask
                         wrote = convs[0].dgrad(g, geos[0], geos[1], gx, add_before=G, **kw)
                 pb.g_out8_ready = gx8 is not None and bool(wrote)     # what the launch actually did (a bf16 fallback drops the twin)
-            if on_bucket_ready and (bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]):
-                on_bucket_ready(f"layer{blk['layer']}", side)
+            if bi == 0 or self.blocks[bi - 1]["layer"] != blk["layer"]:
+                self._flush_wgrads()
+                if on_bucket_ready:
+                    on_bucket_ready(f"layer{blk['layer']}", side)
         self._join_wgrads()
         self._fp8_probe_end(probing)
 

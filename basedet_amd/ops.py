@@ -631,6 +631,36 @@ def sgd_momentum_step(w, v, g, lr, momentum, wd, grad_scale=1.0):
                                    float(grad_scale), stream_ptr()), "bd_sgd_momentum_step")
 
 
+class WgradQueue:
+    """bd_wgrad_queue_*: weight-gradient launches whose reduces are deferred to ONE launch per flush (the solver's gradient buckets).
+    Every queued layer must keep its own workspace untouched until `flush`."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(L().bd_wgrad_queue_create(C.byref(self._h)), "bd_wgrad_queue_create")
+
+    def wgrad(self, d, x, g, dw, dbias, ws, row_scale=None, accumulate=False):
+        check(L().bd_conv2d_wgrad_queued(self._h, C.byref(d), ptr(x), ptr(g), ptr(row_scale), ptr(dw), ptr(dbias), int(accumulate), ptr(ws),
+                                         ws.numel() * ws.element_size(), stream_ptr()), "bd_conv2d_wgrad_queued")
+
+    def pending(self):
+        return int(L().bd_wgrad_queue_pending(self._h))
+
+    def flush(self):
+        check(L().bd_wgrad_queue_flush(self._h, stream_ptr()), "bd_wgrad_queue_flush")
+
+    def close(self):
+        if self._h:
+            L().bd_wgrad_queue_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # noqa: BLE001 (interpreter shutdown)
+            pass
+
+
 def clip_grad_value(g, lower, upper, pre_scale=1.0):
     """megengine.optimizer.clip_grad_value over the flat gradient arena, in place (engine/trainer.py:57-61)."""
     check(L().bd_clip_grad_value(ptr(g), g.numel(), float(pre_scale), float(lower), float(upper), stream_ptr()), "bd_clip_grad_value")

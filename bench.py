@@ -102,6 +102,8 @@ class KernelTimer:
                 # Cout <= 64: the 64-channel tile of conv3x3_pp128.hip; the rest: conv3x3.hip
                 return "conv3x3_pp128_kernel" if (ck % 8 == 0 and co % 8 == 0 and co <= 64) else "conv3x3_patch_kernel"
             is3w = d.R == 3 and d.S == 3 and d.pad == 1 and all((d.Hi[i] - 1) // d.stride + 1 == d.Ho[i] for i in range(d.nseg))
+            if is3w and d.stride == 1 and same and d.Cin >= 64 and d.Cout >= 96:
+                return "conv_wgrad3x3_ring_kernel"         # conv_wgrad3x3_ring.hip (bd_wgrad3x3r_eligible): the wide stride-1 layers
             return "conv_wgrad3x3_kernel" if is3w else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")
 
         def wrap(fn, kind):
@@ -618,12 +620,15 @@ def worker(args):
         solver.comm_profile = []          # per step: (backward done on the main stream, last bucket's all-reduce done on the comm stream)
     t0 = time.perf_counter()
     sampled = 0
+    queue_mode = model.wgrad_queue_mode
     for k in range(args.steps):
         sched.step(it); it += 1
         if timer:
             timer.enabled = (k % max(1, args.roofline_every) == 0)
             sampled += int(timer.enabled)
             model.async_wgrad = not timer.enabled     # instrumented steps run serialised: clean per-kernel durations
+            # ... and with one reduce per layer right behind its kernel, inside the event pair (the timed entry points are the un-queued ones)
+            model.wgrad_queue_mode = "layer" if timer.enabled else queue_mode
         if args.serial_wgrad:
             model.async_wgrad = False
         marks[k].record()
@@ -640,6 +645,7 @@ def worker(args):
     if timer:
         timer.enabled = False
         model.async_wgrad = not args.serial_wgrad
+        model.wgrad_queue_mode = queue_mode
     if comm is not None and world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         comm.allreduce(t, "max")

@@ -116,6 +116,20 @@ size_t bd_conv2d_wgrad_bias_workspace_bytes(const bd_conv_desc* d);
 int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw, float* dbias,
                          int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
+/* Deferred weight-gradient reduces (round 4).  bd_conv2d_wgrad / _bias run a layer's partial-sum kernel and then its fixed-order reduce:
+ * two to three launches per layer, 60 reduce launches per RetinaNet-R50 step.  With a queue the caller runs the partial-sum kernels of
+ * several layers back to back (bd_conv2d_wgrad_queued: same arguments and results as bd_conv2d_wgrad_bias, dbias may be NULL) and ONE
+ * launch (bd_wgrad_queue_flush) reduces all of them, in the same fixed order as the per-layer reduce (bitwise identical results).
+ * Each queued layer needs its OWN workspace, left untouched until the flush; dw / dbias are valid after the flush, in `stream` order.
+ * Replaces the same call sites as bd_conv2d_wgrad (MegEngine's autodiff of the convolutions, solver/default_solver.py:118-124). */
+typedef struct bd_wgrad_queue* bd_wgrad_queue_t;
+int bd_wgrad_queue_create(bd_wgrad_queue_t* out);
+int bd_wgrad_queue_destroy(bd_wgrad_queue_t q);
+int bd_wgrad_queue_pending(bd_wgrad_queue_t q);     /* reduce descriptors waiting for a flush */
+int bd_conv2d_wgrad_queued(bd_wgrad_queue_t q, const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
+                           float* dbias, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
+int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream);
+
 /* debug/measurement knob, bit mask (default 3): bit 0 = 3x3/stride-1 forward and dgrad use the patch kernel
  * (conv3x3.hip); bit 1 = BK=32 tiles for 1x1 convs in the generic kernel; bit 2 = unused.
  * 0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip).

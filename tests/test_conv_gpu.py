@@ -600,3 +600,82 @@ def test_wgrad_ring_kernel_agrees_with_the_register_staged_kernel(case):
     assert rel_l2(outs[0][0], outs[1][0]) < 2e-6 and rel_l2(outs[0][1], outs[1][1]) < 2e-6
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
     assert rel_l2(outs[0][1], gy.float().sum(0).cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("case", [(2, 1024, 256, 50, 84), (2, 128, 512, 40, 56), (1, 512, 2048, 13, 21), (2, 256, 64, 30, 40), (1, 72, 200, 9, 11),
+                                  (1, 64, 64, 2, 3)])
+def test_wgrad1x1_ring_kernel_agrees_with_the_register_staged_kernel(case):
+    """conv_wgrad1x1_ring.hip (LDS-DMA ring, persistent workgroups) against conv_wgrad1x1.hip (bit 2 of bd_wgrad_set_transpose_read routes
+    its shapes back there) and against the fp32 definition dW = G^T X: same products in another order -> fp32 rounding only; two launches
+    of the ring kernel are bit-identical; row scale and accumulate go through the ring reduce."""
+    ops = _ops()
+    N, Cin, Cout, H, W = case
+    gen = torch.Generator().manual_seed(9 + Cin + Cout)
+    geo = ops.single(N, H, W)
+    d = ops.conv_desc(geo, geo, Cin, Cout, 1, 1, 1, 0)
+    x = bf16_round(torch.randn(geo.pixels, Cin, generator=gen))
+    gy = bf16_round(torch.randn(geo.pixels, Cout, generator=gen))
+    ref = (gy.double().t() @ x.double()).float().view(Cout, 1, 1, Cin)
+    xd, gd = x.to(torch.bfloat16).cuda(), gy.to(torch.bfloat16).cuda()
+    ws = torch.empty((ops.conv2d_wgrad_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
+    scale = (torch.rand(Cout, generator=gen) + 0.5).cuda()
+    outs = []
+    for knob in (1, 5, 1):
+        ops.L().bd_wgrad_set_transpose_read(knob)
+        dw = torch.full((Cout, 1, 1, Cin), 3.0, dtype=torch.float32, device="cuda")
+        ops.conv2d_wgrad(d, xd, gd, dw, ws)
+        first = dw.cpu()
+        ops.conv2d_wgrad(d, xd, gd, dw, ws, row_scale=scale, accumulate=True)
+        torch.cuda.synchronize()
+        outs.append((first, dw.cpu()))
+    ops.L().bd_wgrad_set_transpose_read(1)
+    assert rel_l2(outs[0][0], ref) < 1e-5
+    assert rel_l2(outs[0][0], outs[1][0]) < 2e-6
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert rel_l2(outs[0][1], ref * (1 + scale.cpu().view(-1, 1, 1, 1))) < 1e-5
+
+
+def test_wgrad_queue_reduces_several_layers_in_one_launch_bit_identically():
+    """bd_wgrad_queue_*: the partial-sum kernels of five layers (ring 3x3 with bias, ring 1x1, register-staged stride-2 3x3, generic 7x7-like
+    filter, narrow 3x3 with bias) run back to back with their own workspaces, ONE flush reduces them; results are bit-identical to the
+    per-layer entry points (same fixed-order sums), accumulate and row scale included, and nothing is pending afterwards."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(21)
+    layers = [  # N, Cin, Cout, H, W, R, stride, pad, bias
+        (2, 128, 136, 19, 27, 3, 1, 1, True), (2, 256, 128, 30, 40, 1, 1, 0, False), (2, 64, 192, 27, 31, 3, 2, 1, False),
+        (1, 64, 64, 12, 14, 5, 1, 2, False), (2, 64, 72, 19, 27, 3, 1, 1, True)]
+    q = ops.WgradQueue()
+    items = []
+    for (N, Cin, Cout, H, W, R, stride, pad, bias) in layers:
+        gin = ops.single(N, H, W)
+        gout = gin.conv_out(R, stride, pad)
+        d = ops.conv_desc(gin, gout, Cin, Cout, R, R, stride, pad)
+        x = bf16_round(torch.randn(gin.pixels, Cin, generator=gen)).to(torch.bfloat16).cuda()
+        gy = bf16_round(torch.randn(gout.pixels, Cout, generator=gen)).to(torch.bfloat16).cuda()
+        scale = (torch.rand(Cout, generator=gen) + 0.5).cuda()
+        nbytes = ops.conv2d_wgrad_bias_workspace_bytes(d) if bias else ops.conv2d_wgrad_workspace_bytes(d)
+        ws = torch.empty((nbytes // 4 + 4,), dtype=torch.float32, device="cuda")
+        ws_ref = torch.empty_like(ws)
+        dw_ref = torch.full((Cout, R, R, Cin), 2.0, dtype=torch.float32, device="cuda")
+        db_ref = torch.full((Cout,), 2.0, dtype=torch.float32, device="cuda") if bias else None
+        if bias:
+            ops.conv2d_wgrad_bias(d, x, gy, dw_ref, db_ref, ws_ref, row_scale=scale, accumulate=True)
+        else:
+            ops.conv2d_wgrad(d, x, gy, dw_ref, ws_ref, row_scale=scale, accumulate=True)
+        dw = torch.full((Cout, R, R, Cin), 2.0, dtype=torch.float32, device="cuda")
+        db = torch.full((Cout,), 2.0, dtype=torch.float32, device="cuda") if bias else None
+        q.wgrad(d, x, gy, dw, db, ws, row_scale=scale, accumulate=True)
+        items.append((dw, db, dw_ref, db_ref, ws, x, gy, scale))
+    assert q.pending() >= len(layers)
+    before = [it[0].clone() for it in items]
+    torch.cuda.synchronize()
+    assert all(bool((b == 2.0).all()) for b in before)           # nothing is reduced before the flush
+    q.flush()
+    torch.cuda.synchronize()
+    assert q.pending() == 0
+    for i, (dw, db, dw_ref, db_ref, *_rest) in enumerate(items):
+        assert torch.equal(dw, dw_ref), i
+        if db is not None:
+            assert torch.equal(db, db_ref), i
+    q.flush()                                                    # an empty flush is a no-op
+    q.close()
