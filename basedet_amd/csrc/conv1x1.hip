@@ -890,7 +890,11 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
         return 0;
     }
     const size_t lds = 4 * TILE_BYTES;
-    hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, false>), dim3(grid), dim3(256), lds, stream, p);
+    static const int reg_depth = getenv("BD_DENSE1X1_REGDEPTH") ? atoi(getenv("BD_DENSE1X1_REGDEPTH")) : 1;     // register sets in flight (measurement)
+    if (reg_depth == 2) hipLaunchKernelGGL((conv1x1_dense_kernel<2, 3, false>), dim3(grid), dim3(256), lds, stream, p);
+    else if (reg_depth == 3) hipLaunchKernelGGL((conv1x1_dense_kernel<3, 3, false>), dim3(grid), dim3(256), lds, stream, p);
+    else if (reg_depth == 4) hipLaunchKernelGGL((conv1x1_dense_kernel<4, 3, false>), dim3(grid), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, false>), dim3(grid), dim3(256), lds, stream, p);
     return 0;
 }
 

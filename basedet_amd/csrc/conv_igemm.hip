@@ -439,6 +439,7 @@ bool is_3x3s1(const bd_conv_desc* d) {
     return true;
 }
 int g_use_patch3x3 = 1;
+int g_skip_s2_3x3 = 0;          // bd_conv_set_patch3x3 bit 4: timing A/B only -- the stride-2 3x3 forward / data-gradient launches return at once
 int g_bk32_for_1x1 = 1;
 // Stride-2 3x3 layers stay on the generic kernel, and there the tiles are short (the data gradient visits 1 / 2 / 2 / 4 taps per
 // parity class) and bound by the latency of their few K steps: BK=32 tiles (32 KB of LDS instead of 80 KB: four workgroups per CU
@@ -461,6 +462,7 @@ extern int g_pp_persistent;
 extern "C" int bd_conv_set_patch3x3(int enable) {
     g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1;
     g_patch_dma = ((enable >> 3) & 1) ^ 1;
+    g_skip_s2_3x3 = (enable >> 4) & 1;
     g_patch_pp = ((enable >> 6) & 1) ? 0 : (((enable >> 7) & 1) ? 1 : 2);
     g_patch_pp128 = ((enable >> 9) & 1) ? -1 : ((enable >> 8) & 1);
     g_bk32_s2 = ((enable >> 10) & 1) ^ 1;
@@ -507,6 +509,7 @@ static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_p
     }
     BD_REQUIRE(ybits == nullptr && y8 == nullptr, "conv2d_fwd_bits / _ex: the bit-packed ReLU mask and the e4m3 twin are written by the dense "
                "1x1 kernel only (1x1 / stride 1 over one dense level, Cout %% 32 == 0, tensors < 2 GB)");
+    if (g_skip_s2_3x3 && d->R == 3 && d->S == 3 && d->stride == 2) return BD_OK;       // (A/B: "how much of the step are these launches?")
     if (g_use_patch3x3 && is_3x3s1(d)) {
         bd_conv3x3_patch_launch(d, 0, x, w_packed, bias, add, nullptr, y, flags, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_fwd(3x3 patch)");
@@ -580,6 +583,7 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
     }
     BD_REQUIRE(maskbits == nullptr && dx8 == nullptr, "conv2d_dgrad_bits / _ex: the bit-packed ReLU mask is read, and the e5m2 twin written, by "
                "the dense 1x1 kernel only (1x1 / stride 1 over one dense level, Cin %% 32 == 0, tensors < 2 GB)");
+    if (g_skip_s2_3x3 && d->R == 3 && d->S == 3 && d->stride == 2) return BD_OK;
     if (g_use_patch3x3 && is_3x3s1(d)) {
         bd_conv3x3_patch_launch(d, 1, g, w_packed_t, nullptr, add, mask, dx, flags, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_dgrad(3x3 patch)");

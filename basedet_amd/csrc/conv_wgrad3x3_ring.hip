@@ -62,8 +62,8 @@ struct RParams {
 __device__ unsigned long long g_rk_stamp[8][8];
 #endif
 
-__device__ __forceinline__ void rk_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
+__device__ __forceinline__ void rk_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff, int soff = 0) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
 }
 
 __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p) {
@@ -124,11 +124,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
     int c_n = 0, c_s = 0, c_by = 0, c_bx = 0, c_rows = 1;
     RSeg sg = p.seg[0];
     int x_vec[2], g_vec[2];
+    unsigned x_in[2], g_in[2];        // the same offsets with the static validity folded in (X_NONE): what an interior patch requests
     auto level_vectors = [&]() {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             x_vec[k] = ((x_iy[k] * sg.Wi + x_ix[k]) * p.Cin) * 2 + x_cb[k];
             g_vec[k] = ((g_ry[k] * sg.W + g_rx[k]) * p.Cout) * 2 + g_cb[k];
+            x_in[k] = x_ok[k] ? (unsigned)x_vec[k] : X_NONE;
+            g_in[k] = g_ok[k] ? (unsigned)g_vec[k] : X_NONE;
         }
     };
     auto seek = [&](int pid) {
@@ -161,6 +164,16 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
         const unsigned Xs = lds0 + stage * STAGE + wave * 1024;            // LDS byte address of this wave's first piece
         const int ys = c_by * 8 - 1, xs = c_bx * 8 - 1;
         const int xorg = ((c_n * p.in_ppi + sg.in_off + ys * sg.Wi + xs) * p.Cin + ci0) * 2;       // may be negative; valid sums are not
+        // interior patch (a workgroup-uniform test; most patches): the lane offset is the per-level constant, the patch origin rides in the
+        // scalar offset -- no per-lane arithmetic in the load segment
+        if (!dead && ys >= 0 && xs >= 0 && ys + XW <= sg.Hi && xs + XW <= sg.Wi) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k == 1 && !two_x) break;
+                rk_dma16(x_rsrc, Xs + k * 8192, x_in[k], xorg);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (k == 1 && !two_x) break;
@@ -172,6 +185,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
         const unsigned Gs = lds0 + stage * STAGE + X_BYTES + wave * 1024;
         const int y0 = c_by * 8, x0 = c_bx * 8;
         const int gorg = ((c_n * p.out_ppi + sg.out_off + y0 * sg.W + x0) * p.Cout + co0) * 2;
+        if (!dead && y0 + 8 <= sg.H && x0 + 8 <= sg.W) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) rk_dma16(g_rsrc, Gs + k * 8192, g_in[k], gorg);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const bool ok = !dead & g_ok[k] & (y0 + g_ry[k] < sg.H) & (x0 + g_rx[k] < sg.W);

@@ -104,6 +104,10 @@ class KernelTimer:
             is3w = d.R == 3 and d.S == 3 and d.pad == 1 and all((d.Hi[i] - 1) // d.stride + 1 == d.Ho[i] for i in range(d.nseg))
             if is3w and d.stride == 1 and same and d.Cin >= 64 and d.Cout >= 96:
                 return "conv_wgrad3x3_ring_kernel"         # conv_wgrad3x3_ring.hip (bd_wgrad3x3r_eligible): the wide stride-1 layers
+            dense1 = (is1 and d.stride == 1 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0 and d.Cin >= 64 and d.Cout >= 64
+                      and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0])
+            if dense1:
+                return "conv_wgrad1x1_ring_kernel"         # conv_wgrad1x1_ring.hip (bd_wgrad1x1r_eligible): every stride-1 1x1 layer
             return "conv_wgrad3x3_kernel" if is3w else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")
 
         def wrap(fn, kind):
@@ -501,6 +505,11 @@ def main():
                     help="Faster R-CNN: packed-bf16 atomic RoIAlign backward (running bf16 sums; default is the fp32 scatter)")
     ap.add_argument("--dense1x1", type=int, default=None, help="ablation: bd_conv_set_dense1x1 (0 = generic kernel for the dense 1x1 launches)")
     ap.add_argument("--no-mask-bits", action="store_true", help="ablation: bf16 activations instead of bit-packed ReLU gates as dgrad masks")
+    ap.add_argument("--skip-s2-3x3-after-warmup", action="store_true",
+                    help="timing A/B only: after the warm-up steps the 3x3 / stride-2 forward and data-gradient launches become no-ops (their "
+                         "outputs keep the last warm-up step's values): the step-time difference is what those launches cost")
+    ap.add_argument("--wgrad-knob", type=int, default=None,
+                    help="ablation: bd_wgrad_set_transpose_read bit mask (5 = the ring-staged weight-gradient kernels off: rounds 1-3 kernels)")
     ap.add_argument("--conv-knob", type=int, default=None,
                     help="ablation: bd_conv_set_patch3x3 bit mask (include/basedet_hip.h) applied before the run")
     args = ap.parse_args()
@@ -605,6 +614,8 @@ def worker(args):
         ops.L().bd_conv_set_patch3x3(args.conv_knob)
     if args.dense1x1 is not None:
         ops.L().bd_conv_set_dense1x1(args.dense1x1)
+    if args.wgrad_knob is not None:
+        ops.L().bd_wgrad_set_transpose_read(args.wgrad_knob)
     if args.no_mask_bits:
         model.use_mask_bits = False
     if args.roi_bwd_pk:
@@ -615,6 +626,8 @@ def worker(args):
         sched.step(it); it += 1
         last = solver.minimize(model, batch)
     sync()
+    if args.skip_s2_3x3_after_warmup:             # (A/B only: see the flag's help; the result line says so)
+        ops.L().bd_conv_set_patch3x3((args.conv_knob if args.conv_knob is not None else 3) | 16)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]       # step boundaries on the main stream (p50 / p95)
     if comm is not None:
         solver.comm_profile = []          # per step: (backward done on the main stream, last bucket's all-reduce done on the comm stream)
@@ -698,6 +711,8 @@ def worker(args):
             "step_ms_p50": round(float(np.percentile(step_ms, 50)), 3), "step_ms_p95": round(float(np.percentile(step_ms, 95)), 3),
             "step_ms_note": "device time between step boundaries on rank 0's main stream (HIP events), instrumented steps included",
         }
+        if args.skip_s2_3x3_after_warmup:
+            out["INVALID_AS_THROUGHPUT"] = "timing A/B: the 3x3 / stride-2 forward and data-gradient launches were skipped in the timed steps"
         if ref_proto:
             out["reference_protocol"] = ref_proto
         if comm is not None:

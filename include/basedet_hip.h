@@ -134,7 +134,8 @@ int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream);
  * (conv3x3.hip); bit 1 = BK=32 tiles for 1x1 convs in the generic kernel; bit 2 = unused.
  * 0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip).
  * Ablation bits (set = feature OFF unless noted): bit 3 = register-staged instead of LDS-DMA weights in the patch kernel;
- * bit 4 = unused; bit 5 = no early epilogue-operand prefetch in the generic kernel;
+ * bit 4 = (set = ON) TIMING A/B ONLY: every 3x3 / stride-2 forward and data-gradient launch returns at once, its output keeps whatever it
+ * held (scripts: how much of a step the strided launches are; never set in a run whose numbers are compared); bit 5 = no early epilogue-operand prefetch in the generic kernel;
  * bit 6 = no staggered 256-channel patch instance (conv3x3_pp.hip; by default taken for every Cout > 128, Cin % 8 == 0 shape);
  * bit 7 = take it only where its grid fills the chip better than the 128-channel instance's (makespan estimate);
  * bit 8 = (set = ON) staggered 128-channel patch instance (conv3x3_pp128.hip) for every other 3x3/stride-1 shape (its 64-channel

@@ -1,12 +1,13 @@
-"""Regenerates the round-3 measurement tables of DESIGN.md section 5 (between the R3_TABLES markers) from profiles/r03_*.
+"""Regenerates the round-4 measurement tables of DESIGN.md section 5 (between the R4_TABLES markers) and the fp8 stability rows of section 7
+from profiles/r04_*.
 python scripts/design_tables.py"""
 import csv, json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda n: os.path.join(ROOT, "profiles", n)
-d = json.load(open(P("r03_bench.json")))
+d = json.load(open(P("r04_bench.json")))
 rows = [d["roofline"]] + d["roofline_others"]
-sq = json.load(open(P("r03_pmc_sq.json")))["kernels"]
-ks = list(csv.DictReader(open(P("r03_bench_kernel_stats.csv"))))
+sq = json.load(open(P("r04_pmc_sq.json")))["kernels"]
+ks = list(csv.DictReader(open(P("r04_bench_kernel_stats.csv"))))
 
 
 def rocprof_avg(name):
@@ -22,22 +23,22 @@ def rocprof_avg(name):
 
 
 W = {}
-for l in open(P("r03_workloads.txt")).read().strip().splitlines():
+for l in open(P("r04_workloads.txt")).read().strip().splitlines():
     k, v, ms = l.rsplit(" ", 2)
     W[k] = (float(v), float(ms))
-r101 = json.load(open(P("r03_bench_r101_fp8.json"))); r101b = json.load(open(P("r03_bench_r101_bf16_b32.json")))
+r101 = json.load(open(P("r04_bench_r101_fp8.json"))); r101b = json.load(open(P("r04_bench_r101_bf16_b32.json")))
 t = []
-t.append("### Headline and protocol legs (`profiles/r03_bench.json`: the default `python bench.py`, 100 timed steps after 20 warm-up)\n")
+t.append("### Headline and protocol legs (`profiles/r04_bench.json`: the default `python bench.py`, 100 timed steps after 20 warm-up)\n")
 t.append("| leg | img/s | ms/step (mean; p50 / p95) | note |\n|---|---|---|---|")
-t.append(f"| RetinaNet-R50-FPN, inputs resident in HBM (**`value`**) | **{d['value']:.1f}** (round 2: 577.5; driver-run 588.1) | {d['ms_per_step']:.2f}; {d['step_ms_p50']:.2f} / {d['step_ms_p95']:.2f} | `whole_step_mfma_frac` {d['config']['whole_step_mfma_frac']:.3f} |")
+t.append(f"| RetinaNet-R50-FPN, inputs resident in HBM (**`value`**) | **{d['value']:.1f}** (round 3: 614.2; driver-run 611.8) | {d['ms_per_step']:.2f}; {d['step_ms_p50']:.2f} / {d['step_ms_p95']:.2f} | `whole_step_mfma_frac` {d['config']['whole_step_mfma_frac']:.3f} |")
 rp = d["reference_protocol"]
-t.append(f"| same step, the reference harness's protocol (`tools/benchmark.py:125-133`: float64 host batch → fp32 → H2D inside the step, device sync around every step) — PCIe-inclusive, never `value` | **{rp['images_per_sec']:.0f}** (round 2: 275–321) | {rp['ms_per_step_mean']:.1f}; {rp['ms_p50']:.1f} / {rp['ms_p95']:.1f} (round 2: 46.9 / 90.8) | `bd_h2d_submit`: threaded conversion into pinned chunks, per-chunk DMA |")
+t.append(f"| same step, the reference harness's protocol (`tools/benchmark.py:125-133`: float64 host batch → fp32 → H2D inside the step, device sync around every step) — PCIe-inclusive, never `value` | **{rp['images_per_sec']:.0f}** (round 3: 488) | {rp['ms_per_step_mean']:.1f}; {rp['ms_p50']:.1f} / {rp['ms_p95']:.1f} | `bd_h2d_submit`: threaded conversion into pinned chunks, per-chunk DMA |")
 cb = d["cpu_baseline"]
 _m = re.search(r"([0-9.]+) s/iter", cb["sample"])
 s_iter = _m.group(1) if _m else "?"
 t.append(f"| CPU baseline, oracle (`kind: \"port\"`), {cb['cpu']}, {cb['cores']} threads: batch 2 × 800×1344 | {cb['value']:.3f} | {s_iter} s / iter | C1 (R18, 2 × 512×512) in full: {cb['c1_retinanet_r18_2x512x512']['value']:.2f} img/s |")
 t.append("")
-t.append("### Per kernel (HIP events on one step in 25; `traffic` = PMC `FETCH_SIZE` / `WRITE_SIZE` child passes of the same run; rocprofv3 `--kernel-trace --stats` of `bench.py --steps 10 --warmup 3 --serial-wgrad` in `profiles/r03_bench_kernel_stats.csv`)\n")
+t.append("### Per kernel (HIP events on one step in 25; `traffic` = PMC `FETCH_SIZE` / `WRITE_SIZE` child passes of the same run; rocprofv3 `--kernel-trace --stats` of `bench.py --steps 10 --warmup 3 --serial-wgrad` in `profiles/r04_bench_kernel_stats.csv`)\n")
 t.append("| kernel | ms / step | launches | roof | achieved | frac | HBM traffic vs algorithmic per launch | avg launch: events vs rocprofv3 | MFMA busy / wait_any (SQ) |\n|---|---|---|---|---|---|---|---|---|")
 for i, r in enumerate(rows):
     k = r["kernel"]; s = sq.get(k, {}); ra = rocprof_avg(k)
@@ -45,17 +46,44 @@ for i, r in enumerate(rows):
              f"{(r['traffic'] or 0) / 1e6:.0f} vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB | {r['avg_launch_us']:.1f} vs {ra:.1f} µs | {s.get('mfma_busy_frac_of_simd_cycles', '—')} / {s.get('wait_any_frac', '—')} |"
              if ra else f"| `{k}` | {r['ms_per_step']:.2f} | {r['launches_per_step']} | {r['bound'].upper()} | {r['achieved']:.0f} {r['unit']} | **{r['frac']:.3f}** | {(r['traffic'] or 0) / 1e6:.0f} vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB | {r['avg_launch_us']:.1f} µs | — |")
 t.append("")
-t.append("The two weight-gradient rows time the whole `bd_conv2d_wgrad` call with events (kernel + its `wgrad_reduce_kernel` launch), rocprofv3 the kernel alone.\n")
-t.append("### Other workloads (`profiles/r03_workloads.txt`, one box, `--no-roofline`, 20–30 steps; builder-run)\n")
+t.append("The weight-gradient rows time the whole `bd_conv2d_wgrad` call with events (kernel + its reduce: instrumented steps run one reduce per layer), rocprofv3 the kernel alone; "
+         "their `traffic` is the kernel's (slab writes included), the reduce's reads are `wgrad_batch_reduce_kernel`'s.\n")
+t.append("### Other workloads (`profiles/r04_workloads.txt`, one box, `--no-roofline`, 20–30 steps; builder-run)\n")
 t.append("| workload | img/s | ms/step |\n|---|---|---|")
 for k, (v, ms) in W.items():
     t.append(f"| `{k}` | {v:.1f} | {ms:.2f} |")
 t.append("")
-t.append(f"BASELINE config 5 on one GPU (`profiles/r03_bench_r101_fp8.json`, batch 32): **{r101['value']:.1f} img/s**, {r101['ms_per_step']:.1f} ms/step "
+t.append(f"BASELINE config 5 on one GPU (`profiles/r04_bench_r101_fp8.json`, batch 32): **{r101['value']:.1f} img/s**, {r101['ms_per_step']:.1f} ms/step "
          f"(fp8 forward + e5m2 data gradients under per-group delayed scales, the default) against bf16 {r101b['value']:.1f} ({r101b['ms_per_step']:.1f} ms); "
          f"dominant kernel `{r101['roofline']['kernel']}` {r101['roofline']['ms_per_step']:.1f} ms at {r101['roofline']['frac']:.3f} of the {r101['roofline']['peak']:.0f} {r101['roofline']['unit']} roof.\n")
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
-s = re.sub(r"<!-- R3_TABLES_BEGIN -->.*<!-- R3_TABLES_END -->", "<!-- R3_TABLES_BEGIN -->\n" + "\n".join(t).replace("\\", "\\\\") + "\n<!-- R3_TABLES_END -->", s, flags=re.S)
+s = re.sub(r"<!-- R4_TABLES_BEGIN -->.*<!-- R4_TABLES_END -->", "<!-- R4_TABLES_BEGIN -->\n" + "\n".join(t).replace("\\", "\\\\") + "\n<!-- R4_TABLES_END -->", s, flags=re.S)
 open(path, "w").write(s)
-print("DESIGN.md section 5 tables regenerated")
+# fp8 stability rows (section 7)
+rows = []
+import glob
+for f in sorted(glob.glob(P("r04_fp8_stability_lr*.txt")), reverse=True):
+    lr = re.search(r"lr([0-9.]+)\.txt", f).group(1)
+    by = {}
+    for l in open(f):
+        if not l.startswith("seed"):
+            continue
+        _, name, rc, losses, fin = [x.strip() for x in l.split("|")]
+        fl = fin.replace("final/img_s", "").split()
+        ok = rc == "rc 0" and fl and fl[0] not in ("None", "nan")
+        by.setdefault(name, []).append((ok, float(fl[0]) if ok else None, float(fl[1]) if ok and len(fl) > 1 else None))
+    def cell(name):
+        v = by.get(name)
+        if not v:
+            return "—"
+        good = [x for x in v if x[0]]
+        fin = ", ".join(f"{x[1]:.3f}" if x[0] else "diverged" for x in v)
+        ips = sum(x[2] for x in good) / len(good) if good else 0
+        return f"**{len(good)} / {len(v)}** finish ({fin}); {ips:.0f} img/s"
+    rows.append(f"| {lr} (`profiles/{os.path.basename(f)}`) | {cell('bf16')} | {cell('fp8 default (e5m2 dgrad, group scales)')} | {cell('fp8 forward only')} |")
+s = open(path).read()
+if "FP8_ROWS" in s:
+    s = s.replace("FP8_ROWS", "\n".join(rows))
+open(path, "w").write(s)
+print("DESIGN.md section 5 tables and fp8 rows regenerated")
