@@ -115,7 +115,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + (
 // NC = 64-channel wave columns: 2 = the 128-channel tile (four waves); 4 = a 256-channel x 128-pixel tile of EIGHT waves (DMA form only):
 // the activation rows are fetched once per 256 output channels instead of once per 128 -- the class is bound by the bytes it moves
 // between L2 and the CUs -- while the pixel granularity of the grid stays 128.
-template <int DEPTH, int WAVES, bool DMA, int NC = 2>
+template <int DEPTH, int WAVES, bool DMA, int NC = 2, int EBATCH = EPI_BATCH>
 __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1 p) {
     static_assert(NC == 2 || (NC == 4 && DMA), "the 256-channel tile exists in the LDS-DMA form only");
     constexpr int TCW = 64 * NC;                    // channels per tile
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
                 bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
             }
     }
-    constexpr int EB = NC == 4 ? 2 : EPI_BATCH;        // the eight-wave tile runs at a 128-register budget
+    constexpr int EB = NC == 4 ? 2 : EBATCH;           // the eight-wave tile runs at a 128-register budget
 #pragma unroll
     for (int part = 0; part < 8 / EB; ++part) {
     u32x4_t e_aux[EB];     // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
@@ -890,6 +890,8 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
         return 0;
     }
     const size_t lds = 4 * TILE_BYTES;
+    // (round 4, measured and removed: all eight epilogue operands requested at once -- EBATCH = 8 at three waves per SIMD -- 5.44 ms over
+    // the step's launches against 5.41: the epilogue is not short of requests in flight)
     static const int reg_depth = getenv("BD_DENSE1X1_REGDEPTH") ? atoi(getenv("BD_DENSE1X1_REGDEPTH")) : 1;     // register sets in flight (measurement)
     if (reg_depth == 2) hipLaunchKernelGGL((conv1x1_dense_kernel<2, 3, false>), dim3(grid), dim3(256), lds, stream, p);
     else if (reg_depth == 3) hipLaunchKernelGGL((conv1x1_dense_kernel<3, 3, false>), dim3(grid), dim3(256), lds, stream, p);

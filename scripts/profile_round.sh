@@ -31,7 +31,7 @@ for a in "--batch 32 --fp8 --model-opt FP8_DGRAD=0" "--batch 16" "--batch 16 --w
   python3 bench.py --workload retinanet_r101_800x1344 $a --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r101 $a', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 done
 BD_FORCE_ALLREDUCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>$O/torchrun.err | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('torchrun world1 forced allreduce', d['value'], d['ms_per_step'])" >> $O/workloads.txt
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/exp/ingest_rate.hip -o /tmp/ingest_rate 2>/dev/null && /tmp/ingest_rate > $O/r04_ingest_rate.txt
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/exp/ingest_rate_dma.hip -o /tmp/ingest_rate_dma 2>/dev/null && /tmp/ingest_rate_dma > $O/r04_ingest_rate.txt
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/exp/ingest_rate_reg.hip -o /tmp/ingest_rate_reg 2>/dev/null && /tmp/ingest_rate_reg >> $O/r04_ingest_rate.txt
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/exp/ingest_rate_mix.hip -o /tmp/ingest_rate_mix 2>/dev/null && /tmp/ingest_rate_mix >> $O/r04_ingest_rate.txt
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/exp/epi_rows.hip -o /tmp/epi_rows 2>/dev/null && /tmp/epi_rows >> $O/r04_ingest_rate.txt
