@@ -4,8 +4,13 @@ wrappers over the HIP trunk and head kernels.
 The reference composes a detector from these modules (models/det/retinanet.py:40-52, layers/backbone/build.py:20-39,
 layers/head/retina_head.py:9-112, layers/head/point_head.py:12-151).  Here the detector owns its layers in one arena
 (models/fpn_base.py), so each wrapper holds a detector instance and runs the matching slice of its forward: same inputs and outputs
-as the reference module (lists / dicts of NCHW fp32 tensors), computed by the bf16 NHWC kernels.  Forward only -- training goes
-through the model classes, whose backward is the explicit dgrad / wgrad schedule."""
+as the reference module (lists / dicts of NCHW fp32 tensors), computed by the bf16 NHWC kernels.
+
+The head modules also run BACKWARD (round 4): `head.backward(d_logits, d_offsets[, d_ctrness])` takes the gradients of the forward's outputs
+(same lists of NCHW tensors), runs the detector's explicit dgrad / wgrad schedule for the head and returns the gradients with respect to
+the input features; `head.grads()` then holds the parameter gradients under the reference's names (what MegEngine's GradManager would
+hand over for `layers/head/retina_head.py` / `point_head.py`).  So a head can be composed with other code in a training loop; whole-model
+training still goes through the model classes, which fuse target assignment and losses into the same schedule."""
 import torch
 
 from .. import ops
@@ -112,7 +117,29 @@ class _Head(_Trunk):
         return pl
 
 
-class RetinaNetHead(_Head):
+def _store(dst, geom, grads, C):
+    """lists of NCHW gradients -> the detector's multi-level NHWC gradient buffer (channels beyond C -- padding columns -- zeroed)."""
+    N = geom.N
+    v = dst.view(N, geom.pix_per_img, -1)
+    v.zero_()
+    for i, g in enumerate(grads):
+        assert tuple(g.shape[2:]) == (geom.H[i], geom.W[i]) and g.shape[1] == C, "gradient shapes must match the forward outputs"
+        v[:, geom.off[i]: geom.off[i] + g.shape[2] * g.shape[3], :C] = g.permute(0, 2, 3, 1).reshape(N, -1, C).to(dst.dtype)
+
+
+class _HeadBackward:
+    def _finish(self, pl):
+        m = self.model
+        m._join_wgrads()
+        torch.cuda.current_stream().synchronize()
+        return [_level(pl.g_P, pl.pyr, i) for i in range(pl.pyr.nlev)]
+
+    def grads(self):
+        """Parameter gradients of the last backward() under the reference's names (`head.*`)."""
+        return {k: v for k, v in self.model.reference_grads().items() if k.startswith("head.")}
+
+
+class RetinaNetHead(_Head, _HeadBackward):
     """layers/head/retina_head.py:9-112: features [P3..P7] -> (logits [(N, A*K, H, W)], offsets [(N, A*4, H, W)])."""
 
     def __init__(self, cfg, input_shape=None, params=None, model=None):
@@ -123,11 +150,22 @@ class RetinaNetHead(_Head):
         m = self.model
         m.head_forward(pl)
         n = pl.pyr.nlev
+        self._pl = pl
         return ([_level(pl.logits, pl.pyr, i) for i in range(n)],
                 [_level(pl.offsets, pl.pyr, i, m.num_anchors * 4) for i in range(n)])
 
+    def backward(self, d_logits, d_offsets):
+        """Gradients of the last forward's outputs -> gradients of its input features (list of NCHW fp32), parameter gradients in grads()."""
+        pl, m = self._pl, self.model
+        m._cur = pl
+        pl.wq_off, pl.wq_pending = 0, 0
+        _store(pl.d_logits, pl.pyr, d_logits, m.num_anchors * m.num_classes)
+        _store(pl.d_offsets, pl.pyr, d_offsets, m.num_anchors * 4)
+        m.head_backward(pl, pl.wgrad_ws, pl.colsum_ws)
+        return self._finish(pl)
 
-class PointHead(_Head):
+
+class PointHead(_Head, _HeadBackward):
     """layers/head/point_head.py:12-151: features -> (logits [(N, K, H, W)], offsets [(N, 4, H, W)], ctrness [(N, 1, H, W)])."""
 
     def __init__(self, cfg, input_shape=None, params=None, model=None):
@@ -143,4 +181,19 @@ class PointHead(_Head):
         logits = [_level(pl.logits, pl.pyr, i) for i in range(n)]
         offsets = [_level(pl.offsets, pl.pyr, i, 4) for i in range(n)]
         ctr = [_level(pl.raw, pl.pyr, i)[:, 4:5].contiguous() for i in range(n)]
+        self._pl = pl
         return logits, offsets, ctr
+
+    def backward(self, d_logits, d_offsets, d_ctrness):
+        """As RetinaNetHead.backward; d_offsets are the gradients of the DECODED offsets (relu(x * scale_l) * stride_l, point_head.py:143)."""
+        pl, m = self._pl, self.model
+        m._cur = pl
+        pl.wq_off, pl.wq_pending = 0, 0
+        _store(pl.d_logits, pl.pyr, d_logits, m.num_classes)
+        _store(pl.d_off, pl.pyr, d_offsets, 4)
+        N = pl.pyr.N
+        dc = pl.d_ctr.view(N, pl.pyr.pix_per_img)
+        for i, g in enumerate(d_ctrness):
+            dc[:, pl.pyr.off[i]: pl.pyr.off[i] + g.shape[2] * g.shape[3]] = g.reshape(N, -1).to(dc.dtype)
+        m.head_backward(pl, pl.wgrad_ws, pl.colsum_ws)
+        return self._finish(pl)
