@@ -20,6 +20,7 @@ SOURCES = {
     "conv3x3_pp.hip": [],
     "conv3x3_pp128.hip": [],
     "conv1x1.hip": [],
+    "conv1x1_ring.hip": [],
     "bottleneck_fused.hip": [],
     "conv_fp8.hip": [],
     "conv3x3_pp8.hip": [],

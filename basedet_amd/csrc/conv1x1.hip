@@ -42,6 +42,9 @@ struct P1 {
     int s2_src, s2_dst, dW, dHW, bW, bHW, Mbig;
     unsigned sr_seed;         // != 0: stochastic rounding of the e5m2 twin (common.h)
     float inv_dW, inv_dHW;
+#ifdef BD_D1_STAMP
+    int dbg;                  // BD_D1_ABLATE (timing only): 1 no stores, 2 no epilogue operand loads, 4 every tile reads pixel tile 0, 8 no K loop
+#endif
 };
 
 // row of the big grid under small-grid pixel m (m < 2^24: the float quotients are within one of the integer ones)
@@ -115,7 +118,14 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + (
 // NC = 64-channel wave columns: 2 = the 128-channel tile (four waves); 4 = a 256-channel x 128-pixel tile of EIGHT waves (DMA form only):
 // the activation rows are fetched once per 256 output channels instead of once per 128 -- the class is bound by the bytes it moves
 // between L2 and the CUs -- while the pixel granularity of the grid stays 128.
-template <int DEPTH, int WAVES, bool DMA, int NC = 2, int EBATCH = EPI_BATCH>
+#ifdef BD_D1_STAMP          // diagnostic build only (scripts/exp/d1_stamp.py): 100 MHz stamps of every workgroup's phases + where it ran
+__device__ unsigned long long g_d1_stamp[32768][4];
+#define D1_T(k) do { if (threadIdx.x == 0 && blockIdx.x < 32768) g_d1_stamp[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define D1_T(k) do { } while (0)
+#endif
+
+template <int DEPTH, int WAVES, bool DMA, int NC = 2, int EBATCH = EPI_BATCH, bool EARLY = false>
 __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1 p) {
     static_assert(NC == 2 || (NC == 4 && DMA), "the 256-channel tile exists in the LDS-DMA form only");
     constexpr int TCW = 64 * NC;                    // channels per tile
@@ -127,6 +137,11 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
     const int wave = tid >> 6;
     const int wc = wave >> 1;   // channel column (64 channels)
     const int wp = wave & 1;    // pixel half
+    D1_T(0);
+#ifdef BD_D1_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 32768)
+        g_d1_stamp[blockIdx.x][3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
 
     // XCD-aware bijective remap: consecutive tile ids (the channel tiles of one pixel tile, then the next pixel tile) share an XCD's L2
     const int nwg = gridDim.x;
@@ -155,10 +170,18 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
         const int rho = lrow & 15;
         const int co = co0 + (lrow & 64) + 32 * ((lrow >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow >> 4) & 1) + (rho & 3);
         a_voff[i] = co < p.CO ? (unsigned)(co * p.CK + chunk * 8) * 2u : X_NONE;
+#ifdef BD_D1_STAMP
+        const int m = (p.dbg & 4) ? lrow : m0 + lrow;
+#else
         const int m = m0 + lrow;
+#endif
         b_voff[i] = m < p.M ? (unsigned)((p.s2_src ? s2_big_row(p, m) : m) * p.CK + chunk * 8) * 2u : X_NONE;
     }
+#ifdef BD_D1_STAMP
+    const int nsteps = (p.dbg & 8) ? 0 : (p.CK + BK - 1) / BK;
+#else
     const int nsteps = (p.CK + BK - 1) / BK;
+#endif
 
     u32x4_t ra[DEPTH][2], rb[DEPTH][2];
     auto stage_load = [&](int step, u32x4_t (&a)[2], u32x4_t (&b)[2]) {
@@ -212,6 +235,30 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
     const bool want_add = add_before || add_after;
     const bool mask_bf = (p.flags & BD_EPI_MASK) && p.mask;
     const bool mask_bits = (p.flags & BD_EPI_MASK) && p.maskbits && !p.mask;
+    constexpr int EB = NC == 4 ? 2 : (EARLY ? 8 : EBATCH);           // the eight-wave tile runs at a 128-register budget
+    u32x4_t e_aux[EB];     // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
+    unsigned e_bits[EB];
+    auto request = [&](int part) {
+#pragma unroll
+        for (int qq = 0; qq < EB; ++qq) {
+            const int q = part * EB + qq;
+            const int j = q >> 1, half = q & 1;
+            const int m = m0 + wp * 64 + j * 16 + (lane & 15);
+#ifdef BD_D1_STAMP
+            const bool ok = m < p.M && cbase + 32 * half < p.CO && !(p.dbg & 2);
+#else
+            const bool ok = m < p.M && cbase + 32 * half < p.CO;
+#endif
+            const int drow = (p.s2_dst && ok) ? s2_big_row(p, m) : m;
+            const long long idx = (long long)drow * p.CO + cbase + 32 * half;
+            e_aux[qq] = (u32x4_t){0u, 0u, 0u, 0u}; e_bits[qq] = 0u;
+            if (ok && want_add) e_aux[qq] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
+            else if (ok && mask_bf) e_aux[qq] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
+            if (ok && mask_bits) e_bits[qq] = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * (p.s2_dst ? p.Mbig : p.M) + drow];
+        }
+    };
+    // EARLY: the tile's epilogue operands are requested before the K loop (they are in flight under it; the first K step waits for them)
+    if constexpr (EARLY) { request(0); __builtin_amdgcn_sched_barrier(0); }
     if constexpr (DMA) {
         // ---- main loop, LDS-DMA ring: a stage = two operand tiles of 8 pieces of 1 KiB (16 rows x 64 B); this wave owns pieces wave and
         // wave + 4 of both; lane -> row lane >> 2, position lane & 3, source chunk = position ^ ((row >> 1) & 3) (lds_off on the source side)
@@ -230,7 +277,11 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
         for (int k = 0; k < B_PIECES; ++k) {
             const int lrow = 16 * (wave + NWAVE * k) + (lane >> 2);
             const int ch = (lane & 3) ^ ((lrow >> 1) & 3);
+#ifdef BD_D1_STAMP
+            const int m = (p.dbg & 4) ? lrow : m0 + lrow;
+#else
             const int m = m0 + lrow;
+#endif
             b_src[k] = m < p.M ? (unsigned)((p.s2_src ? s2_big_row(p, m) : m) * p.CK + ch * 8) * 2u : X_NONE;
         }
         const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -245,7 +296,7 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
             for (int k = 0; k < B_PIECES; ++k)
                 dma16(x_rsrc, At + A_BYTES + (uwave + NWAVE * k) * 1024, b_src[k], so);
         };
-        dma(0, 0);
+        if (nsteps > 0) dma(0, 0);
         if (nsteps > 1) dma(1, 1);
         int cs = 0, ps = 2;                       // consumer / producer stage
         for (int t = 0; t < nsteps; ++t) {
@@ -263,7 +314,7 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u)
         if (u < nsteps) stage_load(u, ra[u], rb[u]);
-    stage_write(0, ra[0], rb[0]);
+    if (nsteps > 0) stage_write(0, ra[0], rb[0]);
     __syncthreads();
     for (int t0 = 0; t0 < nsteps; t0 += DEPTH) {
 #pragma unroll
@@ -286,6 +337,7 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
     // fragments have left), then consumed in order: as a load - use - store chain per 16 bytes (what the compiler makes of the plain
     // loop: every unit waits on vmcnt(0), i.e. also on the previous unit's store) a wave keeps 1 KB in flight and the epilogue -- half
     // of this class's bytes -- runs at the latency of 16 dependent round trips per tile.
+    D1_T(1);
     float bias[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) bias[k] = 0.f;
@@ -297,24 +349,9 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
                 bias[4 * q] = bv[0]; bias[4 * q + 1] = bv[1]; bias[4 * q + 2] = bv[2]; bias[4 * q + 3] = bv[3];
             }
     }
-    constexpr int EB = NC == 4 ? 2 : EBATCH;           // the eight-wave tile runs at a 128-register budget
 #pragma unroll
     for (int part = 0; part < 8 / EB; ++part) {
-    u32x4_t e_aux[EB];     // the residual; or the bf16 mask when there is no residual (both: the mask is read in place)
-    unsigned e_bits[EB];
-#pragma unroll
-    for (int qq = 0; qq < EB; ++qq) {
-        const int q = part * EB + qq;
-        const int j = q >> 1, half = q & 1;
-        const int m = m0 + wp * 64 + j * 16 + (lane & 15);
-        const bool ok = m < p.M && cbase + 32 * half < p.CO;
-        const int drow = (p.s2_dst && ok) ? s2_big_row(p, m) : m;
-        const long long idx = (long long)drow * p.CO + cbase + 32 * half;
-        e_aux[qq] = (u32x4_t){0u, 0u, 0u, 0u}; e_bits[qq] = 0u;
-        if (ok && want_add) e_aux[qq] = *reinterpret_cast<const u32x4_t*>(p.add + idx);
-        else if (ok && mask_bf) e_aux[qq] = *reinterpret_cast<const u32x4_t*>(p.mask + idx);
-        if (ok && mask_bits) e_bits[qq] = p.maskbits[(long long)((co0 + wc * 64 + 32 * half) >> 5) * (p.s2_dst ? p.Mbig : p.M) + drow];
-    }
+    if constexpr (!EARLY) request(part);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int qq = 0; qq < EB; ++qq) {
@@ -322,7 +359,11 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
         const int j = q >> 1, half = q & 1;
         const int m = m0 + wp * 64 + j * 16 + (lane & 15);
         {
+#ifdef BD_D1_STAMP
+            const bool ok = m < p.M && cbase + 32 * half < p.CO && !((p.dbg & 1) && acc[0][0][0] != 12345.f);
+#else
             const bool ok = m < p.M && cbase + 32 * half < p.CO;      // CO % 8 == 0
+#endif
             const int drow = (p.s2_dst && ok) ? s2_big_row(p, m) : m;
             const long long idx = (long long)drow * p.CO + cbase + 32 * half;
             float v[8];
@@ -383,7 +424,19 @@ __global__ __launch_bounds__(128 * NC, WAVES) void conv1x1_dense_kernel(const P1
         }
     }
     }   // parts
+#ifdef BD_D1_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores have been acknowledged
+    D1_T(2);
+#endif
 }
+
+#ifdef BD_D1_STAMP
+}  // namespace
+extern "C" int bd_debug_d1_stamp(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_d1_stamp), (size_t)n * 32) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 // ---- one-byte operands (BASELINE config 5) ----------------------------------------------------------------------------------------------
 // The 1x1 class is bound by the bytes it moves between L2 and the CUs (see the 256^2 section below), so with e4m3 activations /
@@ -840,12 +893,16 @@ extern "C" int bd_conv_set_dense1x1(int depth) {
     return BD_OK;
 }
 
+int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits, void* y,
+                           unsigned* ybits, void* y8, long long M, int CK, int CO, int flags, hipStream_t stream);      // conv1x1_ring.hip
+
 // Called by bd_conv2d_fwd / bd_conv2d_dgrad (conv_igemm.hip) for 1x1 / stride 1 / pad 0 launches over one dense level.
 // Returns 0 when the launch was taken, 1 when the shape is left to the generic kernel.
 int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits,
                             void* y, unsigned* ybits, void* y8, float q_scale, int y8_bf8, long long M, int CK, int CO, int flags,
                             hipStream_t stream) {
     if (g_conv1x1_depth == 0) return 1;
+    if (g_conv1x1_depth == 1 && bd_conv1x1_ring_launch(x, w, bias, add, mask, maskbits, y, ybits, y8, M, CK, CO, flags, stream) == 0) return 0;
     const long long xb = M * CK * 2, wb = (long long)CO * CK * 2;
     if (xb >= 0x7fffffffll || wb >= 0x7fffffffll || M >= (1ll << 24)) return 1;
     if ((maskbits || ybits) && (CO % 32 != 0)) return 1;
@@ -855,6 +912,9 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     p.maskbits = maskbits; p.y = (bf16_raw*)y; p.ybits = ybits; p.y8 = (unsigned char*)y8; p.q_scale = q_scale; p.y8_bf8 = y8_bf8;
     p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+#ifdef BD_D1_STAMP
+    p.dbg = getenv("BD_D1_ABLATE") ? atoi(getenv("BD_D1_ABLATE")) : 0;
+#endif
     {
         // the 256^2 tile: full 32-channel K steps and at least one full channel tile.  Measured (scripts/micro_1x1_step.py, the step's 16
         // launch classes): on par or slower than the 128^2 tile everywhere (6.2 - 6.5 vs 5.5 - 5.8 ms over the step's launches; its
@@ -885,11 +945,19 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     // per workgroup, three workgroups per CU) is 3 - 11 % faster; shorter K (the epilogue is most of the tile) and the 16 800-pixel res5
     // layers (K = 2048: everything L2-resident, four workgroups per CU hide more) stay on the register-staged loop.  Measured per class
     // with scripts/micro_1x1_step.py; BD_DENSE1X1_DMA_K (read by bd_conv_set_dense1x1) moves the lower bound for A/B.
+    static const int early = getenv("BD_DENSE1X1_EARLY") ? atoi(getenv("BD_DENSE1X1_EARLY")) : 0;     // measurement: epilogue operands requested before the K loop
+    const bool has_ops = (add && (flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER))) || ((flags & BD_EPI_MASK) && (mask || maskbits));
     if (CK % BK == 0 && CK >= g_conv1x1_dma_k && (CK <= 1024 || g_conv1x1_dma_k < 512)) {
-        hipLaunchKernelGGL((conv1x1_dense_kernel<1, 3, true>), dim3(grid), dim3(256), 6 * TILE_BYTES, stream, p);
+        if (early && has_ops) hipLaunchKernelGGL((conv1x1_dense_kernel<1, 3, true, 2, 8, true>), dim3(grid), dim3(256), 6 * TILE_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv1x1_dense_kernel<1, 3, true>), dim3(grid), dim3(256), 6 * TILE_BYTES, stream, p);
         return 0;
     }
     const size_t lds = 4 * TILE_BYTES;
+    if (early && has_ops) {
+        if (early == 2) hipLaunchKernelGGL((conv1x1_dense_kernel<2, 3, false, 2, 8, true>), dim3(grid), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((conv1x1_dense_kernel<1, 3, false, 2, 8, true>), dim3(grid), dim3(256), lds, stream, p);
+        return 0;
+    }
     // (round 4, measured and removed: all eight epilogue operands requested at once -- EBATCH = 8 at three waves per SIMD -- 5.44 ms over
     // the step's launches against 5.41: the epilogue is not short of requests in flight)
     static const int reg_depth = getenv("BD_DENSE1X1_REGDEPTH") ? atoi(getenv("BD_DENSE1X1_REGDEPTH")) : 1;     // register sets in flight (measurement)

@@ -1,0 +1,463 @@
+// Dense 1x1 / stride-1 convolution (forward and data gradient) over one level, round-4 form: y[m][co] = sum_k x[m][k] w[co][k] (+ epilogue)
+// as persistent workgroups with every byte they touch requested ahead of its use.
+//
+// Why (scripts/exp/d1_stamp.py, profiles/r04_d1_*): in conv1x1_dense_kernel (conv1x1.hip: one 128^2 tile per workgroup, 3 - 4 workgroups per
+// CU) a workgroup lives 18 - 45 us -- a K step is one round trip (0.9 - 1.3 us under load), the epilogue two more -- and the launch takes
+// the SUM of what its parts take alone (256->1024 + residual @ 50x84: K loop alone 58 us, epilogue traffic alone 70 us, MFMA + epilogue
+// arithmetic alone 27 us, together 111 us).  Requesting the epilogue operands before the K loop, or staging 2 - 4 K steps deep, shortens a
+// workgroup's life and lowers the residency by the same factor.  Here:
+//   * operands by LDS-DMA into a ring (16 KB stages: 128 output channels + 128 pixels x 32 input channels) that does not stop at a tile
+//     boundary: while a tile's epilogue runs, the next tile's first K steps are already landing;
+//   * the epilogue operands of tile j + 1 (residual, gate bytes) are requested at the START of tile j's epilogue, a whole tile ahead; the
+//     bias vector sits in LDS;
+//   * the epilogue arithmetic runs on packed bf16 pairs where it can (ReLU = max with 0 as int16, gate = AND, gate bits out = int16 > 0) and
+//     the variants are template instantiations: the phase is bound by the instructions the waves issue, not by what they wait for;
+//   * every vector-memory instruction is inline assembly with wave-uniform instruction counts (out-of-range lanes get an offset beyond
+//     num_records, never an exec mask), so that each wait is an exact `s_waitcnt vmcnt(n)`: vmcnt retires in order, and a wait for "K step s
+//     has landed" must let the epilogue loads and stores issued after that step's request stay in flight.
+// Two shapes (template NW): eight waves, one workgroup per CU, eight ring stages (seven K steps = 112 KB in flight); four waves, two
+// workgroups per CU, four stages each.  The tile, fragment and LDS layouts are those of conv1x1_dense_kernel's LDS-DMA variant (64-byte
+// rows, 16-byte chunks XOR-swizzled on the source side, weight rows permuted so that a lane ends up with 8 consecutive channels); results
+// are bit-identical to it.
+// Two hardware facts met on the way: a buffer resource with num_records = 0 is NOT range-checked (absent operands get a small window and
+// out-of-range offsets instead), and a store of more than 64 bits followed within two wait states by a VALU write of its data registers
+// stores the new values (the compiler's hazard recogniser does not look into inline assembly).
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+constexpr int TP = 128, TC = 128, BK = 32;
+constexpr int A_BYTES = TC * 64, STAGE = A_BYTES + TP * 64;       // weight rows, then pixel rows
+constexpr unsigned X_NONE = 0x80000000u;
+constexpr int MAX_CO = 2048;           // bias vector in LDS behind the ring (padded to whole channel tiles)
+
+// epilogue variants (template bits)
+constexpr int E_ADD = 1, E_RELU = 2, E_MASK = 4, E_YBITS = 8;
+
+struct PR {
+    const bf16_raw* x;
+    const bf16_raw* w;
+    const float* bias;
+    const bf16_raw* add;
+    const unsigned* maskbits;
+    bf16_raw* y;
+    unsigned* ybits;
+    int M, CK, CO;
+    unsigned x_bytes, w_bytes, y_bytes, bits_bytes;
+    int n_tiles, tiles, nsteps;
+};
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+
+template <int NW>
+struct Shape {
+    static constexpr int WPX = NW / 2;             // waves along the pixels (two along the channels: 64 each)
+    static constexpr int FJ = 8 / WPX;             // 16-pixel fragments per wave
+    static constexpr int PK = 8 / NW;              // 1 KiB pieces of each operand per wave and K step
+    static constexpr int NP = 2 * PK;              // DMA instructions per wave and K step
+    static constexpr int NU = 2 * FJ;              // 16-byte epilogue units per lane and tile: unit q = 2 j + half
+    static constexpr int NSTAGE = NW == 8 ? 8 : 4; // 128 KB ring, one workgroup per CU / 64 KB, two per CU
+    static constexpr int DEPTH = NSTAGE - 1;
+    static constexpr int RING_BYTES = NSTAGE * STAGE;
+};
+
+template <int NU>
+struct ESet {                // epilogue operands and addresses of one tile, per lane
+    u32x4_t aux[NU];         // residual
+    unsigned bits[NU];       // this lane's gate byte
+    unsigned yv[NU / 2];     // byte offset of unit (j, 0) in y / add (unit (j, 1): + 64, as the instruction offset)
+    unsigned bv[2];          // byte offset of this lane's byte of unit (0, half) in the gate words (unit (j, half): + 64 j)
+    bool full;               // whole tile in range: the offsets as they stand; else checked per unit
+    int m, c;                // first pixel / channel of the lane
+};
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff, int soff) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void load16(u32x4_t& dst, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=&v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void load1(unsigned& dst, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen offset:%3" : "=&v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void store16(u32x4_t v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    // (more than 64 bits of store data are read over several cycles: a VALU write to them within two wait states would be stored instead)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:%3\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rsrc), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void store1(unsigned v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    asm volatile("buffer_store_byte %0, %1, %2, 0 offen offset:%3" : : "v"(v), "v"(voff), "s"(rsrc), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { static_assert(N >= 0 && N < 64, "vmcnt field"); asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+#ifdef BD_R1X_STAMP          // diagnostic build only (scripts/exp/r1x_stamp.py): s_memtime cycles per phase, per wave of one workgroup
+__device__ unsigned long long g_r1x_stamp[8][8];
+#define R1X_T(i) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); st[i] += now__ - last__; last__ = now__; } while (0)
+#else
+#define R1X_T(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
+
+template <int J> using IC = std::integral_constant<int, J>;
+
+template <int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(const PR p) {
+    using S = Shape<NW>;
+    constexpr int WPX = S::WPX, FJ = S::FJ, PK = S::PK, NP = S::NP, NU = S::NU, NSTAGE = S::NSTAGE, DEPTH = S::DEPTH, RING_BYTES = S::RING_BYTES;
+    constexpr bool ADD = EPI & E_ADD, RELU = EPI & E_RELU, MASK = EPI & E_MASK, YBITS = EPI & E_YBITS;
+    constexpr int NLOAD = (ADD ? NU : 0) + (MASK ? NU : 0);     // vector-memory instructions of one epilogue: the NEXT tile's operands ...
+    constexpr int NSTORE = NU + (YBITS ? NU : 0);               // ... then this tile's stores
+    constexpr int NE = NLOAD + NSTORE;
+    typedef ESet<NU> E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WPX;    // 64-channel half of the tile
+    const int wp = wave % WPX;    // block of 16 FJ pixels
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    {   // XCD-aware bijective remap: consecutive ids (neighbouring tile ranges: the same pixel rows, the same weights) share an XCD's L2
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    // this workgroup's tiles: [t_begin, t_end), tile t = pixel tile t / n_tiles, channel tile t % n_tiles
+    const int per = p.tiles / nwg, rem = p.tiles - per * nwg;
+    const int t_begin = bid * per + (bid < rem ? bid : rem);
+    const int t_end = t_begin + per + (bid < rem ? 1 : 0);
+    const int nsteps = p.nsteps;
+    const int n_tiles = p.n_tiles;
+
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)smem));
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t add_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(ADD ? p.add : p.y), 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mb_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(MASK ? p.maskbits : (const unsigned*)p.y), 0, MASK ? p.bits_bytes : 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yb_rsrc = __builtin_amdgcn_make_buffer_rsrc(YBITS ? p.ybits : (unsigned*)p.y, 0, YBITS ? p.bits_bytes : 4, 0x00020000);
+
+    // ---- the bias vector, padded with zeros to whole channel tiles, behind the ring
+    float* bias_lds = reinterpret_cast<float*>(smem + RING_BYTES);
+    for (int i = tid; i < n_tiles * TC; i += 64 * NW) bias_lds[i] = (p.bias && i < p.CO) ? p.bias[i] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // written before this wave's first barrier (the barriers below are bare s_barrier)
+
+    // ---- producer: K step (ptile, pstep) -> ring stage `fill`; this wave owns pieces wave + NW k (16 rows x 64 B each) of both operands
+    int lrow[PK], wperm[PK];
+    unsigned a_lane[PK], b_lane[PK];
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+        lrow[k] = 16 * (wave + NW * k) + (lane >> 2);
+        const int ch = (lane & 3) ^ ((lrow[k] >> 1) & 3);               // lds_off on the source side
+        const int rho = lrow[k] & 15;
+        wperm[k] = (lrow[k] & 64) + 32 * ((lrow[k] >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow[k] >> 4) & 1) + (rho & 3);      // LDS row -> channel of the tile
+        a_lane[k] = (unsigned)(wperm[k] * p.CK + ch * 8) * 2u;
+        b_lane[k] = (unsigned)(lrow[k] * p.CK + ch * 8) * 2u;
+    }
+    const unsigned tile_stride = (unsigned)(128 * p.CK) * 2u;           // bytes between the first rows of neighbouring tiles (either operand)
+    unsigned a_src[PK], b_src[PK];
+    int ptile = t_begin, pstep = 0;
+    int ptm = t_begin / n_tiles, ptn = t_begin - ptm * n_tiles;
+    auto producer_tile = [&]() {
+        const bool live = ptile < t_end;
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+            a_src[k] = (live && ptn * TC + wperm[k] < p.CO) ? a_lane[k] + (unsigned)ptn * tile_stride : X_NONE;
+            b_src[k] = (live && ptm * TP + lrow[k] < p.M) ? b_lane[k] + (unsigned)ptm * tile_stride : X_NONE;
+        }
+    };
+    producer_tile();
+    unsigned fill_addr = lds0 + wave * 1024;
+    auto issue = [&]() {
+        const int so = pstep * (BK * 2);
+#pragma unroll
+        for (int k = 0; k < PK; ++k) dma16(w_rsrc, fill_addr + k * NW * 1024, a_src[k], so);
+#pragma unroll
+        for (int k = 0; k < PK; ++k) dma16(x_rsrc, fill_addr + A_BYTES + k * NW * 1024, b_src[k], so);
+        fill_addr = fill_addr + STAGE >= lds0 + RING_BYTES ? fill_addr + STAGE - RING_BYTES : fill_addr + STAGE;
+        if (++pstep == nsteps) {
+            pstep = 0; ++ptile;
+            if (++ptn == n_tiles) { ptn = 0; ++ptm; }
+            producer_tile();
+        }
+    };
+
+    // ---- epilogue addressing: lane group cg holds channels c + 32 half + 0..7 of pixel m + 16 j
+    const int cg = lane >> 4, l15 = lane & 15;
+    auto address = [&](E& e, int tm, int tn, bool live) {
+        e.m = tm * TP + wp * (16 * FJ) + l15;
+        e.c = tn * TC + wc * 64 + 8 * cg;
+        e.full = live && tm * TP + TP <= p.M && tn * TC + TC <= p.CO;
+        const unsigned y0 = (unsigned)(e.m * p.CO + e.c) * 2u, b0 = (unsigned)((tn * 4 + wc * 2) * p.M + e.m) * 4u + cg;
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) e.yv[j] = y0 + (unsigned)(32 * p.CO) * j;
+        e.bv[0] = b0; e.bv[1] = b0 + (unsigned)(4 * p.M);
+    };
+    // edge tiles: unit (j, half) in range = pixel m + 16 j and channels c + 32 half .. + 7 (CO % 8 == 0)
+    auto unit_ok = [&](const E& e, int j, int half) { return e.m + 16 * j < p.M && e.c + 32 * half < p.CO; };
+    auto request = [&](E& e, int tm, int tn, bool live) {             // NLOAD instructions
+        address(e, tm, tn, live);
+        if (e.full) {
+            auto one = [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if constexpr (j < FJ) {
+                    if constexpr (ADD) { load16<0>(e.aux[2 * j], add_rsrc, e.yv[j]); load16<64>(e.aux[2 * j + 1], add_rsrc, e.yv[j]); }
+                    if constexpr (MASK) { load1<64 * j>(e.bits[2 * j], mb_rsrc, e.bv[0]); load1<64 * j>(e.bits[2 * j + 1], mb_rsrc, e.bv[1]); }
+                }
+            };
+            one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{});
+        } else {
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {
+                const int j = q >> 1, half = q & 1;
+                const bool ok = live && unit_ok(e, j, half);
+                if constexpr (ADD) load16<0>(e.aux[q], add_rsrc, ok ? e.yv[j] + 64u * half : X_NONE);
+                if constexpr (MASK) load1<0>(e.bits[q], mb_rsrc, ok ? e.bv[half] + 64u * j : X_NONE);
+            }
+        }
+    };
+    // the loaded registers are defined from here on (the compiler must not read them before the wait in front of this)
+    auto settle = [&](E& e) {
+#pragma unroll
+        for (int q = 0; q < NU; q += 4) {
+            if constexpr (ADD) asm volatile("" : "+v"(e.aux[q]), "+v"(e.aux[q + 1]), "+v"(e.aux[q + 2]), "+v"(e.aux[q + 3]));
+            if constexpr (MASK) asm volatile("" : "+v"(e.bits[q]), "+v"(e.bits[q + 1]), "+v"(e.bits[q + 2]), "+v"(e.bits[q + 3]));
+        }
+    };
+
+    f32x4_t acc[4][FJ];
+    const int frag_row = lane & 15, frag_chunk = lane >> 4;
+    const int a_off = lds_off(wc * 64 + frag_row, frag_chunk), b_off = A_BYTES + lds_off(wp * (16 * FJ) + frag_row, frag_chunk);   // + i * 1024: same swizzle key
+    struct Frags { bf16x8_t a[4], b[FJ]; };
+    auto read_frags = [&](Frags& f, const unsigned char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const bf16x8_t*>(st + a_off + i * 1024);
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) f.b[j] = *reinterpret_cast<const bf16x8_t*>(st + b_off + j * 1024);
+    };
+    auto mfmas = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+    };
+
+    // one 16-byte unit: 8 channels of one pixel.  The arithmetic after the fp32 sums runs on the packed bf16 pairs: ReLU = max with 0 as
+    // int16 (a negative bf16 is a negative int16), the gate = AND with a mask spread from the gate byte, the gate bits written = (int16 > 0)
+    // (the stored bf16 value is > 0 exactly when the fp32 value is: rounding to nearest cannot reach 0 from a positive normal)
+    auto pack2 = [](float a, float b) -> unsigned {
+        const bf16x2_t pk = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);           // v_cvt_pk_bf16_f32
+        return __builtin_bit_cast(unsigned, pk);
+    };
+    auto unit = [&](const E& e, int q, const f32x4_t (&bias)[4], u32x4_t& out, unsigned& byte) {
+        const int j = q >> 1, half = q & 1;
+        f32x4_t lo = acc[2 * half][j] + bias[2 * half], hi = acc[2 * half + 1][j] + bias[2 * half + 1];
+        if constexpr (ADD) {
+            const u32x4_t av = e.aux[q];
+            lo += (f32x4_t){bf_lo(av[0]), bf_hi(av[0]), bf_lo(av[1]), bf_hi(av[1])};
+            hi += (f32x4_t){bf_lo(av[2]), bf_hi(av[2]), bf_lo(av[3]), bf_hi(av[3])};
+        }
+        unsigned o[4] = {pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+        if constexpr (RELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, o[k]), (s16x2_t){0, 0}));
+        }
+        if constexpr (MASK) {
+            const int gate = (int)e.bits[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned mlo = (unsigned)__builtin_amdgcn_sbfe(gate, 2 * k, 1), mhi = (unsigned)__builtin_amdgcn_sbfe(gate, 2 * k + 1, 1);
+                o[k] &= (mlo & 0xffffu) | (mhi & 0xffff0000u);
+            }
+        }
+        if constexpr (YBITS) {
+            unsigned t = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s16x2_t r = __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, o[k]), (s16x2_t){1, 1});
+                if constexpr (!RELU) r = __builtin_elementwise_max(r, (s16x2_t){0, 0});
+                t |= __builtin_bit_cast(unsigned, r) << (2 * k);
+            }
+            byte = t | (t >> 15);          // low byte: bit 2 k = pair k's low half, bit 2 k + 1 = its high half
+        }
+        out = (u32x4_t){o[0], o[1], o[2], o[3]};
+    };
+    auto epilogue = [&](const E& e) {          // NSTORE instructions
+        f32x4_t bias[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) bias[qq] = *reinterpret_cast<const f32x4_t*>(bias_lds + e.c + 32 * (qq >> 1) + 4 * (qq & 1));
+        if (e.full) {
+            auto one = [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if constexpr (j < FJ) {
+                    u32x4_t o0, o1;
+                    unsigned y0 = 0u, y1 = 0u;
+                    unit(e, 2 * j, bias, o0, y0);
+                    unit(e, 2 * j + 1, bias, o1, y1);
+                    store16<0>(o0, y_rsrc, e.yv[j]); store16<64>(o1, y_rsrc, e.yv[j]);
+                    if constexpr (YBITS) { store1<64 * j>(y0, yb_rsrc, e.bv[0]); store1<64 * j>(y1, yb_rsrc, e.bv[1]); }
+                }
+            };
+            one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{});
+        } else {
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {
+                const int j = q >> 1, half = q & 1;
+                const bool ok = unit_ok(e, j, half);
+                u32x4_t o;
+                unsigned yb = 0u;
+                unit(e, q, bias, o, yb);
+                store16<0>(o, y_rsrc, ok ? e.yv[j] + 64u * half : X_NONE);
+                if constexpr (YBITS) store1<0>(yb, yb_rsrc, ok ? e.bv[half] + 64u * j : X_NONE);
+            }
+        }
+    };
+
+    // ---- schedule -------------------------------------------------------------------------------------------------------------------
+    // Instruction order of a wave: request(first tile); DMA of steps 0 .. DEPTH-1; consumer step c = [wait for DMA(c); barrier;
+    // DMA(c + DEPTH); fragment reads and MFMAs of step c]; after a tile's last step its epilogue: NE instructions (request of the NEXT
+    // tile, then this tile's stores).  vmcnt retires in order, so "DMA(c) has landed" = at most the instructions issued after it are
+    // outstanding: the DMAs of the DEPTH - 1 consumer steps since, plus NE for every epilogue among those steps (`ends`: bit k = consumer
+    // step c - 1 - k closed a tile).
+    // (Measured and dropped: reading the fragments of step c + 1 under the MFMAs of step c -- the wait moves one step earlier and the
+    // launches got 20 - 50 % slower.)
+#ifdef BD_R1X_STAMP
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rbegin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long last__ = st_begin;
+#endif
+    int tm = t_begin / n_tiles, tn = t_begin - tm * n_tiles;            // the consumer's tile
+    E e0, e1;
+    request(e0, tm, tn, true);
+#pragma unroll 1
+    for (int d = 0; d < DEPTH; ++d) issue();
+    const unsigned char* stage = smem;
+    unsigned ends = 0;
+    auto ring_wait = [&]() {
+        const int k = __builtin_popcount(ends & ((1u << DEPTH) - 1));
+        if (k == 0) wait_vm<(DEPTH - 1) * NP>();
+        else if (k == 1) wait_vm<(DEPTH - 1) * NP + NE>();
+        else if constexpr ((DEPTH - 1) * NP + 2 * NE < 64) wait_vm<(DEPTH - 1) * NP + 2 * NE>();       // (three and more: waits for the oldest)
+        else wait_vm<(DEPTH - 1) * NP + NE>();
+    };
+    auto step = [&](bool tile_end) {
+        R1X_T(0);
+        ring_wait();
+        R1X_T(1);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        R1X_T(2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue();
+        __builtin_amdgcn_sched_barrier(0);
+        Frags f;
+        read_frags(f, stage);
+        mfmas(f);
+        stage = stage + STAGE == smem + RING_BYTES ? smem : stage + STAGE;
+        ends = (ends << 1) | (tile_end ? 1u : 0u);
+        R1X_T(3);
+    };
+    bool first = true;
+    auto run_tile = [&](E& cur, E& nxt, int tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int t = 0; t < nsteps; ++t) step(t + 1 == nsteps);
+        // this tile's operands: requested one epilogue ago, before that epilogue's NSTORE stores and this tile's nsteps DMA groups
+        if constexpr (NLOAD > 0) {
+            if (first) wait_vm<(DEPTH - 1) * NP>();
+            else if (nsteps >= DEPTH) wait_vm<NSTORE + DEPTH * NP>();
+            else if (nsteps >= 4) wait_vm<NSTORE + 4 * NP>();
+            else wait_vm<NSTORE + 2 * NP>();
+            settle(cur);
+        }
+        R1X_T(4);
+        if (++tn == n_tiles) { tn = 0; ++tm; }
+        request(nxt, tm, tn, tile + 1 < t_end);
+        epilogue(cur);
+        first = false;
+        R1X_T(5);
+    };
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+        run_tile(e0, e1, tile);
+        if (tile + 1 < t_end) run_tile(e1, e0, tile + 1);
+    }
+    // the ring ran DEPTH (empty) steps past the last tile, and the last request's loads target registers: let all of it land before the
+    // LDS and the registers are handed to another workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef BD_R1X_STAMP
+    if (blockIdx.x == 100 % gridDim.x && lane == 0) {
+        for (int k = 0; k < 6; ++k) g_r1x_stamp[wave][k] = st[k];
+        g_r1x_stamp[wave][6] = __builtin_amdgcn_s_memtime() - st_begin;
+        g_r1x_stamp[wave][7] = ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - st_rbegin) << 24) | ((unsigned long long)(t_end - t_begin) << 8) | (unsigned)nsteps;
+    }
+#endif
+}
+
+template <int EPI, int NW>
+void launch_ring(const PR& p, hipStream_t stream) {
+    using S = Shape<NW>;
+    const int lds = S::RING_BYTES + p.n_tiles * TC * 4;
+    BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ring_kernel<EPI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 S::RING_BYTES + MAX_CO * 4));
+    const int slots = (NW == 8 ? 1 : 2) * bd_num_cus();
+    hipLaunchKernelGGL((conv1x1_ring_kernel<EPI, NW>), dim3(p.tiles < slots ? p.tiles : slots), dim3(64 * NW), lds, stream, p);
+}
+
+}  // namespace
+
+#ifdef BD_R1X_STAMP
+extern "C" int bd_debug_r1x_stamp(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_r1x_stamp), sizeof(g_r1x_stamp)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+// Called by bd_conv1x1_dense_launch (conv1x1.hip) before its own kernels.  0 = taken.
+int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits, void* y,
+                           unsigned* ybits, void* y8, long long M, int CK, int CO, int flags, hipStream_t stream) {
+    // BD_DENSE1X1_RING: 0 = every launch stays on conv1x1_dense_kernel (A/B)
+    static const int mode = getenv("BD_DENSE1X1_RING") ? atoi(getenv("BD_DENSE1X1_RING")) : 1;
+    if (!mode) return 1;
+    // measured per launch class of the step (scripts/micro_1x1_step.py, profiles/r04_dense1x1_ring.txt): the short-K, epilogue-heavy launches
+    // (K <= 256 into >= 256 channels: conv3 forward, conv1's data gradient) gain 9 - 14 %; with K >= 512 the K loop is most of the tile and the
+    // three to four workgroups per CU of conv1x1_dense_kernel hide its LDS latency better than two waves per SIMD do (3 - 12 % slower here), and
+    // a 64-channel result wastes half of the tile either way.  BD_DENSE1X1_RING=2: every legal launch
+    if (mode != 2 && (CK > 256 || CO < 256)) return 1;
+    if (y8 || CK % BK != 0 || CK < 64 || CO % 8 != 0 || CO > MAX_CO) return 1;
+    if ((flags & BD_EPI_MASK) && mask && !maskbits) return 1;                   // bf16 gates: the older kernel
+    if ((maskbits || ybits) && CO % 32 != 0) return 1;
+    if ((flags & BD_EPI_SPARSE) || ((flags & BD_EPI_ADD_AFTER) && add)) return 1;
+    const long long xb = M * CK * 2, wb = (long long)CO * CK * 2, yb = M * CO * 2, bb = (long long)(CO / 32) * M * 4;
+    if (xb >= 0x7fffffffll || wb >= 0x7fffffffll || yb >= 0x7fffffffll || M >= (1ll << 24)) return 1;
+    PR p{};
+    p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.bias = bias; p.add = (const bf16_raw*)add; p.maskbits = maskbits;
+    p.y = (bf16_raw*)y; p.ybits = ybits;
+    p.M = (int)M; p.CK = CK; p.CO = CO;
+    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; p.y_bytes = (unsigned)yb; p.bits_bytes = (unsigned)bb;
+    p.n_tiles = cdiv(CO, TC);
+    p.tiles = (int)cdiv64(M, TP) * p.n_tiles;
+    p.nsteps = CK / BK;
+    const int epi = (((flags & BD_EPI_ADD_BEFORE) && add) ? E_ADD : 0) | ((flags & BD_EPI_RELU) ? E_RELU : 0) |
+                    (((flags & BD_EPI_MASK) && maskbits) ? E_MASK : 0) | (ybits ? E_YBITS : 0);
+    // (the four-wave shape -- two workgroups per CU, Shape<4> -- measured no faster than conv1x1_dense_kernel and is not instantiated:
+    // with two fragment sets it also runs out of registers)
+    switch (epi) {
+#define BD_R1X_CASE(n) case n: launch_ring<n, 8>(p, stream); break;
+        BD_R1X_CASE(0) BD_R1X_CASE(1) BD_R1X_CASE(2) BD_R1X_CASE(3) BD_R1X_CASE(4) BD_R1X_CASE(5) BD_R1X_CASE(6) BD_R1X_CASE(7)
+        BD_R1X_CASE(8) BD_R1X_CASE(9) BD_R1X_CASE(10) BD_R1X_CASE(11) BD_R1X_CASE(12) BD_R1X_CASE(13) BD_R1X_CASE(14) BD_R1X_CASE(15)
+#undef BD_R1X_CASE
+    }
+    return 0;
+}

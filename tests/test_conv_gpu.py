@@ -458,6 +458,65 @@ def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
         ops.L().bd_conv_set_dense1x1(1)
 
 
+@pytest.mark.parametrize("case", [(4, 60, 70, 128, 512), (4, 60, 70, 512, 128), (2, 50, 84, 256, 1024), (2, 50, 84, 1024, 256), (16, 25, 42, 64, 256),
+                                  (1, 33, 47, 96, 200), (3, 40, 50, 160, 320), (1, 11, 9, 2048, 512)])
+def test_conv1x1_ring_kernel_gives_the_dense_kernels_bits(case):
+    """conv1x1_ring.hip (persistent workgroups, eight-stage LDS-DMA ring that runs across tile boundaries, epilogue operands requested a
+    tile ahead, every wait an exact vmcnt) against conv1x1_dense_kernel (bd_conv_set_dense1x1(3)): the same bits for every epilogue the
+    step uses -- K of 2 .. 64 ring steps (fewer / more than the ring is deep), several tiles per workgroup, ragged pixel and channel tiles."""
+    ops = _ops()
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(5 + Cin + Cout + H)
+    M = N * H * W
+    x = bf16_round(torch.randn(M, Cin, generator=g)).to(torch.bfloat16).cuda()
+    w = bf16_round(torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin))
+    wf, wd = pack_weights(ops, w)
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = bf16_round(torch.randn(M, Cout, generator=g)).to(torch.bfloat16).cuda()
+    gy = bf16_round(torch.randn(M, Cout, generator=g)).to(torch.bfloat16).cuda()
+    acc0 = bf16_round(torch.randn(M, Cin, generator=g)).to(torch.bfloat16).cuda()
+    geo = ops.single(N, H, W)
+    d = ops.conv_desc(geo, geo, Cin, Cout, 1, 1, 1, 0)
+    bits_f = Cout % 32 == 0
+    bits_d = Cin % 32 == 0
+    gate = torch.randint(-2 ** 31, 2 ** 31 - 1, (max(Cin // 32, 1), M), dtype=torch.int32, generator=g).cuda()
+    out = {}
+    try:
+        for mode in (3, 1):
+            assert ops.L().bd_conv_set_dense1x1(mode) == 0
+            r = []
+            # forward: residual + ReLU (+ gate bits out); bias only; residual added after the (absent) gate
+            y = torch.full((M, Cout), 7.0, dtype=torch.bfloat16, device="cuda")
+            yb = torch.full((Cout // 32, M), -1, dtype=torch.int32, device="cuda") if bits_f else None
+            ops.conv2d_fwd(d, x, wf, bias, y, add=res, flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE, bits=yb)
+            r += [y, yb]
+            y2 = torch.full((M, Cout), 7.0, dtype=torch.bfloat16, device="cuda")
+            ops.conv2d_fwd(d, x, wf, bias, y2)
+            r.append(y2)
+            y3 = torch.full((M, Cout), 7.0, dtype=torch.bfloat16, device="cuda")
+            ops.conv2d_fwd(d, x, wf, None, y3, add=res, flags=ops.EPI_ADD_AFTER)
+            r.append(y3)
+            # data gradient: plain; gated by bits; accumulated in place and gated by bits
+            dx = torch.full((M, Cin), 7.0, dtype=torch.bfloat16, device="cuda")
+            ops.conv2d_dgrad(d, gy, wd, dx)
+            r.append(dx)
+            if bits_d:
+                dx2 = torch.full((M, Cin), 7.0, dtype=torch.bfloat16, device="cuda")
+                ops.conv2d_dgrad(d, gy, wd, dx2, maskbits=gate, flags=0)
+                dx3 = acc0.clone()
+                ops.conv2d_dgrad(d, gy, wd, dx3, add=dx3, maskbits=gate, flags=ops.EPI_ADD_BEFORE)
+                r += [dx2, dx3]
+            torch.cuda.synchronize()
+            out[mode] = r
+    finally:
+        ops.L().bd_conv_set_dense1x1(1)
+    for k, (a, b) in enumerate(zip(out[3], out[1])):
+        assert (a is None and b is None) or torch.equal(a, b), (case, k)
+    # and against fp32 (the ring path by itself)
+    ref = torch.relu(x.float().cpu() @ w.reshape(Cout, Cin).t() + bias.cpu() + res.float().cpu())
+    assert rel_l2(out[1][0].float().cpu(), ref) < 1e-2
+
+
 @pytest.mark.parametrize("R", [1, 3])
 def test_strided_dgrad_sparse_accumulate(R):
     """BD_EPI_SPARSE: a stride-2 data gradient accumulating in place leaves the input pixels no tap reaches untouched (1x1: three of
