@@ -87,7 +87,12 @@ class KernelTimer:
                             and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0]
                             and (not dgrad or (flags & ops.EPI_SPARSE)))
                 if dense or dense_s2:
-                    return "conv1x1_dense_kernel"          # conv1x1.hip: every 1x1 / stride 1 launch over one dense level
+                    # conv1x1_ring.hip takes the short-K launches into >= 256 channels (bf16, bit-packed gates; bd_conv1x1_ring_launch)
+                    ck_, co_ = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
+                    if (dense and 64 <= ck_ <= 256 and ck_ % 32 == 0 and 256 <= co_ <= 2048 and co_ % 32 == 0 and not (flags & ops.EPI_ADD_AFTER)
+                            and os.environ.get("BD_DENSE1X1_RING", "1") != "0"):
+                        return "conv1x1_ring_kernel"
+                    return "conv1x1_dense_kernel"          # conv1x1.hip: every other 1x1 / stride 1 launch over one dense level
                 if not is3:
                     # generic kernel: BK = 32 instance for 1x1 filters (and Cin <= 32) and for stride-2 launches of >= 512 tiles,
                     # BK = 64 for the rest
