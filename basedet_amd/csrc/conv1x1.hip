@@ -882,11 +882,15 @@ int g_conv1x1_wide_min_k = 0;   // BD_DENSE1X1_WIDE_K: smallest CK that takes th
 
 }  // namespace
 
+void bd_conv1x1_ring_everywhere(bool on);         // conv1x1_ring.hip
+
 extern "C" int bd_conv_set_dense1x1(int depth) {
-    if (depth < 0 || depth > 4) {
-        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 4)", depth);
+    if (depth < 0 || depth > 5) {
+        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 5)", depth);
         return BD_EINVAL;
     }
+    bd_conv1x1_ring_everywhere(depth == 5);          // 5 = as 1, with conv1x1_ring_kernel for every launch it can take (default: K <= 256 into >= 256 channels)
+    if (depth == 5) depth = 1;
     g_conv1x1_depth = depth;
     if (const char* e = getenv("BD_DENSE1X1_DMA_K")) g_conv1x1_dma_k = atoi(e);
     if (const char* e = getenv("BD_DENSE1X1_WIDE_K")) g_conv1x1_wide_min_k = atoi(e);

@@ -28,8 +28,9 @@
 
 namespace {
 
-constexpr int TP = 128, TC = 128, BK = 32;
-constexpr int A_BYTES = TC * 64, STAGE = A_BYTES + TP * 64;       // weight rows, then pixel rows
+constexpr int TP = 128, TC = 128, BK = 64;                         // a K step = 64 input channels: 128-byte rows, two MFMA k-halves
+constexpr int RB = BK * 2;                                         // row bytes
+constexpr int A_BYTES = TC * RB, STAGE = A_BYTES + TP * RB;        // weight rows, then pixel rows: 32 KB
 constexpr unsigned X_NONE = 0x80000000u;
 constexpr int MAX_CO = 2048;           // bias vector in LDS behind the ring (padded to whole channel tiles)
 
@@ -57,10 +58,10 @@ template <int NW>
 struct Shape {
     static constexpr int WPX = NW / 2;             // waves along the pixels (two along the channels: 64 each)
     static constexpr int FJ = 8 / WPX;             // 16-pixel fragments per wave
-    static constexpr int PK = 8 / NW;              // 1 KiB pieces of each operand per wave and K step
+    static constexpr int PK = 16 / NW;             // 1 KiB pieces (8 rows) of each operand per wave and K step
     static constexpr int NP = 2 * PK;              // DMA instructions per wave and K step
     static constexpr int NU = 2 * FJ;              // 16-byte epilogue units per lane and tile: unit q = 2 j + half
-    static constexpr int NSTAGE = NW == 8 ? 8 : 4; // 128 KB ring, one workgroup per CU / 64 KB, two per CU
+    static constexpr int NSTAGE = NW == 8 ? 4 : 2; // 128 KB ring, one workgroup per CU / 64 KB, two per CU
     static constexpr int DEPTH = NSTAGE - 1;
     static constexpr int RING_BYTES = NSTAGE * STAGE;
 };
@@ -105,7 +106,9 @@ __device__ unsigned long long g_r1x_stamp[8][8];
 #define R1X_T(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
+// 128-byte rows, eight 16-byte chunks XOR-swizzled with bits 1..3 of the row: the 16 rows a fragment read touches per chunk column fall on
+// all 64 banks (row parity x eight chunk positions)
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * RB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int J> using IC = std::integral_constant<int, J>;
 
@@ -149,13 +152,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
     for (int i = tid; i < n_tiles * TC; i += 64 * NW) bias_lds[i] = (p.bias && i < p.CO) ? p.bias[i] : 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // written before this wave's first barrier (the barriers below are bare s_barrier)
 
-    // ---- producer: K step (ptile, pstep) -> ring stage `fill`; this wave owns pieces wave + NW k (16 rows x 64 B each) of both operands
+    // ---- producer: K step (ptile, pstep) -> ring stage `fill`; this wave owns pieces wave + NW k (8 rows x 128 B each) of both operands
     int lrow[PK], wperm[PK];
     unsigned a_lane[PK], b_lane[PK];
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
-        lrow[k] = 16 * (wave + NW * k) + (lane >> 2);
-        const int ch = (lane & 3) ^ ((lrow[k] >> 1) & 3);               // lds_off on the source side
+        lrow[k] = 8 * (wave + NW * k) + (lane >> 3);
+        const int ch = (lane & 7) ^ ((lrow[k] >> 1) & 7);               // lds_off on the source side
         const int rho = lrow[k] & 15;
         wperm[k] = (lrow[k] & 64) + 32 * ((lrow[k] >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow[k] >> 4) & 1) + (rho & 3);      // LDS row -> channel of the tile
         a_lane[k] = (unsigned)(wperm[k] * p.CK + ch * 8) * 2u;
@@ -234,19 +237,25 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
 
     f32x4_t acc[4][FJ];
     const int frag_row = lane & 15, frag_chunk = lane >> 4;
-    const int a_off = lds_off(wc * 64 + frag_row, frag_chunk), b_off = A_BYTES + lds_off(wp * (16 * FJ) + frag_row, frag_chunk);   // + i * 1024: same swizzle key
-    struct Frags { bf16x8_t a[4], b[FJ]; };
+    const int a_off = lds_off(wc * 64 + frag_row, frag_chunk), b_off = A_BYTES + lds_off(wp * (16 * FJ) + frag_row, frag_chunk);   // + 16 rows: same swizzle key
+    // k-half kh of a row = chunks 4 kh + frag_chunk: the swizzle key is the row's, so the second half sits at (offset ^ 64)
+    struct Frags { bf16x8_t a[2][4], b[2][FJ]; };
     auto read_frags = [&](Frags& f, const unsigned char* st) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const bf16x8_t*>(st + a_off + i * 1024);
+        for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) f.b[j] = *reinterpret_cast<const bf16x8_t*>(st + b_off + j * 1024);
+            for (int i = 0; i < 4; ++i) f.a[kh][i] = *reinterpret_cast<const bf16x8_t*>(st + (a_off ^ (kh << 6)) + i * 16 * RB);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) f.b[kh][j] = *reinterpret_cast<const bf16x8_t*>(st + (b_off ^ (kh << 6)) + j * 16 * RB);
+        }
     };
     auto mfmas = [&](const Frags& f) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-            for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[kh][i], f.b[kh][j], acc[i][j], 0, 0, 0);
     };
 
     // one 16-byte unit: 8 channels of one pixel.  The arithmetic after the fp32 sums runs on the packed bf16 pairs: ReLU = max with 0 as
@@ -424,18 +433,22 @@ extern "C" int bd_debug_r1x_stamp(unsigned long long* out64) {
 }
 #endif
 
+static bool g_ring_everywhere = false;
+void bd_conv1x1_ring_everywhere(bool on) { g_ring_everywhere = on; }          // bd_conv_set_dense1x1(5): tests / A-B
+
 // Called by bd_conv1x1_dense_launch (conv1x1.hip) before its own kernels.  0 = taken.
 int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits, void* y,
                            unsigned* ybits, void* y8, long long M, int CK, int CO, int flags, hipStream_t stream) {
-    // BD_DENSE1X1_RING: 0 = every launch stays on conv1x1_dense_kernel (A/B)
-    static const int mode = getenv("BD_DENSE1X1_RING") ? atoi(getenv("BD_DENSE1X1_RING")) : 1;
+    // BD_DENSE1X1_RING: 0 = every launch stays on conv1x1_dense_kernel (A/B), 2 = every legal launch comes here (also bd_conv_set_dense1x1(5))
+    static const int env_mode = getenv("BD_DENSE1X1_RING") ? atoi(getenv("BD_DENSE1X1_RING")) : 1;
+    const int mode = g_ring_everywhere ? 2 : env_mode;
     if (!mode) return 1;
-    // measured per launch class of the step (scripts/micro_1x1_step.py, profiles/r04_dense1x1_ring.txt): the short-K, epilogue-heavy launches
-    // (K <= 256 into >= 256 channels: conv3 forward, conv1's data gradient) gain 9 - 14 %; with K >= 512 the K loop is most of the tile and the
-    // three to four workgroups per CU of conv1x1_dense_kernel hide its LDS latency better than two waves per SIMD do (3 - 12 % slower here), and
-    // a 64-channel result wastes half of the tile either way.  BD_DENSE1X1_RING=2: every legal launch
-    if (mode != 2 && (CK > 256 || CO < 256)) return 1;
-    if (y8 || CK % BK != 0 || CK < 64 || CO % 8 != 0 || CO > MAX_CO) return 1;
+    // measured per launch class of the step (scripts/micro_1x1_step.py 5 3, profiles/r04_dense1x1_ring.txt): every launch over the 268 800
+    // pixels of res3 gains 3 - 18 %, and so do the short-K launches into >= 256 channels at 67 200 pixels (conv3 forward, conv1's data
+    // gradient: 14 - 16 %); the other launches at 67 200 / 16 800 pixels have 2 - 8 tiles per CU -- one persistent workgroup per CU pays the
+    // rounding (5 tiles against 4.1) that three to four small workgroups per CU even out -- and stay on conv1x1_dense_kernel (2 - 6 % slower here)
+    if (mode != 2 && !(M >= 131072 || (CK <= 256 && CO >= 256 && M >= 32768))) return 1;
+    if (y8 || CK % BK != 0 || CK < 2 * BK || CO % 8 != 0 || CO > MAX_CO) return 1;
     if ((flags & BD_EPI_MASK) && mask && !maskbits) return 1;                   // bf16 gates: the older kernel
     if ((maskbits || ybits) && CO % 32 != 0) return 1;
     if ((flags & BD_EPI_SPARSE) || ((flags & BD_EPI_ADD_AFTER) && add)) return 1;

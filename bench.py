@@ -87,9 +87,11 @@ class KernelTimer:
                             and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0]
                             and (not dgrad or (flags & ops.EPI_SPARSE)))
                 if dense or dense_s2:
-                    # conv1x1_ring.hip takes the short-K launches into >= 256 channels (bf16, bit-packed gates; bd_conv1x1_ring_launch)
+                    # conv1x1_ring.hip takes the res3-sized launches and the short-K ones into >= 256 channels (bd_conv1x1_ring_launch)
                     ck_, co_ = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
-                    if (dense and 64 <= ck_ <= 256 and ck_ % 32 == 0 and 256 <= co_ <= 2048 and co_ % 32 == 0 and not (flags & ops.EPI_ADD_AFTER)
+                    mpix = d.N * d.Ho[0] * d.Wo[0]
+                    if (dense and ck_ >= 128 and ck_ % 64 == 0 and co_ <= 2048 and co_ % 32 == 0 and not (flags & ops.EPI_ADD_AFTER)
+                            and (mpix >= 131072 or (ck_ <= 256 and co_ >= 256 and mpix >= 32768))
                             and os.environ.get("BD_DENSE1X1_RING", "1") != "0"):
                         return "conv1x1_ring_kernel"
                     return "conv1x1_dense_kernel"          # conv1x1.hip: every other 1x1 / stride 1 launch over one dense level

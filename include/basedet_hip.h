@@ -98,9 +98,10 @@ int bd_conv2d_fwd_ex(const bd_conv_desc* d, const void* x, const void* w_packed,
  * and dx8 (may be NULL) = e5m2(clamp(dx * q_scale)), the gradient operand of a following bd_conv2d_dgrad_fp8. */
 int bd_conv2d_dgrad_ex(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
                        const uint32_t* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream);
-/* measurement knob: 1 (default) = the dense 1x1 kernel (conv1x1.hip) takes every 1x1 / stride 1 launch over one dense level,
- * 0 = the generic kernel does (A/B; the *_bits / _ex entry points then return BD_EINVAL); 2 = its 256 x 256 tile, 3 = its 128 x 128
- * tile only, 4 = its eight-wave 256-channel x 128-pixel tile wherever legal (all A/B: same results bit for bit). */
+/* measurement knob: 1 (default) = the dense 1x1 kernels take every 1x1 / stride 1 launch over one dense level (conv1x1_ring.hip the
+ * short-K launches into >= 256 channels, conv1x1.hip the rest), 0 = the generic kernel does (A/B; the *_bits / _ex entry points then
+ * return BD_EINVAL); 2 = conv1x1.hip's 256 x 256 tile, 3 = its 128 x 128 tile only, 4 = its eight-wave 256-channel x 128-pixel tile
+ * wherever legal, 5 = as 1 with conv1x1_ring.hip for every launch it can take (all A/B: same results bit for bit). */
 int bd_conv_set_dense1x1(int depth);
 
 /* dw[Cout][R][S][Cin] (fp32) = sum over pixels g^T x, times row_scale[Cout] (NULL = 1); split over pixels with

@@ -1,5 +1,5 @@
 """The dense 1x1 launches of one RetinaNet-R50 step (800x1344, batch 16) with their epilogue operands, timed per bd_conv_set_dense1x1
-mode (0 = the generic kernel, 1 = default choice, 2 = the 256^2 LDS-DMA tile wherever legal, 3 = the 128^2 tile only): algorithmic GB/s
+mode (0 = the generic kernel, 1 = default choice, 2 = the 256^2 LDS-DMA tile wherever legal, 3 = the 128^2 tile only, 5 = conv1x1_ring_kernel wherever legal): algorithmic GB/s
 per launch class.   python scripts/micro_1x1_step.py [modes...]"""
 import os
 import sys

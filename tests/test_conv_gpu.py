@@ -459,11 +459,12 @@ def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [(4, 60, 70, 128, 512), (4, 60, 70, 512, 128), (2, 50, 84, 256, 1024), (2, 50, 84, 1024, 256), (16, 25, 42, 64, 256),
-                                  (1, 33, 47, 96, 200), (3, 40, 50, 160, 320), (1, 11, 9, 2048, 512)])
+                                  (1, 33, 47, 192, 200), (3, 40, 50, 320, 320), (1, 11, 9, 2048, 512), (2, 37, 41, 128, 64)])
 def test_conv1x1_ring_kernel_gives_the_dense_kernels_bits(case):
     """conv1x1_ring.hip (persistent workgroups, eight-stage LDS-DMA ring that runs across tile boundaries, epilogue operands requested a
-    tile ahead, every wait an exact vmcnt) against conv1x1_dense_kernel (bd_conv_set_dense1x1(3)): the same bits for every epilogue the
-    step uses -- K of 2 .. 64 ring steps (fewer / more than the ring is deep), several tiles per workgroup, ragged pixel and channel tiles."""
+    tile ahead, every wait an exact vmcnt; bd_conv_set_dense1x1(5): every launch it can take) against conv1x1_dense_kernel
+    (bd_conv_set_dense1x1(3)): the same bits for every epilogue the step uses -- K of 2 .. 32 ring steps (fewer / more than the ring is deep),
+    several tiles per workgroup, ragged pixel and channel tiles."""
     ops = _ops()
     N, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(5 + Cin + Cout + H)
@@ -482,7 +483,7 @@ def test_conv1x1_ring_kernel_gives_the_dense_kernels_bits(case):
     gate = torch.randint(-2 ** 31, 2 ** 31 - 1, (max(Cin // 32, 1), M), dtype=torch.int32, generator=g).cuda()
     out = {}
     try:
-        for mode in (3, 1):
+        for mode in (3, 5):
             assert ops.L().bd_conv_set_dense1x1(mode) == 0
             r = []
             # forward: residual + ReLU (+ gate bits out); bias only; residual added after the (absent) gate
@@ -510,11 +511,11 @@ def test_conv1x1_ring_kernel_gives_the_dense_kernels_bits(case):
             out[mode] = r
     finally:
         ops.L().bd_conv_set_dense1x1(1)
-    for k, (a, b) in enumerate(zip(out[3], out[1])):
+    for k, (a, b) in enumerate(zip(out[3], out[5])):
         assert (a is None and b is None) or torch.equal(a, b), (case, k)
     # and against fp32 (the ring path by itself)
     ref = torch.relu(x.float().cpu() @ w.reshape(Cout, Cin).t() + bias.cpu() + res.float().cpu())
-    assert rel_l2(out[1][0].float().cpu(), ref) < 1e-2
+    assert rel_l2(out[5][0].float().cpu(), ref) < 1e-2
 
 
 @pytest.mark.parametrize("R", [1, 3])
