@@ -6,8 +6,8 @@
 // the SUM of what its parts take alone (256->1024 + residual @ 50x84: K loop alone 58 us, epilogue traffic alone 70 us, MFMA + epilogue
 // arithmetic alone 27 us, together 111 us).  Requesting the epilogue operands before the K loop, or staging 2 - 4 K steps deep, shortens a
 // workgroup's life and lowers the residency by the same factor.  Here:
-//   * operands by LDS-DMA into a ring (16 KB stages: 128 output channels + 128 pixels x 32 input channels) that does not stop at a tile
-//     boundary: while a tile's epilogue runs, the next tile's first K steps are already landing;
+//   * operands by LDS-DMA into a ring (32 KB stages: 128 output channels + 128 pixels x 64 input channels, 128-byte rows) that does not stop
+//     at a tile boundary: while a tile's epilogue runs, the next tile's first K steps are already landing;
 //   * the epilogue operands of tile j + 1 (residual, gate bytes) are requested at the START of tile j's epilogue, a whole tile ahead; the
 //     bias vector sits in LDS;
 //   * the epilogue arithmetic runs on packed bf16 pairs where it can (ReLU = max with 0 as int16, gate = AND, gate bits out = int16 > 0) and
@@ -15,10 +15,15 @@
 //   * every vector-memory instruction is inline assembly with wave-uniform instruction counts (out-of-range lanes get an offset beyond
 //     num_records, never an exec mask), so that each wait is an exact `s_waitcnt vmcnt(n)`: vmcnt retires in order, and a wait for "K step s
 //     has landed" must let the epilogue loads and stores issued after that step's request stay in flight.
-// Two shapes (template NW): eight waves, one workgroup per CU, eight ring stages (seven K steps = 112 KB in flight); four waves, two
-// workgroups per CU, four stages each.  The tile, fragment and LDS layouts are those of conv1x1_dense_kernel's LDS-DMA variant (64-byte
-// rows, 16-byte chunks XOR-swizzled on the source side, weight rows permuted so that a lane ends up with 8 consecutive channels); results
-// are bit-identical to it.
+// Where a tile's ~11 000 cycles go (scripts/exp/r1x_stamp.py, 256->1024 + residual): requesting the K steps 2 200 - 3 200 (the CU's vector
+// memory pipe takes 64 B per clock: 128 KB of operands per tile, and a wave that cannot issue its DMA stalls), fragment reads + MFMAs
+// 1 600 - 1 900, epilogue 3 400 - 4 700 (two waves per SIMD issuing ~250 instructions each, and 64 KB more through the same pipe), waiting
+// for the ring ~400, for the epilogue operands ~300, barrier skew the rest.  32-channel K steps (64-byte rows) were 5 % slower: twice the
+// barriers and ring waits per tile, half the MFMAs behind each fragment read.
+// Shape (template NW): eight waves, one workgroup per CU, four ring stages (three K steps = 96 KB in flight).  (Four waves, two workgroups
+// per CU, two stages each = the dense kernel made persistent: measured no faster than it, not instantiated.)  Tile, fragment and epilogue
+// layouts are conv1x1_dense_kernel's (16-byte chunks XOR-swizzled on the source side, weight rows permuted so that a lane ends up with 8
+// consecutive channels; the K order of the MFMAs is the same): results are bit-identical to it.
 // Two hardware facts met on the way: a buffer resource with num_records = 0 is NOT range-checked (absent operands get a small window and
 // out-of-range offsets instead), and a store of more than 64 bits followed within two wait states by a VALU write of its data registers
 // stores the new values (the compiler's hazard recogniser does not look into inline assembly).
@@ -112,7 +117,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * RB + (
 
 template <int J> using IC = std::integral_constant<int, J>;
 
-template <int EPI, int NW>
+// XRES (K = 128 or 256, i.e. 2 or 4 K steps): the pixel rows of a pixel tile stay in the pixel halves of the four stages while the workgroup
+// walks that pixel tile's channel tiles -- only the weights stream -- and the rows of the pixel tile after (K = 256) / after next (K = 128)
+// are requested into a slot as soon as the last channel tile has consumed it.  A third less through the CU's vector memory pipe per tile.
+template <int EPI, int NW, bool XRES>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(const PR p) {
     using S = Shape<NW>;
     constexpr int WPX = S::WPX, FJ = S::FJ, PK = S::PK, NP = S::NP, NU = S::NU, NSTAGE = S::NSTAGE, DEPTH = S::DEPTH, RING_BYTES = S::RING_BYTES;
@@ -178,12 +186,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
     };
     producer_tile();
     unsigned fill_addr = lds0 + wave * 1024;
+    const int tm_last = (t_end - 1) / n_tiles;
+    // XRES: K step s of pixel tile tmx -> the pixel half of stage `slot`
+    auto issue_x = [&](int tmx, int s, int slot) {
+        const bool live = tmx <= tm_last;
+#pragma unroll
+        for (int k = 0; k < PK; ++k)
+            dma16(x_rsrc, lds0 + slot * STAGE + A_BYTES + (wave + k * NW) * 1024,
+                  (live && tmx * TP + lrow[k] < p.M) ? b_lane[k] + (unsigned)tmx * tile_stride : X_NONE, s * (BK * 2));
+    };
     auto issue = [&]() {
         const int so = pstep * (BK * 2);
 #pragma unroll
         for (int k = 0; k < PK; ++k) dma16(w_rsrc, fill_addr + k * NW * 1024, a_src[k], so);
+        if constexpr (!XRES) {
 #pragma unroll
-        for (int k = 0; k < PK; ++k) dma16(x_rsrc, fill_addr + A_BYTES + k * NW * 1024, b_src[k], so);
+            for (int k = 0; k < PK; ++k) dma16(x_rsrc, fill_addr + A_BYTES + k * NW * 1024, b_src[k], so);
+        }
         fill_addr = fill_addr + STAGE >= lds0 + RING_BYTES ? fill_addr + STAGE - RING_BYTES : fill_addr + STAGE;
         if (++pstep == nsteps) {
             pstep = 0; ++ptile;
@@ -240,13 +259,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
     const int a_off = lds_off(wc * 64 + frag_row, frag_chunk), b_off = A_BYTES + lds_off(wp * (16 * FJ) + frag_row, frag_chunk);   // + 16 rows: same swizzle key
     // k-half kh of a row = chunks 4 kh + frag_chunk: the swizzle key is the row's, so the second half sits at (offset ^ 64)
     struct Frags { bf16x8_t a[2][4], b[2][FJ]; };
-    auto read_frags = [&](Frags& f, const unsigned char* st) {
+    auto read_frags = [&](Frags& f, const unsigned char* st, const unsigned char* stx) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) f.a[kh][i] = *reinterpret_cast<const bf16x8_t*>(st + (a_off ^ (kh << 6)) + i * 16 * RB);
 #pragma unroll
-            for (int j = 0; j < FJ; ++j) f.b[kh][j] = *reinterpret_cast<const bf16x8_t*>(st + (b_off ^ (kh << 6)) + j * 16 * RB);
+            for (int j = 0; j < FJ; ++j) f.b[kh][j] = *reinterpret_cast<const bf16x8_t*>(stx + (b_off ^ (kh << 6)) + j * 16 * RB);
         }
     };
     auto mfmas = [&](const Frags& f) {
@@ -343,21 +362,41 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rbegin = __builtin_amdgcn_s_memrealtime();
     unsigned long long last__ = st_begin;
 #endif
+    // XRES: within a step the pixel rows are requested BEFORE the weights, a refill three steps at the latest before its use -- the wait for
+    // the weights of that step (requested after it) covers it.  W(c) was requested in step c - DEPTH behind that step's pixel rows: the
+    // instructions issued after it = the weights of DEPTH - 1 steps, the pixel rows of those among them that refilled (`xhist`), the epilogues.
+    constexpr int NPW = XRES ? PK : NP;                                 // instructions of a step that every step issues
     int tm = t_begin / n_tiles, tn = t_begin - tm * n_tiles;            // the consumer's tile
     E e0, e1;
     request(e0, tm, tn, true);
+    const int xper = XRES ? NSTAGE / nsteps : 1;                        // pixel tiles resident (XRES: nsteps = 2 or 4)
+    if constexpr (XRES) {
+#pragma unroll 1
+        for (int g = 0; g < NSTAGE; ++g) issue_x(tm + g / nsteps, g % nsteps, g);
+    }
 #pragma unroll 1
     for (int d = 0; d < DEPTH; ++d) issue();
     const unsigned char* stage = smem;
-    unsigned ends = 0;
+    int xslot = 0;                                                      // XRES: the slot of the consumer's K step
+    bool p_last = false; int p_tm = 0, p_s = 0, p_slot = 0;             // XRES: the previous step closed a pixel tile's walk over that slot
+    unsigned ends = 0, xhist = 0;
     auto ring_wait = [&]() {
         const int k = __builtin_popcount(ends & ((1u << DEPTH) - 1));
-        if (k == 0) wait_vm<(DEPTH - 1) * NP>();
-        else if (k == 1) wait_vm<(DEPTH - 1) * NP + NE>();
-        else if constexpr ((DEPTH - 1) * NP + 2 * NE < 64) wait_vm<(DEPTH - 1) * NP + 2 * NE>();       // (three and more: waits for the oldest)
-        else wait_vm<(DEPTH - 1) * NP + NE>();
+        if constexpr (XRES) {
+            const int x = __builtin_popcount(xhist & ((1u << (DEPTH - 1)) - 1));
+            constexpr int B = (DEPTH - 1) * NPW;
+            static_assert(B + (DEPTH - 1) * PK + 2 * NE < 64, "vmcnt field");
+            if (k == 0) { if (x == 0) wait_vm<B>(); else if (x == 1) wait_vm<B + PK>(); else wait_vm<B + 2 * PK>(); }
+            else if (k == 1) { if (x == 0) wait_vm<B + NE>(); else if (x == 1) wait_vm<B + NE + PK>(); else wait_vm<B + NE + 2 * PK>(); }
+            else { if (x == 0) wait_vm<B + 2 * NE>(); else if (x == 1) wait_vm<B + 2 * NE + PK>(); else wait_vm<B + 2 * NE + 2 * PK>(); }
+        } else {
+            if (k == 0) wait_vm<(DEPTH - 1) * NP>();
+            else if (k == 1) wait_vm<(DEPTH - 1) * NP + NE>();
+            else if constexpr ((DEPTH - 1) * NP + 2 * NE < 64) wait_vm<(DEPTH - 1) * NP + 2 * NE>();       // (three and more: waits for the oldest)
+            else wait_vm<(DEPTH - 1) * NP + NE>();
+        }
     };
-    auto step = [&](bool tile_end) {
+    auto step = [&](int s, bool tile_end, bool last_co) {
         R1X_T(0);
         ring_wait();
         R1X_T(1);
@@ -366,13 +405,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
         asm volatile("" ::: "memory");
         R1X_T(2);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (XRES) {
+            if (p_last) issue_x(p_tm + xper, p_s, p_slot);
+            xhist = (xhist << 1) | (p_last ? 1u : 0u);
+        }
         issue();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef BD_R1X_STAMP
+        R1X_T(0);        // (diagnostic build: slot 0 = the DMA requests + producer bookkeeping, slot 3 = fragment reads + MFMAs)
+#endif
         Frags f;
-        read_frags(f, stage);
+        read_frags(f, stage, XRES ? smem + xslot * STAGE : stage);
         mfmas(f);
         stage = stage + STAGE == smem + RING_BYTES ? smem : stage + STAGE;
         ends = (ends << 1) | (tile_end ? 1u : 0u);
+        if constexpr (XRES) { p_last = last_co; p_tm = tm; p_s = s; p_slot = xslot; }
         R1X_T(3);
     };
     bool first = true;
@@ -381,14 +428,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const bool last_co = tn + 1 == n_tiles || tile + 1 == t_end;          // XRES: the pixel tile's rows are read for the last time
+        const int xbase = xslot;
 #pragma unroll 1
-        for (int t = 0; t < nsteps; ++t) step(t + 1 == nsteps);
-        // this tile's operands: requested one epilogue ago, before that epilogue's NSTORE stores and this tile's nsteps DMA groups
+        for (int t = 0; t < nsteps; ++t) {
+            if constexpr (XRES) xslot = xbase + t;
+            step(t, t + 1 == nsteps, last_co);
+        }
+        if constexpr (XRES) xslot = last_co ? ((xbase + nsteps) & (NSTAGE - 1)) : xbase;      // the next pixel tile's slots / the same rows again
+        // this tile's operands: requested one epilogue ago, before that epilogue's NSTORE stores and this tile's nsteps DMA groups (at least
+        // NPW instructions each)
         if constexpr (NLOAD > 0) {
-            if (first) wait_vm<(DEPTH - 1) * NP>();
-            else if (nsteps >= DEPTH) wait_vm<NSTORE + DEPTH * NP>();
-            else if (nsteps >= 4) wait_vm<NSTORE + 4 * NP>();
-            else wait_vm<NSTORE + 2 * NP>();
+            if (first) wait_vm<(DEPTH - 1) * NPW>();
+            else if (nsteps >= DEPTH) wait_vm<NSTORE + DEPTH * NPW>();
+            else wait_vm<NSTORE + 2 * NPW>();
             settle(cur);
         }
         R1X_T(4);
@@ -415,14 +468,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
 #endif
 }
 
-template <int EPI, int NW>
+template <int EPI, int NW, bool XRES>
 void launch_ring(const PR& p, hipStream_t stream) {
     using S = Shape<NW>;
     const int lds = S::RING_BYTES + p.n_tiles * TC * 4;
-    BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ring_kernel<EPI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 S::RING_BYTES + MAX_CO * 4));
+    BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ring_kernel<EPI, NW, XRES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::RING_BYTES + MAX_CO * 4));
     const int slots = (NW == 8 ? 1 : 2) * bd_num_cus();
-    hipLaunchKernelGGL((conv1x1_ring_kernel<EPI, NW>), dim3(p.tiles < slots ? p.tiles : slots), dim3(64 * NW), lds, stream, p);
+    hipLaunchKernelGGL((conv1x1_ring_kernel<EPI, NW, XRES>), dim3(p.tiles < slots ? p.tiles : slots), dim3(64 * NW), lds, stream, p);
 }
 
 }  // namespace
@@ -466,8 +519,11 @@ int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, cons
                     (((flags & BD_EPI_MASK) && maskbits) ? E_MASK : 0) | (ybits ? E_YBITS : 0);
     // (the four-wave shape -- two workgroups per CU, Shape<4> -- measured no faster than conv1x1_dense_kernel and is not instantiated:
     // with two fragment sets it also runs out of registers)
+    // pixel rows resident over a pixel tile's channel tiles: K of exactly 2 or 4 steps and at least two channel tiles (BD_DENSE1X1_XRES=0: off, A/B)
+    static const int xres_on = getenv("BD_DENSE1X1_XRES") ? atoi(getenv("BD_DENSE1X1_XRES")) : 1;
+    const bool xres = xres_on && (p.nsteps == 2 || p.nsteps == 4) && p.n_tiles >= 2;
     switch (epi) {
-#define BD_R1X_CASE(n) case n: launch_ring<n, 8>(p, stream); break;
+#define BD_R1X_CASE(n) case n: if (xres) launch_ring<n, 8, true>(p, stream); else launch_ring<n, 8, false>(p, stream); break;
         BD_R1X_CASE(0) BD_R1X_CASE(1) BD_R1X_CASE(2) BD_R1X_CASE(3) BD_R1X_CASE(4) BD_R1X_CASE(5) BD_R1X_CASE(6) BD_R1X_CASE(7)
         BD_R1X_CASE(8) BD_R1X_CASE(9) BD_R1X_CASE(10) BD_R1X_CASE(11) BD_R1X_CASE(12) BD_R1X_CASE(13) BD_R1X_CASE(14) BD_R1X_CASE(15)
 #undef BD_R1X_CASE

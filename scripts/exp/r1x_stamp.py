@@ -23,7 +23,7 @@ for tag, H, W, Cin, Cout, mode, add, mask, cnt in L:
         v = [out[w * 8 + k] for k in range(8)]
         rt, tiles, nsteps = v[7] >> 24, (v[7] >> 8) & 0xffff, v[7] & 0xff
         n = max(tiles, 1)
-        print(f"  wave {w}: {tiles} tiles x {nsteps} steps; per tile: ring wait {v[1] / n:6.0f}  barrier {v[2] / n:6.0f}  issue+reads+mfma {v[3] / n:6.0f}  operand wait {v[4] / n:6.0f}"
-              f"  epilogue {v[5] / n:6.0f}  other {v[0] / n:5.0f} | total {v[6] / n:6.0f} cycles/tile, {rt * 10 / n:6.0f} ns/tile ({v[6] / max(rt, 1) / 10:.2f} GHz)")
+        print(f"  wave {w}: {tiles} tiles x {nsteps} steps; per tile: ring wait {v[1] / n:6.0f}  barrier {v[2] / n:6.0f}  reads+mfma {v[3] / n:6.0f}  operand wait {v[4] / n:6.0f}"
+              f"  epilogue {v[5] / n:6.0f}  dma issue+loop {v[0] / n:5.0f} | total {v[6] / n:6.0f} cycles/tile, {rt * 10 / n:6.0f} ns/tile ({v[6] / max(rt, 1) / 10:.2f} GHz)")
     del run
     torch.cuda.empty_cache()
