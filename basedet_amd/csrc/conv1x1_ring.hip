@@ -33,9 +33,7 @@
 
 namespace {
 
-constexpr int TP = 128, TC = 128, BK = 64;                         // a K step = 64 input channels: 128-byte rows, two MFMA k-halves
-constexpr int RB = BK * 2;                                         // row bytes
-constexpr int A_BYTES = TC * RB, STAGE = A_BYTES + TP * RB;        // weight rows, then pixel rows: 32 KB
+constexpr int TP = 128, TC = 128;
 constexpr unsigned X_NONE = 0x80000000u;
 constexpr int MAX_CO = 2048;           // bias vector in LDS behind the ring (padded to whole channel tiles)
 
@@ -59,16 +57,25 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) short s16x2_t;
 
-template <int NW>
+// BK = input channels per K step: 64 (128-byte rows, two MFMA k-halves per step, 32 KB stages: one workgroup per CU) or 32 (64-byte rows,
+// 16 KB stages: TWO eight-wave workgroups per CU, four waves per SIMD)
+template <int NW, int BK>
 struct Shape {
+    static constexpr int RB = BK * 2;                                  // row bytes
+    static constexpr int CPR = RB / 16;                                // 16-byte chunks per row
+    static constexpr int KH = BK / 32;                                 // MFMA k-halves per step
+    static constexpr int A_BYTES = TC * RB, STAGE = A_BYTES + TP * RB; // weight rows, then pixel rows
     static constexpr int WPX = NW / 2;             // waves along the pixels (two along the channels: 64 each)
     static constexpr int FJ = 8 / WPX;             // 16-pixel fragments per wave
-    static constexpr int PK = 16 / NW;             // 1 KiB pieces (8 rows) of each operand per wave and K step
+    static constexpr int PK = A_BYTES / 1024 / NW; // 1 KiB pieces of each operand per wave and K step
     static constexpr int NP = 2 * PK;              // DMA instructions per wave and K step
     static constexpr int NU = 2 * FJ;              // 16-byte epilogue units per lane and tile: unit q = 2 j + half
-    static constexpr int NSTAGE = NW == 8 ? 4 : 2; // 128 KB ring, one workgroup per CU / 64 KB, two per CU
+    static constexpr int NSTAGE = 4;
     static constexpr int DEPTH = NSTAGE - 1;
     static constexpr int RING_BYTES = NSTAGE * STAGE;
+    static constexpr int WGS = RING_BYTES <= 64 * 1024 ? 2 : 1;        // workgroups per CU
+    // rows XOR-swizzled in 16-byte chunks with bits 1.. of the row: the 16 rows a fragment read touches per chunk column fall on all 64 banks
+    static __device__ __forceinline__ int lds_off(int row, int chunk) { return row * RB + ((chunk ^ ((row >> 1) & (CPR - 1))) << 4); }
 };
 
 template <int NU>
@@ -111,18 +118,17 @@ __device__ unsigned long long g_r1x_stamp[8][8];
 #define R1X_T(i) do { } while (0)
 #endif
 
-// 128-byte rows, eight 16-byte chunks XOR-swizzled with bits 1..3 of the row: the 16 rows a fragment read touches per chunk column fall on
-// all 64 banks (row parity x eight chunk positions)
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * RB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int J> using IC = std::integral_constant<int, J>;
 
 // XRES (K = 128 or 256, i.e. 2 or 4 K steps): the pixel rows of a pixel tile stay in the pixel halves of the four stages while the workgroup
 // walks that pixel tile's channel tiles -- only the weights stream -- and the rows of the pixel tile after (K = 256) / after next (K = 128)
 // are requested into a slot as soon as the last channel tile has consumed it.  A third less through the CU's vector memory pipe per tile.
-template <int EPI, int NW, bool XRES>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(const PR p) {
-    using S = Shape<NW>;
+template <int EPI, int BK, bool XRES>
+__global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(const PR p) {
+    constexpr int NW = 8;
+    using S = Shape<NW, BK>;
+    constexpr int RB = S::RB, CPR = S::CPR, KH = S::KH, A_BYTES = S::A_BYTES, STAGE = S::STAGE;
     constexpr int WPX = S::WPX, FJ = S::FJ, PK = S::PK, NP = S::NP, NU = S::NU, NSTAGE = S::NSTAGE, DEPTH = S::DEPTH, RING_BYTES = S::RING_BYTES;
     constexpr bool ADD = EPI & E_ADD, RELU = EPI & E_RELU, MASK = EPI & E_MASK, YBITS = EPI & E_YBITS;
     constexpr int NLOAD = (ADD ? NU : 0) + (MASK ? NU : 0);     // vector-memory instructions of one epilogue: the NEXT tile's operands ...
@@ -165,8 +171,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
     unsigned a_lane[PK], b_lane[PK];
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
-        lrow[k] = 8 * (wave + NW * k) + (lane >> 3);
-        const int ch = (lane & 7) ^ ((lrow[k] >> 1) & 7);               // lds_off on the source side
+        lrow[k] = (1024 / RB) * (wave + NW * k) + lane / CPR;
+        const int ch = (lane % CPR) ^ ((lrow[k] >> 1) & (CPR - 1));     // lds_off on the source side
         const int rho = lrow[k] & 15;
         wperm[k] = (lrow[k] & 64) + 32 * ((lrow[k] >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow[k] >> 4) & 1) + (rho & 3);      // LDS row -> channel of the tile
         a_lane[k] = (unsigned)(wperm[k] * p.CK + ch * 8) * 2u;
@@ -193,10 +199,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
 #pragma unroll
         for (int k = 0; k < PK; ++k)
             dma16(x_rsrc, lds0 + slot * STAGE + A_BYTES + (wave + k * NW) * 1024,
-                  (live && tmx * TP + lrow[k] < p.M) ? b_lane[k] + (unsigned)tmx * tile_stride : X_NONE, s * (BK * 2));
+                  (live && tmx * TP + lrow[k] < p.M) ? b_lane[k] + (unsigned)tmx * tile_stride : X_NONE, s * RB);
     };
     auto issue = [&]() {
-        const int so = pstep * (BK * 2);
+        const int so = pstep * RB;
 #pragma unroll
         for (int k = 0; k < PK; ++k) dma16(w_rsrc, fill_addr + k * NW * 1024, a_src[k], so);
         if constexpr (!XRES) {
@@ -256,12 +262,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
 
     f32x4_t acc[4][FJ];
     const int frag_row = lane & 15, frag_chunk = lane >> 4;
-    const int a_off = lds_off(wc * 64 + frag_row, frag_chunk), b_off = A_BYTES + lds_off(wp * (16 * FJ) + frag_row, frag_chunk);   // + 16 rows: same swizzle key
+    const int a_off = S::lds_off(wc * 64 + frag_row, frag_chunk), b_off = A_BYTES + S::lds_off(wp * (16 * FJ) + frag_row, frag_chunk);   // + 16 rows: same swizzle key
     // k-half kh of a row = chunks 4 kh + frag_chunk: the swizzle key is the row's, so the second half sits at (offset ^ 64)
-    struct Frags { bf16x8_t a[2][4], b[2][FJ]; };
+    struct Frags { bf16x8_t a[KH][4], b[KH][FJ]; };
     auto read_frags = [&](Frags& f, const unsigned char* st, const unsigned char* stx) {
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
+        for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) f.a[kh][i] = *reinterpret_cast<const bf16x8_t*>(st + (a_off ^ (kh << 6)) + i * 16 * RB);
 #pragma unroll
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
     };
     auto mfmas = [&](const Frags& f) {
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
+        for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -468,14 +474,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv1x1_ring_kernel(
 #endif
 }
 
-template <int EPI, int NW, bool XRES>
-void launch_ring(const PR& p, hipStream_t stream) {
-    using S = Shape<NW>;
+template <int EPI, int BK, bool XRES>
+void launch_ring(PR p, hipStream_t stream) {
+    using S = Shape<8, BK>;
+    p.nsteps = p.CK / BK;
     const int lds = S::RING_BYTES + p.n_tiles * TC * 4;
-    BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ring_kernel<EPI, NW, XRES>),
+    BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ring_kernel<EPI, BK, XRES>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, S::RING_BYTES + MAX_CO * 4));
-    const int slots = (NW == 8 ? 1 : 2) * bd_num_cus();
-    hipLaunchKernelGGL((conv1x1_ring_kernel<EPI, NW, XRES>), dim3(p.tiles < slots ? p.tiles : slots), dim3(64 * NW), lds, stream, p);
+    const int slots = S::WGS * bd_num_cus();
+    hipLaunchKernelGGL((conv1x1_ring_kernel<EPI, BK, XRES>), dim3(p.tiles < slots ? p.tiles : slots), dim3(512), lds, stream, p);
 }
 
 }  // namespace
@@ -501,7 +508,7 @@ int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, cons
     // gradient: 14 - 16 %); the other launches at 67 200 / 16 800 pixels have 2 - 8 tiles per CU -- one persistent workgroup per CU pays the
     // rounding (5 tiles against 4.1) that three to four small workgroups per CU even out -- and stay on conv1x1_dense_kernel (2 - 6 % slower here)
     if (mode != 2 && !(M >= 131072 || (CK <= 256 && CO >= 256 && M >= 32768))) return 1;
-    if (y8 || CK % BK != 0 || CK < 2 * BK || CO % 8 != 0 || CO > MAX_CO) return 1;
+    if (y8 || CK % 64 != 0 || CK < 128 || CO % 8 != 0 || CO > MAX_CO) return 1;
     if ((flags & BD_EPI_MASK) && mask && !maskbits) return 1;                   // bf16 gates: the older kernel
     if ((maskbits || ybits) && CO % 32 != 0) return 1;
     if ((flags & BD_EPI_SPARSE) || ((flags & BD_EPI_ADD_AFTER) && add)) return 1;
@@ -514,16 +521,17 @@ int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, cons
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; p.y_bytes = (unsigned)yb; p.bits_bytes = (unsigned)bb;
     p.n_tiles = cdiv(CO, TC);
     p.tiles = (int)cdiv64(M, TP) * p.n_tiles;
-    p.nsteps = CK / BK;
     const int epi = (((flags & BD_EPI_ADD_BEFORE) && add) ? E_ADD : 0) | ((flags & BD_EPI_RELU) ? E_RELU : 0) |
                     (((flags & BD_EPI_MASK) && maskbits) ? E_MASK : 0) | (ybits ? E_YBITS : 0);
-    // (the four-wave shape -- two workgroups per CU, Shape<4> -- measured no faster than conv1x1_dense_kernel and is not instantiated:
-    // with two fragment sets it also runs out of registers)
+    // (a four-wave shape, two workgroups per CU, measured no faster than conv1x1_dense_kernel either)
     // pixel rows resident over a pixel tile's channel tiles: K of exactly 2 or 4 steps and at least two channel tiles (BD_DENSE1X1_XRES=0: off, A/B)
     static const int xres_on = getenv("BD_DENSE1X1_XRES") ? atoi(getenv("BD_DENSE1X1_XRES")) : 1;
-    const bool xres = xres_on && (p.nsteps == 2 || p.nsteps == 4) && p.n_tiles >= 2;
+    const bool xres = xres_on && (CK == 128 || CK == 256) && p.n_tiles >= 2;
+    // (Shape<8, 32> -- 32-channel K steps, 64 KB rings, TWO eight-wave workgroups per CU, four waves per SIMD -- passes the same tests and is
+    // 10 % slower over the step's launches than the one-workgroup form, 3 % slower than conv1x1_dense_kernel: more waves do not help, the
+    // CU's LDS and vector-memory pipes are what the waves queue for.  Not instantiated.)
     switch (epi) {
-#define BD_R1X_CASE(n) case n: if (xres) launch_ring<n, 8, true>(p, stream); else launch_ring<n, 8, false>(p, stream); break;
+#define BD_R1X_CASE(n) case n: if (xres) launch_ring<n, 64, true>(p, stream); else launch_ring<n, 64, false>(p, stream); break;
         BD_R1X_CASE(0) BD_R1X_CASE(1) BD_R1X_CASE(2) BD_R1X_CASE(3) BD_R1X_CASE(4) BD_R1X_CASE(5) BD_R1X_CASE(6) BD_R1X_CASE(7)
         BD_R1X_CASE(8) BD_R1X_CASE(9) BD_R1X_CASE(10) BD_R1X_CASE(11) BD_R1X_CASE(12) BD_R1X_CASE(13) BD_R1X_CASE(14) BD_R1X_CASE(15)
 #undef BD_R1X_CASE

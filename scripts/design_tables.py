@@ -32,12 +32,17 @@ t.append("### Headline and protocol legs (`profiles/r04_bench.json`: the default
 t.append("| leg | img/s | ms/step (mean; p50 / p95) | note |\n|---|---|---|---|")
 t.append(f"| RetinaNet-R50-FPN, inputs resident in HBM (**`value`**) | **{d['value']:.1f}** (round 3: 614.2; driver-run 611.8) | {d['ms_per_step']:.2f}; {d['step_ms_p50']:.2f} / {d['step_ms_p95']:.2f} | `whole_step_mfma_frac` {d['config']['whole_step_mfma_frac']:.3f} |")
 d2 = json.load(open(P("r04_bench_box2.json")))
-t.append(f"| the same build and command on another box of the pool (`profiles/r04_bench_box2.json`; box spread of one build this round: 601–631 img/s) | {d2['value']:.1f} | {d2['ms_per_step']:.2f}; {d2['step_ms_p50']:.2f} / {d2['step_ms_p95']:.2f} | dominant kernel `{d2['roofline']['kernel']}` {d2['roofline']['frac']:.3f}, `conv_wgrad3x3_ring_kernel` {[e for e in d2['roofline_others'] if e['kernel'] == 'conv_wgrad3x3_ring_kernel'][0]['frac']:.3f} |")
+t.append(f"| the build BEFORE `conv1x1_ring_kernel` on two other boxes of the pool (`profiles/r04_bench_box2.json`, and 601.6 on the slowest box; spread of one build over the round's boxes: 601–631 img/s) | {d2['value']:.1f} | {d2['ms_per_step']:.2f}; {d2['step_ms_p50']:.2f} / {d2['step_ms_p95']:.2f} | dominant kernel `{d2['roofline']['kernel']}` {d2['roofline']['frac']:.3f}, `conv_wgrad3x3_ring_kernel` {[e for e in d2['roofline_others'] if e['kernel'] == 'conv_wgrad3x3_ring_kernel'][0]['frac']:.3f} |")
 ab = {k: v for k, v in W.items()}
 base = [v for k, v in ab.items() if k.strip() == "retinanet_r50 --batch 16"]
 old_k = ab.get("retinanet_r50 --batch 16 --wgrad-knob 5")
 if base and old_k:
     t.append(f"| same-box A/B of this round's weight-gradient kernels (`profiles/r04_workloads.txt`, box of this profile, 30 steps, uninstrumented): ring kernels + bucket reduce vs `--wgrad-knob 5` (the round-3 kernels) | **{base[-1][0]:.1f} vs {old_k[0]:.1f}** (+{(base[-1][0] / old_k[0] - 1) * 100:.1f} %) | {base[-1][1]:.2f} vs {old_k[1]:.2f} | R101 batch 16: {ab['retinanet_r101 --batch 16'][0]:.1f} vs {ab['retinanet_r101 --batch 16 --wgrad-knob 5'][0]:.1f} img/s (+{(ab['retinanet_r101 --batch 16'][0] / ab['retinanet_r101 --batch 16 --wgrad-knob 5'][0] - 1) * 100:.1f} %) |")
+ring_off = ab.get("retinanet_r50 --batch 16 BD_DENSE1X1_RING=0")
+ring_on = [v for k, v in ab.items() if k.startswith("retinanet_r50 --batch 16") and (k.strip() == "retinanet_r50 --batch 16" or "(again)" in k)]
+if ring_off and ring_on:
+    on = sum(v[0] for v in ring_on) / len(ring_on); onms = sum(v[1] for v in ring_on) / len(ring_on)
+    t.append(f"| same-box A/B of `conv1x1_ring_kernel` (same file): default dispatch vs `BD_DENSE1X1_RING=0` (every dense 1×1 launch on `conv1x1_dense_kernel`) | **{on:.1f} vs {ring_off[0]:.1f}** (+{(on / ring_off[0] - 1) * 100:.1f} %) | {onms:.2f} vs {ring_off[1]:.2f} | an earlier alternation on another box: 638.1 / 638.0 vs 624.2 / 625.4 (+2.1 %) |")
 rp = d["reference_protocol"]
 t.append(f"| same step, the reference harness's protocol (`tools/benchmark.py:125-133`: float64 host batch → fp32 → H2D inside the step, device sync around every step) — PCIe-inclusive, never `value` | **{rp['images_per_sec']:.0f}** (round 3: 488) | {rp['ms_per_step_mean']:.1f}; {rp['ms_p50']:.1f} / {rp['ms_p95']:.1f} | `bd_h2d_submit`: threaded conversion into pinned chunks, per-chunk DMA |")
 cb = d["cpu_baseline"]

@@ -27,6 +27,8 @@ python3 bench.py --workload faster_rcnn_r50_800x1344 --steps 50 --warmup 10 --no
 for a in "--batch 16" "--batch 32" "--batch 16 --fp8" "--batch 32 --fp8" "--batch 32 --fp8 --model-opt FP8_DGRAD=0" "--batch 16 --model-opt FUSE_FROZEN_BLOCKS=0" "--batch 16 --conv-knob 24579" "--batch 16 --wgrad-knob 5" "--batch 16 --model-opt WGRAD_QUEUE=layer" "--batch 16"; do
   python3 bench.py $a --steps 30 --warmup 8 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r50 $a', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 done
+BD_DENSE1X1_RING=0 python3 bench.py --batch 16 --steps 30 --warmup 8 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r50 --batch 16 BD_DENSE1X1_RING=0', d['value'], d['ms_per_step'])" >> $O/workloads.txt
+python3 bench.py --batch 16 --steps 30 --warmup 8 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r50 --batch 16 (again)', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 for a in "--batch 32 --fp8 --model-opt FP8_DGRAD=0" "--batch 16" "--batch 16 --wgrad-knob 5"; do
   python3 bench.py --workload retinanet_r101_800x1344 $a --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet_r101 $a', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 done
@@ -36,6 +38,7 @@ BD_FORCE_ALLREDUCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-nod
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/exp/ingest_rate_mix.hip -o /tmp/ingest_rate_mix 2>/dev/null && /tmp/ingest_rate_mix >> $O/r04_ingest_rate.txt
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/exp/epi_rows.hip -o /tmp/epi_rows 2>/dev/null && /tmp/epi_rows >> $O/r04_ingest_rate.txt
 ( echo "== default"; python3 scripts/micro_1x1_step.py 1 4 2 2>&1 | grep -v amdgpu; for d in 2 3 4; do echo "== no LDS-DMA variant, register sets in flight: $d"; BD_DENSE1X1_DMA_K=99999 BD_DENSE1X1_REGDEPTH=$d python3 scripts/micro_1x1_step.py 1 2>&1 | grep -v amdgpu; done ) > $O/r04_dense1x1_variants.txt
+( echo "# scripts/micro_1x1_step.py 1 5 3: d1 = the default dispatch, d5 = conv1x1_ring_kernel for every legal launch, d3 = conv1x1_dense_kernel only; b = bit-packed gates"; python3 scripts/micro_1x1_step.py 1 5 3 2>&1 | grep -v amdgpu; echo "# phase stamps of conv1x1_ring_kernel (scripts/exp/r1x_stamp.py, -DBD_R1X_STAMP build)"; BASEDET_HIP_LIB=$R/basedet_amd/lib/libbasedet_r1x.so python3 scripts/exp/r1x_stamp.py 2>&1 | grep -v amdgpu ) > $O/r04_dense1x1_ring_final.txt
 python3 scripts/micro_wgrad1x1_ring.py 5 2>&1 | grep -v amdgpu > $O/r04_wgrad1x1_ring_vs_staged.txt
 python3 scripts/micro_wgrad_ring.py 5 2>&1 | grep -v amdgpu > $O/r04_wgrad3x3_ring_vs_staged.txt
 BASEDET_HIP_LIB=$R/basedet_amd/lib/libbasedet_rk.so python3 scripts/exp/rk_stamp.py 2>&1 | grep -v amdgpu > $O/r04_rk_stamps.txt
