@@ -68,6 +68,37 @@ def test_training_step_is_bitwise_reproducible_full_size():
     assert abs(outs[0][0] - outs[1][0]) <= 4 * np.sqrt(n_adds) * 2.0 ** -24 * abs(outs[0][0])
 
 
+def test_training_step_is_bit_identical_with_either_dense_1x1_kernel_full_size():
+    """conv1x1_ring_kernel (round 4) gives conv1x1_dense_kernel's bits launch by launch (tests/test_conv_gpu.py), so a whole RetinaNet-R50
+    step at 4 x 800 x 1344 -- forward, targets, backward through every bottleneck -- must not change by a bit when the ring kernel takes
+    every launch it can (bd_conv_set_dense1x1(5)), only the default ones (1), or none (3)."""
+    from basedet_amd import ops
+    from basedet_amd.configs import RetinaNetConfig
+    from basedet_amd.models import RetinaNet, params as P
+    from basedet_amd.utils import DummyLoader
+    cfg = RetinaNetConfig()
+    cfg.MODEL.BATCHSIZE = 4
+    params = P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2)
+    b = next(DummyLoader(4, (800, 1344), seed=0))
+    batch = {"data": torch.from_numpy(b["data"].astype(np.float32)).cuda(), "gt_boxes": torch.from_numpy(b["gt_boxes"]).cuda(),
+             "im_info": torch.from_numpy(b["im_info"]).cuda()}
+    outs = {}
+    try:
+        for mode in (3, 5, 1):
+            assert ops.L().bd_conv_set_dense1x1(mode) == 0
+            model = RetinaNet(cfg, params=params)
+            model(batch)
+            model.backward()
+            torch.cuda.synchronize()
+            outs[mode] = (model.arena.g.clone(), model._cur.labels.clone())
+    finally:
+        ops.L().bd_conv_set_dense1x1(1)
+    for mode in (5, 1):
+        assert torch.equal(outs[3][1], outs[mode][1])
+        assert torch.equal(outs[3][0], outs[mode][0]), mode          # every gradient of the arena, bit for bit
+    assert float(outs[3][0].abs().max()) > 0
+
+
 def test_fcos_training_step_is_bitwise_reproducible_full_size():
     """FCOS normalises its regression loss by the sum of centre-ness over the foreground points (models/det/fcos.py:139-144); that sum is
     taken in a fixed order (ctr_sum_kernel), GroupNorm's statistics in two fixed-order stages: two runs give bit-identical gradients."""
