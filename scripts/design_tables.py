@@ -31,6 +31,9 @@ t = []
 t.append("### Headline and protocol legs (`profiles/r04_bench.json`: the default `python bench.py`, 100 timed steps after 20 warm-up)\n")
 t.append("| leg | img/s | ms/step (mean; p50 / p95) | note |\n|---|---|---|---|")
 t.append(f"| RetinaNet-R50-FPN, inputs resident in HBM (**`value`**) | **{d['value']:.1f}** (round 3: 614.2; driver-run 611.8) | {d['ms_per_step']:.2f}; {d['step_ms_p50']:.2f} / {d['step_ms_p95']:.2f} | `whole_step_mfma_frac` {d['config']['whole_step_mfma_frac']:.3f} |")
+if os.path.exists(P("r04_bench_box3.json")):
+    d3 = json.load(open(P("r04_bench_box3.json")))
+    t.append(f"| the same build and command on another box (`profiles/r04_bench_box3.json`) | {d3['value']:.1f} | {d3['ms_per_step']:.2f}; {d3['step_ms_p50']:.2f} / {d3['step_ms_p95']:.2f} | `{d3['roofline']['kernel']}` {d3['roofline']['frac']:.3f}; reference-harness protocol {d3['reference_protocol']['images_per_sec']:.0f} img/s |")
 d2 = json.load(open(P("r04_bench_box2.json")))
 t.append(f"| the build BEFORE `conv1x1_ring_kernel` on two other boxes of the pool (`profiles/r04_bench_box2.json`, and 601.6 on the slowest box; spread of one build over the round's boxes: 601–631 img/s) | {d2['value']:.1f} | {d2['ms_per_step']:.2f}; {d2['step_ms_p50']:.2f} / {d2['step_ms_p95']:.2f} | dominant kernel `{d2['roofline']['kernel']}` {d2['roofline']['frac']:.3f}, `conv_wgrad3x3_ring_kernel` {[e for e in d2['roofline_others'] if e['kernel'] == 'conv_wgrad3x3_ring_kernel'][0]['frac']:.3f} |")
 ab = {k: v for k, v in W.items()}
