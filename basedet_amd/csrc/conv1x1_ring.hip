@@ -1,5 +1,7 @@
 // Dense 1x1 / stride-1 convolution (forward and data gradient) over one level, round-4 form: y[m][co] = sum_k x[m][k] w[co][k] (+ epilogue)
-// as persistent workgroups with every byte they touch requested ahead of its use.
+// as persistent workgroups with every byte they touch requested ahead of its use.  The launches: conv1 / conv3 of the reference's
+// Bottleneck (basedet/models/cls/resnet.py:70-113: conv + FrozenBN (+ residual) + ReLU, and their data gradients) and the FPN laterals
+// (basedet/layers/backbone/fpn_backbone.py); entered through bd_conv2d_fwd / bd_conv2d_dgrad (include/basedet_hip.h) like every convolution.
 //
 // Why (scripts/exp/d1_stamp.py, profiles/r04_d1_*): in conv1x1_dense_kernel (conv1x1.hip: one 128^2 tile per workgroup, 3 - 4 workgroups per
 // CU) a workgroup lives 18 - 45 us -- a K step is one round trip (0.9 - 1.3 us under load), the epilogue two more -- and the launch takes
