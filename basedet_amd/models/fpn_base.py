@@ -168,12 +168,15 @@ class FPNDetector:
                     key = "side" if id(c) in side else "main"          # P6 / P7 run on a side stream: their own scratch
                     c.enable_fp8(lambda n, key=key: self._q8_buf(key, n), m.get("FP8_ACT_SCALE", 1.0),
                                  dgrad=bool(m.get("FP8_DGRAD", fp8_dgrad_default)), grad_scale=m.get("FP8_GRAD_SCALE", fp8_scale0),
-                                 # FP8_WGRAD (default 0 = bf16 weight gradients): 1 = the one-byte kernel (bd_conv2d_wgrad_fp8) for the
-                                 # bias-free layers (backbone conv2), 2 = also the towers.  Exact and 1.1 - 1.45x its bf16 launch in
-                                 # isolation, but not faster in the step: R101 batch 32, same box, 469.5 / 470.8 img/s at 0, 466.3 /
-                                 # 468.6 at 1, 468.0 / 467.5 at 2 (bound by its transposing LDS reads, one 8-wave workgroup per CU next
-                                 # to the main stream's kernels, and the towers' bias gradient becomes a separate column-sum pass)
-                                 wgrad=(int(m.get("FP8_WGRAD", 0)) >= (2 if c.has_bias else 1)) and bool(m.get("FP8_DGRAD", fp8_dgrad_default)))
+                                 # FP8_WGRAD: 0 = bf16 weight gradients, 1 = the one-byte kernel (bd_conv2d_wgrad_fp8) for the bias-free
+                                 # layers (backbone conv2), 2 (default since round 4) = also the towers.  Exact on representable inputs;
+                                 # 1.4x the bf16 ring kernel per head-tower launch.  Round 2 kept it opt-in (no gain in the step then,
+                                 # and a repeated-batch run under the static scale lost convergence); under per-group delayed scales and
+                                 # stochastic rounding: R101 batch 32 same box 487.6 / 487.6 img/s at 0, 494.5 / 496.4 at 2; ten of ten
+                                 # seeds through 1 500 repeated-batch steps (profiles/r04_fp8_stability_wgrad.txt; bf16 and the
+                                 # FP8_WGRAD = 0 form: nine of ten each); whole-model gradient cosine vs bf16 0.9814 (0.9818 at 0) at
+                                 # 2 x 800 x 1344 (tests/test_r101_gpu.py)
+                                 wgrad=(int(m.get("FP8_WGRAD", 2)) >= (2 if c.has_bias else 1)) and bool(m.get("FP8_DGRAD", fp8_dgrad_default)))
             # the bottleneck 1x1s around an fp8 3x3 (res4 / res5 blocks after the first) on one-byte operands.  In isolation the reducing
             # direction (conv1 forward, conv3's data gradient: the input is most of the bytes) is 1.5 - 1.6x faster than its bf16 launch
             # and the expanding one about even; in the step the extra twins the neighbouring launches must write take most of it back:

@@ -185,7 +185,8 @@ def test_retinanet_r50_fp8_backward_variants():
     def run(**kw):
         for k in ("WEIGHT_DTYPE", "FP8_DGRAD", "FP8_GRAD_TWINS", "FP8_1X1", "FP8_WGRAD"):
             cfg.MODEL.pop(k, None)
-        for k, v in kw.items():
+        kw.setdefault("FP8_WGRAD", 0)              # (a) - (d) compare the forward / data-gradient variants on bf16 weight gradients; (e) turns
+        for k, v in kw.items():                    # the one-byte weight-gradient kernel on (2: the default since round 4)
             cfg.MODEL[k] = v
         # round-to-nearest gradients here: the variants are compared with each other value by value (stochastic rounding, the training
         # default, is unbiased but lifts tensors that live below the e5m2 floor to the floor's noise level: its own test below)
@@ -207,7 +208,7 @@ def test_retinanet_r50_fp8_backward_variants():
     assert any(b.out8 is not None for b in mc._cur.blk) and any(b.mid8b is not None for b in mc._cur.blk)
     assert any(b.g_out8 is not None and b.g_out8_ready for b in mc._cur.blk) and any(b.g_mid8a is not None for b in mc._cur.blk)
     md, ld, gd = run(WEIGHT_DTYPE="fp8_e4m3", FP8_DGRAD=True, FP8_1X1=False)         # (d): the 1x1 layers on bf16, as (c) otherwise
-    me, le, ge = run(WEIGHT_DTYPE="fp8_e4m3", FP8_DGRAD=True, FP8_WGRAD=2)           # (e): as (c) with the 3x3 weight gradients from the twins (opt-in)
+    me, le, ge = run(WEIGHT_DTYPE="fp8_e4m3", FP8_DGRAD=True, FP8_WGRAD=2)           # (e): as (c) with the 3x3 weight gradients from the twins (the default)
     assert any(c.fp8_wgrad for c in me.convs.values()) and not any(c.fp8_wgrad for c in mc.convs.values())
     assert not any(c.fp8_1x1 for c in md.convs.values())
     assert mc._cur.g_P8 is not None and mb._cur.g_P8 is None

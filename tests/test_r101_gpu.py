@@ -98,21 +98,24 @@ def test_retinanet_r101_bf16_full_size_matches_oracle(r101):
                           "RetinaNet-R101 2x800x1344", bound=3e-2)
 
 
-@pytest.mark.parametrize("dgrad", [False, True])
-def test_retinanet_r101_fp8_full_size_tolerance(r101, dgrad):
-    """WEIGHT_DTYPE = fp8_e4m3 on R101: forward only (dgrad False) and with e5m2 data gradients under per-group delayed scales."""
+@pytest.mark.parametrize("dgrad,wgrad", [(False, 0), (True, 0), (True, 2)])
+def test_retinanet_r101_fp8_full_size_tolerance(r101, dgrad, wgrad):
+    """WEIGHT_DTYPE = fp8_e4m3 on R101: forward only (dgrad False), with e5m2 data gradients under per-group delayed scales, and with the
+    3x3 weight gradients from the one-byte twins as well (FP8_WGRAD = 2: conv_wgrad3x3_fp8_kernel, the default since round 4)."""
     from basedet_amd.models import RetinaNet
     cfg, names, ref, aux, b16 = r101["cfg"], r101["names"], r101["ref"], r101["aux"], r101["bf16"]
     cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
     cfg.MODEL.FP8_DGRAD = dgrad
+    cfg.MODEL.FP8_WGRAD = wgrad
     cfg.MODEL.FP8_STOCHASTIC_ROUNDING = False
     try:
         m8 = RetinaNet(cfg, params=r101["params"])
     finally:
-        for k in ("WEIGHT_DTYPE", "FP8_DGRAD", "FP8_STOCHASTIC_ROUNDING"):
+        for k in ("WEIGHT_DTYPE", "FP8_DGRAD", "FP8_WGRAD", "FP8_STOCHASTIC_ROUNDING"):
             cfg.MODEL.pop(k, None)
     assert any(c.fp8 for c in m8.convs.values())
     assert any(c.fp8_dgrad for c in m8.convs.values()) == dgrad
+    assert any(c.fp8_wgrad for c in m8.convs.values()) == (wgrad > 0)
     out8 = m8(r101["batch"])
     m8.backward()
     torch.cuda.synchronize()
@@ -126,5 +129,12 @@ def test_retinanet_r101_fp8_full_size_tolerance(r101, dgrad):
     b = torch.cat([b16["grads"][n].double().reshape(-1) for n in names])
     assert bool(torch.isfinite(a).all())
     cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-    print(f"R101 gradient cosine fp8 (dgrad={dgrad}) vs bf16: {cos:.5f}")
+    print(f"R101 gradient cosine fp8 (dgrad={dgrad}, wgrad={wgrad}) vs bf16: {cos:.5f}")
     assert cos >= 0.98, cos
+    # ... and layer by layer over the 3x3 weights (what the one-byte weight-gradient kernel produces when wgrad is on): a two-image batch at
+    # the pre-probe scales; the lowest layer is a thin backbone conv2 or, with fp8 weight gradients, the deepest conv of the classification tower
+    worst = min((float(torch.dot(g8[n].double().reshape(-1), b16["grads"][n].double().reshape(-1)) /
+                       (g8[n].double().norm() * b16["grads"][n].double().norm())), n)
+                for n in names if n.endswith(".weight") and g8[n].dim() == 4 and g8[n].shape[-1] == 3)
+    print(f"worst 3x3 weight-gradient cosine (dgrad={dgrad}, wgrad={wgrad}):", worst)
+    assert worst[0] >= 0.85, worst            # observed: 0.910 forward only (layer2.0.conv2), 0.895 with e5m2 data gradients, 0.869 with fp8 weight gradients
