@@ -69,7 +69,7 @@ for k, (v, ms) in W.items():
     t.append(f"| `{k}` | {v:.1f} | {ms:.2f} |")
 t.append("")
 t.append(f"BASELINE config 5 on one GPU (`profiles/r04_bench_r101_fp8.json`, batch 32): **{r101['value']:.1f} img/s**, {r101['ms_per_step']:.1f} ms/step "
-         f"(fp8 forward + e5m2 data gradients under per-group delayed scales, the default) against bf16 {r101b['value']:.1f} ({r101b['ms_per_step']:.1f} ms); "
+         f"(fp8 forward + e5m2 data gradients + one-byte 3×3 weight gradients under per-group delayed scales, the default) against bf16 {r101b['value']:.1f} ({r101b['ms_per_step']:.1f} ms); "
          f"dominant kernel `{r101['roofline']['kernel']}` {r101['roofline']['ms_per_step']:.1f} ms at {r101['roofline']['frac']:.3f} of the {r101['roofline']['peak']:.0f} {r101['roofline']['unit']} roof.\n")
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
