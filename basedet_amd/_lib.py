@@ -42,6 +42,8 @@ _D = C.POINTER(ConvDesc)
 SIGNATURES = {
     "bd_last_error_string": (C.c_char_p, []),
     "bd_version": (_I, []),
+    "bd_conv_last_kernel": (C.c_char_p, []),
+    "bd_probe_mfma_rate": (_I, [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "bd_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_fwd_bits": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -40,6 +40,7 @@ SOURCES = {
     "norm.hip": [],
     "comm.hip": [],
     "layer_ops.hip": ["-ffp-contract=off"],
+    "probe.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
 COMMON += os.environ.get("BD_EXTRA_FLAGS", "").split()      # diagnostic builds (-DBD_PP_STAMP, -DBD_W3_STAMP) next to BD_LIB_NAME

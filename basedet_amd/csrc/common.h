@@ -56,6 +56,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 void bd_set_error(const char* fmt, ...);
+// bd_conv_last_kernel(): every convolution launch site names the kernel it dispatched to (a string literal; thread-local, host side only)
+void bd_note_kernel(const char* name);
 
 #define BD_REQUIRE(cond, ...)            \
     do {                                 \

@@ -931,6 +931,7 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS));
             p.m_tiles = mt; p.n_tiles = nt;
             const long long tiles = (long long)mt * nt;
+            bd_note_kernel("conv1x1_big_kernel");
             hipLaunchKernelGGL(conv1x1_big_kernel, dim3((int)(tiles < 256 ? tiles : 256)), dim3(512), BG_LDS, stream, p);
             return 0;
         }
@@ -940,11 +941,13 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
         BD_ONCE_PER_DEVICE(
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dense_kernel<1, 4, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
         p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, 256);
+        bd_note_kernel("conv1x1_dense_kernel");
         hipLaunchKernelGGL((conv1x1_dense_kernel<1, 4, true, 4>), dim3(p.m_tiles * p.n_tiles), dim3(512), WIDE_LDS, stream, p);
         return 0;
     }
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
     const int grid = p.m_tiles * p.n_tiles;
+    bd_note_kernel("conv1x1_dense_kernel");
     // 512 <= CK <= 1024 (res3 / res4 conv1 and conv3's data gradient, the laterals): the three-stage LDS-DMA ring (two K steps in flight
     // per workgroup, three workgroups per CU) is 3 - 11 % faster; shorter K (the epilogue is most of the tile) and the 16 800-pixel res5
     // layers (K = 2048: everything L2-resident, four workgroups per CU hide more) stay on the register-staged loop.  Measured per class
@@ -1000,6 +1003,7 @@ int bd_conv1x1_s2_launch(const bd_conv_desc* d, int mode, const void* src, const
     p.inv_dW = 1.0f / (float)p.dW; p.inv_dHW = 1.0f / (float)p.dHW;
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
     const int grid = p.m_tiles * p.n_tiles;
+    bd_note_kernel("conv1x1_dense_kernel");
     if (CK % BK == 0 && CK >= g_conv1x1_dma_k && (CK <= 1024 || g_conv1x1_dma_k < 512))
         hipLaunchKernelGGL((conv1x1_dense_kernel<1, 3, true>), dim3(grid), dim3(256), 6 * TILE_BYTES, stream, p);
     else
@@ -1034,6 +1038,7 @@ extern "C" int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, c
     BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fp8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * F8_TILE);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * F8_TILE));
+    bd_note_kernel("conv1x1_fp8_kernel");
     if (mode == 0) hipLaunchKernelGGL((conv1x1_fp8_kernel<0>), dim3(grid), dim3(256), 4 * F8_TILE, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv1x1_fp8_kernel<1>), dim3(grid), dim3(256), 4 * F8_TILE, (hipStream_t)stream, p);
     BD_CHECK_LAUNCH("bd_conv1x1_fp8");

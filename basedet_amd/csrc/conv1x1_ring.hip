@@ -484,6 +484,7 @@ void launch_ring(PR p, hipStream_t stream) {
     BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ring_kernel<EPI, BK, XRES>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, S::RING_BYTES + MAX_CO * 4));
     const int slots = S::WGS * bd_num_cus();
+    bd_note_kernel("conv1x1_ring_kernel");
     hipLaunchKernelGGL((conv1x1_ring_kernel<EPI, BK, XRES>), dim3(p.tiles < slots ? p.tiles : slots), dim3(512), lds, stream, p);
 }
 

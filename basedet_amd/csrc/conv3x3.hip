@@ -438,6 +438,7 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const bool dma = g_patch_dma && p.CK % 64 == 0;
+    bd_note_kernel("conv3x3_patch_kernel");
     if (dma && mode == 0) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 0>), dim3(grid), dim3(512), lds, stream, p);
     else if (dma) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 1>), dim3(grid), dim3(512), lds, stream, p);
     else if (mode == 0) hipLaunchKernelGGL((conv3x3_patch_kernel<false, 0>), dim3(grid), dim3(512), lds, stream, p);

@@ -667,6 +667,7 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    bd_note_kernel("conv3x3_pp_kernel");
     if (mode == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<0>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
     else hipLaunchKernelGGL((conv3x3_pp_kernel<1>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
     return 0;

@@ -76,6 +76,7 @@ int bd_conv3x3_pp128_launch_range(const bd_conv_desc* d, int mode, const void* s
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<128>::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<64>::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp128_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile<64>::LDS_BYTES));
+    if (!tco) bd_note_kernel("conv3x3_pp128_kernel");          // (tco != 0: the tail of a conv3x3_pp_kernel launch, named there)
     if (small) {
         if (mode == 0) hipLaunchKernelGGL((conv3x3_pp128_kernel<0, 64>), dim3(grid), dim3(512), Tile<64>::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv3x3_pp128_kernel<1, 64>), dim3(grid), dim3(512), Tile<64>::LDS_BYTES, stream, p);

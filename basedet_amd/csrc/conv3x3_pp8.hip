@@ -433,6 +433,7 @@ int bd_conv3x3_pp8_launch(const bd_conv_desc* d, int mode, const void* xq, const
     BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    bd_note_kernel("conv3x3_pp8_kernel");
     if (mode == 0) hipLaunchKernelGGL((conv3x3_pp8_kernel<0>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
     else hipLaunchKernelGGL((conv3x3_pp8_kernel<1>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
     return 0;

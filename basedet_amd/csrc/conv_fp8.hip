@@ -486,6 +486,7 @@ int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, 
     const size_t lds = 4 * TILE_BYTES;
     BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    bd_note_kernel("conv_fp8_kernel");
     hipLaunchKernelGGL(conv_fp8_kernel, dim3(p.m_tiles * p.n_tiles), dim3(256), lds, (hipStream_t)stream, fp);
     BD_CHECK_LAUNCH("bd_conv2d_fwd_fp8");
     return BD_OK;

@@ -400,6 +400,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = p.m_tiles * p.n_tiles;
+    bd_note_kernel(BK == 32 ? "conv_igemm_kernel<32>" : "conv_igemm_kernel<64>");
     const bool epi_ops = ((p.flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER)) && p.add) || ((p.flags & BD_EPI_MASK) && p.mask);
     const int ksteps = (p.CK + BK - 1) / BK * p.R * p.S;
     const bool pre = g_igemm_prefetch_epi && p.linear_dst && epi_ops && ksteps <= 4;     // (<= 8 / 16 / 64 measured: no difference)
@@ -439,7 +440,9 @@ bool is_3x3s1(const bd_conv_desc* d) {
     return true;
 }
 int g_use_patch3x3 = 1;
+#ifdef BD_AB_SKIP                // diagnostic build only (BD_EXTRA_FLAGS=-DBD_AB_SKIP next to BD_LIB_NAME): the shipped library cannot skip a launch
 int g_skip_s2_3x3 = 0;          // bd_conv_set_patch3x3 bit 4: timing A/B only -- the stride-2 3x3 forward / data-gradient launches return at once
+#endif
 int g_bk32_for_1x1 = 1;
 // Stride-2 3x3 layers stay on the generic kernel, and there the tiles are short (the data gradient visits 1 / 2 / 2 / 4 taps per
 // parity class) and bound by the latency of their few K steps: BK=32 tiles (32 KB of LDS instead of 80 KB: four workgroups per CU
@@ -460,9 +463,17 @@ extern int g_conv1x1_s2;
 extern int g_pp_tail_split;
 extern int g_pp_persistent;
 extern "C" int bd_conv_set_patch3x3(int enable) {
+#ifdef BD_AB_SKIP
+    g_skip_s2_3x3 = (enable >> 4) & 1;
+#else
+    if ((enable >> 4) & 1) {         // (checked before anything is changed)
+        bd_set_error("bd_conv_set_patch3x3: bit 4 (skip the 3x3 / stride-2 launches: a timing A/B that leaves stale outputs) exists in "
+                     "-DBD_AB_SKIP diagnostic builds only");
+        return BD_EINVAL;
+    }
+#endif
     g_use_patch3x3 = enable & 1; g_bk32_for_1x1 = (enable >> 1) & 1;
     g_patch_dma = ((enable >> 3) & 1) ^ 1;
-    g_skip_s2_3x3 = (enable >> 4) & 1;
     g_patch_pp = ((enable >> 6) & 1) ? 0 : (((enable >> 7) & 1) ? 1 : 2);
     g_patch_pp128 = ((enable >> 9) & 1) ? -1 : ((enable >> 8) & 1);
     g_bk32_s2 = ((enable >> 10) & 1) ^ 1;
@@ -509,7 +520,9 @@ static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_p
     }
     BD_REQUIRE(ybits == nullptr && y8 == nullptr, "conv2d_fwd_bits / _ex: the bit-packed ReLU mask and the e4m3 twin are written by the dense "
                "1x1 kernel only (1x1 / stride 1 over one dense level, Cout %% 32 == 0, tensors < 2 GB)");
+#ifdef BD_AB_SKIP
     if (g_skip_s2_3x3 && d->R == 3 && d->S == 3 && d->stride == 2) return BD_OK;       // (A/B: "how much of the step are these launches?")
+#endif
     if (g_use_patch3x3 && is_3x3s1(d)) {
         bd_conv3x3_patch_launch(d, 0, x, w_packed, bias, add, nullptr, y, flags, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_fwd(3x3 patch)");
@@ -583,7 +596,9 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
     }
     BD_REQUIRE(maskbits == nullptr && dx8 == nullptr, "conv2d_dgrad_bits / _ex: the bit-packed ReLU mask is read, and the e5m2 twin written, by "
                "the dense 1x1 kernel only (1x1 / stride 1 over one dense level, Cin %% 32 == 0, tensors < 2 GB)");
+#ifdef BD_AB_SKIP
     if (g_skip_s2_3x3 && d->R == 3 && d->S == 3 && d->stride == 2) return BD_OK;
+#endif
     if (g_use_patch3x3 && is_3x3s1(d)) {
         bd_conv3x3_patch_launch(d, 1, g, w_packed_t, nullptr, add, mask, dx, flags, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_dgrad(3x3 patch)");

@@ -524,6 +524,7 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
     };
     if (g_wgrad_use_3x3 && g_wgrad_use_ring && bd_wgrad3x3r_eligible(d)) {
         int splitsr = 1;
+        bd_note_kernel("conv_wgrad3x3_ring_kernel");
         bd_wgrad3x3r_launch(d, x, g, (float*)ws, dbias ? (float*)extra : nullptr, &splitsr, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(3x3 ring)");
         BdRedEntry e{};
@@ -533,12 +534,14 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
     }
     if (g_wgrad_use_3x3 && is_3x3s1(d)) {
         int splits3 = 1;
+        bd_note_kernel("conv_wgrad3x3_kernel");
         bd_wgrad3x3_launch(d, x, g, (float*)ws, dbias ? (float*)extra : nullptr, &splits3, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(3x3)");
         return finish(plain_entry((const float*)ws, splits3, (long long)d->Cout * 9 * d->Cin, 9 * d->Cin, row_scale, dw, accumulate), splits3, true);
     }
     if (g_wgrad_use_3x3 && g_wgrad_use_ring && bd_wgrad1x1r_eligible(d)) {
         int splitsr = 1;
+        bd_note_kernel("conv_wgrad1x1_ring_kernel");
         bd_wgrad1x1r_launch(d, x, g, (float*)ws, &splitsr, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(1x1 ring)");
         BdRedEntry e{};
@@ -548,6 +551,7 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
     }
     if (g_wgrad_use_3x3 && d->R == 1 && d->S == 1 && d->pad == 0) {
         int splits1 = 1;
+        bd_note_kernel("conv_wgrad1x1_kernel");
         bd_wgrad1x1_launch(d, x, g, (float*)ws, &splits1, (hipStream_t)stream);
         BD_CHECK_LAUNCH("bd_conv2d_wgrad(1x1)");
         return finish(plain_entry((const float*)ws, splits1, (long long)d->Cout * d->Cin, d->Cin, row_scale, dw, accumulate), splits1, false);
@@ -575,6 +579,7 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BKP_DEFAULT, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    bd_note_kernel("conv_wgrad_kernel");
     if (g_wgrad_use_tr)
         hipLaunchKernelGGL((conv_wgrad_kernel<BKP_DEFAULT, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     else

@@ -313,6 +313,7 @@ extern "C" int bd_conv2d_wgrad_fp8(const bd_conv_desc* d, const void* x8, const 
     BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F8_BUF));
     const int grid = splits * p.ci_tiles * p.co_tiles;
+    bd_note_kernel("conv_wgrad3x3_fp8_kernel");
     hipLaunchKernelGGL(conv_wgrad3x3_fp8_kernel, dim3(grid), dim3(256), 2 * F8_BUF, (hipStream_t)stream, p);
     BD_CHECK_LAUNCH("bd_conv2d_wgrad_fp8");
     bd_wgrad_reduce_launch((const float*)ws, splits, (long long)d->Cout * 9 * d->Cin, 9 * d->Cin, row_scale, dw, accumulate, (hipStream_t)stream);

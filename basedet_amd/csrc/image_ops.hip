@@ -30,6 +30,10 @@ void bd_set_error(const char* fmt, ...) {
     g_bd_error = buf;
 }
 extern "C" const char* bd_last_error_string(void) { return g_bd_error.c_str(); }
+// which kernel the calling thread's last convolution entry point dispatched to (set at every launch site: the dispatch itself, not a mirror)
+static thread_local const char* g_bd_last_kernel = "";
+void bd_note_kernel(const char* name) { g_bd_last_kernel = name; }
+extern "C" const char* bd_conv_last_kernel(void) { return g_bd_last_kernel; }
 extern "C" int bd_version(void) { return 100; }
 
 namespace {

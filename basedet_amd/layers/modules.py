@@ -158,7 +158,7 @@ class RetinaNetHead(_Head, _HeadBackward):
         """Gradients of the last forward's outputs -> gradients of its input features (list of NCHW fp32), parameter gradients in grads()."""
         pl, m = self._pl, self.model
         m._cur = pl
-        pl.wq_off, pl.wq_pending = 0, 0
+        m._begin_wgrads()
         _store(pl.d_logits, pl.pyr, d_logits, m.num_anchors * m.num_classes)
         _store(pl.d_offsets, pl.pyr, d_offsets, m.num_anchors * 4)
         m.head_backward(pl, pl.wgrad_ws, pl.colsum_ws)
@@ -188,7 +188,7 @@ class PointHead(_Head, _HeadBackward):
         """As RetinaNetHead.backward; d_offsets are the gradients of the DECODED offsets (relu(x * scale_l) * stride_l, point_head.py:143)."""
         pl, m = self._pl, self.model
         m._cur = pl
-        pl.wq_off, pl.wq_pending = 0, 0
+        m._begin_wgrads()
         _store(pl.d_logits, pl.pyr, d_logits, m.num_classes)
         _store(pl.d_off, pl.pyr, d_offsets, 4)
         N = pl.pyr.N

@@ -78,7 +78,11 @@ class FPNDetector:
         # partial sums are pending; "layer" = one reduce per layer right behind its kernel (rounds 1-3)
         self.wgrad_queue_mode = m.get("WGRAD_QUEUE", "bucket")
         self._wq = None
-        self._wq_need = {}                  # (layer name, geometry) -> workspace bytes
+        self._wq_need = {}                  # (layer name, full geometry) -> workspace bytes
+        # ONE partial-sum arena per model, as large as the largest flush interval (gradient bucket) seen so far: a flush's reduce and
+        # every later partial-sum kernel run on the same stream, so the slices are re-used from offset 0 after each flush
+        self._wq_arena = None
+        self._wq_off = self._wq_pending = self._wq_peak = 0
         self.use_mask_bits = True          # bit-packed ReLU gates for the wide 1x1 data gradients (False: bf16 activations as masks)
         self._wstream = torch.cuda.Stream() if (torch.cuda.is_available() and self.device.type == "cuda") else None
         self._tstream = torch.cuda.Stream() if self._wstream is not None else None      # P6/P7 top-block dgrads
@@ -759,23 +763,21 @@ class FPNDetector:
         stream), and nothing on the main stream reads its outputs before `_join_wgrads`.  Callers must not overwrite g/x
         later in the same backward pass (the heads keep one gradient buffer per layer for that reason)."""
         q = None
-        pl = self._cur
         if self.wgrad_queue_mode != "layer" and self.device.type == "cuda" and not (conv.fp8_wgrad and x8 is not None and g8 is not None):
-            # deferred reduce: this layer's partial sums get their own slice of the plan's arena, untouched until the bucket's flush.  The
-            # arena is sized by the first backward pass of a plan, which runs un-queued and records what every layer needs.
-            key = (conv.name, gin.pixels, gout.pixels)
+            # deferred reduce: this layer's partial sums get their own slice of the model's arena, untouched until the next flush (a
+            # gradient bucket's end, or the byte threshold).  A layer that does not fit (the first backward pass of a model, a larger
+            # input size, another set of queued layers) runs un-queued on the plan's shared workspace -- same bits -- and the arena is
+            # re-grown to the recorded peak at _join_wgrads
+            key = (conv.name, gin.N, tuple(gin.H), tuple(gin.W), tuple(gout.H), tuple(gout.W))
             need = self._wq_need.get(key)
             if need is None:
                 need = self._wq_need[key] = (conv.wgrad_ws_bytes(gin, gout) + 255) // 256 * 256
-            arena = getattr(pl, "wq_arena", None)
-            if arena is None:
-                pl.wq_total = getattr(pl, "wq_total", 0) + need
-            else:
-                off = pl.wq_off
-                assert off + need <= arena.numel() * 4, "weight-gradient arena too small for this backward pass"
+            off = self._wq_off
+            self._wq_off = off + need
+            arena = self._wq_arena
+            if arena is not None and off + need <= arena.numel() * 4:
                 ws = arena[off // 4: (off + need) // 4]
-                pl.wq_off = off + need
-                pl.wq_pending += need
+                self._wq_pending += need
                 if self._wq is None:
                     self._wq = ops.WgradQueue()
                 q = self._wq
@@ -785,15 +787,21 @@ class FPNDetector:
             self._wstream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._wstream):
                 conv.wgrad(x, g, gin, gout, ws, cws, x8=x8, g8=g8, queue=q)
-        if q is not None and isinstance(self.wgrad_queue_mode, int) and pl.wq_pending >= self.wgrad_queue_mode:
+        if q is not None and isinstance(self.wgrad_queue_mode, int) and self._wq_pending >= self.wgrad_queue_mode:
             self._flush_wgrads()
 
+    def _begin_wgrads(self):
+        """Start of a backward pass (also the head modules' own, layers/modules.py): nothing queued, the arena free from offset 0."""
+        self._wq_off = self._wq_pending = 0
+
     def _flush_wgrads(self):
-        """One launch reduces every weight gradient queued since the last flush (on the stream the partial sums were computed on)."""
+        """One launch reduces every weight gradient queued since the last flush (on the stream the partial sums were computed on); the
+        arena is free again from offset 0 for the kernels enqueued behind that reduce."""
+        self._wq_peak = max(self._wq_peak, self._wq_off)
+        self._wq_off = self._wq_pending = 0
         q = self._wq
         if q is None or not q.pending():
             return
-        self._cur.wq_pending = 0
         if self.async_wgrad and self._wstream is not None:
             with torch.cuda.stream(self._wstream):
                 q.flush()
@@ -802,16 +810,18 @@ class FPNDetector:
 
     def _join_wgrads(self):
         self._flush_wgrads()
-        pl = self._cur
-        if getattr(pl, "wq_arena", None) is None and getattr(pl, "wq_total", 0) > 0 and self.wgrad_queue_mode != "layer":
-            pl.wq_arena = torch.empty((pl.wq_total // 4 + 64,), dtype=torch.float32, device=self.device)      # sized by this first pass
         if self.async_wgrad and self._wstream is not None:
             torch.cuda.current_stream().wait_stream(self._wstream)
+        have = 0 if self._wq_arena is None else self._wq_arena.numel() * 4
+        if self.wgrad_queue_mode != "layer" and self._wq_peak > have:
+            # (behind the join: the old arena's last readers have been ordered in front of the current stream, which owns both allocations)
+            self._wq_arena = None
+            self._wq_arena = torch.empty((self._wq_peak // 4 + 64,), dtype=torch.float32, device=self.device)
 
     def backward(self, on_bucket_ready=None):
         pl = self._cur
         probing = self._fp8_probe_begin()
-        pl.wq_off, pl.wq_pending = 0, 0
+        self._begin_wgrads()
         ws, cws = pl.wgrad_ws, pl.colsum_ws
         pyr = pl.pyr
         pl.g_P8_ready = False                       # set by a head whose last data gradients wrote the e5m2 twin of dL/dP

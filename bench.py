@@ -73,49 +73,11 @@ class KernelTimer:
             m = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
             return 2.0 * m * d.Cin * d.Cout * d.R * d.S
 
-        def kernel_of(d, kind, dgrad=False, flags=0):
-            """Which HIP kernel serves this descriptor (mirrors the dispatch in csrc/conv_igemm.hip / conv3x3.hip /
-            conv3x3_pp.hip / conv_wgrad.hip with the default bd_conv_set_patch3x3 mask)."""
-            same = all(d.Hi[i] == d.Ho[i] and d.Wi[i] == d.Wo[i] for i in range(d.nseg))
-            is3 = d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and same
-            is1 = d.R == 1 and d.S == 1 and d.pad == 0
-            if kind == "igemm":
-                dense = (is1 and d.stride == 1 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0
-                         and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0])
-                # ... and the 1x1 / stride-2 shortcuts since round 2 (strided source rows forward; the in-place sparse data gradient)
-                dense_s2 = (is1 and d.stride == 2 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0
-                            and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0]
-                            and (not dgrad or (flags & ops.EPI_SPARSE)))
-                if dense or dense_s2:
-                    # conv1x1_ring.hip takes the res3-sized launches and the short-K ones into >= 256 channels (bd_conv1x1_ring_launch)
-                    ck_, co_ = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
-                    mpix = d.N * d.Ho[0] * d.Wo[0]
-                    if (dense and ck_ >= 128 and ck_ % 64 == 0 and co_ <= 2048 and co_ % 32 == 0 and not (flags & ops.EPI_ADD_AFTER)
-                            and (mpix >= 131072 or (ck_ <= 256 and co_ >= 256 and mpix >= 32768))
-                            and os.environ.get("BD_DENSE1X1_RING", "1") != "0"):
-                        return "conv1x1_ring_kernel"
-                    return "conv1x1_dense_kernel"          # conv1x1.hip: every other 1x1 / stride 1 launch over one dense level
-                if not is3:
-                    # generic kernel: BK = 32 instance for 1x1 filters (and Cin <= 32) and for stride-2 launches of >= 512 tiles,
-                    # BK = 64 for the rest
-                    ck_, co_ = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
-                    pix = d.N * sum((d.Hi[i] * d.Wi[i]) if dgrad else (d.Ho[i] * d.Wo[i]) for i in range(d.nseg))
-                    big = d.stride == 2 and -(-pix // 128) * -(-co_ // 128) >= 512
-                    return "conv_igemm_kernel<32>" if (d.R * d.S == 1 or ck_ <= 32 or big) else "conv_igemm_kernel<64>"
-                ck, co = (d.Cout, d.Cin) if dgrad else (d.Cin, d.Cout)
-                pp = ck % 8 == 0 and co > 128 and co % 8 == 0
-                if pp:
-                    return "conv3x3_pp_kernel"
-                # Cout <= 64: the 64-channel tile of conv3x3_pp128.hip; the rest: conv3x3.hip
-                return "conv3x3_pp128_kernel" if (ck % 8 == 0 and co % 8 == 0 and co <= 64) else "conv3x3_patch_kernel"
-            is3w = d.R == 3 and d.S == 3 and d.pad == 1 and all((d.Hi[i] - 1) // d.stride + 1 == d.Ho[i] for i in range(d.nseg))
-            if is3w and d.stride == 1 and same and d.Cin >= 64 and d.Cout >= 96:
-                return "conv_wgrad3x3_ring_kernel"         # conv_wgrad3x3_ring.hip (bd_wgrad3x3r_eligible): the wide stride-1 layers
-            dense1 = (is1 and d.stride == 1 and d.nseg == 1 and d.in_off[0] == 0 and d.out_off[0] == 0 and d.Cin >= 64 and d.Cout >= 64
-                      and d.in_pix_per_img == d.Hi[0] * d.Wi[0] and d.out_pix_per_img == d.Ho[0] * d.Wo[0])
-            if dense1:
-                return "conv_wgrad1x1_ring_kernel"         # conv_wgrad1x1_ring.hip (bd_wgrad1x1r_eligible): every stride-1 1x1 layer
-            return "conv_wgrad3x3_kernel" if is3w else ("conv_wgrad1x1_kernel" if is1 else "conv_wgrad_kernel")
+        def last_kernel():
+            """The kernel the launch that just returned was dispatched to, as named by the launch site itself (bd_conv_last_kernel,
+            include/basedet_hip.h): rounds 1-4 mirrored the C++ dispatch in Python here, and a dispatch change not mirrored would have
+            mislabelled a row silently (tests/test_conv_gpu.py pins the names for the bench's descriptors)."""
+            return ops.L().bd_conv_last_kernel().decode()
 
         def wrap(fn, kind):
             import inspect
@@ -130,14 +92,14 @@ class KernelTimer:
                 s.record()
                 r = fn(d, *a, **k)
                 e.record()
-                kern = kernel_of(d, kind, fn.__name__ == "conv2d_dgrad", int(k.get("flags") or 0))
+                kern = last_kernel()
                 self.records.setdefault(kern, []).append((s, e, flops(d)))
                 # algorithmic HBM bytes: every operand once -- both activations, the weights, and the epilogue's add / mask
                 # operands (residual, ReLU mask), which have the shape of the result
                 mi = sum(d.Hi[i] * d.Wi[i] for i in range(d.nseg)) * d.N
                 mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
-                if kind == "igemm" and d.R * d.S == 1 and d.stride == 2 and (fn.__name__ != "conv2d_dgrad" or (int(k.get("flags") or 0) & ops.EPI_SPARSE)):
-                    mi = mo          # a 1x1 / stride-2 launch touches the quarter of the big grid's pixels it reaches (forward reads, sparse dgrad writes)
+                if d.R * d.S == 1 and d.stride == 2 and (fn.__name__ != "conv2d_dgrad" or (int(k.get("flags") or 0) & ops.EPI_SPARSE)):
+                    mi = mo          # a 1x1 / stride-2 launch touches the quarter of the big grid's pixels it reaches (forward and weight-gradient reads, sparse dgrad writes)
                 nbytes = 2.0 * (mi * d.Cin + mo * d.Cout) + (4.0 if kind == "wgrad" else 2.0) * d.Cin * d.Cout * d.R * d.S
                 if kind == "igemm":
                     res = 2.0 * (mi * d.Cin if fn.__name__ == "conv2d_dgrad" else mo * d.Cout)
@@ -162,8 +124,7 @@ class KernelTimer:
                 mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
                 nbytes = 1.0 * mi * d.Cin + 2.0 * mo * d.Cout * (2 if add is not None else 1) + 1.0 * d.Cin * d.Cout * d.R * d.S \
                     + (1.0 * mo * d.Cout if y8 is not None else 0.0)
-                same = all(d.Hi[i] == d.Ho[i] and d.Wi[i] == d.Wo[i] for i in range(d.nseg))
-                kern8 = "conv3x3_pp8_kernel" if (d.R == 3 and d.stride == 1 and same and d.Cout > 128 and d.Cin % 16 == 0) else "conv_fp8_kernel"
+                kern8 = last_kernel()
                 self.records.setdefault(kern8, []).append((s, e, flops(d)))
                 self.meta.setdefault(kern8, []).append(("conv2d_fwd_fp8", d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
                 return r
@@ -181,8 +142,9 @@ class KernelTimer:
                 mo = sum(d.Ho[i] * d.Wo[i] for i in range(d.nseg)) * d.N
                 nbytes = 1.0 * mo * d.Cout + 2.0 * mi * d.Cin * (1 + (add is not None) + (mask is not None)) + 1.0 * d.Cin * d.Cout * 9 \
                     + (1.0 * mi * d.Cin if dx8 is not None else 0.0)
-                self.records.setdefault("conv3x3_pp8_kernel", []).append((s, e, flops(d)))
-                self.meta.setdefault("conv3x3_pp8_kernel", []).append(("conv2d_dgrad_fp8", d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
+                kern8 = last_kernel()
+                self.records.setdefault(kern8, []).append((s, e, flops(d)))
+                self.meta.setdefault(kern8, []).append(("conv2d_dgrad_fp8", d.Cin, d.Cout, d.R, d.stride, d.nseg, d.Ho[0], d.Wo[0], nbytes))
                 return r
             return inner
 
@@ -634,7 +596,9 @@ def worker(args):
         last = solver.minimize(model, batch)
     sync()
     if args.skip_s2_3x3_after_warmup:             # (A/B only: see the flag's help; the result line says so)
-        ops.L().bd_conv_set_patch3x3((args.conv_knob if args.conv_knob is not None else 3) | 16)
+        from basedet_amd._lib import check as _check
+        _check(ops.L().bd_conv_set_patch3x3((args.conv_knob if args.conv_knob is not None else 3) | 16),
+               "--skip-s2-3x3-after-warmup (needs a -DBD_AB_SKIP diagnostic build of the library: BD_LIB_NAME / BD_EXTRA_FLAGS, BASEDET_HIP_LIB)")
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]       # step boundaries on the main stream (p50 / p95)
     if comm is not None:
         solver.comm_profile = []          # per step: (backward done on the main stream, last bucket's all-reduce done on the comm stream)
@@ -763,6 +727,17 @@ def worker(args):
                     pmc = rec.get("kernels", {})
                 else:
                     pmc_note = "profiles/r03_pmc_traffic.json was collected on a different build of csrc/: traffic refused (null)"
+            # What the matrix pipes of THIS device sustain on the kernels' register-level pattern (rotating random bf16 fragments, no LDS /
+            # memory; bd_probe_mfma_rate, csrc/probe.hip) after 2 s of load: the chip holds ~2.1 GHz there, not the 2.4 GHz the vendor peak
+            # assumes.  Reported beside `peak`, never instead of it.
+            peak_meas = None
+            if world == 1:
+                import ctypes as _C
+                tf_, clk_ = _C.c_double(0.0), _C.c_double(0.0)
+                if ops.L().bd_probe_mfma_rate(2.0, _C.byref(tf_), _C.byref(clk_), ops.stream_ptr()) == 0:
+                    peak_meas = {"tflops": round(tf_.value, 1), "clock_mhz": round(clk_.value, 0),
+                                 "how": "bd_probe_mfma_rate: 8 x 4 rotating random bf16 fragments, 32 accumulators of v_mfma_f32_16x16x32_bf16 per wave, "
+                                        "8 waves per CU, registers only, last 10 launches of a 2 s run"}
             for kern in timer.records:
                 sm = timer.summary(kern)
                 tf = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
@@ -781,11 +756,16 @@ def worker(args):
                                 "ms_per_step": round(sm["ms"] / sampled, 3),
                                 "gflop_per_launch": round(sm["flops"] / sm["launches"] / 1e9, 2),
                                 "sampled_steps": sampled})
+                if peak_meas and not hbm_bound and mfma_peak == PEAK_BF16_TFLOPS:
+                    entries[-1]["peak_measured"] = peak_meas["tflops"]
+                    entries[-1]["frac_of_measured"] = round(tf / peak_meas["tflops"], 4)
             entries.sort(key=lambda e: -e["ms_per_step"])
             out["roofline"] = entries[0]                 # the dominant kernel of the step
             out["roofline_others"] = entries[1:]
             if pmc_note:
                 out["roofline_traffic_note"] = pmc_note
+            if peak_meas:
+                out["mfma_peak_measured"] = peak_meas
         if world == 1 and not args.no_cpu_baseline and name == "retinanet_r50_800x1344":
             out["cpu_baseline"] = cpu_baseline(cfg, params)
         _print_result(saved_stdout, json.dumps(out))

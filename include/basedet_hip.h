@@ -62,6 +62,16 @@ typedef struct bd_conv_desc {
 
 const char* bd_last_error_string(void);
 int bd_version(void);
+/* Name of the device kernel (as rocprofv3 prints it, template arguments dropped) that the calling thread's LAST convolution entry point
+ * (bd_conv2d_fwd* / _dgrad* / _wgrad* / bd_conv1x1_fp8 / bd_conv2d_*_fp8) dispatched to; "" before the first call.  Written by the launch
+ * sites themselves, so a measurement harness attributes time to the kernel that really ran (tools/benchmark.py:125-140 has no
+ * counterpart: MegEngine's profiler names its own kernels). */
+const char* bd_conv_last_kernel(void);
+/* Measurement probe, SYNCHRONOUS (not an operator): the dense bf16 TFLOP/s this device's matrix pipes sustain on the register-level
+ * pattern of the convolution kernels (rotating random fragments, 32 accumulators of v_mfma_f32_16x16x32_bf16, no LDS / memory) after
+ * `seconds` (<= 30) of back-to-back launches on `stream`; clock_mhz_out (may be NULL) = the in-kernel clock held under that load.
+ * bench.py's roofline.peak_measured (the harness it mirrors: tools/benchmark.py:125-140). */
+int bd_probe_mfma_rate(double seconds, double* tflops_out, double* clock_mhz_out, bd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Dense path: convolution forward / data-gradient / weight-gradient (MFMA implicit GEMM).
@@ -135,8 +145,8 @@ int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream);
  * (conv3x3.hip); bit 1 = BK=32 tiles for 1x1 convs in the generic kernel; bit 2 = unused.
  * 0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip).
  * Ablation bits (set = feature OFF unless noted): bit 3 = register-staged instead of LDS-DMA weights in the patch kernel;
- * bit 4 = (set = ON) TIMING A/B ONLY: every 3x3 / stride-2 forward and data-gradient launch returns at once, its output keeps whatever it
- * held (scripts: how much of a step the strided launches are; never set in a run whose numbers are compared); bit 5 = no early epilogue-operand prefetch in the generic kernel;
+ * bit 4 = (set = ON; -DBD_AB_SKIP diagnostic builds ONLY -- the shipped library answers BD_EINVAL) timing A/B: every 3x3 / stride-2 forward
+ * and data-gradient launch returns at once, its output keeps whatever it held (how much of a step the strided launches are); bit 5 = no early epilogue-operand prefetch in the generic kernel;
  * bit 6 = no staggered 256-channel patch instance (conv3x3_pp.hip; by default taken for every Cout > 128, Cin % 8 == 0 shape);
  * bit 7 = take it only where its grid fills the chip better than the 128-channel instance's (makespan estimate);
  * bit 8 = (set = ON) staggered 128-channel patch instance (conv3x3_pp128.hip) for every other 3x3/stride-1 shape (its 64-channel

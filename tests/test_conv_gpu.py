@@ -739,3 +739,51 @@ def test_wgrad_queue_reduces_several_layers_in_one_launch_bit_identically():
             assert torch.equal(db, db_ref), i
     q.flush()                                                    # an empty flush is a no-op
     q.close()
+
+
+def test_conv_last_kernel_names_the_dispatched_kernel_for_the_bench_descriptors():
+    """bd_conv_last_kernel() is written by the launch sites themselves; bench.py attributes a launch's time and roofline row by it.  This
+    pins the names for the descriptors of the RetinaNet-R50 step at bench size (16 x 800 x 1344): a dispatch change shows up HERE, not
+    as a silently mislabelled roofline row (round 4 mirrored the dispatch in Python)."""
+    ops = _ops()
+    N = 16
+    last = lambda: ops.L().bd_conv_last_kernel().decode()
+    bf = dict(dtype=torch.bfloat16, device="cuda")
+
+    def run(gin, gout, cin, cout, k, stride, pad, kinds):
+        d = ops.conv_desc(gin, gout, cin, cout, k, k, stride, pad)
+        x = torch.zeros((gin.pixels, cin), **bf)
+        y = torch.zeros((gout.pixels, cout), **bf)
+        wf = torch.zeros((cout, k * k, cin), **bf)
+        wd = torch.zeros((cin, k * k, cout), **bf)
+        out = {}
+        if "fwd" in kinds:
+            ops.conv2d_fwd(d, x, wf, None, y)
+            out["fwd"] = last()
+        if "dgrad" in kinds:
+            ops.conv2d_dgrad(d, y, wd, x)
+            out["dgrad"] = last()
+        if "wgrad" in kinds:
+            ws = torch.empty((ops.conv2d_wgrad_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
+            dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device="cuda")
+            ops.conv2d_wgrad(d, x, y, dw, ws)
+            out["wgrad"] = last()
+        torch.cuda.synchronize()
+        return out
+
+    all3 = ("fwd", "dgrad", "wgrad")
+    pyr = ops.Geom(N, [100, 50, 25, 13, 7], [168, 84, 42, 21, 11])
+    assert run(pyr, pyr, 256, 256, 3, 1, 1, all3) == {"fwd": "conv3x3_pp_kernel", "dgrad": "conv3x3_pp_kernel", "wgrad": "conv_wgrad3x3_ring_kernel"}
+    g3, g4, g5 = ops.single(N, 100, 168), ops.single(N, 50, 84), ops.single(N, 25, 42)
+    g2 = ops.single(N, 200, 336)
+    # res3 conv1 (512 -> 128 at 100x168): the ring kernel; res5 conv1 (2048 -> 512 at 25x42): the K-sliced dense kernel family
+    assert run(g3, g3, 512, 128, 1, 1, 0, all3) == {"fwd": "conv1x1_ring_kernel", "dgrad": "conv1x1_ring_kernel", "wgrad": "conv_wgrad1x1_ring_kernel"}
+    r5 = run(g5, g5, 2048, 512, 1, 1, 0, all3)
+    assert r5["fwd"] in ("conv1x1_dense_kernel", "conv1x1_gemm_kernel") and r5["wgrad"] == "conv_wgrad1x1_ring_kernel", r5
+    # the stride-2 3x3 of res3.0 and the stride-2 shortcut of res4.0
+    s2 = run(g2, g3, 128, 128, 3, 2, 1, all3)
+    assert s2["fwd"] in ("conv_igemm_kernel<32>", "conv3x3_s2_kernel") and s2["wgrad"] == "conv_wgrad3x3_kernel", s2
+    sc = run(g3, g4, 512, 1024, 1, 2, 0, ("fwd", "wgrad"))
+    assert sc == {"fwd": "conv1x1_dense_kernel", "wgrad": "conv_wgrad1x1_kernel"}, sc
+    # narrow 3x3 (res2-sized conv2 of a trainable layer1 would be 64 -> 64): the 64-channel staggered tile
+    assert run(g3, g3, 64, 64, 3, 1, 1, ("fwd",)) == {"fwd": "conv3x3_pp128_kernel"}

@@ -15,7 +15,11 @@ import torch
 pytestmark = pytest.mark.gpu
 SIZE = (800, 1344)
 N = 2
-LOOSE = 0.40        # per-parameter rel-L2 vs the plain fp32 oracle; observed maxima (printed with -s): RetinaNet < 0.25, FCOS 0.30
+# Against the PLAIN fp32 oracle a parameter gradient differs by bf16 forward noise flipping ReLU gates near zero: not a tight bound (the
+# tight one is the injected-activation comparison, 2e-2).  Round 5: the direction is bounded instead of a 0.40 rel-L2 that asserted
+# almost nothing -- per-parameter cosine and the whole-model cosine; the rel-L2 maxima are printed as a diagnostic (-s).
+MIN_COS_PARAM = 0.93        # observed minima are printed by every run
+MIN_COS_MODEL = 0.97
 
 
 def _rel(a, b):
@@ -23,17 +27,32 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def _check_grads(names, got, plain, injected, tag):
-    worst_plain, worst_inj = ("", 0.0), ("", 0.0)
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
+def _check_grads(names, got, plain, injected, tag, min_cos_param=MIN_COS_PARAM, min_cos_model=MIN_COS_MODEL):
+    worst_plain, worst_inj, worst_cos = ("", 0.0), ("", 0.0), ("", 1.0)
+    dot = na = nb = 0.0
     for n in names:
-        rp = _rel(got[n], plain[n].detach())
+        g, p_ = got[n].double().reshape(-1).cpu(), plain[n].detach().double().reshape(-1)
+        rp = _rel(g, p_)
         ri = _rel(got[n], injected[n].detach())
+        c = _cos(g, p_)
+        dot += float((g * p_).sum()); na += float((g * g).sum()); nb += float((p_ * p_).sum())
         if rp > worst_plain[1]:
             worst_plain = (n, rp)
         if ri > worst_inj[1]:
             worst_inj = (n, ri)
-    print(f"[{tag}] worst per-parameter gradient rel-L2: plain oracle {worst_plain}, injected oracle {worst_inj}")
-    assert worst_plain[1] < LOOSE, worst_plain
+        if c < worst_cos[1]:
+            worst_cos = (n, c)
+    model_cos = dot / (np.sqrt(na) * np.sqrt(nb) + 1e-300)
+    print(f"[{tag}] per-parameter gradient vs the plain oracle: worst rel-L2 {worst_plain} (diagnostic), worst cosine {worst_cos}, "
+          f"whole-model cosine {model_cos:.5f}, norm ratio {np.sqrt(na / nb):.4f}; vs the injected oracle: worst rel-L2 {worst_inj}")
+    assert worst_cos[1] > min_cos_param, worst_cos
+    assert model_cos > min_cos_model, model_cos
+    assert 0.9 < np.sqrt(na / nb) < 1.1, np.sqrt(na / nb)
     assert worst_inj[1] < 2e-2, worst_inj
 
 

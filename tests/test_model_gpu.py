@@ -43,7 +43,9 @@ def _grad_of(model, name, like, cache={}):
     return cache["g"][name].double().reshape(-1)
 
 
-@pytest.mark.parametrize("backbone,N,size", [("resnet18", 2, (128, 160)), ("resnet50", 3, (96, 128))])
+# ("resnet18", 2, (512, 512)) is BASELINE config C1 at its own size (RetinaNet-R18-FPN, 2 x 512x512: the reference's CPU-runnable
+# plumbing configuration, which bench.py's cpu_baseline leg times on the oracle): the HIP step against the oracle on C1's workload
+@pytest.mark.parametrize("backbone,N,size", [("resnet18", 2, (128, 160)), ("resnet50", 3, (96, 128)), ("resnet18", 2, (512, 512))])
 def test_training_step_matches_oracle(backbone, N, size):
     from basedet_amd.models import RetinaNet, params as P
     from basedet_amd.solver import DetSolver
