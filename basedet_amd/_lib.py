@@ -104,9 +104,10 @@ SIGNATURES = {
     "bd_smooth_l1_fwd_bwd": (_I, [_P, _P, _P, _L, _I, _I, _F, _P, _I, _F, _P, _P, _P]),
     "bd_giou_ltrb_fwd_bwd": (_I, [_P, _P, _P, _P, _L, _P, _F, _P, _P, _P]),
     "bd_bce_logits_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
-    "bd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I]),
+    "bd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _L]),
     "bd_groupnorm_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _L, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "bd_groupnorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
+    "bd_groupnorm_set_chunks": (_I, [_I, _I]),
     "bd_fcos_offsets_fwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _L, _P, _P]),
     "bd_fcos_offsets_workspace_bytes": (_Z, []),
     "bd_fcos_offsets_bwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _Z, _P]),

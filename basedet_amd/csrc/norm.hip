@@ -3,34 +3,54 @@
 //
 // Activations are pixel-major NHWC bf16 with several pyramid levels per image; one GroupNorm instance (shared weights)
 // normalises every (image, level, group) independently over H_l*W_l pixels x C/32 channels.  With C = 256 a group is
-// exactly 8 channels = one 16-byte chunk per pixel, so every lane moves one chunk.  All four passes are HBM-bound:
-//   fwd: stats (read y) -> apply (read y, write z)            bwd: sums (read dz, y, z) -> apply (read dz, y, z, write dy)
-// Reductions are two-stage with a fixed partial order (no float atomics): bitwise reproducible.
+// exactly 8 channels = one 16-byte chunk per pixel, so every lane moves one chunk.  All passes are HBM-bound:
+//   fwd: stats (read y) -> apply (read y, write z)            bwd: sums (read dz, y) -> apply (read dz, y, write dy)
+// Round 5 (rounds 1-4: ten tensor passes per tower layer, 3.1 ms of the FCOS step):
+//   * the backward no longer reads z: the ReLU gate z > 0 is recomputed from y with the forward's own arithmetic (gn_affine: pinned
+//     fma / mul / sub, bf16 rounding keeps the sign of a normal float) -- seven passes become five;
+//   * both directions run image chunk by image chunk (stats of chunk c, then apply of chunk c): what the second kernel re-reads is
+//     what the first one has just pulled through the 256 MB Infinity Cache (bd_groupnorm_set_chunks);
+//   * the partial stage is cut into fixed 128-pixel slots (a chunk of four images still fills the chip).
+// Reductions are two-stage with a fixed partial order (no float atomics): bitwise reproducible, and independent of the chunking.
 #include "common.h"
 
 namespace {
 
-constexpr int GN_CHUNKS = 16;     // pixel chunks per (image, level) in the partial stage
+constexpr int GN_SLOT_PX = 128;   // pixels per partial-stage slot
 constexpr int MAXL = BD_MAX_SEGS;
 
-struct GnLevels { int L; int off[MAXL]; int cnt[MAXL]; };
+// slot0[l] = first slot of level l inside an image's slot list (slot0[L] = slots per image)
+struct GnLevels { int L; int off[MAXL]; int cnt[MAXL]; int slot0[MAXL + 1]; };
 
-// block = 256 threads = 32 groups x 8 pixel lanes; grid = (GN_CHUNKS, L, N)
-// partial[((n*L + l)*GN_CHUNKS + chunk)*32 + g][2] = (sum, sumsq)
+// z = relu(xhat * gamma + beta) with xhat = (y - mean) * rstd: ONE instruction sequence for the forward's value and the backward's gate
+__device__ __forceinline__ float gn_xhat(float y, float mean, float rstd) { return __fmul_rn(__fsub_rn(y, mean), rstd); }
+__device__ __forceinline__ float gn_affine(float y, float mean, float rstd, float gamma, float beta) {
+    return __fmaf_rn(gn_xhat(y, mean, rstd), gamma, beta);
+}
+
+__device__ __forceinline__ int slot_level(const GnLevels& lv, int slot) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < MAXL; ++k)
+        if (k < lv.L && slot >= lv.slot0[k]) l = k;
+    return l;
+}
+
+// block = 256 threads = 32 groups x 8 pixel lanes; grid = (slots per image, images of the chunk)
+// partial[(n * S + slot) * 32 + g][2] = (sum, sumsq)
 __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const bf16_raw* __restrict__ y, GnLevels lv, int ppi, int C,
                                                                float* __restrict__ partial) {
     __shared__ float red[256][2];
     const int g = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int chunk = blockIdx.x, l = blockIdx.y, n = blockIdx.z;
+    const int slot = blockIdx.x, n = blockIdx.y, S = lv.slot0[lv.L];
+    const int l = slot_level(lv, slot);
     const int cnt = lv.cnt[l];
-    const int per = (cnt + GN_CHUNKS - 1) / GN_CHUNKS;
-    const int p0 = chunk * per;
-    int p1 = p0 + per;
+    const int p0 = (slot - lv.slot0[l]) * GN_SLOT_PX;
+    int p1 = p0 + GN_SLOT_PX;
     if (p1 > cnt) p1 = cnt;
     const bf16_raw* base = y + ((long long)n * ppi + lv.off[l]) * C + g * 8;
     float s = 0.f, ss = 0.f;
-    // four pixels per thread and trip: four independent 16-byte loads in flight (the largest level gives a workgroup ~1000 pixels,
-    // and with one load per trip the kernel sat at 2.4 TB/s)
+    // four pixels per thread and trip: four independent 16-byte loads in flight
     for (int p = p0 + pl; p < p1; p += 32) {
         u32x4_t v[4];
 #pragma unroll
@@ -51,20 +71,20 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const bf16_raw* _
     if (pl == 0) {
         float ts = 0.f, tss = 0.f;
         for (int k = 0; k < 8; ++k) { ts += red[k * 32 + g][0]; tss += red[k * 32 + g][1]; }
-        float* o = partial + ((((long long)n * lv.L + l) * GN_CHUNKS + chunk) * 32 + g) * 2;
+        float* o = partial + (((long long)n * S + slot) * 32 + g) * 2;
         o[0] = ts; o[1] = tss;
     }
 }
 
-// stats[(n*L + l)*32 + g] = (mean, rstd)
+// stats[(n*L + l)*32 + g] = (mean, rstd): the slots of a level summed in slot order
 __global__ void gn_stats_final_kernel(const float* __restrict__ partial, GnLevels lv, int N, int cpg, float eps,
                                       float* __restrict__ stats) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * lv.L * 32) return;
-    const int g = i & 31, nl = i >> 5, l = nl % lv.L;
+    const int g = i & 31, nl = i >> 5, l = nl % lv.L, n = nl / lv.L, S = lv.slot0[lv.L];
     float s = 0.f, ss = 0.f;
-    for (int c = 0; c < GN_CHUNKS; ++c) {
-        const float* o = partial + (((long long)nl * GN_CHUNKS + c) * 32 + g) * 2;
+    for (int c = lv.slot0[l]; c < lv.slot0[l + 1]; ++c) {
+        const float* o = partial + (((long long)n * S + c) * 32 + g) * 2;
         s += o[0]; ss += o[1];
     }
     const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
@@ -93,11 +113,13 @@ __global__ void gn_apply_kernel(const bf16_raw* __restrict__ y, const float* __r
         const int l = level_of(lv, p);
         const float mean = stats[((n * lv.L + l) * 32 + g) * 2], rstd = stats[((n * lv.L + l) * 32 + g) * 2 + 1];
         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(y + i * 8);
+        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gamma + g * 8), g1 = *reinterpret_cast<const f32x4_t*>(gamma + g * 8 + 4);
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(beta + g * 8), b1 = *reinterpret_cast<const f32x4_t*>(beta + g * 8 + 4);
         float o[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float xv = (k & 1) ? bf_hi(v[k >> 1]) : bf_lo(v[k >> 1]);
-            o[k] = (xv - mean) * rstd * gamma[g * 8 + k] + beta[g * 8 + k];
+            o[k] = gn_affine(xv, mean, rstd, k < 4 ? g0[k & 3] : g1[k & 3], k < 4 ? b0[k & 3] : b1[k & 3]);
         }
         u32x4_t w;
 #pragma unroll
@@ -107,49 +129,47 @@ __global__ void gn_apply_kernel(const bf16_raw* __restrict__ y, const float* __r
     }
 }
 
-// backward sums per (n, l, chunk, g): A = sum dzm*gamma*xhat, B = sum dzm*gamma ; and per channel dgamma / dbeta partials
-// pg[((n*L + l)*GN_CHUNKS + chunk)*32 + g][2], pc[(((n*L + l)*GN_CHUNKS + chunk)*C + c)][2]
+// backward sums per (n, slot, g): A = sum dzm*gamma*xhat, B = sum dzm*gamma ; and per channel dgamma / dbeta partials
+// pg[(n*S + slot)*32 + g][2], pc[((n*S + slot)*C + c)][2];  dzm = dz where relu(xhat*gamma + beta) > 0 (relu != 0), else dz
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
-                                                             const bf16_raw* __restrict__ z, const float* __restrict__ stats,
-                                                             const float* __restrict__ gamma, GnLevels lv, int ppi, int C,
+                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, GnLevels lv, int ppi, int C,
                                                              int relu, float* __restrict__ pg, float* __restrict__ pc) {
     __shared__ float red[256][18];
     const int g = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int chunk = blockIdx.x, l = blockIdx.y, n = blockIdx.z;
+    const int slot = blockIdx.x, n = blockIdx.y, S = lv.slot0[lv.L];
+    const int l = slot_level(lv, slot);
     const int cnt = lv.cnt[l];
-    const int per = (cnt + GN_CHUNKS - 1) / GN_CHUNKS;
-    const int p0 = chunk * per;
-    int p1 = p0 + per;
+    const int p0 = (slot - lv.slot0[l]) * GN_SLOT_PX;
+    int p1 = p0 + GN_SLOT_PX;
     if (p1 > cnt) p1 = cnt;
     const long long base = ((long long)n * ppi + lv.off[l]) * C + g * 8;
     const float mean = stats[((n * lv.L + l) * 32 + g) * 2], rstd = stats[((n * lv.L + l) * 32 + g) * 2 + 1];
-    float gm[8];
+    float gm[8], bt[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) gm[k] = gamma[g * 8 + k];
+    for (int k = 0; k < 8; ++k) { gm[k] = gamma[g * 8 + k]; bt[k] = beta[g * 8 + k]; }
     float A = 0.f, B = 0.f, dg[8], db[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { dg[k] = 0.f; db[k] = 0.f; }
-    for (int p = p0 + pl; p < p1; p += 16) {          // two pixels per trip: six independent loads in flight
-        u32x4_t vd[2], vy[2], vz[2];
+    for (int p = p0 + pl; p < p1; p += 32) {          // four pixels per trip: eight independent loads in flight
+        u32x4_t vd[4], vy[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int q = p + 8 * u;
             const long long o = base + (long long)(q < p1 ? q : p) * C;
             vd[u] = *reinterpret_cast<const u32x4_t*>(dz + o);
             vy[u] = *reinterpret_cast<const u32x4_t*>(y + o);
-            vz[u] = *reinterpret_cast<const u32x4_t*>(z + o);
             if (q >= p1) vd[u] = (u32x4_t){0u, 0u, 0u, 0u};      // a zero gradient contributes nothing
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int w = k >> 1;
                 float d = (k & 1) ? bf_hi(vd[u][w]) : bf_lo(vd[u][w]);
                 const float yy = (k & 1) ? bf_hi(vy[u][w]) : bf_lo(vy[u][w]);
-                const float zz = (k & 1) ? bf_hi(vz[u][w]) : bf_lo(vz[u][w]);
-                if (relu && !(zz > 0.f)) d = 0.f;
-                const float xh = (yy - mean) * rstd;
+                const float xh = gn_xhat(yy, mean, rstd);
+                if (relu && !(__fmaf_rn(xh, gm[k], bt[k]) > 0.f)) d = 0.f;
                 A += d * gm[k] * xh; B += d * gm[k];
                 dg[k] += d * xh; db[k] += d;
             }
@@ -165,10 +185,10 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_raw* __r
         for (int k = 0; k < 8; ++k)
 #pragma unroll
             for (int q = 0; q < 18; ++q) t[q] += red[k * 32 + g][q];
-        const long long slot = ((long long)n * lv.L + l) * GN_CHUNKS + chunk;
-        pg[(slot * 32 + g) * 2] = t[0]; pg[(slot * 32 + g) * 2 + 1] = t[1];
+        const long long sl = (long long)n * S + slot;
+        pg[(sl * 32 + g) * 2] = t[0]; pg[(sl * 32 + g) * 2 + 1] = t[1];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { pc[(slot * C + g * 8 + k) * 2] = t[2 + k]; pc[(slot * C + g * 8 + k) * 2 + 1] = t[10 + k]; }
+        for (int k = 0; k < 8; ++k) { pc[(sl * C + g * 8 + k) * 2] = t[2 + k]; pc[(sl * C + g * 8 + k) * 2 + 1] = t[10 + k]; }
     }
 }
 
@@ -177,10 +197,10 @@ __global__ void gn_bwd_final_kernel(const float* __restrict__ pg, GnLevels lv, i
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int ngl = N * lv.L * 32;
     if (i < ngl) {
-        const int g = i & 31, nl = i >> 5, l = nl % lv.L;
+        const int g = i & 31, nl = i >> 5, l = nl % lv.L, n = nl / lv.L, S = lv.slot0[lv.L];
         float A = 0.f, B = 0.f;
-        for (int c = 0; c < GN_CHUNKS; ++c) {
-            const float* o = pg + (((long long)nl * GN_CHUNKS + c) * 32 + g) * 2;
+        for (int c = lv.slot0[l]; c < lv.slot0[l + 1]; ++c) {
+            const float* o = pg + (((long long)n * S + c) * 32 + g) * 2;
             A += o[0]; B += o[1];
         }
         const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
@@ -188,8 +208,8 @@ __global__ void gn_bwd_final_kernel(const float* __restrict__ pg, GnLevels lv, i
     }
 }
 
-// dgamma[c], dbeta[c] (+)= sums over every (n, l, chunk) slot: a block owns 8 channels, 32 lanes walk the slots (each reads the
-// 64 contiguous bytes of its 8 channels), then a fixed-order LDS reduction -- reproducible, and no 1 280-long serial chains
+// dgamma[c], dbeta[c] (+)= sums over every (n, slot): a block owns 8 channels, 32 lanes walk the slots (each reads the
+// 64 contiguous bytes of its 8 channels), then a fixed-order LDS reduction -- reproducible, and no long serial chains
 __global__ __launch_bounds__(256) void gn_bwd_final_c_kernel(const float* __restrict__ pc, int slots, int C, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int accumulate) {
     __shared__ float red[32][8][2];
@@ -209,8 +229,8 @@ __global__ __launch_bounds__(256) void gn_bwd_final_c_kernel(const float* __rest
 }
 
 // dy = rstd * (dzm*gamma - B - xhat*A)
-__global__ void gn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y, const bf16_raw* __restrict__ z,
-                                    const float* __restrict__ stats, const float* __restrict__ ab, const float* __restrict__ gamma,
+__global__ void gn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y, const float* __restrict__ stats,
+                                    const float* __restrict__ ab, const float* __restrict__ gamma, const float* __restrict__ beta,
                                     GnLevels lv, int N, int ppi, int relu, bf16_raw* __restrict__ dy) {
     const long long total = (long long)N * ppi * 32;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -222,17 +242,18 @@ __global__ void gn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_
         const float mean = stats[si], rstd = stats[si + 1], A = ab[si], B = ab[si + 1];
         const u32x4_t vd = *reinterpret_cast<const u32x4_t*>(dz + i * 8);
         const u32x4_t vy = *reinterpret_cast<const u32x4_t*>(y + i * 8);
-        const u32x4_t vz = *reinterpret_cast<const u32x4_t*>(z + i * 8);
+        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gamma + g * 8), g1 = *reinterpret_cast<const f32x4_t*>(gamma + g * 8 + 4);
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(beta + g * 8), b1 = *reinterpret_cast<const f32x4_t*>(beta + g * 8 + 4);
         float o[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int w = k >> 1;
             float d = (k & 1) ? bf_hi(vd[w]) : bf_lo(vd[w]);
             const float yy = (k & 1) ? bf_hi(vy[w]) : bf_lo(vy[w]);
-            const float zz = (k & 1) ? bf_hi(vz[w]) : bf_lo(vz[w]);
-            if (relu && !(zz > 0.f)) d = 0.f;
-            const float xh = (yy - mean) * rstd;
-            o[k] = rstd * (d * gamma[g * 8 + k] - B - xh * A);
+            const float gk = k < 4 ? g0[k & 3] : g1[k & 3], bk = k < 4 ? b0[k & 3] : b1[k & 3];
+            const float xh = gn_xhat(yy, mean, rstd);
+            if (relu && !(__fmaf_rn(xh, gk, bk) > 0.f)) d = 0.f;
+            o[k] = rstd * (d * gk - B - xh * A);
         }
         u32x4_t w4;
 #pragma unroll
@@ -318,16 +339,29 @@ __global__ void fcos_dscale_final_kernel(const float* __restrict__ partial, int 
 inline GnLevels make_levels(int L, const int32_t* off, const int32_t* cnt) {
     GnLevels lv{};
     lv.L = L;
-    for (int i = 0; i < L; ++i) { lv.off[i] = off[i]; lv.cnt[i] = cnt[i]; }
+    int s = 0;
+    for (int i = 0; i < L; ++i) { lv.off[i] = off[i]; lv.cnt[i] = cnt[i]; lv.slot0[i] = s; s += cdiv(cnt[i], GN_SLOT_PX); }
+    for (int i = L; i <= MAXL; ++i) lv.slot0[i] = s;
     return lv;
 }
 inline int egrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 constexpr int OFF_BLOCKS = 512;
 
+// images per chunk of the forward / backward (0 = the whole batch in one chunk): bd_groupnorm_set_chunks
+int g_gn_chunk_fwd = 8, g_gn_chunk_bwd = 4;
+
 }  // namespace
 
-extern "C" size_t bd_groupnorm_workspace_bytes(int N, int L, int C) {
-    return (size_t)N * L * GN_CHUNKS * (32 * 2 + (size_t)C * 2) * sizeof(float) + (size_t)N * L * 32 * 2 * sizeof(float);
+extern "C" int bd_groupnorm_set_chunks(int fwd_images, int bwd_images) {
+    BD_REQUIRE(fwd_images >= 0 && bwd_images >= 0, "bd_groupnorm_set_chunks: negative chunk");
+    g_gn_chunk_fwd = fwd_images; g_gn_chunk_bwd = bwd_images;
+    return BD_OK;
+}
+
+// slots per image <= pix_per_img / 128 + L
+extern "C" size_t bd_groupnorm_workspace_bytes(int N, int L, int C, int64_t pix_per_img) {
+    const size_t S = (size_t)(pix_per_img / GN_SLOT_PX) + (size_t)L + 1;
+    return (size_t)N * S * (32 * 2 + (size_t)C * 2) * sizeof(float) + (size_t)N * L * 32 * 2 * sizeof(float);
 }
 
 extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* beta, int N, int L, const int32_t* lvl_off_host,
@@ -336,36 +370,56 @@ extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* 
     BD_REQUIRE(y && gamma && beta && stats && z && ws && lvl_off_host && lvl_cnt_host, "groupnorm_fwd: null pointer");
     BD_REQUIRE(C == 256, "groupnorm_fwd: C=%d unsupported (32 groups x 8 channels only)", C);
     BD_REQUIRE(L >= 1 && L <= MAXL && N >= 1, "groupnorm_fwd: bad N/L");
-    if (ws_bytes < bd_groupnorm_workspace_bytes(N, L, C)) { bd_set_error("groupnorm_fwd: workspace too small"); return BD_EWORKSPACE; }
+    if (ws_bytes < bd_groupnorm_workspace_bytes(N, L, C, pix_per_img)) { bd_set_error("groupnorm_fwd: workspace too small"); return BD_EWORKSPACE; }
     const GnLevels lv = make_levels(L, lvl_off_host, lvl_cnt_host);
+    const int S = lv.slot0[L];
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(GN_CHUNKS, L, N), dim3(256), 0, st, (const bf16_raw*)y, lv, (int)pix_per_img, C, (float*)ws);
-    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(cdiv(N * L * 32, 256)), dim3(256), 0, st, (const float*)ws, lv, N, C / 32, eps, stats);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(egrid((long long)N * pix_per_img * 32)), dim3(256), 0, st, (const bf16_raw*)y,
-                       (const float*)stats, gamma, beta, lv, N, (int)pix_per_img, relu, (bf16_raw*)z);
+    const int step = g_gn_chunk_fwd > 0 ? g_gn_chunk_fwd : N;
+    for (int n0 = 0; n0 < N; n0 += step) {
+        const int nc = n0 + step <= N ? step : N - n0;
+        const bf16_raw* yc = (const bf16_raw*)y + (long long)n0 * pix_per_img * C;
+        bf16_raw* zc = (bf16_raw*)z + (long long)n0 * pix_per_img * C;
+        float* part = (float*)ws + (size_t)n0 * S * 64;
+        float* stc = stats + (size_t)n0 * L * 64;
+        hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, nc), dim3(256), 0, st, yc, lv, (int)pix_per_img, C, part);
+        hipLaunchKernelGGL(gn_stats_final_kernel, dim3(cdiv(nc * L * 32, 256)), dim3(256), 0, st, (const float*)part, lv, nc, C / 32, eps, stc);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3(egrid((long long)nc * pix_per_img * 32)), dim3(256), 0, st, yc, (const float*)stc, gamma, beta,
+                           lv, nc, (int)pix_per_img, relu, zc);
+    }
     BD_CHECK_LAUNCH("bd_groupnorm_fwd");
     return BD_OK;
 }
 
-extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const void* z, const float* gamma, const float* stats, int N, int L,
+extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamma, const float* beta, const float* stats, int N, int L,
                                 const int32_t* lvl_off_host, const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, int relu,
                                 void* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
-    BD_REQUIRE(dz && y && z && gamma && stats && dy && dgamma && dbeta && ws, "groupnorm_bwd: null pointer");
+    BD_REQUIRE(dz && y && gamma && beta && stats && dy && dgamma && dbeta && ws, "groupnorm_bwd: null pointer");
     BD_REQUIRE(C == 256, "groupnorm_bwd: C=%d unsupported", C);
     BD_REQUIRE(L >= 1 && L <= MAXL && N >= 1, "groupnorm_bwd: bad N/L");
-    if (ws_bytes < bd_groupnorm_workspace_bytes(N, L, C)) { bd_set_error("groupnorm_bwd: workspace too small"); return BD_EWORKSPACE; }
+    if (ws_bytes < bd_groupnorm_workspace_bytes(N, L, C, pix_per_img)) { bd_set_error("groupnorm_bwd: workspace too small"); return BD_EWORKSPACE; }
     const GnLevels lv = make_levels(L, lvl_off_host, lvl_cnt_host);
+    const int S = lv.slot0[L];
     hipStream_t st = (hipStream_t)stream;
     float* pg = (float*)ws;
-    float* pc = pg + (size_t)N * L * GN_CHUNKS * 32 * 2;
-    float* ab = pc + (size_t)N * L * GN_CHUNKS * C * 2;
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(GN_CHUNKS, L, N), dim3(256), 0, st, (const bf16_raw*)dz, (const bf16_raw*)y,
-                       (const bf16_raw*)z, stats, gamma, lv, (int)pix_per_img, C, relu, pg, pc);
-    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * L * 32, 256)), dim3(256), 0, st, (const float*)pg, lv, N, C / 32, ab);
-    hipLaunchKernelGGL(gn_bwd_final_c_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)pc, N * L * GN_CHUNKS, C, dgamma, dbeta,
-                       accumulate);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(egrid((long long)N * pix_per_img * 32)), dim3(256), 0, st, (const bf16_raw*)dz,
-                       (const bf16_raw*)y, (const bf16_raw*)z, stats, (const float*)ab, gamma, lv, N, (int)pix_per_img, relu, (bf16_raw*)dy);
+    float* pc = pg + (size_t)N * S * 32 * 2;
+    float* ab = pc + (size_t)N * S * C * 2;
+    const int step = g_gn_chunk_bwd > 0 ? g_gn_chunk_bwd : N;
+    for (int n0 = 0; n0 < N; n0 += step) {
+        const int nc = n0 + step <= N ? step : N - n0;
+        const long long eo = (long long)n0 * pix_per_img * C;
+        const bf16_raw* dzc = (const bf16_raw*)dz + eo;
+        const bf16_raw* yc = (const bf16_raw*)y + eo;
+        const float* stc = stats + (size_t)n0 * L * 64;
+        float* abc = ab + (size_t)n0 * L * 64;
+        hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(S, nc), dim3(256), 0, st, dzc, yc, stc, gamma, beta, lv, (int)pix_per_img, C, relu,
+                           pg + (size_t)n0 * S * 64, pc + (size_t)n0 * S * C * 2);
+        hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(nc * L * 32, 256)), dim3(256), 0, st, (const float*)(pg + (size_t)n0 * S * 64), lv, nc,
+                           C / 32, abc);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(egrid((long long)nc * pix_per_img * 32)), dim3(256), 0, st, dzc, yc, stc, (const float*)abc,
+                           gamma, beta, lv, nc, (int)pix_per_img, relu, (bf16_raw*)dy + eo);
+    }
+    // dgamma / dbeta over every (image, slot) of the batch, in slot order: independent of the chunking
+    hipLaunchKernelGGL(gn_bwd_final_c_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)pc, N * S, C, dgamma, dbeta, accumulate);
     BD_CHECK_LAUNCH("bd_groupnorm_bwd");
     return BD_OK;
 }

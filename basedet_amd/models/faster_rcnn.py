@@ -207,6 +207,7 @@ class FasterRCNN(FPNDetector):
             # the RPN head's backward needs nothing from the proposal chain: it runs now, under it, and leaves the FIRST contribution
             # to dL/dP; the RoIAlign backward joins it later (head_backward: the fp32 pyramid through an accumulating conversion,
             # the packed atomics directly on top)
+            self._flush_wgrads()          # (partial sums left by a get_losses() that was never followed by backward(): reduce them now, free the arena)
             self._rpn_head_backward(pl, pl.wgrad_ws, pl.colsum_ws, first=True)
             pl.rpn_bwd_done = True
         # ---- RCNN: sampling, RoIAlign, box head, losses

@@ -94,7 +94,7 @@ class FCOS(FPNDetector):
         pl.gt_ctr = torch.empty((N, P_total), **f32)
         pl.stats = torch.zeros((2,), **f32)          # (num_fg, sum_ctr)
         pl.loss_buf = torch.zeros((3,), **f32)
-        pl.gn_ws = torch.empty((ops.groupnorm_workspace_bytes(N, L, ch) // 4 + 16,), **f32)
+        pl.gn_ws = torch.empty((ops.groupnorm_workspace_bytes(N, L, ch, pl.pyr.pix_per_img) // 4 + 16,), **f32)
         pl.off_ws = torch.empty((ops.fcos_offsets_workspace_bytes() // 4,), **f32)
 
     # ---- forward -----------------------------------------------------------------------------------------
@@ -176,7 +176,7 @@ class FCOS(FPNDetector):
             for i in range(nc - 1, -1, -1):
                 gy = pl.g_y[ti][i]
                 # g_z = dL/dz_i  ->  gy = dL/dy_i (conv output)
-                ops.groupnorm_bwd(pl.g_z, bufs["y"][i], bufs["z"][i], gammas[i].w, bufs["stats"][i], pyr, ch, True, gy,
+                ops.groupnorm_bwd(pl.g_z, bufs["y"][i], gammas[i].w, betas[i].w, bufs["stats"][i], pyr, ch, True, gy,
                                   gammas[i].g, betas[i].g, pl.gn_ws)
                 x = bufs["z"][i - 1] if i > 0 else pl.P
                 self._wgrad(convs[i], x, gy, pyr, pyr, ws, cws)

@@ -791,8 +791,12 @@ class FPNDetector:
             self._flush_wgrads()
 
     def _begin_wgrads(self):
-        """Start of a backward pass (also the head modules' own, layers/modules.py): nothing queued, the arena free from offset 0."""
-        self._wq_off = self._wq_pending = 0
+        """Start of a backward pass (also the head modules' own, layers/modules.py): the arena is free from offset 0 -- UNLESS partial sums
+        are already waiting for the head bucket's flush: Faster R-CNN runs its RPN head's backward inside get_losses, under the proposal
+        chain, and those slices must survive until then.  (Rounds 4's reset here let the box head's kernels overwrite them: the RPN
+        weight gradients of every queued step were wrong -- found by tests/test_wgrad_queue_gpu.py, the first test of the queued path.)"""
+        if self._wq is None or not self._wq.pending():
+            self._wq_off = self._wq_pending = 0
 
     def _flush_wgrads(self):
         """One launch reduces every weight gradient queued since the last flush (on the stream the partial sums were computed on); the

@@ -585,8 +585,8 @@ def bce_logits_fwd_bwd(pred, target, labels, rows, norm, loss_sum, dpred, ld=1, 
 
 
 # ---- FCOS head pieces -------------------------------------------------------------------------------------
-def groupnorm_workspace_bytes(N, Ln, Cn):
-    return int(L().bd_groupnorm_workspace_bytes(N, Ln, Cn))
+def groupnorm_workspace_bytes(N, Ln, Cn, pix_per_img):
+    return int(L().bd_groupnorm_workspace_bytes(N, Ln, Cn, int(pix_per_img)))
 
 
 def _lvl_arrays(geom: Geom):
@@ -600,9 +600,10 @@ def groupnorm_fwd(y, gamma, beta, geom: Geom, Cn, eps, relu, stats, z, ws):
     return z
 
 
-def groupnorm_bwd(dz, y, z, gamma, stats, geom: Geom, Cn, relu, dy, dgamma, dbeta, ws, accumulate=False):
+def groupnorm_bwd(dz, y, gamma, beta, stats, geom: Geom, Cn, relu, dy, dgamma, dbeta, ws, accumulate=False):
+    """The ReLU gate (relu=True) is recomputed from y, stats, gamma, beta: the forward's output z is not an operand."""
     off, cnt = _lvl_arrays(geom)
-    check(L().bd_groupnorm_bwd(ptr(dz), ptr(y), ptr(z), ptr(gamma), ptr(stats), geom.N, geom.nlev, off, cnt, geom.pix_per_img, Cn,
+    check(L().bd_groupnorm_bwd(ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(stats), geom.N, geom.nlev, off, cnt, geom.pix_per_img, Cn,
                                int(relu), ptr(dy), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel() * ws.element_size(),
                                stream_ptr()), "bd_groupnorm_bwd")
     return dy

@@ -479,6 +479,8 @@ def main():
                          "outputs keep the last warm-up step's values): the step-time difference is what those launches cost")
     ap.add_argument("--wgrad-knob", type=int, default=None,
                     help="ablation: bd_wgrad_set_transpose_read bit mask (5 = the ring-staged weight-gradient kernels off: rounds 1-3 kernels)")
+    ap.add_argument("--gn-chunks", default=None, metavar="F,B",
+                    help="ablation (FCOS family): bd_groupnorm_set_chunks -- images per chunk of the GroupNorm forward / backward (0 = whole batch)")
     ap.add_argument("--conv-knob", type=int, default=None,
                     help="ablation: bd_conv_set_patch3x3 bit mask (include/basedet_hip.h) applied before the run")
     args = ap.parse_args()
@@ -583,6 +585,8 @@ def worker(args):
         ops.L().bd_conv_set_patch3x3(args.conv_knob)
     if args.dense1x1 is not None:
         ops.L().bd_conv_set_dense1x1(args.dense1x1)
+    if args.gn_chunks is not None:
+        ops.L().bd_groupnorm_set_chunks(*[int(v) for v in args.gn_chunks.split(",")])
     if args.wgrad_knob is not None:
         ops.L().bd_wgrad_set_transpose_read(args.wgrad_knob)
     if args.no_mask_bits:

@@ -400,16 +400,22 @@ int bd_bce_logits_fwd_bwd(const void* pred, int ld, int off, const float* target
 
 /* GroupNorm(32, C=256) (+ReLU) over every (image, pyramid level, group) of a pixel-major multi-level tensor:
  * level l of image n = pixel rows [n*pix_per_img + lvl_off[l], + lvl_cnt[l]).  stats: fp32 [N][L][32][2] = (mean, rstd),
- * kept for the backward.  Two-stage fixed-order reductions (reproducible).  ws: bd_groupnorm_workspace_bytes. */
-size_t bd_groupnorm_workspace_bytes(int N, int L, int C);
+ * kept for the backward.  Two-stage fixed-order reductions over 128-pixel slots (reproducible, independent of the chunking below).
+ * ws: bd_groupnorm_workspace_bytes. */
+size_t bd_groupnorm_workspace_bytes(int N, int L, int C, int64_t pix_per_img);
 int bd_groupnorm_fwd(const void* y, const float* gamma, const float* beta, int N, int L, const int32_t* lvl_off_host,
                      const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, float eps, int relu, float* stats,
                      void* z, void* ws, size_t ws_bytes, bd_stream_t stream);
-/* dz = gradient w.r.t. the (ReLU'd) output z; relu != 0 gates it with z > 0.  dy: gradient w.r.t. the conv output y;
+/* dz = gradient w.r.t. the (ReLU'd) output z; relu != 0 gates it with z > 0, RECOMPUTED from y, stats, gamma and beta with the forward's
+ * own arithmetic (round 5: z is no longer read -- two of the backward's seven tensor passes).  dy: gradient w.r.t. the conv output y;
  * dgamma/dbeta fp32 [C] (accumulate != 0 adds). */
-int bd_groupnorm_bwd(const void* dz, const void* y, const void* z, const float* gamma, const float* stats, int N, int L,
+int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamma, const float* beta, const float* stats, int N, int L,
                      const int32_t* lvl_off_host, const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, int relu,
                      void* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
+/* measurement knob: images per chunk of bd_groupnorm_fwd / _bwd (0 = the whole batch at once; defaults 8 / 4).  A chunk's statistics
+ * pass is followed at once by its apply pass, which then re-reads the chunk from the 256 MB Infinity Cache instead of HBM; results do
+ * not depend on it (bit for bit). */
+int bd_groupnorm_set_chunks(int fwd_images, int bwd_images);
 
 /* offsets = relu(bbox_pred * scale_l) * stride_l (point_head.py:143).  raw: bf16 [pixels][ld = 8] (channels 0-3 =
  * bbox_pred, 4 = ctrness logit, 5-7 = 0), scales: device fp32 [L]; out: bf16 [pixels][4]. */

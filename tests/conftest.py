@@ -20,8 +20,8 @@ def golden_dir():
 # The library's measurement knobs are process-global (include/basedet_hip.h: bd_conv_set_patch3x3, bd_conv_set_dense1x1,
 # bd_wgrad_set_transpose_read, bd_focal_set_fast, bd_conv_fp8_set_patch).  A test that flips one and then fails would leave it flipped
 # for every later test of the run: every GPU test ends with the defaults restored, whatever happened inside it.
-_KNOB_DEFAULTS = (("bd_conv_set_patch3x3", 3), ("bd_conv_set_dense1x1", 1), ("bd_wgrad_set_transpose_read", 1), ("bd_focal_set_fast", 1),
-                  ("bd_conv_fp8_set_patch", 1))
+_KNOB_DEFAULTS = (("bd_conv_set_patch3x3", (3,)), ("bd_conv_set_dense1x1", (1,)), ("bd_wgrad_set_transpose_read", (1,)), ("bd_focal_set_fast", (1,)),
+                  ("bd_conv_fp8_set_patch", (1,)), ("bd_groupnorm_set_chunks", (8, 4)))
 
 
 @pytest.fixture(autouse=True)
@@ -32,4 +32,4 @@ def _restore_library_knobs(request):
     from basedet_amd import _lib
     lib = _lib.load()
     for name, value in _KNOB_DEFAULTS:
-        assert getattr(lib, name)(value) == 0, name
+        assert getattr(lib, name)(*value) == 0, name
