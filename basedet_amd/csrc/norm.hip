@@ -8,9 +8,11 @@
 // Round 5 (rounds 1-4: ten tensor passes per tower layer, 3.1 ms of the FCOS step):
 //   * the backward no longer reads z: the ReLU gate z > 0 is recomputed from y with the forward's own arithmetic (gn_affine: pinned
 //     fma / mul / sub, bf16 rounding keeps the sign of a normal float) -- seven passes become five;
-//   * both directions run image chunk by image chunk (stats of chunk c, then apply of chunk c): what the second kernel re-reads is
-//     what the first one has just pulled through the 256 MB Infinity Cache (bd_groupnorm_set_chunks);
-//   * the partial stage is cut into fixed 128-pixel slots (a chunk of four images still fills the chip).
+//   * the partial stage is cut into fixed 128-pixel slots;
+//   * measured and left OFF (bd_groupnorm_set_chunks, default 0 / 0 = the whole batch per launch): both directions image chunk by image
+//     chunk (stats of chunk c, then apply of chunk c), so that the second kernel re-reads what the first has just pulled through the
+//     256 MB Infinity Cache -- FCOS-R50 batch 16, one box: 622.7 img/s unchunked, 589.1 at 8 / 4 images per chunk, 544.0 at 4 / 2, 520.4
+//     at 2 / 2 (profiles/r05_gn_chunks.txt): the smaller launches lose more in ramps and tails than the cache returns.
 // Reductions are two-stage with a fixed partial order (no float atomics): bitwise reproducible, and independent of the chunking.
 #include "common.h"
 
@@ -348,7 +350,7 @@ inline int egrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 
 constexpr int OFF_BLOCKS = 512;
 
 // images per chunk of the forward / backward (0 = the whole batch in one chunk): bd_groupnorm_set_chunks
-int g_gn_chunk_fwd = 8, g_gn_chunk_bwd = 4;
+int g_gn_chunk_fwd = 0, g_gn_chunk_bwd = 0;
 
 }  // namespace
 

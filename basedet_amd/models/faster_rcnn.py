@@ -117,6 +117,7 @@ class FasterRCNN(FPNDetector):
         pl.rpn_offsets = torch.empty((N, tot, 4), **f32)
         pl.rpn_num_fg = torch.zeros((1,), **i32)
         pl.rpn_num_valid = torch.zeros((1,), **i32)
+        pl.assign_ws = None                   # scratch of bd_rpn_assign_encode (N x Gmax floats): sized by the first batch
         lvl_pixels = [h * w for h, w in pl.sizes]
         post = self.post_k[True]
         assert self.post_k[False] == post, "train / test post-NMS top-k share the proposal slots"
@@ -175,7 +176,6 @@ class FasterRCNN(FPNDetector):
         pre = self.pre_process(inputs)
         pl = pre["plan"]
         self._cur = pl
-        self.network_forward(pl)
         m = self.cfg.MODEL
         A = self.num_anchors
         N = pl.N
@@ -183,6 +183,30 @@ class FasterRCNN(FPNDetector):
         info = pre["img_info"]
         num_gt = info[:, 4].to(torch.int32).contiguous()
         Gmax = gt.shape[1]
+        thr = m.MATCHER.THRESHOLDS
+        nsa = m.RPN.NUM_SAMPLE_ANCHORS
+
+        def rpn_targets():
+            """RPN.get_ground_truth (rpn.py:215-240): anchors, ground truth and random keys in, labels / offsets out -- nothing of the network."""
+            ops.rpn_assign_encode(pl.anchors, gt, num_gt, thr[0], thr[1], m.MATCHER.ALLOW_LOW_QUALITY, m.RPN_BOX_REG.MEAN,
+                                  m.RPN_BOX_REG.STD, pl.rpn_labels, pl.rpn_match, pl.rpn_offsets, pl.rpn_num_fg, pl.assign_ws)
+            ops.sample_labels(pl.rpn_labels, self._keys(inputs, "rpn_pos", (N, pl.A_total)), self._keys(inputs, "rpn_neg", (N, pl.A_total)),
+                              int(m.RPN.POSITIVE_ANCHOR_RATIO * nsa), nsa, pl.rpn_num_valid)
+            if not (self.deterministic_roi_bwd or self.roi_bwd_pk):
+                pl.g_feat32.zero_()           # the fp32 pyramid RoIAlign's backward scatters into (1.5 GB at batch 16): cleared here, not in backward
+                pl.g_feat32_clean = True
+
+        # Round 5: the RPN targets (0.7 ms of one-workgroup-per-image kernels at batch 16: gt_rowmax, assignment, the radix select over
+        # 268 569 keys per image) and that clear run on the weight-gradient stream, which is idle during the forward pass, UNDER the
+        # backbone -- as RetinaNet's assignment does (rounds 1-4 ran them between the forward and the RPN losses, on the main chain).
+        early = self._wstream if (self.async_wgrad and self._wstream is not None and m.get("RPN_TARGETS_EARLY", True)) else None
+        if pl.assign_ws is None or pl.assign_ws.numel() < N * Gmax:
+            pl.assign_ws = torch.empty((N * Gmax,), dtype=torch.float32, device=self.device)
+        if early is not None:
+            early.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(early):
+                rpn_targets()
+        self.network_forward(pl)
         # ---- RPN: proposals (detached), targets, losses.  The proposal chain (decode, per-level top-k, batched NMS: ~2 ms of
         # kernels with 16 workgroups each) runs on a side stream under the anchor assignment, anchor sampling and RPN losses
         side = self._tstream if (self.async_wgrad and self._tstream is not None) else None
@@ -192,13 +216,10 @@ class FasterRCNN(FPNDetector):
                 self._proposals(pl, info)
         else:
             self._proposals(pl, info)
-        thr = m.MATCHER.THRESHOLDS
-        ws = pl.wgrad_ws[: N * Gmax]
-        ops.rpn_assign_encode(pl.anchors, gt, num_gt, thr[0], thr[1], m.MATCHER.ALLOW_LOW_QUALITY, m.RPN_BOX_REG.MEAN,
-                              m.RPN_BOX_REG.STD, pl.rpn_labels, pl.rpn_match, pl.rpn_offsets, pl.rpn_num_fg, ws)
-        nsa = m.RPN.NUM_SAMPLE_ANCHORS
-        ops.sample_labels(pl.rpn_labels, self._keys(inputs, "rpn_pos", (N, pl.A_total)), self._keys(inputs, "rpn_neg", (N, pl.A_total)),
-                          int(m.RPN.POSITIVE_ANCHOR_RATIO * nsa), nsa, pl.rpn_num_valid)
+        if early is not None:
+            torch.cuda.current_stream().wait_stream(early)
+        else:
+            rpn_targets()
         pl.loss_buf.zero_()
         ops.rpn_loss_fwd_bwd(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.rpn_labels, pl.rpn_offsets, pl.pyr.pixels,
                              m.LOSSES.RPN_SMOOTH_L1_BETA, pl.rpn_num_valid, pl.loss_buf[0:2], pl.d_rpn_raw)
@@ -257,7 +278,9 @@ class FasterRCNN(FPNDetector):
             ops.roi_align_bwd_pk(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
                                  self.pool, 2, pl.g_P)
         else:
-            pl.g_feat32.zero_()
+            if not getattr(pl, "g_feat32_clean", False):      # (normally cleared by get_losses, under the forward pass)
+                pl.g_feat32.zero_()
+            pl.g_feat32_clean = False
             ops.roi_align_bwd(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
                               self.pool, 2, pl.g_feat32)
             ops.f32_to_bf16(pl.g_feat32, pl.g_P, accumulate=pl.rpn_bwd_done)

@@ -412,9 +412,9 @@ int bd_groupnorm_fwd(const void* y, const float* gamma, const float* beta, int N
 int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamma, const float* beta, const float* stats, int N, int L,
                      const int32_t* lvl_off_host, const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, int relu,
                      void* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
-/* measurement knob: images per chunk of bd_groupnorm_fwd / _bwd (0 = the whole batch at once; defaults 8 / 4).  A chunk's statistics
- * pass is followed at once by its apply pass, which then re-reads the chunk from the 256 MB Infinity Cache instead of HBM; results do
- * not depend on it (bit for bit). */
+/* measurement knob: images per chunk of bd_groupnorm_fwd / _bwd (0 = the whole batch at once: the default, 0 / 0).  A chunk's statistics
+ * pass is followed at once by its apply pass, which then re-reads the chunk from the 256 MB Infinity Cache instead of HBM -- measured
+ * slower at every chunk size (csrc/norm.hip); results do not depend on it (bit for bit). */
 int bd_groupnorm_set_chunks(int fwd_images, int bwd_images);
 
 /* offsets = relu(bbox_pred * scale_l) * stride_l (point_head.py:143).  raw: bf16 [pixels][ld = 8] (channels 0-3 =

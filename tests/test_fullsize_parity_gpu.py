@@ -18,8 +18,9 @@ N = 2
 # Against the PLAIN fp32 oracle a parameter gradient differs by bf16 forward noise flipping ReLU gates near zero: not a tight bound (the
 # tight one is the injected-activation comparison, 2e-2).  Round 5: the direction is bounded instead of a 0.40 rel-L2 that asserted
 # almost nothing -- per-parameter cosine and the whole-model cosine; the rel-L2 maxima are printed as a diagnostic (-s).
-MIN_COS_PARAM = 0.93        # observed minima are printed by every run
-MIN_COS_MODEL = 0.97
+MIN_COS_PARAM = 0.975       # RetinaNet-R50: observed worst parameter 0.9909 (layer2.1.conv1), whole model 0.99954, norm ratio 1.003
+MIN_COS_MODEL = 0.998
+FCOS_MIN_COS = (0.93, 0.99)  # FCOS-R50 (GroupNorm towers amplify the flipped gates): observed 0.9550 (layer2.3.conv1) / 0.99659
 
 
 def _rel(a, b):
@@ -139,7 +140,7 @@ def test_fcos_r50_full_size_matches_oracle():
     acts = model.debug_activations()
     orc2 = Oracle(params, P.oracle_arch(cfg), trainable=names, sim_bf16=True, inject=acts)
     l2, _ = orc2.fcos_losses(batch)
-    _check_grads(names, got, ref_grads, orc2.grads(l2["total_loss"]), "FCOS-R50 2x800x1344")
+    _check_grads(names, got, ref_grads, orc2.grads(l2["total_loss"]), "FCOS-R50 2x800x1344", *FCOS_MIN_COS)
     _check_forward_layers(Oracle(params, P.oracle_arch(cfg), record={"_compare": acts}), batch, "fcos_losses", "FCOS-R50 2x800x1344", bound=3e-2)
 
 
