@@ -449,8 +449,13 @@ int g_bk32_for_1x1 = 1;
 // instead of two) run them 10-35 % faster as long as the grid still fills the chip (P6's 70-tile forward keeps BK=64).
 // bd_conv_set_patch3x3 bit 10 clears it.
 int g_bk32_s2 = 1;
+// conv_igemm_wide.hip (round 5): 1 = the stride-2 3x3 launches whose grid fills the chip (default), 0 = never (bd_conv_set_patch3x3 bit 15),
+// 2 = every launch of this file that kernel can take (bit 16: tests / A-B; same bits as the generic kernel either way)
+int g_igemm_wide = 1;
 
 }  // namespace
+
+int bd_conv_igemm_wide_launch(igemm::IgemmParams p, bool everywhere, hipStream_t stream);
 
 int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias,
                             const void* add, const void* mask, void* dst, int flags, hipStream_t stream);
@@ -482,6 +487,7 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_conv1x1_s2 = ((enable >> 12) & 1) ^ 1;
     g_pp_tail_split = ((enable >> 13) & 1) ^ 1;
     g_pp_persistent = ((enable >> 14) & 1) ^ 1;
+    g_igemm_wide = ((enable >> 15) & 1) ? 0 : (((enable >> 16) & 1) ? 2 : 1);
     return BD_OK;
 }
 
@@ -551,6 +557,10 @@ static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_p
     p.M = (int)m;
     p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
     set_buffer_sizes(p, d->N);
+    if (g_igemm_wide && bd_conv_igemm_wide_launch(p, g_igemm_wide == 2, (hipStream_t)stream) == 0) {
+        BD_CHECK_LAUNCH("bd_conv2d_fwd(wide)");
+        return BD_OK;
+    }
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
         launch_igemm<64>(p, (hipStream_t)stream);
@@ -647,6 +657,10 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
     p.M = (int)m;
     p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
     set_buffer_sizes(p, d->N);
+    if (g_igemm_wide && bd_conv_igemm_wide_launch(p, g_igemm_wide == 2, (hipStream_t)stream) == 0) {
+        BD_CHECK_LAUNCH("bd_conv2d_dgrad(wide)");
+        return BD_OK;
+    }
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
         launch_igemm<64>(p, (hipStream_t)stream);

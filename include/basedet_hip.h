@@ -159,7 +159,10 @@ int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream);
  * the 64-channel tile of conv3x3_pp128_body.h, in 4 r short workgroups at the end of the same grid, instead of paying a whole round of
  * 256-channel workgroups for r tiles; same bits);
  * bit 14 = one workgroup per tile in conv3x3_pp.hip instead of the persistent grid (by default one workgroup per CU walks up to 16 tiles
- * and requests the next tile's operands inside the current tile's last K block; same bits). */
+ * and requests the next tile's operands inside the current tile's last K block; same bits);
+ * bit 15 = the stride-2 3x3 launches stay on the generic kernel instead of conv_igemm_wide.hip (round 5: 128-channel x 256-pixel
+ * workgroup tile, 128 x 64 wave tiles, both operands by LDS-DMA; same bits as the generic kernel);
+ * bit 16 = (set = ON) conv_igemm_wide.hip for EVERY launch of the generic path it can take (tests / A-B). */
 int bd_conv_set_patch3x3(int enable);
 
 /* debug/measurement knob: 1 (default) = operand transposes through ds_read_b64_tr_b16, 0 = scalar 16-bit LDS reads
