@@ -118,6 +118,7 @@ SIGNATURES = {
     "bd_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "bd_rpn_proposals_workspace_bytes": (_Z, [_I, _I, _P, _I, _I, _I]),
     "bd_rpn_proposals": (_I, [_P, _I, _I, _I, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _I, _F, _I, _P, _P, _P, _Z, _P]),
+    "bd_rpn_set_nms_per_level": (_I, [_I]),
     "bd_rcnn_sample_targets": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bd_roi_align_fwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "bd_roi_align_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

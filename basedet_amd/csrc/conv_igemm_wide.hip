@@ -1,7 +1,8 @@
 // Implicit-GEMM convolution forward / data gradient, WIDE wave tile: the stride-2 3x3 family (res3.0 / res4.0 / res5.0 conv2, P6, P7).
 //
-// Same GEMM, parameter block and K order as conv_igemm.hip (taps ascending, 32 channels per MFMA, fp32 accumulation: the SAME BITS), re-cut
-// for the two things that bound that kernel on these layers (rounds 3-4: 0.197 / 0.049 of their roofs, HBM traffic 2.2-2.9 x):
+// Same GEMM and parameter block as conv_igemm.hip (32 channels per MFMA, fp32 accumulation; the K ORDER differs -- see `request` -- so the
+// results agree to fp32 summation order, not bit for bit), re-cut for what bounded that kernel on these layers (rounds 3-4: 0.197 /
+// 0.049 of their roofs, HBM traffic 2.2-2.9 x the algorithmic bytes):
 //   * wave tile 128 channels x 64 pixels (acc[8][4]) instead of 64 x 64: 12 ds_read_b128 per 32 MFMAs instead of 8 per 16 -- a 128 x 128
 //     workgroup tile of 64 x 64 wave tiles reads ~1 000 LDS cycles of fragments per 512 matrix cycles and is LDS-bound whatever feeds it
 //     (round 4's gather-on-ring attempt ran exactly as fast as the generic kernel for that reason);
@@ -111,13 +112,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_wide_kernel(const IgemmPara
     const int kblocks = p.CK / WBK;                 // the host takes CK % 32 == 0 only
     const int nsteps = __popc(tapmask) * kblocks;
 
-    // ---- producer state: the (tap, K block) of the NEXT step to request
+    // ---- producer state: the (K-block pair, tap, half) of the NEXT step to request.  K ORDER (what this kernel is about, measured round 5:
+    // with the generic kernel's order -- tap outer, K block inner -- this kernel ran exactly as fast as the generic one, 141 vs 141 us on
+    // res3.0's forward, at 2.2 x the algorithmic HBM traffic): a gathered input pixel is wanted again by a NEIGHBOURING tap (stride 2: tap
+    // column 2 of output x and tap column 0 of output x + 1 are the same pixel), and the two 64-byte K blocks of a pixel share a 128-byte
+    // line.  Tap-outer order puts 2 x kblocks steps x 16 KB per workgroup between those uses -- 8 MB per XCD with 64 workgroups in flight,
+    // twice its L2 -- so every re-use went back to the fabric.  Here: pairs of K blocks outermost, the taps inside, the pair's two halves
+    // innermost: a line's second half is the next step, a neighbouring tap's re-use two to four steps away.
     unsigned int rem_mask = tapmask;
-    int i_tap = 0, i_kb = kblocks;                  // forces a tap advance on the first request
+    int i_tap = 0, i_g = 0, i_h = 0, i_hmax = 0;    // i_hmax = 0 forces a tap advance on the first request
     unsigned b_voff[4];
     auto request = [&](int stage) {
-        if (i_kb == kblocks) {                      // next filter tap (workgroup-uniform): the source pixel of every staged row moves
-            i_kb = 0;
+        if (i_h >= i_hmax) {                        // next filter tap (workgroup-uniform): the source pixel of every staged row moves
+            i_h = 0;
+            if (rem_mask == 0) { rem_mask = tapmask; ++i_g; }          // every tap of this K-block pair done: next pair
+            i_hmax = kblocks - 2 * i_g < 2 ? kblocks - 2 * i_g : 2;
             i_tap = __ffs(rem_mask) - 1;
             rem_mask &= rem_mask - 1;
             const int tap_r = i_tap / p.S, tap_s = i_tap - tap_r * p.S;
@@ -138,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_wide_kernel(const IgemmPara
                 b_voff[k] = ok ? (unsigned)((b_base[k] + sy * b_ws[k] + sx) * p.CK + b_ch[k]) * 2u : X_NONE;
             }
         }
+        const int i_kb = 2 * i_g + i_h;
         int so_a = (i_tap * p.CK + i_kb * WBK) * 2, so_b = i_kb * WBK * 2;
         asm volatile("" : "+s"(so_a), "+s"(so_b));            // keep the K-block offsets in the scalar operand
         unsigned char* At = smem + stage * W_STAGE;
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_wide_kernel(const IgemmPara
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_w_t*)(At + W_A_BYTES + (wave + 4 * k) * 1024), 16, b_voff[k], so_b, 0, 0);
-        ++i_kb;
+        ++i_h;
     };
 
     f32x4_t acc[8][4];
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_wide_kernel(const IgemmPara
 // 0 = launched; 1 = not this kernel's shape (the caller keeps the generic kernel).  `everywhere`: every launch the kernel CAN take (tests / A-B),
 // else the stride-2 3x3 launches whose grid fills the chip.
 int bd_conv_igemm_wide_launch(IgemmParams p, bool everywhere, hipStream_t stream) {
-    if (p.CK % WBK != 0 || p.CO % 8 != 0 || p.src_bytes == 0 || p.w_bytes == 0 || p.R * p.S > 32 || p.linear_src) return 1;
+    if (p.CK % WBK != 0 || p.CO % 8 != 0 || p.src_bytes == 0 || p.w_bytes == 0 || p.R * p.S > 32) return 1;
     if (!everywhere && !(p.stride == 2 && p.R == 3 && p.S == 3)) return 1;
     p.m_tiles = cdiv(p.M, WT_P); p.n_tiles = cdiv(p.CO, WT_C);
     const int grid = p.m_tiles * p.n_tiles;

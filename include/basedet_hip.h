@@ -479,6 +479,10 @@ int bd_rpn_proposals(const void* raw, int ldc, int A, int cls_off, int box_off, 
                      const float* im_info, int info_ld, const float* mean4_host, const float* std4_host, int pre_k,
                      float nms_thresh, int post_k, float* rois, int32_t* num_rois, void* ws, size_t ws_bytes,
                      bd_stream_t stream);
+/* measurement knob: 1 (default, round 5) = bd_rpn_proposals runs its batched NMS level by level (N x L independent problems of <= pre_k
+ * boxes, then a merge into the joint order), 0 = as one problem per image (rounds 1-4).  The proposals are the same bit for bit: boxes of
+ * different levels never overlap after batched_nms's shift (post_processing.py:44-45), which both forms apply. */
+int bd_rpn_set_nms_per_level(int on);
 
 /* RCNN.get_ground_truth (rcnn.py:95-147) per image: candidates = proposals + gt boxes, IoU max/argmax over the gts,
  * fg (>= fg_thresh) / bg ([bg_lo, bg_hi)) masks, random subsampling with caller-supplied keys (see

@@ -21,7 +21,7 @@ def golden_dir():
 # bd_wgrad_set_transpose_read, bd_focal_set_fast, bd_conv_fp8_set_patch).  A test that flips one and then fails would leave it flipped
 # for every later test of the run: every GPU test ends with the defaults restored, whatever happened inside it.
 _KNOB_DEFAULTS = (("bd_conv_set_patch3x3", (3,)), ("bd_conv_set_dense1x1", (1,)), ("bd_wgrad_set_transpose_read", (1,)), ("bd_focal_set_fast", (1,)),
-                  ("bd_conv_fp8_set_patch", (1,)), ("bd_groupnorm_set_chunks", (0, 0)))
+                  ("bd_conv_fp8_set_patch", (1,)), ("bd_groupnorm_set_chunks", (0, 0)), ("bd_rpn_set_nms_per_level", (1,)))
 
 
 @pytest.fixture(autouse=True)

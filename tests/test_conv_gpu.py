@@ -783,7 +783,7 @@ def test_conv_last_kernel_names_the_dispatched_kernel_for_the_bench_descriptors(
     assert r5["fwd"] in ("conv1x1_dense_kernel", "conv1x1_gemm_kernel") and r5["wgrad"] == "conv_wgrad1x1_ring_kernel", r5
     # the stride-2 3x3 of res3.0 and the stride-2 shortcut of res4.0
     s2 = run(g2, g3, 128, 128, 3, 2, 1, all3)
-    assert s2["fwd"] in ("conv_igemm_kernel<32>", "conv3x3_s2_kernel") and s2["wgrad"] == "conv_wgrad3x3_kernel", s2
+    assert s2 == {"fwd": "conv_igemm_wide_kernel", "dgrad": "conv_igemm_wide_kernel", "wgrad": "conv_wgrad3x3_kernel"}, s2
     sc = run(g3, g4, 512, 1024, 1, 2, 0, ("fwd", "wgrad"))
     assert sc == {"fwd": "conv1x1_dense_kernel", "wgrad": "conv_wgrad1x1_kernel"}, sc
     # narrow 3x3 (res2-sized conv2 of a trainable layer1 would be 64 -> 64): the 64-channel staggered tile
@@ -799,10 +799,11 @@ def test_conv_last_kernel_names_the_dispatched_kernel_for_the_bench_descriptors(
     (2, 64, 136, 21, 17, 3, 1, 1),       # stride 1 through the same kernel (bit 16), ragged channel tile (136 = 128 + 8)
     (3, 96, 64, 9, 11, 5, 1, 2),         # 5x5 filter, 25 taps, three K blocks
 ])
-def test_igemm_wide_gives_the_generic_kernels_bits(case):
-    """conv_igemm_wide_kernel (round 5: 128 x 256 workgroup tile, 128 x 64 wave tiles, LDS-DMA ring) walks the taps and the channels in the
-    generic kernel's order with the same MFMA and fp32 accumulation: forward and data gradient -- every epilogue -- must match
-    conv_igemm_kernel bit for bit (and the torch reference within the bf16 tolerance: test_conv_fwd_dgrad_wgrad, knob 4)."""
+def test_igemm_wide_agrees_with_the_generic_kernel(case):
+    """conv_igemm_wide_kernel (round 5: 128 x 256 workgroup tile, 128 x 64 wave tiles, LDS-DMA ring) computes the generic kernel's GEMM with the
+    same MFMA and fp32 accumulation in ANOTHER K order (K-block pairs outermost, taps inside: L2 re-use): forward and data gradient --
+    every epilogue -- agree with conv_igemm_kernel to fp32 summation order (a bf16 result may round the other way: rel-L2 <= 1e-3), two
+    launches are bit-identical, and the torch reference holds within the bf16 tolerance (test_conv_fwd_dgrad_wgrad, knob 4)."""
     ops = _ops()
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(77 + Cin + H)
@@ -816,7 +817,7 @@ def test_igemm_wide_gives_the_generic_kernels_bits(case):
     bias = torch.randn(Cout, generator=g).cuda()
     res, addt, maskt = bf(gout.pixels, Cout), bf(gin.pixels, Cin), bf(gin.pixels, Cin)
     outs = {}
-    for name, knob in (("generic", 1 << 15), ("wide", 1 << 16)):
+    for name, knob in (("generic", 1 << 15), ("wide", 1 << 16), ("wide2", 1 << 16)):
         assert ops.L().bd_conv_set_patch3x3(knob) == 0
         y1 = torch.empty((gout.pixels, Cout), dtype=torch.bfloat16, device="cuda")
         y2 = torch.empty_like(y1)
@@ -831,9 +832,10 @@ def test_igemm_wide_gives_the_generic_kernels_bits(case):
         ops.conv2d_dgrad(d, gy, wd, dx3)
         torch.cuda.synchronize()
         outs[name] = (y1, y2, dx1, dx2, dx3)
-        want = "conv_igemm_wide_kernel" if name == "wide" else ("conv_igemm_kernel<32>", "conv_igemm_kernel<64>")
+        want = "conv_igemm_wide_kernel" if name.startswith("wide") else ("conv_igemm_kernel<32>", "conv_igemm_kernel<64>")
         assert k1 in want and k2 in want, (name, k1, k2)
     ops.L().bd_conv_set_patch3x3(3)
-    for i, (a, b) in enumerate(zip(outs["generic"], outs["wide"])):
-        assert torch.equal(a, b), i
+    for i, (a, b, c) in enumerate(zip(outs["generic"], outs["wide"], outs["wide2"])):
+        assert rel_l2(b.float().cpu(), a.float().cpu()) < 1e-3, i
+        assert torch.equal(b, c), i
     assert float(outs["wide"][0].float().abs().max()) > 0 and float(outs["wide"][4].float().abs().max()) > 0

@@ -125,7 +125,11 @@ def _anchors(sizes):
     return ob.default_anchors(sizes, STRIDES, scales, ratios, 0.5)
 
 
-def test_rpn_proposals():
+@pytest.mark.parametrize("pre_k,post_k,per_level", [(500, 300, 1), (500, 300, 0), (2000, 1000, 1), (2000, 120, 1)])
+def test_rpn_proposals(pre_k, post_k, per_level):
+    """per_level = 1 (round 5, default): the batched NMS level by level + a merge into the joint order; 0: one problem per image (rounds
+    1-4).  Both against the oracle's joint batched_nms; (2000, 1000): the configured sizes (every level of this pyramid below pre_k keeps
+    all its anchors); (2000, 120): the per-level cap and the merge cut the lists."""
     ops = _ops()
     rng = np.random.default_rng(2)
     N, A, ldc = 2, 3, 16
@@ -135,13 +139,20 @@ def test_rpn_proposals():
     anchors = _anchors(sizes)
     anc_all = np.concatenate(anchors, 0)
     im_info = np.array([[H, W, H, W, 3], [180, 300, 180, 300, 2]], np.float32)
-    pre_k, post_k, thr = 500, 300, 0.7
+    thr = 0.7
     geom = _geom(N, sizes)
     rois = torch.empty((N, post_k, 4), dtype=torch.float32, device="cuda")
     num = torch.empty((N,), dtype=torch.int32, device="cuda")
     ws = torch.empty((ops.rpn_proposals_workspace_bytes(N, [h * w for h, w in sizes], A, pre_k, post_k),), dtype=torch.uint8, device="cuda")
+    assert ops.L().bd_rpn_set_nms_per_level(per_level) == 0
     ops.rpn_proposals(raw_dev, ldc, A, 0, A, geom, _dev(anc_all), _dev(im_info), [0, 0, 0, 0], [1, 1, 1, 1], pre_k, thr, post_k, rois, num, ws)
     gr, gn = rois.cpu().numpy(), num.cpu().numpy()
+    if per_level:            # ... and the joint form gives the same proposals bit for bit
+        rois0, num0 = torch.empty_like(rois), torch.empty_like(num)
+        ops.L().bd_rpn_set_nms_per_level(0)
+        ops.rpn_proposals(raw_dev, ldc, A, 0, A, geom, _dev(anc_all), _dev(im_info), [0, 0, 0, 0], [1, 1, 1, 1], pre_k, thr, post_k, rois0, num0, ws)
+        ops.L().bd_rpn_set_nms_per_level(1)
+        assert torch.equal(num, num0) and torch.equal(rois, rois0)
     for n in range(N):
         sc, of = [], []
         o = 0
