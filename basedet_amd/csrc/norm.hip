@@ -78,22 +78,32 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const bf16_raw* _
     }
 }
 
-// stats[(n*L + l)*32 + g] = (mean, rstd): the slots of a level summed in slot order
-__global__ void gn_stats_final_kernel(const float* __restrict__ partial, GnLevels lv, int N, int cpg, float eps,
-                                      float* __restrict__ stats) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * lv.L * 32) return;
-    const int g = i & 31, nl = i >> 5, l = nl % lv.L, n = nl / lv.L, S = lv.slot0[lv.L];
+// stats[(n*L + l)*32 + g] = (mean, rstd).  One workgroup per (image, level): 8 lanes per group walk the level's slots (lane q: slots q,
+// q + 8, ...), then the eight partial sums are added in lane order -- a fixed order; a single thread per (n, l, g) summing the 132 slots
+// of the largest level one after the other took 37 us per launch (rocprofv3, first form of this round).
+__global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __restrict__ partial, GnLevels lv, int cpg, float eps,
+                                                             float* __restrict__ stats) {
+    __shared__ float red[8][32][2];
+    const int g = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int l = blockIdx.x, n = blockIdx.y, S = lv.slot0[lv.L];
     float s = 0.f, ss = 0.f;
-    for (int c = lv.slot0[l]; c < lv.slot0[l + 1]; ++c) {
+    for (int c = lv.slot0[l] + q; c < lv.slot0[l + 1]; c += 8) {
         const float* o = partial + (((long long)n * S + c) * 32 + g) * 2;
         s += o[0]; ss += o[1];
     }
-    const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
-    const float mean = s * inv;
-    const float var = fmaxf(ss * inv - mean * mean, 0.f);
-    stats[i * 2] = mean;
-    stats[i * 2 + 1] = rsqrtf(var + eps);
+    red[q][g][0] = s; red[q][g][1] = ss;
+    __syncthreads();
+    if (q == 0) {
+        s = 0.f; ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s += red[k][g][0]; ss += red[k][g][1]; }
+        const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
+        const float mean = s * inv;
+        const float var = fmaxf(ss * inv - mean * mean, 0.f);
+        const int i = (n * lv.L + l) * 32 + g;
+        stats[i * 2] = mean;
+        stats[i * 2 + 1] = rsqrtf(var + eps);
+    }
 }
 
 __device__ __forceinline__ int level_of(const GnLevels& lv, int p) {
@@ -194,37 +204,49 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_raw* __r
     }
 }
 
-// ab[(n*L + l)*32 + g] = (A, B) / count
-__global__ void gn_bwd_final_kernel(const float* __restrict__ pg, GnLevels lv, int N, int cpg, float* __restrict__ ab) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ngl = N * lv.L * 32;
-    if (i < ngl) {
-        const int g = i & 31, nl = i >> 5, l = nl % lv.L, n = nl / lv.L, S = lv.slot0[lv.L];
-        float A = 0.f, B = 0.f;
-        for (int c = lv.slot0[l]; c < lv.slot0[l + 1]; ++c) {
-            const float* o = pg + (((long long)n * S + c) * 32 + g) * 2;
-            A += o[0]; B += o[1];
-        }
+// ab[(n*L + l)*32 + g] = (A, B) / count: one workgroup per (image, level), as gn_stats_final_kernel
+__global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restrict__ pg, GnLevels lv, int cpg, float* __restrict__ ab) {
+    __shared__ float red[8][32][2];
+    const int g = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int l = blockIdx.x, n = blockIdx.y, S = lv.slot0[lv.L];
+    float A = 0.f, B = 0.f;
+    for (int c = lv.slot0[l] + q; c < lv.slot0[l + 1]; c += 8) {
+        const float* o = pg + (((long long)n * S + c) * 32 + g) * 2;
+        A += o[0]; B += o[1];
+    }
+    red[q][g][0] = A; red[q][g][1] = B;
+    __syncthreads();
+    if (q == 0) {
+        A = 0.f; B = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { A += red[k][g][0]; B += red[k][g][1]; }
         const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
+        const int i = (n * lv.L + l) * 32 + g;
         ab[i * 2] = A * inv; ab[i * 2 + 1] = B * inv;
     }
 }
 
-// dgamma[c], dbeta[c] (+)= sums over every (n, slot): a block owns 8 channels, 32 lanes walk the slots (each reads the
-// 64 contiguous bytes of its 8 channels), then a fixed-order LDS reduction -- reproducible, and no long serial chains
-__global__ __launch_bounds__(256) void gn_bwd_final_c_kernel(const float* __restrict__ pc, int slots, int C, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int accumulate) {
-    __shared__ float red[32][8][2];
+// dgamma[c], dbeta[c] (+)= sums over every (n, slot): a block owns 8 channels, 128 lanes walk the slots (each reads the 64 contiguous bytes
+// of its 8 channels), then a fixed-order LDS reduction in two steps -- reproducible, and no long serial chains (2 848 slots at batch 16)
+__global__ __launch_bounds__(1024) void gn_bwd_final_c_kernel(const float* __restrict__ pc, int slots, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[128][8][2];
     const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
     float dg = 0.f, db = 0.f;
     if (c < C)
-        for (int s = sl; s < slots; s += 32) { dg += pc[((long long)s * C + c) * 2]; db += pc[((long long)s * C + c) * 2 + 1]; }
+        for (int s = sl; s < slots; s += 128) { dg += pc[((long long)s * C + c) * 2]; db += pc[((long long)s * C + c) * 2 + 1]; }
     red[sl][cl][0] = dg; red[sl][cl][1] = db;
+    __syncthreads();
+    float a16 = 0.f, b16 = 0.f;
+    if (sl < 8)                        // 16 partials each, in order
+        for (int k = 0; k < 16; ++k) { a16 += red[sl * 16 + k][cl][0]; b16 += red[sl * 16 + k][cl][1]; }
+    __syncthreads();
+    if (sl < 8) { red[sl][cl][0] = a16; red[sl][cl][1] = b16; }
     __syncthreads();
     if (sl == 0 && c < C) {
         float a = 0.f, b = 0.f;
-        for (int k = 0; k < 32; ++k) { a += red[k][cl][0]; b += red[k][cl][1]; }
+        for (int k = 0; k < 8; ++k) { a += red[k][cl][0]; b += red[k][cl][1]; }
         dgamma[c] = accumulate ? dgamma[c] + a : a;
         dbeta[c] = accumulate ? dbeta[c] + b : b;
     }
@@ -384,7 +406,7 @@ extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* 
         float* part = (float*)ws + (size_t)n0 * S * 64;
         float* stc = stats + (size_t)n0 * L * 64;
         hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, nc), dim3(256), 0, st, yc, lv, (int)pix_per_img, C, part);
-        hipLaunchKernelGGL(gn_stats_final_kernel, dim3(cdiv(nc * L * 32, 256)), dim3(256), 0, st, (const float*)part, lv, nc, C / 32, eps, stc);
+        hipLaunchKernelGGL(gn_stats_final_kernel, dim3(L, nc), dim3(256), 0, st, (const float*)part, lv, C / 32, eps, stc);
         hipLaunchKernelGGL(gn_apply_kernel, dim3(egrid((long long)nc * pix_per_img * 32)), dim3(256), 0, st, yc, (const float*)stc, gamma, beta,
                            lv, nc, (int)pix_per_img, relu, zc);
     }
@@ -415,13 +437,12 @@ extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamm
         float* abc = ab + (size_t)n0 * L * 64;
         hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(S, nc), dim3(256), 0, st, dzc, yc, stc, gamma, beta, lv, (int)pix_per_img, C, relu,
                            pg + (size_t)n0 * S * 64, pc + (size_t)n0 * S * C * 2);
-        hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(nc * L * 32, 256)), dim3(256), 0, st, (const float*)(pg + (size_t)n0 * S * 64), lv, nc,
-                           C / 32, abc);
+        hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(L, nc), dim3(256), 0, st, (const float*)(pg + (size_t)n0 * S * 64), lv, C / 32, abc);
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(egrid((long long)nc * pix_per_img * 32)), dim3(256), 0, st, dzc, yc, stc, (const float*)abc,
                            gamma, beta, lv, nc, (int)pix_per_img, relu, (bf16_raw*)dy + eo);
     }
     // dgamma / dbeta over every (image, slot) of the batch, in slot order: independent of the chunking
-    hipLaunchKernelGGL(gn_bwd_final_c_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)pc, N * S, C, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(gn_bwd_final_c_kernel, dim3(cdiv(C, 8)), dim3(1024), 0, st, (const float*)pc, N * S, C, dgamma, dbeta, accumulate);
     BD_CHECK_LAUNCH("bd_groupnorm_bwd");
     return BD_OK;
 }

@@ -9,3 +9,5 @@ for rep in 1 2; do
   done
 done > gpurun_out/r05_wide_ab.txt
 $B --workload faster_rcnn_r50_800x1344 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('faster_rcnn per-level NMS', d['value'], d['ms_per_step'])" > gpurun_out/r05_frcnn_nms.txt
+python -m pytest tests/test_groupnorm_gpu.py tests/test_fullsize_gpu.py::test_fcos_training_step_is_bitwise_reproducible_full_size -x -q -m gpu 2>&1 | tail -5 >> gpurun_out/r05_t5.log
+$B --workload fcos_r50_800x1344 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fcos (parallel GN finals)', d['value'], d['ms_per_step'])" > gpurun_out/r05_fcos_gn2.txt
