@@ -832,8 +832,10 @@ def test_igemm_wide_agrees_with_the_generic_kernel(case):
         ops.conv2d_dgrad(d, gy, wd, dx3)
         torch.cuda.synchronize()
         outs[name] = (y1, y2, dx1, dx2, dx3)
-        want = "conv_igemm_wide_kernel" if name.startswith("wide") else ("conv_igemm_kernel<32>", "conv_igemm_kernel<64>")
-        assert k1 in want and k2 in want, (name, k1, k2)
+        want = ("conv_igemm_wide_kernel",) if name.startswith("wide") else ("conv_igemm_kernel<32>", "conv_igemm_kernel<64>")
+        assert k1 in want, (name, k1)
+        if not (name.startswith("wide") and Cout % 32):       # (a data gradient whose K = Cout is no multiple of 32 stays on the generic kernel)
+            assert k2 in want, (name, k2)
     ops.L().bd_conv_set_patch3x3(3)
     for i, (a, b, c) in enumerate(zip(outs["generic"], outs["wide"], outs["wide2"])):
         assert rel_l2(b.float().cpu(), a.float().cpu()) < 1e-3, i
