@@ -76,6 +76,18 @@ void bd_note_kernel(const char* name);
         }                                                                         \
     } while (0)
 
+// Measurement switches from the ENVIRONMENT (tile targets, staging depths, A/B routes of scripts/) exist in -DBD_TUNING diagnostic builds
+// only (BD_LIB_NAME / BD_EXTRA_FLAGS of basedet_amd/build.py): the shipped library reads no environment variable except BD_RCCL_LIB (where
+// RCCL lives: deployment, not behaviour).  What is left process-global are the documented bd_*_set_* knobs of include/basedet_hip.h.
+#ifdef BD_TUNING
+#include <stdlib.h>
+static inline int bd_tune_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline const char* bd_tune_env_str(const char* name) { return getenv(name); }
+#else
+static inline int bd_tune_env(const char*, int dflt) { return dflt; }
+static inline const char* bd_tune_env_str(const char*) { return nullptr; }
+#endif
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

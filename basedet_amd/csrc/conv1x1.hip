@@ -885,15 +885,17 @@ int g_conv1x1_wide_min_k = 0;   // BD_DENSE1X1_WIDE_K: smallest CK that takes th
 void bd_conv1x1_ring_everywhere(bool on);         // conv1x1_ring.hip
 
 extern "C" int bd_conv_set_dense1x1(int depth) {
-    if (depth < 0 || depth > 5) {
-        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 5)", depth);
+    if (depth < 0 || depth > 6) {
+        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 6)", depth);
         return BD_EINVAL;
     }
     bd_conv1x1_ring_everywhere(depth == 5);          // 5 = as 1, with conv1x1_ring_kernel for every launch it can take (default: K <= 256 into >= 256 channels)
+    // 6 = conv1x1_dense_kernel only (as 3) with its LDS-DMA ring variant for every K that allows it (default: 512 <= K <= 1024): test coverage
+    g_conv1x1_dma_k = bd_tune_env("BD_DENSE1X1_DMA_K", depth == 6 ? 32 : 512);
     if (depth == 5) depth = 1;
+    if (depth == 6) depth = 3;
     g_conv1x1_depth = depth;
-    if (const char* e = getenv("BD_DENSE1X1_DMA_K")) g_conv1x1_dma_k = atoi(e);
-    if (const char* e = getenv("BD_DENSE1X1_WIDE_K")) g_conv1x1_wide_min_k = atoi(e);
+    g_conv1x1_wide_min_k = bd_tune_env("BD_DENSE1X1_WIDE_K", g_conv1x1_wide_min_k);
     return BD_OK;
 }
 
@@ -952,7 +954,7 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     // per workgroup, three workgroups per CU) is 3 - 11 % faster; shorter K (the epilogue is most of the tile) and the 16 800-pixel res5
     // layers (K = 2048: everything L2-resident, four workgroups per CU hide more) stay on the register-staged loop.  Measured per class
     // with scripts/micro_1x1_step.py; BD_DENSE1X1_DMA_K (read by bd_conv_set_dense1x1) moves the lower bound for A/B.
-    static const int early = getenv("BD_DENSE1X1_EARLY") ? atoi(getenv("BD_DENSE1X1_EARLY")) : 0;     // measurement: epilogue operands requested before the K loop
+    static const int early = bd_tune_env("BD_DENSE1X1_EARLY", 0);     // measurement: epilogue operands requested before the K loop
     const bool has_ops = (add && (flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER))) || ((flags & BD_EPI_MASK) && (mask || maskbits));
     if (CK % BK == 0 && CK >= g_conv1x1_dma_k && (CK <= 1024 || g_conv1x1_dma_k < 512)) {
         if (early && has_ops) hipLaunchKernelGGL((conv1x1_dense_kernel<1, 3, true, 2, 8, true>), dim3(grid), dim3(256), 6 * TILE_BYTES, stream, p);
@@ -967,7 +969,7 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     }
     // (round 4, measured and removed: all eight epilogue operands requested at once -- EBATCH = 8 at three waves per SIMD -- 5.44 ms over
     // the step's launches against 5.41: the epilogue is not short of requests in flight)
-    static const int reg_depth = getenv("BD_DENSE1X1_REGDEPTH") ? atoi(getenv("BD_DENSE1X1_REGDEPTH")) : 1;     // register sets in flight (measurement)
+    static const int reg_depth = bd_tune_env("BD_DENSE1X1_REGDEPTH", 1);     // register sets in flight (measurement)
     if (reg_depth == 2) hipLaunchKernelGGL((conv1x1_dense_kernel<2, 3, false>), dim3(grid), dim3(256), lds, stream, p);
     else if (reg_depth == 3) hipLaunchKernelGGL((conv1x1_dense_kernel<3, 3, false>), dim3(grid), dim3(256), lds, stream, p);
     else if (reg_depth == 4) hipLaunchKernelGGL((conv1x1_dense_kernel<4, 3, false>), dim3(grid), dim3(256), lds, stream, p);

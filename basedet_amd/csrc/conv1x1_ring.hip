@@ -503,7 +503,7 @@ void bd_conv1x1_ring_everywhere(bool on) { g_ring_everywhere = on; }          //
 int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits, void* y,
                            unsigned* ybits, void* y8, long long M, int CK, int CO, int flags, hipStream_t stream) {
     // BD_DENSE1X1_RING: 0 = every launch stays on conv1x1_dense_kernel (A/B), 2 = every legal launch comes here (also bd_conv_set_dense1x1(5))
-    static const int env_mode = getenv("BD_DENSE1X1_RING") ? atoi(getenv("BD_DENSE1X1_RING")) : 1;
+    static const int env_mode = bd_tune_env("BD_DENSE1X1_RING", 1);
     const int mode = g_ring_everywhere ? 2 : env_mode;
     if (!mode) return 1;
     // measured per launch class of the step (scripts/micro_1x1_step.py 5 3, profiles/r04_dense1x1_ring.txt): every launch over the 268 800
@@ -528,7 +528,7 @@ int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, cons
                     (((flags & BD_EPI_MASK) && maskbits) ? E_MASK : 0) | (ybits ? E_YBITS : 0);
     // (a four-wave shape, two workgroups per CU, measured no faster than conv1x1_dense_kernel either)
     // pixel rows resident over a pixel tile's channel tiles: K of exactly 2 or 4 steps and at least two channel tiles (BD_DENSE1X1_XRES=0: off, A/B)
-    static const int xres_on = getenv("BD_DENSE1X1_XRES") ? atoi(getenv("BD_DENSE1X1_XRES")) : 1;
+    static const int xres_on = bd_tune_env("BD_DENSE1X1_XRES", 1);
     const bool xres = xres_on && (CK == 128 || CK == 256) && p.n_tiles >= 2;
     // (Shape<8, 32> -- 32-channel K steps, 64 KB rings, TWO eight-wave workgroups per CU, four waves per SIMD -- passes the same tests and is
     // 10 % slower over the step's launches than the one-workgroup form, 3 % slower than conv1x1_dense_kernel: more waves do not help, the

@@ -449,9 +449,9 @@ int g_bk32_for_1x1 = 1;
 // instead of two) run them 10-35 % faster as long as the grid still fills the chip (P6's 70-tile forward keeps BK=64).
 // bd_conv_set_patch3x3 bit 10 clears it.
 int g_bk32_s2 = 1;
-// conv_igemm_wide.hip (round 5): 1 = the stride-2 3x3 launches whose grid fills the chip (default), 0 = never (bd_conv_set_patch3x3 bit 15),
-// 2 = every launch of this file that kernel can take (bit 16: tests / A-B; same bits as the generic kernel either way)
-int g_igemm_wide = 1;
+// conv_igemm_wide.hip (round 5 experiment, measured no faster than this file's kernel on the stride-2 3x3 layers -- DESIGN.md): 0 = never
+// (default), 2 = every launch of this file that kernel can take (bd_conv_set_patch3x3 bit 16: tests / A-B)
+int g_igemm_wide = 0;
 
 }  // namespace
 
@@ -487,7 +487,7 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_conv1x1_s2 = ((enable >> 12) & 1) ^ 1;
     g_pp_tail_split = ((enable >> 13) & 1) ^ 1;
     g_pp_persistent = ((enable >> 14) & 1) ^ 1;
-    g_igemm_wide = ((enable >> 15) & 1) ? 0 : (((enable >> 16) & 1) ? 2 : 1);
+    g_igemm_wide = ((enable >> 16) & 1) ? 2 : 0;
     return BD_OK;
 }
 

@@ -1,4 +1,12 @@
-// Implicit-GEMM convolution forward / data gradient, WIDE wave tile: the stride-2 3x3 family (res3.0 / res4.0 / res5.0 conv2, P6, P7).
+// Implicit-GEMM convolution forward / data gradient, WIDE wave tile -- a round-5 EXPERIMENT for the stride-2 3x3 family (res3.0 / res4.0 /
+// res5.0 conv2), opt-in (bd_conv_set_patch3x3 bit 16), NOT on the default path: on those layers it runs exactly as fast as conv_igemm.hip's
+// kernel, with either K order (forward 137 / 138 / 142 us against 140 / 126 / 123; data gradient 222 / 173 / 156 against 214 / 169 / 145:
+// profiles/r05_s2_micro.txt), and 20-35 % slower than conv1x1.hip on the dense 1x1 launches (profiles/r05_dense1x1_wide.txt).  What both
+// kernels share is what bounds them: ~96 KB of gathered operand bytes in flight per CU (LDS holds no more beside the tiles) over a loaded
+// fabric round trip of ~2.5 us, i.e. ~40 GB/s per CU, and a gather that fetches every input pixel 2.25 times (the nine taps of a stride-2
+// filter reach each pixel one, two, two or four times) with re-use distances of an L2's size.  Fewer LDS reads per MFMA (this tile) and
+// shorter re-use distances (this K order) move neither; staging each input pixel ONCE per K block (phase-major patches in LDS, as
+// conv3x3_pp.hip does for stride 1) would, and does not fit LDS beside a weight ring at a 256-pixel tile.
 //
 // Same GEMM and parameter block as conv_igemm.hip (32 channels per MFMA, fp32 accumulation; the K ORDER differs -- see `request` -- so the
 // results agree to fp32 summation order, not bit for bit), re-cut for what bounded that kernel on these layers (rounds 3-4: 0.197 /
@@ -271,11 +279,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_wide_kernel(const IgemmPara
 // else the stride-2 3x3 launches whose grid fills the chip.
 int bd_conv_igemm_wide_launch(IgemmParams p, bool everywhere, hipStream_t stream) {
     if (p.CK % WBK != 0 || p.CO % 8 != 0 || p.src_bytes == 0 || p.w_bytes == 0 || p.R * p.S > 32) return 1;
-    if (!everywhere && !(p.stride == 2 && p.R == 3 && p.S == 3)) return 1;
+    if (!everywhere) return 1;
     p.m_tiles = cdiv(p.M, WT_P); p.n_tiles = cdiv(p.CO, WT_C);
     const int grid = p.m_tiles * p.n_tiles;
-    // small grids (P6: 18 x 2 tiles, P7) leave most CUs idle with either tile; the generic kernel's smaller tile spreads them wider
-    if (!everywhere && grid < bd_num_cus()) return 1;
     BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     bd_note_kernel("conv_igemm_wide_kernel");

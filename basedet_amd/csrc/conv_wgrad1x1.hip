@@ -316,7 +316,7 @@ int bd_wgrad1x1_launch(const bd_conv_desc* d, const void* x, const void* g, floa
     p.ci_tiles = cdiv(d->Cin, tci); p.co_tiles = cdiv(d->Cout, tco);
     const int grid = splits * p.ci_tiles * p.co_tiles;
     const long long xb = (long long)d->N * d->in_pix_per_img * d->Cin * 2, gb = (long long)d->N * d->out_pix_per_img * d->Cout * 2;
-    static const bool env_ptr = getenv("BD_W1_PTR") != nullptr;
+    static const bool env_ptr = bd_tune_env_str("BD_W1_PTR") != nullptr;
     const bool buf = g_w1_buf && !env_ptr && xb < 0x7fffffffll && gb < 0x7fffffffll;
     p.x_bytes = buf ? (unsigned)xb : 0u; p.g_bytes = buf ? (unsigned)gb : 0u;
     if (tci == 128) { if (buf) launch_w1<128, 512, 32, true>(p, grid, stream); else launch_w1<128, 512, 32, false>(p, grid, stream); }

@@ -197,7 +197,7 @@ struct R1Plan { int tci, tco, fi, fj, ci_tiles, co_tiles, tiles, splits, total_s
 // bytes; the smaller tile wins until the re-reads of operand rows by the tiles of one split (served by that XCD's L2) outgrow it.
 // BD_WGRAD1R_TILE = "tci,tco" forces a tile (measurement).
 void ring1_tile(const bd_conv_desc* d, int& tci, int& tco, int& fi, int& fj) {
-    static const char* env = getenv("BD_WGRAD1R_TILE");
+    static const char* env = bd_tune_env_str("BD_WGRAD1R_TILE");
     int et = 0, eo = 0;
     if (env && sscanf(env, "%d,%d", &et, &eo) == 2) { tci = et; tco = eo; }
     else {
@@ -225,7 +225,7 @@ R1Plan ring1_plan(const bd_conv_desc* d) {
     pl.ci_tiles = cdiv(d->Cin, pl.tci);
     pl.co_tiles = cdiv(d->Cout, pl.tco);
     pl.tiles = pl.ci_tiles * pl.co_tiles;
-    static const int target_env = getenv("BD_WGRAD1R_TARGET") ? atoi(getenv("BD_WGRAD1R_TARGET")) : 0;      // workgroups per launch (measurement knob)
+    static const int target_env = bd_tune_env("BD_WGRAD1R_TARGET", 0);      // workgroups per launch (measurement knob)
     const int target = target_env > 0 ? target_env : bd_num_cus();
     int splits = target / pl.tiles;
     if (splits < 1) splits = 1;

@@ -354,7 +354,7 @@ int bd_wgrad3x3_splits(const bd_conv_desc* d, int* total_patches_out, int* patch
     for (int s = 0; s < d->nseg; ++s) ppi += cdiv(d->Ho[s], ph) * cdiv(d->Wo[s], PATCH);
     const int total = ppi * d->N;
     const int tiles = cdiv(d->Cin, TILE_CI) * cdiv(d->Cout, TILE_CO);
-    static const int target = getenv("BD_WGRAD3_TARGET") ? atoi(getenv("BD_WGRAD3_TARGET")) : 512;   // workgroups per launch (measurement knob)
+    static const int target = bd_tune_env("BD_WGRAD3_TARGET", 512);   // workgroups per launch (measurement knob)
     int splits = target / tiles;
     if (splits < 1) splits = 1;
     if (splits > total) splits = total;

@@ -378,7 +378,7 @@ RPlan ring_plan(const bd_conv_desc* d) {
     pl.ci_tiles = cdiv(d->Cin, RK_CI);
     pl.co_tiles = cdiv(d->Cout, RK_CO);
     pl.tiles = pl.ci_tiles * pl.co_tiles;
-    static const int target_env = getenv("BD_WGRAD3R_TARGET") ? atoi(getenv("BD_WGRAD3R_TARGET")) : 0;      // workgroups per launch (measurement knob)
+    static const int target_env = bd_tune_env("BD_WGRAD3R_TARGET", 0);      // workgroups per launch (measurement knob)
     const int target = target_env > 0 ? target_env : bd_num_cus();
     int splits = target / pl.tiles;
     if (splits < 1) splits = 1;

@@ -1558,7 +1558,7 @@ extern "C" int bd_roi_align_bwd(const void* gout, int64_t pix_per_img, int C, in
     if (R == 0) return BD_OK;
     RoiLevels lv{};
     BD_REQUIRE(fill_roi_levels(lv, L, lvl_pix_off_host, lvl_h_host, lvl_w_host, strides_host) == 0, "roi_align_bwd: strides must be powers of two");
-    static const int use_sep = getenv("BD_ROI_BWD_SEP") ? atoi(getenv("BD_ROI_BWD_SEP")) : 1;       // 0: the per-bin scatter (A/B)
+    static const int use_sep = bd_tune_env("BD_ROI_BWD_SEP", 1);       // 0: the per-bin scatter (A/B)
     if (use_sep && PH == 7 && PW == 7 && 7 * sample_points <= 64)      // the separable kernel builds its row / column tables with 7 * S threads each
         hipLaunchKernelGGL(roi_align_bwd_sep_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
                            C, lv, rois, labels, rois_per_img, sample_points, gfeat);

@@ -208,14 +208,15 @@ class FasterRCNN(FPNDetector):
                 rpn_targets()
         self.network_forward(pl)
         # ---- RPN: proposals (detached), targets, losses.
-        # Round 5 schedule.  Two chains leave the forward pass: (a) proposals -> RoI sampling -> RoIAlign -> box head -> its losses, and
-        # later its backward and RoIAlign's atomic scatter: small grids, latency- and atomic-bound; (b) RPN losses -> the RPN head's
-        # backward (two 3x3 / 1x1 data gradients over P2-P6 and their weight gradients: matrix-bound, ~2 ms).  Neither needs the other
-        # until dL/dP is summed.  Rounds 3-4 ran (a)'s proposal chain on the side stream and (b) on the main one and joined them BEFORE
-        # the RoI sampling: whatever of (b) the 2 ms proposal chain did not cover was exposed.  Now (b) runs on the side stream until the
-        # RoIAlign backward's sum into dL/dP (head_backward), under ALL of (a); the main stream only waits for the RPN loss values.
+        # Two chains leave the forward pass: (a) proposals -> RoI sampling -> RoIAlign -> box head -> its losses, and later its backward and
+        # RoIAlign's atomic scatter: small grids, latency- and atomic-bound; (b) RPN losses -> the RPN head's backward (two data gradients
+        # over P2-P6 and their weight gradients: matrix-bound, ~2 ms).  Default (rounds 3-5): (a)'s proposal chain on the side stream under
+        # (b) on the main one, joined before the RoI sampling.  MODEL.RPN_BWD_SIDE = 1 (round 5 experiment, measured and left off): (b) on
+        # the side stream until the RoIAlign backward's sum into dL/dP, under ALL of (a) -- 523-524 img/s against 545-547 on one box
+        # (profiles/r05_frcnn_ab.txt): the persistent one-workgroup-per-CU convolution kernels of (b) keep (a)'s many small grids waiting
+        # for a CU, and (a) is the critical path.
         side = self._tstream if (self.async_wgrad and self._tstream is not None) else None
-        rpn_side = side is not None and not self.deterministic_roi_bwd and bool(m.get("RPN_BWD_SIDE", True))
+        rpn_side = side is not None and not self.deterministic_roi_bwd and bool(m.get("RPN_BWD_SIDE", False))
         pl.loss_buf.zero_()
         pl.rpn_bwd_done = False
         pl.rpn_bwd_stream = None

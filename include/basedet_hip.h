@@ -111,7 +111,8 @@ int bd_conv2d_dgrad_ex(const bd_conv_desc* d, const void* g, const void* w_packe
 /* measurement knob: 1 (default) = the dense 1x1 kernels take every 1x1 / stride 1 launch over one dense level (conv1x1_ring.hip the
  * short-K launches into >= 256 channels, conv1x1.hip the rest), 0 = the generic kernel does (A/B; the *_bits / _ex entry points then
  * return BD_EINVAL); 2 = conv1x1.hip's 256 x 256 tile, 3 = its 128 x 128 tile only, 4 = its eight-wave 256-channel x 128-pixel tile
- * wherever legal, 5 = as 1 with conv1x1_ring.hip for every launch it can take (all A/B: same results bit for bit). */
+ * wherever legal, 5 = as 1 with conv1x1_ring.hip for every launch it can take, 6 = as 3 with the 128 x 128 tile's LDS-DMA ring variant for
+ * every K that allows it (default: 512 <= K <= 1024) (all A/B: same results bit for bit). */
 int bd_conv_set_dense1x1(int depth);
 
 /* dw[Cout][R][S][Cin] (fp32) = sum over pixels g^T x, times row_scale[Cout] (NULL = 1); split over pixels with
@@ -160,9 +161,10 @@ int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream);
  * 256-channel workgroups for r tiles; same bits);
  * bit 14 = one workgroup per tile in conv3x3_pp.hip instead of the persistent grid (by default one workgroup per CU walks up to 16 tiles
  * and requests the next tile's operands inside the current tile's last K block; same bits);
- * bit 15 = the stride-2 3x3 launches stay on the generic kernel instead of conv_igemm_wide.hip (round 5: 128-channel x 256-pixel
- * workgroup tile, 128 x 64 wave tiles, both operands by LDS-DMA; same bits as the generic kernel);
- * bit 16 = (set = ON) conv_igemm_wide.hip for EVERY launch of the generic path it can take (tests / A-B). */
+ * bit 15 = unused;
+ * bit 16 = (set = ON) conv_igemm_wide.hip (round 5 experiment: 128-channel x 256-pixel workgroup tile, 128 x 64 wave tiles, both operands
+ * by LDS-DMA, K-block pairs outermost) for EVERY launch of the generic path it can take (tests / A-B: measured no faster than the generic
+ * kernel on the stride-2 3x3 layers, which stay there). */
 int bd_conv_set_patch3x3(int enable);
 
 /* debug/measurement knob: 1 (default) = operand transposes through ds_read_b64_tr_b16, 0 = scalar 16-bit LDS reads

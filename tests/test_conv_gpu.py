@@ -39,10 +39,10 @@ CASES = [
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops = _ops()
-    # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel (incl. the stride-2 3x3: bit 15);
+    # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel;
     # 2: specialised kernels without any staggered instance (bits 6 + 9); 3: the staggered 128 / 64-channel instances everywhere (bits 6 + 8);
     # 4: no patch kernels, and conv_igemm_wide.hip for every launch of the generic path it can take (bit 16: 3x3 / stride 1 and 2, P6)
-    ops.L().bd_conv_set_patch3x3({0: 1 << 15, 1: 3, 2: 3 | 64 | 512, 3: 3 | 64 | 256, 4: 1 << 16}[patch3x3])
+    ops.L().bd_conv_set_patch3x3({0: 0, 1: 3, 2: 3 | 64 | 512, 3: 3 | 64 | 256, 4: 1 << 16}[patch3x3])
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -384,18 +384,14 @@ def test_wgrad_bias_multilevel(chans):
     assert rel_l2(db.cpu(), gy.sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("depth", [1, 0, 2, 3, 4, 101])
-def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
+@pytest.mark.parametrize("depth", [1, 0, 2, 3, 4, 6])
+def test_dense_1x1_kernel_and_mask_bits(depth):
     """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_set_dense1x1: 0 = the generic kernel,
     1 = the default choice, 2 = 256^2 wherever legal, 3 = 128^2 only, 4 = the eight-wave 256-channel x 128-pixel tile wherever legal): forward with
     residual + ReLU and the data gradient with accumulate + mask against torch-CPU fp32; the bit-packed ReLU mask written by the
     forward launch equals (y > 0) bit for bit, and a data gradient gated by it equals the one gated by the bf16 activation."""
     ops = _ops()
-    if depth == 101:          # the 128^2 tile's LDS-DMA ring variant for every K that allows it (default: CK >= 512 only)
-        monkeypatch.setenv("BD_DENSE1X1_DMA_K", "32")
-        depth = 1
-    else:
-        monkeypatch.setenv("BD_DENSE1X1_DMA_K", "512")
+    # 6: the 128^2 tile's LDS-DMA ring variant for every K that allows it (default: 512 <= K <= 1024 only)
     assert ops.L().bd_conv_set_dense1x1(depth) == 0
     try:
         for (N, Cin, Cout, H, W) in ((2, 256, 64, 23, 37), (1, 64, 256, 50, 41), (2, 200, 192, 9, 13), (1, 1024, 256, 20, 21), (1, 32, 544, 7, 9),
@@ -438,7 +434,7 @@ def test_dense_1x1_kernel_and_mask_bits(depth, monkeypatch):
                                  flags=ops.EPI_ADD_BEFORE)
                 assert torch.equal(dx, dx2)
                 # one-byte twins (e4m3 of the forward output, e5m2 of the data gradient): the same bytes from either tile
-                if depth in (2, 3, 4):
+                if depth in (2, 3, 4, 6):
                     tw = {}
                     for dd in (2, 3, 4):
                         ops.L().bd_conv_set_dense1x1(dd)
@@ -783,7 +779,7 @@ def test_conv_last_kernel_names_the_dispatched_kernel_for_the_bench_descriptors(
     assert r5["fwd"] in ("conv1x1_dense_kernel", "conv1x1_gemm_kernel") and r5["wgrad"] == "conv_wgrad1x1_ring_kernel", r5
     # the stride-2 3x3 of res3.0 and the stride-2 shortcut of res4.0
     s2 = run(g2, g3, 128, 128, 3, 2, 1, all3)
-    assert s2 == {"fwd": "conv_igemm_wide_kernel", "dgrad": "conv_igemm_wide_kernel", "wgrad": "conv_wgrad3x3_kernel"}, s2
+    assert s2 == {"fwd": "conv_igemm_kernel<32>", "dgrad": "conv_igemm_kernel<32>", "wgrad": "conv_wgrad3x3_kernel"}, s2
     sc = run(g3, g4, 512, 1024, 1, 2, 0, ("fwd", "wgrad"))
     assert sc == {"fwd": "conv1x1_dense_kernel", "wgrad": "conv_wgrad1x1_kernel"}, sc
     # narrow 3x3 (res2-sized conv2 of a trainable layer1 would be 64 -> 64): the 64-channel staggered tile
@@ -800,7 +796,7 @@ def test_conv_last_kernel_names_the_dispatched_kernel_for_the_bench_descriptors(
     (3, 96, 64, 9, 11, 5, 1, 2),         # 5x5 filter, 25 taps, three K blocks
 ])
 def test_igemm_wide_agrees_with_the_generic_kernel(case):
-    """conv_igemm_wide_kernel (round 5: 128 x 256 workgroup tile, 128 x 64 wave tiles, LDS-DMA ring) computes the generic kernel's GEMM with the
+    """conv_igemm_wide_kernel (round 5 experiment, opt-in: 128 x 256 workgroup tile, 128 x 64 wave tiles, LDS-DMA ring) computes the generic kernel's GEMM with the
     same MFMA and fp32 accumulation in ANOTHER K order (K-block pairs outermost, taps inside: L2 re-use): forward and data gradient --
     every epilogue -- agree with conv_igemm_kernel to fp32 summation order (a bf16 result may round the other way: rel-L2 <= 1e-3), two
     launches are bit-identical, and the torch reference holds within the bf16 tolerance (test_conv_fwd_dgrad_wgrad, knob 4)."""
@@ -817,7 +813,7 @@ def test_igemm_wide_agrees_with_the_generic_kernel(case):
     bias = torch.randn(Cout, generator=g).cuda()
     res, addt, maskt = bf(gout.pixels, Cout), bf(gin.pixels, Cin), bf(gin.pixels, Cin)
     outs = {}
-    for name, knob in (("generic", 1 << 15), ("wide", 1 << 16), ("wide2", 1 << 16)):
+    for name, knob in (("generic", 0), ("wide", 1 << 16), ("wide2", 1 << 16)):
         assert ops.L().bd_conv_set_patch3x3(knob) == 0
         y1 = torch.empty((gout.pixels, Cout), dtype=torch.bfloat16, device="cuda")
         y2 = torch.empty_like(y1)
