@@ -207,58 +207,36 @@ class FasterRCNN(FPNDetector):
             with torch.cuda.stream(early):
                 rpn_targets()
         self.network_forward(pl)
-        # ---- RPN: proposals (detached), targets, losses.
-        # Two chains leave the forward pass: (a) proposals -> RoI sampling -> RoIAlign -> box head -> its losses, and later its backward and
-        # RoIAlign's atomic scatter: small grids, latency- and atomic-bound; (b) RPN losses -> the RPN head's backward (two data gradients
-        # over P2-P6 and their weight gradients: matrix-bound, ~2 ms).  Default (rounds 3-5): (a)'s proposal chain on the side stream under
-        # (b) on the main one, joined before the RoI sampling.  MODEL.RPN_BWD_SIDE = 1 (round 5 experiment, measured and left off): (b) on
-        # the side stream until the RoIAlign backward's sum into dL/dP, under ALL of (a) -- 523-524 img/s against 545-547 on one box
-        # (profiles/r05_frcnn_ab.txt): the persistent one-workgroup-per-CU convolution kernels of (b) keep (a)'s many small grids waiting
-        # for a CU, and (a) is the critical path.
+        # ---- RPN: proposals (detached), targets, losses.  The proposal chain (decode, per-level top-k, NMS level by level + merge: small
+        # grids) runs on a side stream under the RPN losses and the RPN head's backward on the main one.
+        # (Round 5, measured and REMOVED: the other way round -- RPN losses + the RPN head's backward on the side stream until the RoIAlign
+        # backward's sum into dL/dP, under the whole proposal / box-head chain: 523-524 img/s against 545-547 on one box,
+        # profiles/r05_frcnn_ab.txt -- the persistent one-workgroup-per-CU convolution kernels keep the box chain's many small grids
+        # waiting for a CU, and the box chain is the critical path; that schedule also failed the bench-batch parity test once.)
         side = self._tstream if (self.async_wgrad and self._tstream is not None) else None
-        rpn_side = side is not None and not self.deterministic_roi_bwd and bool(m.get("RPN_BWD_SIDE", False))
-        pl.loss_buf.zero_()
-        pl.rpn_bwd_done = False
-        pl.rpn_bwd_stream = None
-
-        def rpn_losses():
-            ops.rpn_loss_fwd_bwd(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.rpn_labels, pl.rpn_offsets, pl.pyr.pixels,
-                                 m.LOSSES.RPN_SMOOTH_L1_BETA, pl.rpn_num_valid, pl.loss_buf[0:2], pl.d_rpn_raw)
-
-        if early is None:
-            rpn_targets()
-        loss_ready = None
-        if rpn_side:
-            side.wait_stream(torch.cuda.current_stream())          # the forward pass, the cleared loss buffer
-            if early is not None:
-                side.wait_stream(early)                            # the RPN targets
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                rpn_losses()
-                loss_ready = torch.cuda.Event()
-                loss_ready.record(side)
-                self._flush_wgrads()      # (partial sums left by a get_losses() that was never followed by backward(): reduce them now, free the arena)
-                self._rpn_head_backward(pl, pl.wgrad_ws, pl.colsum_ws, first=True)        # the FIRST contribution to dL/dP
-            pl.rpn_bwd_done = True
-            pl.rpn_bwd_stream = side
-            if early is not None:
-                torch.cuda.current_stream().wait_stream(early)     # (long done: the cleared fp32 pyramid is this stream's to scatter into)
-            self._proposals(pl, info)
-        else:
-            if side is not None:          # rounds 3-4: the proposal chain on the side stream under the RPN losses (and the RPN head's backward)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    self._proposals(pl, info)
-            else:
                 self._proposals(pl, info)
-            if early is not None:
-                torch.cuda.current_stream().wait_stream(early)
-            rpn_losses()
-            if side is not None and not self.deterministic_roi_bwd:
-                self._flush_wgrads()
-                self._rpn_head_backward(pl, pl.wgrad_ws, pl.colsum_ws, first=True)
-                pl.rpn_bwd_done = True
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)
+        else:
+            self._proposals(pl, info)
+        if early is not None:
+            torch.cuda.current_stream().wait_stream(early)
+        else:
+            rpn_targets()
+        pl.loss_buf.zero_()
+        ops.rpn_loss_fwd_bwd(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.rpn_labels, pl.rpn_offsets, pl.pyr.pixels,
+                             m.LOSSES.RPN_SMOOTH_L1_BETA, pl.rpn_num_valid, pl.loss_buf[0:2], pl.d_rpn_raw)
+        pl.rpn_bwd_done = False
+        if side is not None and not self.deterministic_roi_bwd:
+            # the RPN head's backward needs nothing from the proposal chain: it runs now, under it, and leaves the FIRST contribution
+            # to dL/dP; the RoIAlign backward joins it later (head_backward: the fp32 pyramid through an accumulating conversion,
+            # the packed atomics directly on top)
+            self._flush_wgrads()          # (partial sums left by a get_losses() that was never followed by backward(): reduce them now, free the arena)
+            self._rpn_head_backward(pl, pl.wgrad_ws, pl.colsum_ws, first=True)
+            pl.rpn_bwd_done = True
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         # ---- RCNN: sampling, RoIAlign, box head, losses
         S = m.RCNN.NUM_ROIS
         key_ld = pl.rois.shape[1] + Gmax
@@ -269,8 +247,6 @@ class FasterRCNN(FPNDetector):
         self._box_head(pl)
         ops.rcnn_loss_fwd_bwd(pl.rcnn_raw, self.rcnn_ld, self.num_classes, self.num_classes + 1, pl.s_labels, pl.s_targets, pl.R,
                               m.LOSSES.RCNN_SMOOTH_L1_BETA, pl.s_total, pl.loss_buf[2:4], pl.d_rcnn_raw)
-        if loss_ready is not None:
-            torch.cuda.current_stream().wait_event(loss_ready)     # the RPN loss VALUES (its backward keeps running on the side stream)
         lb = pl.loss_buf
         return {"total_loss": lb[0] + lb[1] + lb[2] + lb[3], "rpn_cls_loss": lb[0], "rpn_reg_loss": lb[1],
                 "rcnn_cls_loss": lb[2], "rcnn_reg_loss": lb[3]}
@@ -296,19 +272,11 @@ class FasterRCNN(FPNDetector):
         self.fc2.dgrad(pl.g_fc2, g, g, pl.g_fc1, mask=pl.fc1_out)
         self._wgrad(self.fc1, pl.pooled, pl.g_fc1, g, g, ws, cws)
         self.fc1.dgrad(pl.g_fc1, g, g, pl.g_pooled)
-        def join_rpn():
-            """The RPN head's backward (on the side stream since get_losses) wrote the first contribution to dL/dP: wait for it HERE, in
-            front of the first launch that touches dL/dP -- the fp32 scatter below does not, and runs beside it."""
-            if getattr(pl, "rpn_bwd_stream", None) is not None:
-                torch.cuda.current_stream().wait_stream(pl.rpn_bwd_stream)
-                pl.rpn_bwd_stream = None
         # first contribution to dL/dP: every pyramid level is written (zeros where no RoI sample lands, all of P6)
         if self.deterministic_roi_bwd:      # gather kernel: fixed summation order, ~2x slower than the atomic scatter (DESIGN.md)
-            join_rpn()
             ops.roi_align_bwd_bf16(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4),
                                    pl.s_labels.view(-1), S, self.pool, 2, pl.g_P, pl.roi_bwd_ws)
         elif self.roi_bwd_pk:
-            join_rpn()
             if not pl.rpn_bwd_done:
                 pl.g_P.zero_()
             ops.roi_align_bwd_pk(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
@@ -319,7 +287,6 @@ class FasterRCNN(FPNDetector):
             pl.g_feat32_clean = False
             ops.roi_align_bwd(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
                               self.pool, 2, pl.g_feat32)
-            join_rpn()
             ops.f32_to_bf16(pl.g_feat32, pl.g_P, accumulate=pl.rpn_bwd_done)
         # RPN head (unless get_losses already ran it under the proposal chain)
         if not pl.rpn_bwd_done:

@@ -216,6 +216,9 @@ class KernelTimer:
         wrap_stream("bottleneck_fwd", "bottleneck_fused_kernel",
                     lambda k: k["N"] * k["H"] * k["W"] * (k["cin"] + k["cout"]) * 2.0
                     + 2.0 * (k["cin"] * k["cmid"] + 9 * k["cmid"] * k["cmid"] + k["cmid"] * k["cout"] + (k["cin"] * k["cout"] if k["wd"] is not None else 0)))
+        # GroupNorm + ReLU of the FCOS towers (bd_groupnorm_fwd: statistics + apply; _bwd: sums + apply; every operand once: y, z / dz, y, dy)
+        wrap_stream("groupnorm_fwd", "gn_stats + gn_apply (bd_groupnorm_fwd)", lambda k: k["y"].numel() * 2.0 * 2)
+        wrap_stream("groupnorm_bwd", "gn_bwd_partial + gn_bwd_apply (bd_groupnorm_bwd)", lambda k: k["y"].numel() * 2.0 * 3)
         wrap_stream("pad_normalize", "pad_normalize_kernel",
                     lambda k: k["x"].numel() * 4.0 + k["x"].shape[0] * (k["Hp"] + 6) * (k["Wp"] + 8) * 8.0)
 

@@ -27,7 +27,7 @@ done
 for w in fcos_r50_800x1344 faster_rcnn_r50_800x1344 atss_r50_800x1344 ota_r50_800x1344 freeanchor_r50_800x1344 retinanet_r101_800x1344; do
   python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 done
-for a in "--model-opt RPN_BWD_SIDE=0" "--model-opt RPN_TARGETS_EARLY=0" "--model-opt RPN_BWD_SIDE=0 --model-opt RPN_TARGETS_EARLY=0" ""; do
+for a in "--model-opt RPN_TARGETS_EARLY=0" ""; do
   python3 bench.py --workload faster_rcnn_r50_800x1344 $a --steps 30 --warmup 8 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('faster_rcnn_r50 $a', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 done
 python3 bench.py --workload retinanet_r101_800x1344 --fp8 --steps 20 --warmup 5 --no-cpu-baseline --ref-protocol-steps 0 > $O/r05_bench_r101_fp8.json 2>/dev/null

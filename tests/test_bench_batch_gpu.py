@@ -188,10 +188,6 @@ def test_faster_rcnn_bench_batch_equals_tiled_batch2():
             return FasterRCNN(cfg, params=params)
         return f
     outs = ("rpn_labels", "rois", "num_rois", "s_labels", "s_rois", "s_targets")
-    import os
-    if os.environ.get("BD_TEST_NMS_PER_LEVEL") is not None:          # (bisecting aid: the joint form of the proposals' NMS)
-        from basedet_amd import ops
-        ops.L().bd_rpn_set_nms_per_level(int(os.environ["BD_TEST_NMS_PER_LEVEL"]))
     small, g2, _, l2 = _run(make(2), batch2, outs)
     big, gB, _, lB = _run(make(B), _tile(batch2, B), outs)
     assert big["rpn_labels"].shape == (B, A_total)
