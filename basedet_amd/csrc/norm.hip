@@ -115,10 +115,12 @@ __device__ __forceinline__ int level_of(const GnLevels& lv, int p) {
 }
 
 // z = relu((y - mean) * rstd * gamma + beta); thread per (pixel, group)
+// rev: walk the tensor from its END (the statistics pass before it walked from the start: its last ~100 MB are still in the Infinity Cache)
 __global__ void gn_apply_kernel(const bf16_raw* __restrict__ y, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, GnLevels lv, int N, int ppi, int relu, bf16_raw* __restrict__ z) {
+                                const float* __restrict__ beta, GnLevels lv, int N, int ppi, int relu, int rev, bf16_raw* __restrict__ z) {
     const long long total = (long long)N * ppi * 32;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = rev ? total - 1 - i0 : i0;
         const int g = (int)(i & 31);
         const long long pix = i >> 5;
         const int n = (int)(pix / ppi), p = (int)(pix - (long long)n * ppi);
@@ -255,9 +257,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_final_c_kernel(const float* __res
 // dy = rstd * (dzm*gamma - B - xhat*A)
 __global__ void gn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y, const float* __restrict__ stats,
                                     const float* __restrict__ ab, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    GnLevels lv, int N, int ppi, int relu, bf16_raw* __restrict__ dy) {
+                                    GnLevels lv, int N, int ppi, int relu, int rev, bf16_raw* __restrict__ dy) {
     const long long total = (long long)N * ppi * 32;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = rev ? total - 1 - i0 : i0;
         const int g = (int)(i & 31);
         const long long pix = i >> 5;
         const int n = (int)(pix / ppi), p = (int)(pix - (long long)n * ppi);
@@ -377,8 +380,7 @@ int g_gn_chunk_fwd = 0, g_gn_chunk_bwd = 0;
 }  // namespace
 
 extern "C" int bd_groupnorm_set_chunks(int fwd_images, int bwd_images) {
-    BD_REQUIRE(fwd_images >= 0 && bwd_images >= 0, "bd_groupnorm_set_chunks: negative chunk");
-    g_gn_chunk_fwd = fwd_images; g_gn_chunk_bwd = bwd_images;
+    g_gn_chunk_fwd = fwd_images; g_gn_chunk_bwd = bwd_images;       // < 0: the whole batch at once, the apply pass walking it from the END
     return BD_OK;
 }
 
@@ -399,6 +401,7 @@ extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* 
     const int S = lv.slot0[L];
     hipStream_t st = (hipStream_t)stream;
     const int step = g_gn_chunk_fwd > 0 ? g_gn_chunk_fwd : N;
+    const int rev = g_gn_chunk_fwd < 0;
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nc = n0 + step <= N ? step : N - n0;
         const bf16_raw* yc = (const bf16_raw*)y + (long long)n0 * pix_per_img * C;
@@ -408,7 +411,7 @@ extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* 
         hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, nc), dim3(256), 0, st, yc, lv, (int)pix_per_img, C, part);
         hipLaunchKernelGGL(gn_stats_final_kernel, dim3(L, nc), dim3(256), 0, st, (const float*)part, lv, C / 32, eps, stc);
         hipLaunchKernelGGL(gn_apply_kernel, dim3(egrid((long long)nc * pix_per_img * 32)), dim3(256), 0, st, yc, (const float*)stc, gamma, beta,
-                           lv, nc, (int)pix_per_img, relu, zc);
+                           lv, nc, (int)pix_per_img, relu, rev, zc);
     }
     BD_CHECK_LAUNCH("bd_groupnorm_fwd");
     return BD_OK;
@@ -428,6 +431,7 @@ extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamm
     float* pc = pg + (size_t)N * S * 32 * 2;
     float* ab = pc + (size_t)N * S * C * 2;
     const int step = g_gn_chunk_bwd > 0 ? g_gn_chunk_bwd : N;
+    const int rev = g_gn_chunk_bwd < 0;
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nc = n0 + step <= N ? step : N - n0;
         const long long eo = (long long)n0 * pix_per_img * C;
@@ -439,7 +443,7 @@ extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamm
                            pg + (size_t)n0 * S * 64, pc + (size_t)n0 * S * C * 2);
         hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(L, nc), dim3(256), 0, st, (const float*)(pg + (size_t)n0 * S * 64), lv, C / 32, abc);
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(egrid((long long)nc * pix_per_img * 32)), dim3(256), 0, st, dzc, yc, stc, (const float*)abc,
-                           gamma, beta, lv, nc, (int)pix_per_img, relu, (bf16_raw*)dy + eo);
+                           gamma, beta, lv, nc, (int)pix_per_img, relu, rev, (bf16_raw*)dy + eo);
     }
     // dgamma / dbeta over every (image, slot) of the batch, in slot order: independent of the chunking
     hipLaunchKernelGGL(gn_bwd_final_c_kernel, dim3(cdiv(C, 8)), dim3(1024), 0, st, (const float*)pc, N * S, C, dgamma, dbeta, accumulate);

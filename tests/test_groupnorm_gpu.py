@@ -52,7 +52,7 @@ def test_groupnorm_fwd_bwd_matches_torch_and_is_chunk_independent(N, sizes):
     ws = torch.empty((ops.groupnorm_workspace_bytes(N, geom.nlev, C, geom.pix_per_img) // 4 + 16,), dtype=torch.float32, device="cuda")
     outs = []
     try:
-        for chunks in ((0, 0), (8, 4), (1, 1), (2, 5)):
+        for chunks in ((0, 0), (8, 4), (1, 1), (2, 5), (-1, -1)):
             assert ops.L().bd_groupnorm_set_chunks(*chunks) == 0
             stats = torch.empty((N, geom.nlev, 32, 2), dtype=torch.float32, device="cuda")
             z = torch.empty_like(yd)
