@@ -73,10 +73,13 @@ class FPNDetector:
         # weight-gradient kernels run on a side stream, concurrently with the dgrad chain they do not feed: tails and
         # barrier bubbles of one kernel are filled by the other (set False to serialise, e.g. for per-kernel timing)
         self.async_wgrad = True
-        # WGRAD_QUEUE: "bucket" (default) = the weight-gradient reduces of a gradient bucket (head / fpn / layer4 / layer3 / layer2) in ONE
-        # launch (bd_wgrad_queue_*: 5 reduce launches per step instead of 60); an integer = additionally flush whenever that many bytes of
-        # partial sums are pending; "layer" = one reduce per layer right behind its kernel (rounds 1-3)
-        self.wgrad_queue_mode = m.get("WGRAD_QUEUE", "bucket")
+        # WGRAD_QUEUE: "layer" (default again since round 5) = one fixed-order reduce per layer right behind its partial-sum kernel: the slabs
+        # are still in the Infinity Cache when they are read back; "bucket" (round 4's default) = the reduces of a gradient bucket (head /
+        # fpn / layer4 / layer3 / layer2) in ONE launch (bd_wgrad_queue_*: 5 reduce launches per step instead of 60); an integer =
+        # additionally flush whenever that many bytes of partial sums are pending.  Same bits in every mode (tests/test_wgrad_queue_gpu.py).
+        # Measured, alternating on one box (profiles/r05_workloads.txt, r05_queue_ab.txt; round 4 had read the same sign and called it
+        # neutral): layer 635.8 / 637.0 / 636.3 img/s, bucket 632.0 / 630.9 / 635.1 -- and 647.4 / 643.7 against 643.2 / 639.5 on two other boxes.
+        self.wgrad_queue_mode = m.get("WGRAD_QUEUE", "layer")
         self._wq = None
         self._wq_need = {}                  # (layer name, full geometry) -> workspace bytes
         # ONE partial-sum arena per model, as large as the largest flush interval (gradient bucket) seen so far: a flush's reduce and

@@ -1,5 +1,6 @@
-"""The DEFAULT weight-gradient path of a training step: partial sums of a whole gradient bucket queued in one arena, ONE fixed-order
-reduce per bucket (WGRAD_QUEUE = "bucket", models/fpn_base.py).  The first backward pass of a model runs un-queued (it sizes the arena),
+"""The QUEUED weight-gradient path of a training step (round 4's default; round 5: opt-in, WGRAD_QUEUE = "bucket" or a byte threshold --
+"layer" measured 0.6 % faster): partial sums of a whole gradient bucket queued in one arena, ONE fixed-order reduce per bucket
+(models/fpn_base.py).  The first backward pass of a model runs un-queued (it sizes the arena),
 so a test that builds a model and calls backward() once never reaches the queued path: here every model runs forward + backward TWICE
 and a third time after a forced overflow, against WGRAD_QUEUE = "layer" (one reduce per layer, rounds 1-3) and an integer byte
 threshold -- every gradient of the parameter arena bit for bit (replaces autodiff: basedet/solver/default_solver.py:118-124)."""
