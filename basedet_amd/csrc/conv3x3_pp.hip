@@ -317,6 +317,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     // slot is tap 8's -- is requested at the head of the epilogue): phase (0, 1) awaits nothing, and the first counted wait, in phase (1, 1),
     // comes ~3 500 cycles after the epilogue's stores.  Loads and stores share one vmcnt: a counted wait for a load that is younger than the
     // stores waits for the stores' acknowledgements too, with the matrix pipe idle.
+#if defined(BD_PP_PRIO) && BD_PP_PRIO == 1
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);      // (MI355X_MICROARCH.md, two waves per SIMD, item 4: static priority for the younger half)
+#endif
     for (;;) {
     const int pt_next = pt + pt_step;
     const bool more = pt_next < p.px_tiles;
@@ -383,9 +386,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 // ---------------- MFMA segment ----------------
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PP_FENCE();
+                // (no s_setprio around the MFMA segment since round 5.  Rounds 2-4 raised the priority here and dropped it behind the
+                // segment; alternating on one box, three repetitions: those flips 648.0 / 645.1 / 641.9 img/s, one static priority for
+                // waves 4-7 649.1 / 647.7 / 647.0, none 649.5 / 649.2 / 647.6 -- profiles/r05_prio.txt; -DBD_PP_PRIO=0 brings the flips back)
+#if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(1);
+#endif
                 mfma_khalf();
+#if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(0);
+#endif
                 PP_FENCE();
                 PP_BARRIER();
                 PP_FENCE();

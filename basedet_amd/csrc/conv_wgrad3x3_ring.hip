@@ -287,6 +287,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
 #define RK_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define RK_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+#if defined(BD_PP_PRIO) && BD_PP_PRIO == 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     if (nsteps > 0) {
         seek(pbeg);
 #pragma unroll 1
@@ -333,9 +336,16 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
                 // ---------------- MFMA segment ----------------
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 RK_FENCE();
+                // (no s_setprio around the MFMA segment since round 5.  Rounds 2-4 raised the priority here and dropped it behind the
+                // segment; alternating on one box, three repetitions: those flips 648.0 / 645.1 / 641.9 img/s, one static priority for
+                // waves 4-7 649.1 / 647.7 / 647.0, none 649.5 / 649.2 / 647.6 -- profiles/r05_prio.txt; -DBD_PP_PRIO=0 brings the flips back)
+#if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(1);
+#endif
                 mfma_half();
+#if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(0);
+#endif
                 RK_FENCE();
                 RK_T(2);
                 RK_BARRIER();
