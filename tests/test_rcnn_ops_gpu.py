@@ -125,20 +125,25 @@ def _anchors(sizes):
     return ob.default_anchors(sizes, STRIDES, scales, ratios, 0.5)
 
 
-@pytest.mark.parametrize("pre_k,post_k,per_level", [(500, 300, 1), (500, 300, 0), (2000, 1000, 1), (2000, 120, 1)])
-def test_rpn_proposals(pre_k, post_k, per_level):
+@pytest.mark.parametrize("pre_k,post_k,per_level,ties", [(500, 300, 1, 0), (500, 300, 0, 0), (2000, 1000, 1, 0), (2000, 120, 1, 0),
+                                                         (2000, 1000, 1, 1), (700, 64, 1, 1)])
+def test_rpn_proposals(pre_k, post_k, per_level, ties):
     """per_level = 1 (round 5, default): the batched NMS level by level + a merge into the joint order; 0: one problem per image (rounds
     1-4).  Both against the oracle's joint batched_nms; (2000, 1000): the configured sizes (every level of this pyramid below pre_k keeps
-    all its anchors); (2000, 120): the per-level cap and the merge cut the lists."""
+    all its anchors); (2000, 120): the per-level cap and the merge cut the lists; ties = 1: five images whose scores take 17 distinct
+    values only -- the merge's tie rule (lower level first, then candidate index) decides most of the joint order."""
     ops = _ops()
     rng = np.random.default_rng(2)
-    N, A, ldc = 2, 3, 16
+    N, A, ldc = (5 if ties else 2), 3, 16
     sizes = [(48, 80), (24, 40), (12, 20), (6, 10), (3, 5)]
     H, W = 192, 320
     raw, raw_dev, ppi = _pyramid_inputs(rng, N, sizes, A, ldc)
+    if ties:
+        raw[:, :, :A] = np.round(raw[:, :, :A] * 2) / 2          # multiples of 0.5 in about [-4, 4]: exact in bf16
+        raw_dev = _bf16(raw).cuda().reshape(N * ppi, ldc).contiguous()
     anchors = _anchors(sizes)
     anc_all = np.concatenate(anchors, 0)
-    im_info = np.array([[H, W, H, W, 3], [180, 300, 180, 300, 2]], np.float32)
+    im_info = np.array([[H, W, H, W, 3], [180, 300, 180, 300, 2]] + [[H, W, H, W, 1]] * (N - 2), np.float32)
     thr = 0.7
     geom = _geom(N, sizes)
     rois = torch.empty((N, post_k, 4), dtype=torch.float32, device="cuda")
