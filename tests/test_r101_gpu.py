@@ -98,6 +98,9 @@ def test_retinanet_r101_bf16_full_size_matches_oracle(r101):
                           "RetinaNet-R101 2x800x1344", bound=3e-2)
 
 
+_FP8_COS = {}          # results of the parametrised runs below, in order: (True, 2) is compared with (True, 0)
+
+
 @pytest.mark.parametrize("dgrad,wgrad", [(False, 0), (True, 0), (True, 2)])
 def test_retinanet_r101_fp8_full_size_tolerance(r101, dgrad, wgrad):
     """WEIGHT_DTYPE = fp8_e4m3 on R101: forward only (dgrad False), with e5m2 data gradients under per-group delayed scales, and with the
@@ -130,11 +133,19 @@ def test_retinanet_r101_fp8_full_size_tolerance(r101, dgrad, wgrad):
     assert bool(torch.isfinite(a).all())
     cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
     print(f"R101 gradient cosine fp8 (dgrad={dgrad}, wgrad={wgrad}) vs bf16: {cos:.5f}")
-    assert cos >= 0.98, cos
+    # floors with real margin (observed 0.9814-0.9818 with e5m2 data gradients), and the one-byte weight gradients are
+    # judged AGAINST the same run without them: what they may cost is a delta, not a coincidence with an absolute number
+    assert cos >= 0.975, cos
+    _FP8_COS[(dgrad, wgrad)] = cos
+    if wgrad and (dgrad, 0) in _FP8_COS:
+        assert cos >= _FP8_COS[(dgrad, 0)] - 0.003, (cos, _FP8_COS[(dgrad, 0)])          # observed: -0.0004
     # ... and layer by layer over the 3x3 weights (what the one-byte weight-gradient kernel produces when wgrad is on): a two-image batch at
     # the pre-probe scales; the lowest layer is a thin backbone conv2 or, with fp8 weight gradients, the deepest conv of the classification tower
     worst = min((float(torch.dot(g8[n].double().reshape(-1), b16["grads"][n].double().reshape(-1)) /
                        (g8[n].double().norm() * b16["grads"][n].double().norm())), n)
                 for n in names if n.endswith(".weight") and g8[n].dim() == 4 and g8[n].shape[-1] == 3)
     print(f"worst 3x3 weight-gradient cosine (dgrad={dgrad}, wgrad={wgrad}):", worst)
-    assert worst[0] >= 0.85, worst            # observed: 0.910 forward only (layer2.0.conv2), 0.895 with e5m2 data gradients, 0.869 with fp8 weight gradients
+    assert worst[0] >= 0.84, worst            # observed: 0.910 forward only (layer2.0.conv2), 0.895 with e5m2 data gradients, 0.869 with fp8 weight gradients
+    _FP8_COS[("worst", dgrad, wgrad)] = worst[0]
+    if wgrad and ("worst", dgrad, 0) in _FP8_COS:
+        assert worst[0] >= _FP8_COS[("worst", dgrad, 0)] - 0.05, (worst, _FP8_COS[("worst", dgrad, 0)])      # observed: -0.026
