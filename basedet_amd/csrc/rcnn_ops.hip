@@ -47,6 +47,12 @@ __global__ __launch_bounds__(1024) void segment_topk_kernel(const void* __restri
         return f32_asc_key(v);
     };
     const SelResult r = radix_select_largest(cnt, k, BF16 ? 2 : 4, key, hist, sh);
+    // bf16 scores: two radix passes fix the upper 16 key bits, and r.T carries zeros below them -- but the key of a NEGATIVE bf16 has 0xffff
+    // there (f32_asc_key complements negative values).  Rounds 1-4 compared whole keys with r.T: every item of a negative threshold bin then
+    // counted as "above" it, none as a tie.  With few ties that only over-filled `keys` by the surplus (still sorted and cut correctly);
+    // with many (found by round 5's tie-heavy proposal test: 17 distinct scores) the surplus ran over the slots of the later ties and past
+    // the array.  The threshold tests use the selected bits only.
+    const unsigned int sel_mask = BF16 ? 0xffff0000u : 0xffffffffu;
     for (int i = tid; i < TOPK_MAX; i += 1024) keys[i] = 0ull;
     if (tid == 0) sh[4] = 0;
     __syncthreads();
@@ -56,9 +62,9 @@ __global__ __launch_bounds__(1024) void segment_topk_kernel(const void* __restri
     for (int i = tid; i < cnt; i += 1024) {
         bool valid;
         const unsigned int kv = key(i, valid);
-        if (valid && (r.take_all || kv > r.T)) {
+        if (valid && (r.take_all || (kv & sel_mask) > r.T)) {
             const int p = atomicAdd(&sh[4], 1);
-            keys[p] = ((unsigned long long)kv << 32) | (0xffffffffu - (unsigned int)i);
+            if (p < TOPK_MAX) keys[p] = ((unsigned long long)kv << 32) | (0xffffffffu - (unsigned int)i);
         }
     }
     // ties at the threshold: lowest indices first
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(1024) void segment_topk_kernel(const void* __restri
             bool valid = false;
             unsigned int kv = 0;
             if (i < cnt) kv = key(i, valid);
-            const bool eq = valid && kv == r.T;
+            const bool eq = valid && (kv & sel_mask) == r.T;
             int tot;
             const int my = eq_base + block_rank_1024(eq, wcnt, tot);
             if (eq && my < r.need_eq) keys[n_gt + my] = ((unsigned long long)kv << 32) | (0xffffffffu - (unsigned int)i);
