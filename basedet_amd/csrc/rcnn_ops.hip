@@ -1046,200 +1046,242 @@ __global__ __launch_bounds__(256) void roi_align_bwd_sep_kernel(const bf16_raw* 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// deterministic RoIAlign backward: RoIs are binned into 4x8-pixel tiles of their pyramid level (count -> scan -> fill), then one
-// wave per (image, tile, 64-channel slice) gathers the contributions of the RoI samples whose bilinear footprint touches the
-// tile.  One lane per channel owns a private column of the LDS accumulator, so there are no float atomics and the summation
-// order is fixed (the tile's RoI list is sorted by slot).  The result is written as bf16 straight into the feature-gradient
-// pyramid (every level; zeros where no RoI lands).
+// deterministic RoIAlign backward (round 5: the training step's default).  The gradient pyramid is cut into 8x8-pixel tiles; every tile
+// gets the list of the RoIs whose sample footprint touches it, IN SLOT ORDER (one thread per tile walks its image's <= 512 footprints:
+// count, scan, fill -- no atomics anywhere), and one wave per (tile, 128-channel slice) sums the tile in registers:
+//     dF[y][x] += sum_ph A[y][ph] * (sum_pw B[x][pw] * g[ph][pw])          (the separable form of roi_align_bwd_sep_kernel above)
+// with A (8 rows x 7 bins) and B (8 columns x 7 bins) restricted to the tile, two channels per lane as packed fp32 pairs, the 49 pooled
+// gradients of the next RoI requested under the arithmetic of the current one.  The result is written ONCE as bf16 -- optionally added to
+// what the buffer holds (the RPN head's dL/dP): no fp32 pyramid to clear, no float atomics, no conversion pass, fixed summation order.
+// Tiles no RoI touches cost a list lookup (accumulate) or a zero fill.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int RTY = 4, RTX = 8;          // pixel tile of one workgroup
-constexpr int ROI_LIST_MAX = 512;        // RoIs per tile the gather kernel can hold in LDS (= RoI slots per image)
-constexpr int ROI_BINS_MAX = 64;         // PH * PW <= 64
-constexpr int ROI_TILES_MAX = 96;        // tile-list entries reserved per RoI
-struct PyrTiles { int pix_off[BD_MAX_SEGS]; int H[BD_MAX_SEGS]; int W[BD_MAX_SEGS]; int tile_start[BD_MAX_SEGS + 1]; int tiles_x[BD_MAX_SEGS]; int tiles_y[BD_MAX_SEGS]; int L; };
+constexpr int RT = 8;                    // tile side
+constexpr int ROI_LIST_MAX = 512;        // RoI slots per image (the footprints of an image sit in LDS)
+constexpr int ROI_TILES_MAX = 96;        // tile-list entries reserved per RoI slot (an elongated 336 x 2 footprint on P2: 43 x 2 tiles)
+struct PyrTiles { int pix_off[BD_MAX_SEGS]; int H[BD_MAX_SEGS]; int W[BD_MAX_SEGS]; int tile_start[BD_MAX_SEGS + 1]; int tiles_x[BD_MAX_SEGS]; int L; };
 
-struct RoiFoot { int l, tx0, tx1, ty0, ty1; };
-// conservative tile range of the sample footprint of one RoI on its level (samples clamp into the map: clamp the range as well)
-__device__ __forceinline__ RoiFoot roi_footprint(const Box& b, const RoiLevels& lv, const PyrTiles& pt) {
-    RoiFoot f;
-    f.l = roi_level(b, lv);
-    const float sc = lv.scale[f.l];
-    const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
-    const float ew = b.x2 * sc - 0.5f, eh = b.y2 * sc - 0.5f;
-    float fx0 = fminf(sw, ew) - 1.f, fx1 = fmaxf(sw, ew) + 1.f, fy0 = fminf(sh_, eh) - 1.f, fy1 = fmaxf(sh_, eh) + 1.f;
-    const float W = (float)pt.W[f.l], H = (float)pt.H[f.l];
-    if (!(fx0 == fx0 && fx1 == fx1 && fy0 == fy0 && fy1 == fy1)) { fx0 = 0.f; fx1 = W; fy0 = 0.f; fy1 = H; }
-    fx0 = fminf(fmaxf(fx0, 0.f), W - 1.f); fx1 = fminf(fmaxf(fx1, 0.f), W - 1.f);
-    fy0 = fminf(fmaxf(fy0, 0.f), H - 1.f); fy1 = fminf(fmaxf(fy1, 0.f), H - 1.f);
-    f.tx0 = (int)fx0 / RTX; f.tx1 = (int)fx1 / RTX; f.ty0 = (int)fy0 / RTY; f.ty1 = (int)fy1 / RTY;
-    return f;
-}
-
-// pass 0: count (fill == 0) or fill (fill == 1) the per-tile RoI lists; one thread per RoI slot
-__global__ __launch_bounds__(256) void roi_tile_bin_kernel(const float* __restrict__ rois, const int* __restrict__ labels, int S, int total,
-                                                           RoiLevels lv, PyrTiles pt, int fill, int* __restrict__ tile_cnt,
-                                                           const int* __restrict__ tile_off, int* __restrict__ entries,
-                                                           int cap, int* __restrict__ overflow) {
+// conservative tile range of the sample footprint of every RoI slot on its level (samples clamp into the map: the range as well):
+// foot[r] = {level or -1 (empty slot), tx0 | tx1 << 16, ty0 | ty1 << 16, 0}
+__global__ __launch_bounds__(256) void roi_foot_kernel(const float* __restrict__ rois, const int* __restrict__ labels, int total, RoiLevels lv,
+                                                       PyrTiles pt, int4* __restrict__ foot) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= total) return;
-    if (labels && labels[r] < 0) return;
-    const int n = r / S, slot = r - n * S;
-    const RoiFoot f = roi_footprint(ld_box(rois + r * 4ll), lv, pt);
-    const int tiles_per_img = pt.tile_start[pt.L];
-    for (int ty = f.ty0; ty <= f.ty1; ++ty)
-        for (int tx = f.tx0; tx <= f.tx1; ++tx) {
-            const int t = n * tiles_per_img + pt.tile_start[f.l] + ty * pt.tiles_x[f.l] + tx;
-            const int pos = atomicAdd(&tile_cnt[t], 1);
-            if (fill) {
-                const int o = tile_off[t] + pos;
-                if (o < cap) entries[o] = slot; else *overflow = 1;
-            }
-        }
-}
-
-// exclusive scan of the tile counts (single workgroup), zeroing the counters for the fill pass
-__global__ __launch_bounds__(1024) void roi_tile_scan_kernel(int* __restrict__ tile_cnt, int* __restrict__ tile_off, int ntiles) {
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < ntiles; i0 += 1024) {
-        const int i = i0 + tid;
-        const int v = i < ntiles ? tile_cnt[i] : 0;
-        int inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int before = carry;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (i < ntiles) { tile_off[i] = before + inc - v; tile_cnt[i] = 0; }
-        __syncthreads();
-        if (tid == 1023) carry = before + inc;
-        __syncthreads();
+    int4 f = make_int4(-1, 0, 0, 0);
+    if (!(labels && labels[r] < 0)) {
+        const Box b = ld_box(rois + r * 4ll);
+        const int l = roi_level(b, lv);
+        const float sc = lv.scale[l];
+        const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
+        const float ew = b.x2 * sc - 0.5f, eh = b.y2 * sc - 0.5f;
+        float fx0 = fminf(sw, ew) - 1.f, fx1 = fmaxf(sw, ew) + 1.f, fy0 = fminf(sh_, eh) - 1.f, fy1 = fmaxf(sh_, eh) + 1.f;
+        const float W = (float)pt.W[l], H = (float)pt.H[l];
+        if (!(fx0 == fx0 && fx1 == fx1 && fy0 == fy0 && fy1 == fy1)) { fx0 = 0.f; fx1 = W; fy0 = 0.f; fy1 = H; }
+        fx0 = fminf(fmaxf(fx0, 0.f), W - 1.f); fx1 = fminf(fmaxf(fx1, 0.f), W - 1.f);
+        fy0 = fminf(fmaxf(fy0, 0.f), H - 1.f); fy1 = fminf(fmaxf(fy1, 0.f), H - 1.f);
+        f = make_int4(l, ((int)fx0 / RT) | (((int)fx1 / RT) << 16), ((int)fy0 / RT) | (((int)fy1 / RT) << 16), 0);
     }
-    if (tid == 0) tile_off[ntiles] = carry;
+    foot[r] = f;
 }
 
-__device__ __forceinline__ void sample_range(float lo, float hi, float start, float step, int nsamp, int& j0, int& j1) {
-    j0 = 0; j1 = nsamp - 1;
-    if (step > 1e-6f) {
-        const float a = (lo - start) / step - 0.5f, b = (hi - start) / step - 0.5f;
-        if (a == a && b == b) {
-            const float fa = floorf(a) - 1.f, fb = ceilf(b) + 1.f;
-            if (fa > (float)j0) j0 = fa > (float)nsamp ? nsamp : (int)fa;
-            if (fb < (float)j1) j1 = fb < -1.f ? -1 : (int)fb;
-        }
-    }
-}
-
-__global__ __launch_bounds__(64) void roi_align_bwd_gather_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv,
-                                                                  PyrTiles pt, const float* __restrict__ rois, int S, int PH, int PW,
-                                                                  int SP, const int* __restrict__ tile_cnt,
-                                                                  const int* __restrict__ tile_off, const int* __restrict__ entries,
-                                                                  bf16_raw* __restrict__ gfeat) {
-    __shared__ float acc[RTY * RTX * 64];          //  8 KB: lane-private columns
-    __shared__ bf16_raw s_g[ROI_BINS_MAX * 64];    //  8 KB: pooled gradients of the current RoI, lane-private columns
-    __shared__ float s_par[64][4];                 // sw, sh, bw, bh of the current chunk of RoIs
-    __shared__ short s_slot[ROI_LIST_MAX];
-    __shared__ short s_sorted[ROI_LIST_MAX];
-    const int lane = threadIdx.x;
-    const int slices = (C + 63) / 64;
-    const int slice = blockIdx.x % slices;
-    const int tb = blockIdx.x / slices;            // global tile index: n * tiles_per_img + t
-    const int tiles_per_img = pt.tile_start[pt.L];
-    const int n = tb / tiles_per_img;
-    const int t = tb - n * tiles_per_img;
-    int la = 0;
+__device__ __forceinline__ void tile_decode(const PyrTiles& pt, int t, int& la, int& ty, int& tx) {
+    la = 0;
     for (int q = 1; q < pt.L; ++q) if (t >= pt.tile_start[q]) la = q;
     const int tt = t - pt.tile_start[la];
-    const int ty0 = (tt / pt.tiles_x[la]) * RTY, tx0 = (tt % pt.tiles_x[la]) * RTX;
-    const int H = pt.H[la], W = pt.W[la];
-    const int nb = PH * PW;
-    const float inv = 1.f / (float)(SP * SP);
-    int cnt = tile_cnt[tb];
-    if (cnt > ROI_LIST_MAX) cnt = ROI_LIST_MAX;
-    const int* ent = entries + tile_off[tb];
-    const float sc = la < lv.L ? lv.scale[la] : 1.f;
-    const int c = slice * 64 + lane;
-    const bool cok = c < C;
-#pragma unroll
-    for (int p = 0; p < RTY * RTX; ++p) acc[p * 64 + lane] = 0.f;
+    ty = tt / pt.tiles_x[la];
+    tx = tt - ty * pt.tiles_x[la];
+}
 
-    // the tile's RoI list sorted by slot (the fill order of the binning pass is not deterministic)
-    for (int q = lane; q < cnt; q += 64) s_slot[q] = (short)ent[q];
+// count (fill == 0) or write (fill == 1) the RoI list of every tile, slots ascending: one WAVE per tile walks its image's footprints 64 at a
+// time (ballot + prefix count: the order within the list is the slot order, whatever the hardware does); blockIdx.y = image
+__global__ __launch_bounds__(1024) void roi_tile_list_kernel(const int4* __restrict__ foot, int S, PyrTiles pt, int fill, int* __restrict__ tile_cnt,
+                                                             const int* __restrict__ tile_off, unsigned short* __restrict__ entries, int cap) {
+    __shared__ int4 s_f[ROI_LIST_MAX];
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tpi = pt.tile_start[pt.L];
+    for (int i = tid; i < S; i += 1024) s_f[i] = foot[(long long)n * S + i];
     __syncthreads();
-    for (int q = lane; q < cnt; q += 64) {
-        const int v = s_slot[q];
-        int rank = 0;
-        for (int k = 0; k < cnt; ++k) rank += s_slot[k] < v;       // slots are distinct
-        s_sorted[rank] = (short)v;
-    }
-    __syncthreads();
-
-    for (int q0 = 0; q0 < cnt; q0 += 64) {
-        const int nq = min(64, cnt - q0);
-        if (lane < nq) {                                            // parameters of up to 64 RoIs, one per lane
-            const long long r = (long long)n * S + s_sorted[q0 + lane];
-            const Box b = ld_box(rois + r * 4);
-            const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
-            const float rw = (b.x2 * sc - 0.5f) - sw, rh = (b.y2 * sc - 0.5f) - sh_;
-            s_par[lane][0] = sw; s_par[lane][1] = sh_; s_par[lane][2] = rw / (float)PW; s_par[lane][3] = rh / (float)PH;
+    const int t = blockIdx.x * 16 + wave;
+    if (t >= tpi) return;
+    int la, ty, tx;
+    tile_decode(pt, t, la, ty, tx);
+    const int base = fill ? tile_off[n * tpi + t] : 0;
+    int cnt = 0;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+        const int i = i0 + lane;
+        bool hit = false;
+        if (i < S) {
+            const int4 f = s_f[i];
+            hit = f.x == la && tx >= (f.y & 0xffff) && tx <= (f.y >> 16) && ty >= (f.z & 0xffff) && ty <= (f.z >> 16);
         }
-        __syncthreads();
-        for (int q = 0; q < nq; ++q) {
-            const float sw = s_par[q][0], sh_ = s_par[q][1], bw = s_par[q][2], bh = s_par[q][3];
-            const long long r = (long long)n * S + s_sorted[q0 + q];
-            int jy0, jy1, jx0, jx1;
-            sample_range((float)(ty0 - 1), (float)(ty0 + RTY), sh_, bh / (float)SP, PH * SP, jy0, jy1);
-            sample_range((float)(tx0 - 1), (float)(tx0 + RTX), sw, bw / (float)SP, PW * SP, jx0, jx1);
-            if (jy0 > jy1 || jx0 > jx1) continue;
-            // pooled gradients of this lane's channel: independent loads (all in flight together) into the lane-private column
-            const bf16_raw* go = gout + r * nb * C + (cok ? c : 0);
-            const int ph0 = jy0 / SP, ph1 = jy1 / SP, pw0 = jx0 / SP, pw1 = jx1 / SP;
-            for (int ph = ph0; ph <= ph1; ++ph)
-                for (int pw = pw0; pw <= pw1; ++pw) s_g[(ph * PW + pw) * 64 + lane] = go[(long long)(ph * PW + pw) * C];
-            for (int jy = jy0; jy <= jy1; ++jy) {
-                const int ph = jy / SP, iy = jy - ph * SP;
-                const float y = sh_ + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)SP;
-                for (int jx = jx0; jx <= jx1; ++jx) {
-                    const int pw = jx / SP, ix = jx - pw * SP;
-                    const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)SP;
-                    const Bilinear bl = bilinear_setup(y, x, H, W);
-                    if (!bl.ok) continue;
-                    const int ya = bl.y0 - ty0, yb = bl.y1 - ty0, xa = bl.x0 - tx0, xb = bl.x1 - tx0;
-                    const bool ya_in = (unsigned)ya < RTY, yb_in = (unsigned)yb < RTY, xa_in = (unsigned)xa < RTX, xb_in = (unsigned)xb < RTX;
-                    // a corner duplicated by the border clamp carries weight 0: skipping zero weights keeps the four targets distinct,
-                    // so the four read-modify-writes are independent (reads first, then the adds, then the writes)
-                    const bool u00 = ya_in && xa_in && bl.w00 != 0.f, u01 = ya_in && xb_in && bl.w01 != 0.f;
-                    const bool u10 = yb_in && xa_in && bl.w10 != 0.f, u11 = yb_in && xb_in && bl.w11 != 0.f;
-                    if (!(u00 || u01 || u10 || u11)) continue;
-                    const float g = bf2f(s_g[(ph * PW + pw) * 64 + lane]) * inv;
-                    float* p00 = acc + ((u00 ? ya * RTX + xa : 0) * 64 + lane);
-                    float* p01 = acc + ((u01 ? ya * RTX + xb : 0) * 64 + lane);
-                    float* p10 = acc + ((u10 ? yb * RTX + xa : 0) * 64 + lane);
-                    float* p11 = acc + ((u11 ? yb * RTX + xb : 0) * 64 + lane);
-                    const float v00 = *p00, v01 = *p01, v10 = *p10, v11 = *p11;
-                    if (u00) *p00 = v00 + bl.w00 * g;
-                    if (u01) *p01 = v01 + bl.w01 * g;
-                    if (u10) *p10 = v10 + bl.w10 * g;
-                    if (u11) *p11 = v11 + bl.w11 * g;
-                }
+        const unsigned long long bal = __ballot(hit);
+        if (fill && hit) {
+            const int o = base + cnt + __popcll(bal & ((1ull << lane) - 1ull));
+            if (o < cap) entries[o] = (unsigned short)i;
+        }
+        cnt += __popcll(bal);
+    }
+    if (!fill && lane == 0) tile_cnt[n * tpi + t] = cnt;
+}
+
+// exclusive scan of the tile counts (single workgroup, one contiguous run of counts per thread)
+__global__ __launch_bounds__(1024) void roi_tile_scan_kernel(const int* __restrict__ tile_cnt, int* __restrict__ tile_off, int ntiles) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (ntiles + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(i0 + per, ntiles);
+    int s = 0;
+    for (int i = i0; i < i1; ++i) s += tile_cnt[i];
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = inc - s;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    for (int i = i0; i < i1; ++i) { tile_off[i] = before; before += tile_cnt[i]; }
+    if (tid == 1023) tile_off[ntiles] = before;
+}
+
+__global__ __launch_bounds__(64, 2) void roi_align_bwd_tile_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv, PyrTiles pt,
+                                                                   const float* __restrict__ rois, int S, int SP, const int* __restrict__ tile_off,
+                                                                   const unsigned short* __restrict__ entries, int cap,
+                                                                   bf16_raw* __restrict__ gfeat, int accumulate) {
+    constexpr int P = 7;
+    __shared__ f32x4_t s_par[2][64];               // sw, sh, bw, bh of the RoIs of the current / next chunk of the list
+    __shared__ int s_slot[2][64];
+    const int lane = threadIdx.x;
+    const int slices = (C + 127) / 128;
+    int bid = blockIdx.x;
+    {   // neighbouring tiles share RoIs: every XCD (blocks go round-robin over the eight) takes a contiguous range of them
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int slice = bid % slices;
+    const int tb = bid / slices;                   // n * tiles_per_img + t
+    const int tpi = pt.tile_start[pt.L];
+    const int n = tb / tpi;
+    int la, tyi, txi;
+    tile_decode(pt, tb - n * tpi, la, tyi, txi);
+    const int ty0 = tyi * RT, tx0 = txi * RT;
+    const int H = pt.H[la], W = pt.W[la];
+    const int beg = min(tile_off[tb], cap), cnt = min(tile_off[tb + 1], cap) - beg;
+    const int c0 = slice * 128 + lane * 2;
+    const bool cok = c0 < C;                        // (C is even)
+    unsigned int* gp_out = reinterpret_cast<unsigned int*>(gfeat + ((long long)n * ppi + pt.pix_off[la]) * C + (cok ? c0 : 0));
+    const int rowp = C / 2;                         // pixel pitch in 32-bit words
+    if (cnt == 0) {
+        if (!accumulate && cok)
+            for (int y = 0; y < RT && ty0 + y < H; ++y)
+                for (int x = 0; x < RT && tx0 + x < W; ++x) gp_out[((long long)(ty0 + y) * W + tx0 + x) * rowp] = 0u;
+        return;
+    }
+    const float sc = lv.scale[la];                  // (tiles with a list are on a RoI level)
+    const float inv_sp = 1.f / (float)SP;
+    // the tile's list and the geometry of its RoIs, 64 at a time: one coalesced read and one box per lane instead of a chain of
+    // dependent loads (list entry -> box -> pooled gradients) in front of every RoI
+    auto stage = [&](int q0) {
+        const int q = q0 + lane;
+        if (q < cnt) {
+            const int slot = entries[beg + q];
+            const Box b = ld_box(rois + ((long long)n * S + slot) * 4);
+            const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
+            s_par[(q0 >> 6) & 1][lane] = (f32x4_t){sw, sh_, ((b.x2 * sc - 0.5f) - sw) / (float)P, ((b.y2 * sc - 0.5f) - sh_) / (float)P};
+            s_slot[(q0 >> 6) & 1][lane] = slot;
+        }
+    };
+    f32x2_t acc[RT][RT];
+#pragma unroll
+    for (int y = 0; y < RT; ++y)
+#pragma unroll
+        for (int x = 0; x < RT; ++x) acc[y][x] = (f32x2_t){0.f, 0.f};
+    stage(0);
+    const int iy = lane / P, pb = lane - iy * P;    // lanes 0..55: (tile row / column, bin)
+    const unsigned int* gbase = reinterpret_cast<const unsigned int*>(gout + (long long)n * S * (P * P) * C + (cok ? c0 : 0));
+    for (int q = 0; q < cnt; ++q) {
+        if ((q & 63) == 0) {                         // (the chunk staged 64 RoIs ago becomes visible; the next one goes into the buffer just left)
+            __syncthreads();
+            if (q + 64 < cnt) stage(q + 64);
+        }
+        const f32x4_t par = s_par[(q >> 6) & 1][q & 63];
+        const int slot = __builtin_amdgcn_readfirstlane(s_slot[(q >> 6) & 1][q & 63]);
+        const float sw = par[0], sh_ = par[1], bw = par[2], bh = par[3];
+        // A (row weights of the tile's 8 rows x 7 bins) and B (columns): lane y * 7 + ph holds A[y][ph] and B[y][ph].  Which rows / columns
+        // carry any weight comes from two ballots (scalar); the weights themselves are read as SCALARS right where they are used
+        // (v_readlane into an SGPR pair, two weights per pair, picked by op_sel): 128 VGPRs of sums and 98 of pooled gradients leave no
+        // room for 112 weights in registers at two waves per SIMD, and an LDS round trip per row costs more than seven lane reads
+        float av = 0.f, bv = 0.f;
+        if (lane < RT * P) {
+            for (int iq = 0; iq < SP; ++iq) {        // sample positions and validity exactly as in roi_align_fwd_kernel
+                const Lin1 ly = linear_setup(sh_ + (float)pb * bh + ((float)iq + 0.5f) * bh / (float)SP, H);
+                const Lin1 lx = linear_setup(sw + (float)pb * bw + ((float)iq + 0.5f) * bw / (float)SP, W);
+                if (ly.ok) { if (ly.i0 == ty0 + iy) av += ly.w0; if (ly.i1 == ty0 + iy) av += ly.w1; }
+                if (lx.ok) { if (lx.i0 == tx0 + iy) bv += lx.w0; if (lx.i1 == tx0 + iy) bv += lx.w1; }
+            }
+            av *= inv_sp; bv *= inv_sp;
+        }
+        const unsigned long long amask = __ballot(av != 0.f), bmask = __ballot(bv != 0.f);
+        if (amask == 0ull || bmask == 0ull) continue;            // (the footprints of the lists are conservative)
+        f32x2_t g[P * P];
+        {
+            const unsigned int* go = gbase + (long long)slot * (P * P) * rowp;
+            unsigned int gpk[P * P];
+#pragma unroll
+            for (int k = 0; k < P * P; ++k) gpk[k] = go[k * rowp];
+#pragma unroll
+            for (int k = 0; k < P * P; ++k) g[k] = (f32x2_t){__uint_as_float(gpk[k] << 16), __uint_as_float(gpk[k] & 0xffff0000u)};
+        }
+        float a[RT][P];                               // (volatile: a lane read the compiler may not repeat at every use -- it would, 8 times)
+#pragma unroll
+        for (int y = 0; y < RT; ++y)
+#pragma unroll
+            for (int ph = 0; ph < P; ++ph) asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(a[y][ph]) : "v"(av), "n"(y * P + ph));
+#pragma unroll
+        for (int x = 0; x < RT; ++x) {
+            if (((bmask >> (x * P)) & 0x7full) == 0ull) continue;                   // a pixel column no sample of this RoI touches
+            f32x2_t tt[P];
+            {
+                float bx[P];
+#pragma unroll
+                for (int pw = 0; pw < P; ++pw) bx[pw] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), x * P + pw));
+#pragma unroll
+                for (int ph = 0; ph < P; ++ph) tt[ph] = g[ph * P] * bx[0];
+#pragma unroll
+                for (int pw = 1; pw < P; ++pw)                // (explicit FMAs: this file is compiled with -ffp-contract=off)
+#pragma unroll
+                    for (int ph = 0; ph < P; ++ph) tt[ph] = __builtin_elementwise_fma(g[ph * P + pw], (f32x2_t){bx[pw], bx[pw]}, tt[ph]);
+            }
+#pragma unroll
+            for (int y = 0; y < RT; ++y) {
+                if (((amask >> (y * P)) & 0x7full) == 0ull) continue;
+#pragma unroll
+                for (int ph = 0; ph < P; ++ph) acc[y][x] = __builtin_elementwise_fma(tt[ph], (f32x2_t){a[y][ph], a[y][ph]}, acc[y][x]);
             }
         }
-        __syncthreads();
     }
-    if (cok) {
-        bf16_raw* gp = gfeat + ((long long)n * ppi + pt.pix_off[la]) * C + c;
-        for (int p = 0; p < RTY * RTX; ++p) {
-            const int y = ty0 + p / RTX, x = tx0 + p % RTX;
-            if (y < H && x < W) gp[((long long)y * W + x) * C] = f2bf(acc[p * 64 + lane]);
-        }
+    if (cok && accumulate) {          // every old value requested before the first store (loads do not move across stores that may alias them)
+        unsigned int old[RT][RT];
+#pragma unroll
+        for (int y = 0; y < RT; ++y)
+#pragma unroll
+            for (int x = 0; x < RT; ++x)
+                old[y][x] = (ty0 + y < H && tx0 + x < W) ? gp_out[(long long)((ty0 + y) * W + tx0 + x) * rowp] : 0u;
+#pragma unroll
+        for (int y = 0; y < RT; ++y)
+#pragma unroll
+            for (int x = 0; x < RT; ++x) { acc[y][x][0] += __uint_as_float(old[y][x] << 16); acc[y][x][1] += __uint_as_float(old[y][x] & 0xffff0000u); }
     }
+    if (cok)
+#pragma unroll
+        for (int y = 0; y < RT; ++y)
+#pragma unroll
+            for (int x = 0; x < RT; ++x)
+                if (ty0 + y < H && tx0 + x < W) {
+                    unsigned int* o = gp_out + (long long)((ty0 + y) * W + tx0 + x) * rowp;
+                    *o = (unsigned int)f2bf(acc[y][x][0]) | ((unsigned int)f2bf(acc[y][x][1]) << 16);
+                }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1641,26 +1683,27 @@ extern "C" int bd_f32_to_bf16_add(const float* src, void* dst, int64_t n, bd_str
 
 static int roi_tiles_per_img(int L_all, const int32_t* H, const int32_t* W) {
     int ts = 0;
-    for (int l = 0; l < L_all; ++l) ts += cdiv(W[l], RTX) * cdiv(H[l], RTY);
+    for (int l = 0; l < L_all; ++l) ts += cdiv(W[l], RT) * cdiv(H[l], RT);
     return ts;
 }
 
+// workspace: tile counts | tile offsets (+1) | footprints (int4 per RoI slot) | tile lists (u16 slots)
 extern "C" size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L_all, const int32_t* lvl_h_host, const int32_t* lvl_w_host,
                                                         int rois_per_img) {
     if (N <= 0 || L_all <= 0 || L_all > BD_MAX_SEGS || rois_per_img <= 0 || !lvl_h_host || !lvl_w_host) return 256;
     const size_t ntiles = (size_t)N * roi_tiles_per_img(L_all, lvl_h_host, lvl_w_host);
-    return 2 * align256((ntiles + 1) * 4) + align256((size_t)N * rois_per_img * ROI_TILES_MAX * 4) + 256;
+    return 2 * align256((ntiles + 1) * 4) + align256((size_t)N * rois_per_img * 16) + align256((size_t)N * rois_per_img * ROI_TILES_MAX * 2) + 256;
 }
 
 extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int C, int L, int L_all, const int32_t* lvl_pix_off_host,
                                      const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
                                      const float* rois, const int32_t* labels, int N, int rois_per_img, int PH, int PW,
-                                     int sample_points, void* gfeat, void* ws, size_t ws_bytes, bd_stream_t stream) {
+                                     int sample_points, void* gfeat, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
     BD_REQUIRE(gout && lvl_pix_off_host && lvl_h_host && lvl_w_host && strides_host && rois && gfeat && ws, "roi_align_bwd_bf16: null pointer");
-    BD_REQUIRE(L > 0 && L <= L_all && L_all <= BD_MAX_SEGS && C > 0 && PH > 0 && PW > 0 && sample_points > 0 && rois_per_img > 0 && N > 0,
+    BD_REQUIRE(L > 0 && L <= L_all && L_all <= BD_MAX_SEGS && C > 0 && C % 2 == 0 && sample_points > 0 && rois_per_img > 0 && N > 0,
                "roi_align_bwd_bf16: bad sizes");
+    BD_REQUIRE(PH == 7 && PW == 7, "roi_align_bwd_bf16: the pooled size is 7 x 7 (got %d x %d)", PH, PW);
     BD_REQUIRE(rois_per_img <= ROI_LIST_MAX, "roi_align_bwd_bf16: %d RoIs per image exceed %d", rois_per_img, ROI_LIST_MAX);
-    BD_REQUIRE(PH * PW <= ROI_BINS_MAX, "roi_align_bwd_bf16: %d bins exceed %d", PH * PW, ROI_BINS_MAX);
     if (ws_bytes < bd_roi_align_bwd_bf16_workspace_bytes(N, L_all, lvl_h_host, lvl_w_host, rois_per_img)) {
         bd_set_error("roi_align_bwd_bf16: workspace %zu < %zu bytes", ws_bytes,
                      bd_roi_align_bwd_bf16_workspace_bytes(N, L_all, lvl_h_host, lvl_w_host, rois_per_img));
@@ -1673,30 +1716,30 @@ extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int 
     int ts = 0;
     for (int l = 0; l < L_all; ++l) {
         pt.pix_off[l] = lvl_pix_off_host[l]; pt.H[l] = lvl_h_host[l]; pt.W[l] = lvl_w_host[l];
-        pt.tiles_x[l] = cdiv(lvl_w_host[l], RTX); pt.tiles_y[l] = cdiv(lvl_h_host[l], RTY);
+        pt.tiles_x[l] = cdiv(lvl_w_host[l], RT);
+        BD_REQUIRE(pt.tiles_x[l] < 65536 && cdiv(lvl_h_host[l], RT) < 65536, "roi_align_bwd_bf16: level too large");
         pt.tile_start[l] = ts;
-        ts += pt.tiles_x[l] * pt.tiles_y[l];
+        ts += pt.tiles_x[l] * cdiv(lvl_h_host[l], RT);
     }
     pt.tile_start[L_all] = ts;
     const int ntiles = N * ts;
+    const int total = N * rois_per_img;
     unsigned char* wb = (unsigned char*)ws;
     int* tile_cnt = (int*)wb;
     int* tile_off = (int*)(wb + align256(((size_t)ntiles + 1) * 4));
-    int* entries = (int*)(wb + 2 * align256(((size_t)ntiles + 1) * 4));
-    const int cap = N * rois_per_img * ROI_TILES_MAX;
-    int* overflow = entries + cap;
-    const int total = N * rois_per_img;
+    int4* foot = (int4*)(wb + 2 * align256(((size_t)ntiles + 1) * 4));
+    unsigned short* entries = (unsigned short*)((unsigned char*)foot + align256((size_t)total * 16));
+    const int cap = total * ROI_TILES_MAX;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(tile_cnt, 0, ((size_t)ntiles + 1) * 4, st);
-    (void)hipMemsetAsync(overflow, 0, 4, st);
-    hipLaunchKernelGGL(roi_tile_bin_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, rois, labels, rois_per_img, total, lv, pt, 0, tile_cnt,
-                       (const int*)tile_off, entries, cap, overflow);
-    hipLaunchKernelGGL(roi_tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_cnt, tile_off, ntiles);
-    hipLaunchKernelGGL(roi_tile_bin_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, rois, labels, rois_per_img, total, lv, pt, 1, tile_cnt,
-                       (const int*)tile_off, entries, cap, overflow);
-    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3(ntiles * cdiv(C, 64)), dim3(64), 0, st, (const bf16_raw*)gout, (long long)pix_per_img,
-                       C, lv, pt, rois, rois_per_img, PH, PW, sample_points, (const int*)tile_cnt, (const int*)tile_off, (const int*)entries,
-                       (bf16_raw*)gfeat);
+    hipLaunchKernelGGL(roi_foot_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, rois, labels, total, lv, pt, foot);
+    hipLaunchKernelGGL(roi_tile_list_kernel, dim3(cdiv(ts, 16), N), dim3(1024), 0, st, (const int4*)foot, rois_per_img, pt, 0, tile_cnt,
+                       (const int*)tile_off, entries, cap);
+    hipLaunchKernelGGL(roi_tile_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)tile_cnt, tile_off, ntiles);
+    hipLaunchKernelGGL(roi_tile_list_kernel, dim3(cdiv(ts, 16), N), dim3(1024), 0, st, (const int4*)foot, rois_per_img, pt, 1, tile_cnt,
+                       (const int*)tile_off, entries, cap);
+    hipLaunchKernelGGL(roi_align_bwd_tile_kernel, dim3(ntiles * cdiv(C, 128)), dim3(64), 0, st, (const bf16_raw*)gout, (long long)pix_per_img,
+                       C, lv, pt, rois, rois_per_img, sample_points, (const int*)tile_off, (const unsigned short*)entries, cap,
+                       (bf16_raw*)gfeat, accumulate);
     BD_CHECK_LAUNCH("bd_roi_align_bwd_bf16");
     return BD_OK;
 }

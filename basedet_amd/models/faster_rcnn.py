@@ -73,11 +73,11 @@ class FasterRCNN(FPNDetector):
             self.base_anchors.append(torch.tensor(base, dtype=torch.float32, device=dev))
         self.pre_k = {True: m.RPN.TRAIN_PREV_NMS_TOPK, False: m.RPN.TEST_PREV_NMS_TOPK}
         self.post_k = {True: m.RPN.TRAIN_POST_NMS_TOPK, False: m.RPN.TEST_POST_NMS_TOPK}
-        self.deterministic_roi_bwd = False
-        # RoIAlign backward: fp32 atomic scatter + one conversion pass by default.  roi_bwd_pk = True accumulates with packed-bf16 atomics
-        # straight into the bf16 gradient pyramid (half the atomic operations, no staging buffer: ~10 % on the whole step) at the price
-        # of running bf16 sums on top of the RPN head's gradient (rel-L2 0.6-0.9 % per level instead of 0.1 %, arrival-order dependent):
-        # opt-in (bench.py --roi-bwd-pk).  deterministic_roi_bwd = True is the fixed-order gather.
+        # RoIAlign backward.  Default (round 5): the tiled fixed-order sum (bd_roi_align_bwd_bf16: per-tile RoI lists in slot order, sums in
+        # registers, written once on top of the RPN head's dL/dP) -- bitwise reproducible and the fastest of the three.
+        # deterministic_roi_bwd = False restores the fp32 atomic scatter + conversion pass of rounds 2-4; roi_bwd_pk = True (bench.py
+        # --roi-bwd-pk) the packed-bf16 atomics straight into the bf16 pyramid (running bf16 sums: rel-L2 0.6-0.9 % per level).
+        self.deterministic_roi_bwd = True
         self.roi_bwd_pk = False
         self._gen = torch.Generator(device=dev) if self.device.type == "cuda" else None
         if self._gen is not None:
@@ -143,7 +143,7 @@ class FasterRCNN(FPNDetector):
         pl.g_fc2 = torch.empty((R, 1024), **bf)
         pl.g_fc1 = torch.empty((R, 1024), **bf)
         pl.g_pooled = torch.empty((R, fin), **bf)
-        pl.g_feat32 = torch.zeros((pyr.pixels, ch), **f32)
+        pl.g_feat32 = None                # (the fp32 scatter's staging pyramid, 1.5 GB at batch 16: allocated when that variant runs)
         pl.roi_bwd_ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(pyr, S),), dtype=torch.uint8, device=dev)
         pl.g_fc = ops.single(1, R, 1)
         pl.loss_buf = torch.zeros((4,), **f32)
@@ -192,7 +192,9 @@ class FasterRCNN(FPNDetector):
                                   m.RPN_BOX_REG.STD, pl.rpn_labels, pl.rpn_match, pl.rpn_offsets, pl.rpn_num_fg, pl.assign_ws)
             ops.sample_labels(pl.rpn_labels, self._keys(inputs, "rpn_pos", (N, pl.A_total)), self._keys(inputs, "rpn_neg", (N, pl.A_total)),
                               int(m.RPN.POSITIVE_ANCHOR_RATIO * nsa), nsa, pl.rpn_num_valid)
-            if not (self.deterministic_roi_bwd or self.roi_bwd_pk):
+            if not (self.deterministic_roi_bwd or self.roi_bwd_pk):     # (the fp32 scatter only)
+                if pl.g_feat32 is None:
+                    pl.g_feat32 = torch.empty((pl.pyr.pixels, self.fpn_ch), dtype=torch.float32, device=self.device)
                 pl.g_feat32.zero_()           # the fp32 pyramid RoIAlign's backward scatters into (1.5 GB at batch 16): cleared here, not in backward
                 pl.g_feat32_clean = True
 
@@ -228,7 +230,7 @@ class FasterRCNN(FPNDetector):
         ops.rpn_loss_fwd_bwd(pl.rpn_raw, self.rpn_ld, A, 0, A, pl.rpn_labels, pl.rpn_offsets, pl.pyr.pixels,
                              m.LOSSES.RPN_SMOOTH_L1_BETA, pl.rpn_num_valid, pl.loss_buf[0:2], pl.d_rpn_raw)
         pl.rpn_bwd_done = False
-        if side is not None and not self.deterministic_roi_bwd:
+        if side is not None:
             # the RPN head's backward needs nothing from the proposal chain: it runs now, under it, and leaves the FIRST contribution
             # to dL/dP; the RoIAlign backward joins it later (head_backward: the fp32 pyramid through an accumulating conversion,
             # the packed atomics directly on top)
@@ -273,15 +275,17 @@ class FasterRCNN(FPNDetector):
         self._wgrad(self.fc1, pl.pooled, pl.g_fc1, g, g, ws, cws)
         self.fc1.dgrad(pl.g_fc1, g, g, pl.g_pooled)
         # first contribution to dL/dP: every pyramid level is written (zeros where no RoI sample lands, all of P6)
-        if self.deterministic_roi_bwd:      # gather kernel: fixed summation order, ~2x slower than the atomic scatter
-            ops.roi_align_bwd_bf16(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4),
-                                   pl.s_labels.view(-1), S, self.pool, 2, pl.g_P, pl.roi_bwd_ws)
-        elif self.roi_bwd_pk:
+        if self.roi_bwd_pk:
             if not pl.rpn_bwd_done:
                 pl.g_P.zero_()
             ops.roi_align_bwd_pk(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
                                  self.pool, 2, pl.g_P)
+        elif self.deterministic_roi_bwd:    # per-tile sums in registers, fixed order, written once (added to the RPN head's dL/dP when that ran first)
+            ops.roi_align_bwd_bf16(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4),
+                                   pl.s_labels.view(-1), S, self.pool, 2, pl.g_P, pl.roi_bwd_ws, accumulate=pl.rpn_bwd_done)
         else:
+            if pl.g_feat32 is None:
+                pl.g_feat32 = torch.empty((pyr.pixels, self.fpn_ch), dtype=torch.float32, device=self.device)
             if not getattr(pl, "g_feat32_clean", False):      # (normally cleared by get_losses, under the forward pass)
                 pl.g_feat32.zero_()
             pl.g_feat32_clean = False

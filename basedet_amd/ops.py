@@ -504,10 +504,11 @@ def roi_align_bwd_bf16_workspace_bytes(geom: Geom, rois_per_img):
     return int(L().bd_roi_align_bwd_bf16_workspace_bytes(geom.N, geom.nlev, i32arr(geom.H), i32arr(geom.W), rois_per_img))
 
 
-def roi_align_bwd_bf16(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_img, pool, sample_points, gfeat, ws):
+def roi_align_bwd_bf16(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_img, pool, sample_points, gfeat, ws, accumulate=False):
     check(L().bd_roi_align_bwd_bf16(ptr(gout), geom.pix_per_img, Cn, nlev, geom.nlev, i32arr(geom.off), i32arr(geom.H), i32arr(geom.W),
                                     i32arr(strides[:nlev]), ptr(rois), ptr(labels), geom.N, rois_per_img, pool[0], pool[1], sample_points,
-                                    ptr(gfeat), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "bd_roi_align_bwd_bf16")
+                                    ptr(gfeat), int(bool(accumulate)), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()),
+          "bd_roi_align_bwd_bf16")
 
 
 def subsample2x_fwd(src, gsrc: Geom, dst, gdst: Geom, Cn):

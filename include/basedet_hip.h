@@ -520,16 +520,19 @@ int bd_roi_align_bwd_pk(const void* gout, int64_t pix_per_img, int C, int L, con
                         const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
                         int sample_points, void* gfeat_bf16, bd_stream_t stream);
 
-/* Deterministic backward of bd_roi_align_fwd for the training step: the RoIs are binned into 4x8-pixel tiles of their level
- * (count, scan, fill), then one wave per (image, tile, 64-channel slice) gathers every sample touching the tile -- no float
- * atomics, fixed summation order.  Writes the bf16 gradient of ALL L_all pyramid levels of the pixel-major buffer (levels >= L
- * and untouched pixels get zeros).  lvl_* arrays have L_all entries, strides the first L.  rois_per_img <= 512. */
+/* Deterministic backward of bd_roi_align_fwd (the training step's default since round 5; roi_pool.py:35-78 under autograd): the gradient
+ * pyramid is cut into 8x8-pixel tiles, every tile gets the list of the RoIs whose samples touch it in slot order (count, scan, fill: no
+ * atomics), and one wave per (tile, 128-channel slice) sums dF = A^T (g / S^2) B in registers -- fixed summation order, bitwise
+ * reproducible.  gfeat: the bf16 gradient of ALL L_all pyramid levels of the pixel-major buffer.  accumulate == 0: every pixel is written
+ * (zeros on levels >= L and where no sample lands); accumulate != 0: the sums are ADDED to what gfeat holds (one bf16 rounding of the
+ * total), untouched pixels are left alone.  lvl_* arrays have L_all entries, strides the first L.  PH == PW == 7, C even,
+ * rois_per_img <= 512. */
 size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L_all, const int32_t* lvl_h_host, const int32_t* lvl_w_host,
                                              int rois_per_img);
 int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int C, int L, int L_all, const int32_t* lvl_pix_off_host,
                           const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
                           const float* rois, const int32_t* labels, int N, int rois_per_img, int PH, int PW,
-                          int sample_points, void* gfeat, void* ws, size_t ws_bytes, bd_stream_t stream);
+                          int sample_points, void* gfeat, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 
 /* FPNP6 (fpn_backbone.py:172-183): dst[n,y,x,:] = src[n,2y,2x,:]; backward adds gdst into gsrc at the even pixels. */
 int bd_subsample2x_fwd(const void* src, int64_t src_pix_per_img, int64_t src_off, int Hs, int Ws, void* dst,

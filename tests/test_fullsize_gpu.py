@@ -126,6 +126,38 @@ def test_fcos_training_step_is_bitwise_reproducible_full_size():
     assert torch.equal(outs[0][1], outs[1][1])          # every gradient of the arena, bit for bit
 
 
+def test_faster_rcnn_training_step_is_bitwise_reproducible_full_size():
+    """Round 5: RoIAlign's backward sums every 8 x 8-pixel tile of the gradient pyramid over its RoI list in slot order
+    (bd_roi_align_bwd_bf16) instead of scattering with float atomics -- with the proposals' NMS, both samplers and the losses already in
+    fixed order, two runs of a Faster R-CNN step with the same sampling keys give bit-identical gradients."""
+    from basedet_amd.configs import FasterRCNNConfig
+    from basedet_amd.models import FasterRCNN, params as P
+    from basedet_amd.utils import DummyLoader
+    cfg = FasterRCNNConfig()
+    cfg.MODEL.BATCHSIZE = 2
+    params = P.init_faster_rcnn_params(cfg, 0, residual_gamma=0.25)
+    b = next(DummyLoader(2, (800, 1344), seed=0))
+    b["data"] = (b["data"] * 255).astype(np.float32)
+    Gmax = b["gt_boxes"].shape[1]
+    A_total, R = 268569, cfg.MODEL.RPN.TRAIN_POST_NMS_TOPK
+    rng = np.random.default_rng(11)
+    b["sample_keys"] = dict(rpn_pos=rng.random((2, A_total), dtype=np.float32), rpn_neg=rng.random((2, A_total), dtype=np.float32),
+                            rcnn_fg=rng.random((2, R + Gmax), dtype=np.float32), rcnn_bg=rng.random((2, R + Gmax), dtype=np.float32))
+    outs = []
+    for _ in range(2):
+        model = FasterRCNN(cfg, params=params)
+        assert model.deterministic_roi_bwd and not model.roi_bwd_pk
+        model(b)
+        model.backward()
+        torch.cuda.synchronize()
+        pl = model._cur
+        outs.append((model.arena.g.clone(), pl.s_rois.clone(), pl.s_labels.clone(), pl.g_P.clone()))
+    assert float(outs[0][0].abs().max()) > 0 and int((outs[0][2] > 0).sum()) > 0
+    for a, c in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a, c)
+    assert torch.equal(outs[0][0], outs[1][0])          # every gradient of the arena, bit for bit
+
+
 def test_anchor_grid_invariants_full_size():
     from basedet_amd import ops
     from oracle import box_ops

@@ -372,15 +372,15 @@ def test_faster_rcnn_minimize_runs():
 
 def test_faster_rcnn_roi_backward_variants_agree():
     """RoIAlign backward variants inside the model (dL/dP already holds the RPN head's gradient when the RoI contributions arrive):
-    the fp32 atomic scatter (the default), the deterministic gather and the packed-bf16 atomics (opt-in: running bf16 sums, ~10 %
-    faster step) must give the same parameter gradients for one step with identical sampling keys -- per parameter rel-L2 <= 2e-2
-    against the deterministic variant (observed: fp32 scatter <= 3e-3, packed bf16 <= 8e-3)."""
+    the tiled fixed-order sum (the default since round 5), the fp32 atomic scatter (the default of rounds 2-4) and the packed-bf16
+    atomics (opt-in: running bf16 sums) must give the same parameter gradients for one step with identical sampling keys -- per
+    parameter rel-L2 <= 2e-2 against the deterministic variant (observed: fp32 scatter <= 3e-3, packed bf16 <= 8e-3)."""
     from basedet_amd.models import FasterRCNN
     grads = {}
     for name in ("det", "fp32", "pk"):
         cfg, params, batch = _frcnn_setup(2, (128, 160), seed=3)
         model = FasterRCNN(cfg, params=params)
-        assert model.roi_bwd_pk is False and model.deterministic_roi_bwd is False          # the default is the fp32 scatter
+        assert model.roi_bwd_pk is False and model.deterministic_roi_bwd is True           # the default is the tiled fixed-order sum
         model.roi_bwd_pk = name == "pk"
         model.deterministic_roi_bwd = name == "det"
         pl = model._plan(2, 128, 160)

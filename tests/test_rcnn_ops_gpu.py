@@ -447,6 +447,19 @@ def test_roi_align_fwd_bwd():
     gbf2 = torch.empty_like(gbf)
     ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gbf2, ws)
     assert torch.equal(gbf, gbf2)
+    # accumulating form: added to what the buffer holds (one bf16 rounding of the total), pixels no sample reaches untouched
+    base = _bf16(rng.normal(0, 1, (N * ppi, C)).astype(np.float32))
+    gacc = base.cuda().clone()
+    ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, gacc, ws, accumulate=True)
+    ga = gacc.float().cpu().numpy().reshape(N, ppi, C)
+    bb = base.float().numpy().reshape(N, ppi, C)
+    o = 0
+    for l, (h, w) in enumerate(sizes[:nlev]):
+        np.testing.assert_allclose(ga[:, o:o + h * w].reshape(N, h, w, C), refg[l] + bb[:, o:o + h * w].reshape(N, h, w, C), rtol=2 ** -7, atol=2e-3)
+        untouched = (refg[l] == 0).all(-1)
+        assert np.array_equal(ga[:, o:o + h * w].reshape(N, h, w, C)[untouched], bb[:, o:o + h * w].reshape(N, h, w, C)[untouched])
+        o += h * w
+    assert np.array_equal(ga[:, o:], bb[:, o:])
 
 
 def test_subsample_and_convert():

@@ -59,15 +59,9 @@ def test_queued_weight_gradients_equal_the_per_layer_ones_bit_for_bit(kind):
     b = _keys(ref_model, batch, kind)
     ref = _grads(ref_model, b)
     assert float(ref.abs().max()) > 0
-    # RoIAlign's backward scatters with float atomics (Faster R-CNN): the FPN / backbone gradients below it are not bitwise reproducible
-    # from run to run; everything the queue touches is compared through the heads, which are
-    exact = kind != "faster_rcnn"
-
+    # (round 5: RoIAlign's backward is the tiled fixed-order sum -- Faster R-CNN is bitwise reproducible like the other two)
     def same(a, tag):
-        if exact:
-            assert torch.equal(a, ref), tag
-        else:
-            assert float((a.double() - ref.double()).norm() / ref.double().norm()) < 2e-3, tag
+        assert torch.equal(a, ref), tag
 
     for mode in ("bucket", 48 << 20):
         m = _build(kind, mode)
@@ -77,8 +71,7 @@ def test_queued_weight_gradients_equal_the_per_layer_ones_bit_for_bit(kind):
         second = _grads(m, b)                 # queued: every layer in the arena, one reduce per bucket (or per 48 MB)
         assert m._wq is not None and m._wq.pending() == 0
         same(first, (mode, "first")); same(second, (mode, "second"))
-        if exact:
-            assert torch.equal(first, second)
+        assert torch.equal(first, second)
         # the arena holds the LARGEST flush interval, not the sum over the pass
         total = sum(m._wq_need.values())
         assert peak < total, (peak, total)
