@@ -934,7 +934,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
     }
 }
 
-// Separable form of the scatter (round 3), 7 x 7 bins.  A bilinear weight factors into a row and a column part and every sample of a bin
+// Separable form of the scatter (round 3; the training default of rounds 3-4, since round 5 behind model.deterministic_roi_bwd = False: the
+// default is roi_align_bwd_tile_kernel below, which has no atomics), 7 x 7 bins.  A bilinear weight factors into a row and a column part and every sample of a bin
 // carries the same gradient, so the gradient of an RoI on its level is  dF = A^T (g / S^2) B  with A[ph][y] = sum of the row weights of bin
 // row ph's samples on pixel row y (B likewise for columns): ONE atomic per pixel of the RoI's footprint and channel -- an RoI on its own
 // level spans 7-14 pixels a side, ~80-260 pixels -- instead of one per distinct pixel of every bin (49 x ~9 = 441).  The scatter runs at the

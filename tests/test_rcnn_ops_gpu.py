@@ -375,6 +375,64 @@ def test_roi_align_bwd_pk_full_size():
     assert np.all(gk[:, o:] == 0) and np.array_equal(gk2[:, o:], b[:, o:])
 
 
+def test_roi_align_bwd_tiles_full_size():
+    """The training default since round 5 (bd_roi_align_bwd_bf16: per-tile RoI lists in slot order, sums in registers) at C4's sizes --
+    256 channels, 512 RoIs per image, P2..P5 of an 800x1344 input -- against the float64 adjoint of the oracle: written into a buffer full
+    of garbage (every pixel must be written), and added to an existing gradient (one bf16 rounding of the total; pixels no sample reaches
+    keep their bits).  The RoI set carries what stresses the tile lists: footprints hundreds of pixels long and two pixels high, the whole
+    image, zero-area and out-of-image boxes, empty slots.  Two launches give identical bits."""
+    ops = _ops()
+    rng = np.random.default_rng(12)
+    N, C, rpi = 2, 256, 512
+    sizes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    nlev = 4
+    geom = _geom(N, sizes)
+    ppi = geom.pix_per_img
+    rois = np.concatenate([_rand_boxes(rng, rpi, 1344, 800, 8, 700) for _ in range(N)], 0)
+    rois[0] = [0, 0, 1344, 800]                  # the whole image (P5: every tile of the level)
+    rois[1] = [0, 100, 1344, 109]                # 1344 x 9: sqrt(area) = 110 -> P2, a footprint 336 pixels long and 2-3 high
+    rois[2] = [40, 0, 52, 800]                   # 12 x 800 -> P2, 200 pixels high
+    rois[3] = [0, 300, 1344, 337]                # 1344 x 37 -> P3, 168 pixels long
+    rois[4] = [500, 500, 500, 620]               # zero area
+    rois[5] = [-300, -200, -20, -10]             # outside the image
+    rois[6] = [1300, 760, 1500, 900]             # hanging over the bottom-right corner
+    rois[rpi + 7] = [3, 3, 11, 9]                # smaller than one bin per pixel: every bin of a row lands on the same pixels
+    labels = np.ones(N * rpi, np.int32)
+    labels[rng.integers(8, N * rpi, 40)] = -1    # empty sample slots
+    bidx = np.repeat(np.arange(N), rpi)
+    gout = _bf16(rng.normal(0, 1, (N * rpi, 49, C)).astype(np.float32))
+    g_in = gout.float().numpy().copy()
+    g_in[labels < 0] = 0
+    shapes = [(N, h, w, C) for h, w in sizes[:nlev]]
+    refg = orc.roi_align_backward(g_in, shapes, rois, bidx, STRIDES[:nlev], 7, 7, 2)
+    ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(geom, rpi),), dtype=torch.uint8, device="cuda")
+    out = torch.full((N * ppi, C), 3.0, dtype=torch.bfloat16, device="cuda")
+    ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, out, ws)
+    out2 = torch.full((N * ppi, C), -5.0, dtype=torch.bfloat16, device="cuda")
+    ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, out2, ws)
+    assert torch.equal(out, out2)
+    base = _bf16(rng.normal(0, 0.5, (N * ppi, C)).astype(np.float32))
+    acc = base.clone().cuda()
+    ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, acc, ws, accumulate=True)
+    g1 = out.float().cpu().numpy().reshape(N, ppi, C)
+    g2 = acc.float().cpu().numpy().reshape(N, ppi, C)
+    b = base.float().numpy().reshape(N, ppi, C)
+    o = n_untouched = 0
+    for l, (h, w) in enumerate(sizes[:nlev]):
+        sl = slice(o, o + h * w)
+        ref_l = refg[l].reshape(N, h * w, C)
+        # an fp32 sum stored as bf16: half an ulp per element (2^-9 relative), rel-L2 ~1.1e-3
+        np.testing.assert_allclose(g1[:, sl], ref_l, rtol=2 ** -8, atol=2e-3)
+        assert np.linalg.norm(g1[:, sl] - ref_l) <= 2e-3 * np.linalg.norm(ref_l), l
+        np.testing.assert_allclose(g2[:, sl], ref_l + b[:, sl], rtol=2 ** -8, atol=4e-3)
+        untouched = (ref_l == 0).all(-1)
+        n_untouched += int(untouched.sum())
+        assert np.array_equal(g2[:, sl][untouched], b[:, sl][untouched])
+        o += h * w
+    assert n_untouched > 1000
+    assert np.all(g1[:, o:] == 0) and np.array_equal(g2[:, o:], b[:, o:])
+
+
 def test_roi_align_fwd_bwd():
     ops = _ops()
     rng = np.random.default_rng(5)
