@@ -121,6 +121,8 @@ SIGNATURES = {
     "bd_rpn_set_nms_per_level": (_I, [_I]),
     "bd_rcnn_sample_targets": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bd_roi_align_fwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "bd_conv1x1_thin_bwd_workspace_bytes": (_Z, []),
+    "bd_conv1x1_thin_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_roi_align_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "bd_roi_align_bwd_pk": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "bd_roi_align_bwd_bf16_workspace_bytes": (_Z, [_I, _I, _P, _P, _I]),

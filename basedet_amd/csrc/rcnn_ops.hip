@@ -1124,15 +1124,15 @@ __global__ __launch_bounds__(1024) void roi_tile_list_kernel(const int4* __restr
     if (!fill && lane == 0) tile_cnt[n * tpi + t] = cnt;
 }
 
-// exclusive scan of the tile counts (single workgroup, one contiguous run of counts per thread)
-__global__ __launch_bounds__(1024) void roi_tile_scan_kernel(const int* __restrict__ tile_cnt, int* __restrict__ tile_off, int ntiles) {
+// exclusive scan of the tile counts in two small launches: every workgroup scans its own 1024 counts (coalesced) and leaves their total;
+// the second launch adds the totals of the workgroups in front (at most a few dozen)
+__global__ __launch_bounds__(1024) void roi_tile_scan_local_kernel(const int* __restrict__ tile_cnt, int* __restrict__ tile_off, int ntiles,
+                                                                   int* __restrict__ chunk_tot) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (ntiles + 1023) / 1024;
-    const int i0 = tid * per, i1 = min(i0 + per, ntiles);
-    int s = 0;
-    for (int i = i0; i < i1; ++i) s += tile_cnt[i];
-    int inc = s;
+    const int i = blockIdx.x * 1024 + tid;
+    const int v = i < ntiles ? tile_cnt[i] : 0;
+    int inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(inc, o, 64);
@@ -1140,10 +1140,18 @@ __global__ __launch_bounds__(1024) void roi_tile_scan_kernel(const int* __restri
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    int before = inc - s;
+    int before = 0;
     for (int w = 0; w < wave; ++w) before += wsum[w];
-    for (int i = i0; i < i1; ++i) { tile_off[i] = before; before += tile_cnt[i]; }
-    if (tid == 1023) tile_off[ntiles] = before;
+    if (i < ntiles) tile_off[i] = before + inc - v;
+    if (tid == 1023) chunk_tot[blockIdx.x] = before + inc;
+}
+
+__global__ __launch_bounds__(1024) void roi_tile_scan_add_kernel(int* __restrict__ tile_off, int ntiles, const int* __restrict__ chunk_tot) {
+    int before = 0;
+    for (int b = 0; b < (int)blockIdx.x; ++b) before += chunk_tot[b];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < ntiles) tile_off[i] += before;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) tile_off[ntiles] = before + chunk_tot[blockIdx.x];
 }
 
 __global__ __launch_bounds__(64, 2) void roi_align_bwd_tile_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv, PyrTiles pt,
@@ -1688,12 +1696,13 @@ static int roi_tiles_per_img(int L_all, const int32_t* H, const int32_t* W) {
     return ts;
 }
 
-// workspace: tile counts | tile offsets (+1) | footprints (int4 per RoI slot) | tile lists (u16 slots)
+// workspace: tile counts | tile offsets (+1) | footprints (int4 per RoI slot) | tile lists (u16 slots) | totals of the 1024-tile scan chunks
 extern "C" size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L_all, const int32_t* lvl_h_host, const int32_t* lvl_w_host,
                                                         int rois_per_img) {
     if (N <= 0 || L_all <= 0 || L_all > BD_MAX_SEGS || rois_per_img <= 0 || !lvl_h_host || !lvl_w_host) return 256;
     const size_t ntiles = (size_t)N * roi_tiles_per_img(L_all, lvl_h_host, lvl_w_host);
-    return 2 * align256((ntiles + 1) * 4) + align256((size_t)N * rois_per_img * 16) + align256((size_t)N * rois_per_img * ROI_TILES_MAX * 2) + 256;
+    return 2 * align256((ntiles + 1) * 4) + align256((size_t)N * rois_per_img * 16) + align256((size_t)N * rois_per_img * ROI_TILES_MAX * 2) +
+           align256((ntiles / 1024 + 1) * 4) + 256;
 }
 
 extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int C, int L, int L_all, const int32_t* lvl_pix_off_host,
@@ -1735,7 +1744,10 @@ extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int 
     hipLaunchKernelGGL(roi_foot_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, rois, labels, total, lv, pt, foot);
     hipLaunchKernelGGL(roi_tile_list_kernel, dim3(cdiv(ts, 16), N), dim3(1024), 0, st, (const int4*)foot, rois_per_img, pt, 0, tile_cnt,
                        (const int*)tile_off, entries, cap);
-    hipLaunchKernelGGL(roi_tile_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)tile_cnt, tile_off, ntiles);
+    const int chunks = cdiv(ntiles, 1024);
+    int* chunk_tot = (int*)((unsigned char*)entries + align256((size_t)cap * 2));      // (behind the lists)
+    hipLaunchKernelGGL(roi_tile_scan_local_kernel, dim3(chunks), dim3(1024), 0, st, (const int*)tile_cnt, tile_off, ntiles, chunk_tot);
+    hipLaunchKernelGGL(roi_tile_scan_add_kernel, dim3(chunks), dim3(1024), 0, st, tile_off, ntiles, (const int*)chunk_tot);
     hipLaunchKernelGGL(roi_tile_list_kernel, dim3(cdiv(ts, 16), N), dim3(1024), 0, st, (const int4*)foot, rois_per_img, pt, 1, tile_cnt,
                        (const int*)tile_off, entries, cap);
     hipLaunchKernelGGL(roi_align_bwd_tile_kernel, dim3(ntiles * cdiv(C, 128)), dim3(64), 0, st, (const bf16_raw*)gout, (long long)pix_per_img,

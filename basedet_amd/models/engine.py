@@ -245,6 +245,18 @@ class ConvLayer:
         else:
             ops.conv2d_wgrad(d, x, g, self.gw, ws, row_scale=self.row_scale)
 
+    def thin_backward_ok(self, gin: Geom):
+        """True when bd_conv1x1_thin_bwd covers this layer on geometry gin: 1x1 / stride 1, 256 -> 16 (padded) channels, bf16, no BN scale,
+        every pixel row of the buffer (all levels of the pyramid, contiguous)."""
+        return (self.k == 1 and self.stride == 1 and self.pad == 0 and self.cin == 256 and self.cout == 16 and self.trainable
+                and self.row_scale is None and self.gb is not None and not (self.fp8 or self.fp8_1x1)
+                and sum(h * w for h, w in zip(gin.H, gin.W)) == gin.pix_per_img)
+
+    def thin_backward(self, x, g, gin: Geom, dx, ws):
+        """dx = (x > 0) * conv^T(g), dW, dbias in one pass over x (x = the ReLU output this layer reads).  Same results as
+        wgrad(x, g) + dgrad(g, mask=x) up to fp32 summation order."""
+        ops.conv1x1_thin_bwd(x, g, self.w, gin.pixels, self.cin, self.cout, dx, self.gw, self.gb, self.cout_real, ws)
+
     def wgrad_ws_bytes(self, gin, gout):
         d = self.desc(gin, gout)
         n = ops.conv2d_wgrad_bias_workspace_bytes(d) if self.gb is not None else ops.conv2d_wgrad_workspace_bytes(d)

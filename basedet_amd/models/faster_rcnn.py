@@ -78,6 +78,7 @@ class FasterRCNN(FPNDetector):
         # deterministic_roi_bwd = False restores the fp32 atomic scatter + conversion pass of rounds 2-4; roi_bwd_pk = True (bench.py
         # --roi-bwd-pk) the packed-bf16 atomics straight into the bf16 pyramid (running bf16 sums: rel-L2 0.6-0.9 % per level).
         self.deterministic_roi_bwd = True
+        self.thin_rpn_bwd = bool(m.get("THIN_RPN_BWD", True))     # RPN prediction layer: fused one-pass backward (0: the generic weight / data gradient kernels)
         self.roi_bwd_pk = False
         self._gen = torch.Generator(device=dev) if self.device.type == "cuda" else None
         if self._gen is not None:
@@ -298,8 +299,14 @@ class FasterRCNN(FPNDetector):
 
     def _rpn_head_backward(self, pl, ws, cws, first):
         pyr = pl.pyr
-        self._wgrad(self.rpn_pred, pl.rpn_t, pl.d_rpn_raw, pyr, pyr, ws, cws)
-        self.rpn_pred.dgrad(pl.d_rpn_raw, pyr, pyr, pl.g_rpn_t, mask=pl.rpn_t)
+        if self.thin_rpn_bwd and self.rpn_pred.thin_backward_ok(pyr):
+            # the prediction layer (256 -> 3 + 12 channels): data, weight and bias gradient in one pass over rpn_t (csrc/conv1x1_thin.hip)
+            if getattr(pl, "thin_ws", None) is None:
+                pl.thin_ws = torch.empty((ops.conv1x1_thin_bwd_workspace_bytes(),), dtype=torch.uint8, device=self.device)
+            self.rpn_pred.thin_backward(pl.rpn_t, pl.d_rpn_raw, pyr, pl.g_rpn_t, pl.thin_ws)
+        else:
+            self._wgrad(self.rpn_pred, pl.rpn_t, pl.d_rpn_raw, pyr, pyr, ws, cws)
+            self.rpn_pred.dgrad(pl.d_rpn_raw, pyr, pyr, pl.g_rpn_t, mask=pl.rpn_t)
         self._wgrad(self.rpn_conv, pl.P, pl.g_rpn_t, pyr, pyr, ws, cws)
         self.rpn_conv.dgrad(pl.g_rpn_t, pyr, pyr, pl.g_P, first=first)
 

@@ -479,6 +479,16 @@ def rcnn_sample_targets(rois, num_rois, gt_boxes, num_gt, keys_fg, keys_bg, num_
                                      ptr(out_targets), ptr(out_count), ptr(total_count), stream_ptr()), "bd_rcnn_sample_targets")
 
 
+def conv1x1_thin_bwd_workspace_bytes():
+    return int(L().bd_conv1x1_thin_bwd_workspace_bytes())
+
+
+def conv1x1_thin_bwd(x, g, w, M, Cin, Cout, dx, dw, dbias, cout_real, ws):
+    """Data + weight + bias gradient of a thin 1x1 prediction layer in one pass over its (ReLU-output) input: bd_conv1x1_thin_bwd."""
+    check(L().bd_conv1x1_thin_bwd(ptr(x), ptr(g), ptr(w), int(M), Cin, Cout, ptr(dx), ptr(dw), ptr(dbias), cout_real, ptr(ws),
+                                  ws.numel() * ws.element_size(), stream_ptr()), "bd_conv1x1_thin_bwd")
+
+
 def roi_align_fwd(feat, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_img, pool, sample_points, out):
     R = rois.shape[0]
     check(L().bd_roi_align_fwd(ptr(feat), geom.pix_per_img, Cn, nlev, i32arr(geom.off[:nlev]), i32arr(geom.H[:nlev]),

@@ -641,6 +641,18 @@ int bd_weight_pack_fp8_t(const float* w, const float* row_scale, int Cout, int R
                          bd_stream_t stream);
 int bd_conv2d_dgrad_fp8(const bd_conv_desc* d, const void* g8, const void* wq_t, const float* wscale_t, const void* add, const void* mask,
                         void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream);
+/* Backward of a THIN 1x1 prediction layer in one pass over its input (Faster R-CNN's RPN objectness + box deltas: rpn.py:60-68 under
+ * autograd; 3 + 12 output channels padded to 16 over every pixel of the pyramid).  x: bf16 [M][Cin] the layer's input, the output of the
+ * ReLU in front of it (rpn.py:70-75) -- its non-zero pattern gates dx; g: bf16 [M][Cout] dL/d(prediction); w: the fp32 master weights
+ * [Cout][Cin] (rounded to bf16 in the kernel, as bd_weight_pack does).
+ *   dx[p][c] = (x[p][c] > 0) * sum_o g[p][o] w[o][c]      dw[o][c] = sum_p g[p][o] x[p][c]      dbias[o] = sum_p g[p][o] (may be NULL)
+ * Rows >= cout_real of dw / dbias are written as zeros.  Supported: Cin == 256, Cout == 16.  Fixed summation order (per-workgroup
+ * partial sums in ws, added in workgroup order): bitwise reproducible.  Replaces bd_conv2d_wgrad_bias + bd_conv2d_dgrad_ex(EPI_MASK)
+ * for such a layer (1.05 -> 0.3 ms at C4's 1.43 M pixels). */
+size_t bd_conv1x1_thin_bwd_workspace_bytes(void);
+int bd_conv1x1_thin_bwd(const void* x, const void* g, const float* w, int64_t M, int Cin, int Cout, void* dx, float* dw, float* dbias,
+                        int cout_real, void* ws, size_t ws_bytes, bd_stream_t stream);
+
 /* fp8 form of the dense 1x1 launches (the ResNet bottleneck's conv1 / conv3, models/cls/resnet.py:70-113; 1x1 / stride 1 / pad 0 over one
  * dense level, K % 128 == 0, produced channels % 32 == 0).  mode 0 = forward: xq = e4m3 twin of the NHWC input (x * act_scale), wq /
  * wscale from bd_weight_pack_fp8 (RS = 1); mode 1 = data gradient: xq = e5m2 twin of the output gradient (g * grad_scale), wq / wscale
