@@ -122,6 +122,7 @@ SIGNATURES = {
     "bd_rcnn_sample_targets": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bd_roi_align_fwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "bd_conv1x1_thin_bwd_workspace_bytes": (_Z, []),
+    "bd_conv1x1_thin_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "bd_conv1x1_thin_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_roi_align_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "bd_roi_align_bwd_pk": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

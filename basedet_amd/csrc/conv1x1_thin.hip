@@ -150,9 +150,59 @@ __global__ __launch_bounds__(256) void conv1x1_thin_reduce_kernel(const float* _
     else if (e < TO * TCIN + TO && dbias) dbias[e - TO * TCIN] = e - TO * TCIN < cout_real ? s : 0.f;
 }
 
+// Forward of the same layer: y[p][o] = sum_c x[p][c] W[o][c] + bias[o].  One wave per group of 16 pixels and K step of 32 channels:
+// v_mfma_f32_16x16x32_bf16 with the weights on the rows (all eight K steps of W in 32 registers) and the pixels on the columns -- the B
+// operand of lane (p, q) is the 16 bytes x[p][32 k + 8 q ..], loaded straight from memory, one group ahead -- so that every lane ends up
+// with 4 consecutive output channels of its pixel (an 8-byte store; a group's 16 x 32 bytes are contiguous).
+__global__ __launch_bounds__(256) void conv1x1_thin_fwd_kernel(const bf16_raw* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               bf16_raw* __restrict__ y, long long M, int groups) {
+    const int lane = threadIdx.x & 63, px = lane & 15, q = lane >> 4;
+    bf16x8_t a[TW];
+#pragma unroll
+    for (int k = 0; k < TW; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[k][i] = (__bf16)w[px * TCIN + 32 * k + 8 * q + i];
+    f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b4 = (f32x4_t){bias[4 * q], bias[4 * q + 1], bias[4 * q + 2], bias[4 * q + 3]};
+    const int nw = gridDim.x * 4;
+    int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    u32x4_t cur[TW], nxt[TW];
+    auto load = [&](u32x4_t (&v)[TW], int g) {
+        long long row = (long long)g * 16 + px;
+        if (g >= groups || row >= M) row = 0;
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(x + row * TCIN + 8 * q);
+#pragma unroll
+        for (int k = 0; k < TW; ++k) v[k] = src[4 * k];
+    };
+    load(cur, grp);
+    for (; grp < groups; grp += nw) {
+        load(nxt, grp + nw);
+        f32x4_t acc = b4;
+#pragma unroll
+        for (int k = 0; k < TW; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], __builtin_bit_cast(bf16x8_t, cur[k]), acc, 0, 0, 0);
+        const long long row = (long long)grp * 16 + px;
+        if (row < M) *reinterpret_cast<u32x2_t*>(y + row * TO + 4 * q) = (u32x2_t){pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+#pragma unroll
+        for (int k = 0; k < TW; ++k) cur[k] = nxt[k];
+    }
+}
+
 int thin_grid() { return bd_num_cus(); }
 
 }  // namespace
+
+extern "C" int bd_conv1x1_thin_fwd(const void* x, const float* w, const float* bias, int64_t M, int Cin, int Cout, void* y, bd_stream_t stream) {
+    BD_REQUIRE(x && w && y, "conv1x1_thin_fwd: null pointer");
+    BD_REQUIRE(Cin == TCIN && Cout == TO && M > 0 && M < (1ll << 31) * 16, "conv1x1_thin_fwd: the layer is %d -> %d channels (supported: %d -> %d)",
+               Cin, Cout, TCIN, TO);
+    const int groups = (int)((M + 15) / 16);
+    int grid = bd_num_cus() * 4;
+    if (grid > (groups + 3) / 4) grid = (groups + 3) / 4;
+    hipLaunchKernelGGL(conv1x1_thin_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x, w, bias, (bf16_raw*)y, (long long)M, groups);
+    BD_CHECK_LAUNCH("bd_conv1x1_thin_fwd");
+    bd_note_kernel("conv1x1_thin_fwd_kernel");
+    return BD_OK;
+}
 
 extern "C" size_t bd_conv1x1_thin_bwd_workspace_bytes(void) { return (size_t)thin_grid() * (TO * TCIN + TO) * 4 + 256; }
 

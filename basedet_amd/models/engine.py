@@ -252,6 +252,10 @@ class ConvLayer:
                 and self.row_scale is None and self.gb is not None and not (self.fp8 or self.fp8_1x1)
                 and sum(h * w for h, w in zip(gin.H, gin.W)) == gin.pix_per_img)
 
+    def thin_forward(self, x, gin: Geom, y):
+        """y = conv(x) + bias on the thin-layer kernel (fp32 master weights rounded to bf16 in the kernel, as pack() does)."""
+        ops.conv1x1_thin_fwd(x, self.w, self.b, gin.pixels, self.cin, self.cout, y)
+
     def thin_backward(self, x, g, gin: Geom, dx, ws):
         """dx = (x > 0) * conv^T(g), dW, dbias in one pass over x (x = the ReLU output this layer reads).  Same results as
         wgrad(x, g) + dgrad(g, mask=x) up to fp32 summation order."""

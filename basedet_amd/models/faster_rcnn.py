@@ -153,7 +153,10 @@ class FasterRCNN(FPNDetector):
     def head_forward(self, pl):
         """RPN.forward predictions (rpn.py:78-100), all five levels per launch."""
         self.rpn_conv.forward(pl.P, pl.pyr, pl.pyr, pl.rpn_t, relu=True)
-        self.rpn_pred.forward(pl.rpn_t, pl.pyr, pl.pyr, pl.rpn_raw)
+        if self.thin_rpn_bwd and self.rpn_pred.thin_backward_ok(pl.pyr):        # (the prediction layer on its own kernels: csrc/conv1x1_thin.hip)
+            self.rpn_pred.thin_forward(pl.rpn_t, pl.pyr, pl.rpn_raw)
+        else:
+            self.rpn_pred.forward(pl.rpn_t, pl.pyr, pl.pyr, pl.rpn_raw)
 
     def _keys(self, inputs, name, shape):
         sk = inputs.get("sample_keys") if isinstance(inputs, dict) else None

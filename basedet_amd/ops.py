@@ -479,6 +479,10 @@ def rcnn_sample_targets(rois, num_rois, gt_boxes, num_gt, keys_fg, keys_bg, num_
                                      ptr(out_targets), ptr(out_count), ptr(total_count), stream_ptr()), "bd_rcnn_sample_targets")
 
 
+def conv1x1_thin_fwd(x, w, bias, M, Cin, Cout, y):
+    check(L().bd_conv1x1_thin_fwd(ptr(x), ptr(w), ptr(bias), int(M), Cin, Cout, ptr(y), stream_ptr()), "bd_conv1x1_thin_fwd")
+
+
 def conv1x1_thin_bwd_workspace_bytes():
     return int(L().bd_conv1x1_thin_bwd_workspace_bytes())
 

@@ -219,6 +219,12 @@ class KernelTimer:
         # GroupNorm + ReLU of the FCOS towers (bd_groupnorm_fwd: statistics + apply; _bwd: sums + apply; every operand once: y, z / dz, y, dy)
         wrap_stream("groupnorm_fwd", "gn_stats + gn_apply (bd_groupnorm_fwd)", lambda k: k["y"].numel() * 2.0 * 2)
         wrap_stream("groupnorm_bwd", "gn_bwd_partial + gn_bwd_apply (bd_groupnorm_bwd)", lambda k: k["y"].numel() * 2.0 * 3)
+        # Faster R-CNN (round 5).  RPN prediction layer on its own kernels: x once (+ dx once) + the 16-channel side; RoIAlign backward as a
+        # tiled sum: the pooled gradients once + the touched part of the gradient pyramid (read + written; counted as the pooled bytes again)
+        wrap_stream("conv1x1_thin_fwd", "conv1x1_thin_fwd_kernel", lambda k: k["M"] * (k["Cin"] + k["Cout"]) * 2.0)
+        wrap_stream("conv1x1_thin_bwd", "conv1x1_thin_bwd_kernel", lambda k: k["M"] * (2 * k["Cin"] + k["Cout"]) * 2.0)
+        wrap_stream("roi_align_bwd_bf16", "roi_align_bwd_tile_kernel", lambda k: k["gout"].numel() * 2.0 * 2)
+        wrap_stream("roi_align_fwd", "roi_align_fwd_kernel", lambda k: k["out"].numel() * 2.0 * 2)
         wrap_stream("pad_normalize", "pad_normalize_kernel",
                     lambda k: k["x"].numel() * 4.0 + k["x"].shape[0] * (k["Hp"] + 6) * (k["Wp"] + 8) * 8.0)
 

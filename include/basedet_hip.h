@@ -650,6 +650,8 @@ int bd_conv2d_dgrad_fp8(const bd_conv_desc* d, const void* g8, const void* wq_t,
  * partial sums in ws, added in workgroup order): bitwise reproducible.  Replaces bd_conv2d_wgrad_bias + bd_conv2d_dgrad_ex(EPI_MASK)
  * for such a layer (1.05 -> 0.3 ms at C4's 1.43 M pixels). */
 size_t bd_conv1x1_thin_bwd_workspace_bytes(void);
+/* Forward of the same layer: y[p][o] = sum_c x[p][c] w[o][c] + bias[o] (bias may be NULL), bf16 [M][Cout]; Cin == 256, Cout == 16. */
+int bd_conv1x1_thin_fwd(const void* x, const float* w, const float* bias, int64_t M, int Cin, int Cout, void* y, bd_stream_t stream);
 int bd_conv1x1_thin_bwd(const void* x, const void* g, const float* w, int64_t M, int Cin, int Cout, void* dx, float* dw, float* dbias,
                         int cout_real, void* ws, size_t ws_bytes, bd_stream_t stream);
 

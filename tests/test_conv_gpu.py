@@ -869,6 +869,12 @@ def test_thin_1x1_backward_in_one_pass(M):
         outs.append((dx.clone(), dw.clone(), db.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+    # forward of the same layer (bd_conv1x1_thin_fwd)
+    bias = rng.normal(0, 0.1, (Cout,)).astype(np.float32)
+    y = torch.full((M, Cout), 9.0, dtype=torch.bfloat16, device="cuda")
+    ops.conv1x1_thin_fwd(xd, wd, torch.from_numpy(bias).cuda(), M, Cin, Cout, y)
+    y_ref = xb.astype(np.float64) @ wb.astype(np.float64).T + bias
+    assert rel_l2(y.float().cpu(), torch.from_numpy(y_ref)) <= 3e-3
     dx_ref = (gb.astype(np.float64) @ wb.astype(np.float64)) * (xb > 0)
     dw_ref = gb.astype(np.float64).T @ xb.astype(np.float64)
     db_ref = gb.astype(np.float64).sum(0)
