@@ -103,6 +103,9 @@ __global__ __launch_bounds__(1024) void fa_gt_kernel(const bf16_raw* __restrict_
     bool pos_only = true;
     auto key = [&](int i, bool& valid) -> unsigned int {
         const Box ab = ld_box(anchors + 4ll * i);
+        // round 5: an anchor without a positive-width intersection has IoU exactly 0 (box_inter) and is not a candidate of the first pass --
+        // decided on four min / max before the areas and the division; anchors come in (level, y, x) order, so whole waves leave here
+        if (pos_only && !(fminf(gb.x2, ab.x2) > fmaxf(gb.x1, ab.x1) && fminf(gb.y2, ab.y2) > fmaxf(gb.y1, ab.y1))) { valid = false; return 0u; }
         const float u = box_iou_dev(gb, garea, ab, box_area(ab));
         valid = !pos_only || u > 0.f;
         return f32_asc_key(u);
@@ -237,6 +240,20 @@ __global__ __launch_bounds__(256) void fa_neg_kernel(const bf16_raw* __restrict_
     const int nel = (A - a0 < FA_NEG_ANCH ? A - a0 : FA_NEG_ANCH) * K;
     const long long e0 = ((long long)n * A + a0) * K;
     auto elem = [&](float x, float bpv, float& g) -> float {
+        if (gamma == 2.f) {
+            // round 5: the default focal exponent on the raw transcendental instructions (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp), as
+            // focal_g2_kernel (losses.hip): expf / logf / the two divisions compile to ~80 vector instructions per logit, this to ~25
+            const float e = __builtin_amdgcn_exp2f(-x * 1.4426950408889634f);
+            const float s = __builtin_amdgcn_rcpf(1.f + e);
+            const float keep = 1.f - bpv;
+            const float q = s * keep;
+            const float om = 1.f - q;
+            const float nl = -0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(om, FLT_MIN));
+            const float qg = q * q;
+            const float dq = 2.f * q * nl + (om > FLT_MIN ? qg * __builtin_amdgcn_rcpf(om) : 0.f);
+            g = scale * dq * s * (1.f - s) * keep;
+            return qg * nl;
+        }
         const float s = sigmoidf_(x);
         const float keep = 1.f - bpv;
         const float q = s * keep;
