@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_sep_kernel(const bf16_raw* 
 // ------------------------------------------------------------------------------------------------------------
 constexpr int RT = 8;                    // tile side
 constexpr int ROI_LIST_MAX = 512;        // RoI slots per image (the footprints of an image sit in LDS)
-constexpr int ROI_TILES_MAX = 96;        // tile-list entries reserved per RoI slot (an elongated 336 x 2 footprint on P2: 43 x 2 tiles)
+// tile-list entries reserved per RoI slot = the tiles of the largest level: no RoI can touch more, the lists cannot overflow (typical: ~11)
 struct PyrTiles { int pix_off[BD_MAX_SEGS]; int H[BD_MAX_SEGS]; int W[BD_MAX_SEGS]; int tile_start[BD_MAX_SEGS + 1]; int tiles_x[BD_MAX_SEGS]; int L; };
 
 // conservative tile range of the sample footprint of every RoI slot on its level (samples clamp into the map: the range as well):
@@ -1695,13 +1695,18 @@ static int roi_tiles_per_img(int L_all, const int32_t* H, const int32_t* W) {
     for (int l = 0; l < L_all; ++l) ts += cdiv(W[l], RT) * cdiv(H[l], RT);
     return ts;
 }
+static int roi_tiles_max_level(int L_all, const int32_t* H, const int32_t* W) {
+    int m = 1;
+    for (int l = 0; l < L_all; ++l) m = std::max(m, cdiv(W[l], RT) * cdiv(H[l], RT));
+    return m;
+}
 
 // workspace: tile counts | tile offsets (+1) | footprints (int4 per RoI slot) | tile lists (u16 slots) | totals of the 1024-tile scan chunks
 extern "C" size_t bd_roi_align_bwd_bf16_workspace_bytes(int N, int L_all, const int32_t* lvl_h_host, const int32_t* lvl_w_host,
                                                         int rois_per_img) {
     if (N <= 0 || L_all <= 0 || L_all > BD_MAX_SEGS || rois_per_img <= 0 || !lvl_h_host || !lvl_w_host) return 256;
     const size_t ntiles = (size_t)N * roi_tiles_per_img(L_all, lvl_h_host, lvl_w_host);
-    return 2 * align256((ntiles + 1) * 4) + align256((size_t)N * rois_per_img * 16) + align256((size_t)N * rois_per_img * ROI_TILES_MAX * 2) +
+    return 2 * align256((ntiles + 1) * 4) + align256((size_t)N * rois_per_img * 16) + align256((size_t)N * rois_per_img * roi_tiles_max_level(L_all, lvl_h_host, lvl_w_host) * 2) +
            align256((ntiles / 1024 + 1) * 4) + 256;
 }
 
@@ -1739,7 +1744,9 @@ extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int 
     int* tile_off = (int*)(wb + align256(((size_t)ntiles + 1) * 4));
     int4* foot = (int4*)(wb + 2 * align256(((size_t)ntiles + 1) * 4));
     unsigned short* entries = (unsigned short*)((unsigned char*)foot + align256((size_t)total * 16));
-    const int cap = total * ROI_TILES_MAX;
+    const long long cap_ll = (long long)total * roi_tiles_max_level(L_all, lvl_h_host, lvl_w_host);
+    BD_REQUIRE(cap_ll < 0x7fffffffll, "roi_align_bwd_bf16: tile lists too large");
+    const int cap = (int)cap_ll;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(roi_foot_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, rois, labels, total, lv, pt, foot);
     hipLaunchKernelGGL(roi_tile_list_kernel, dim3(cdiv(ts, 16), N), dim3(1024), 0, st, (const int4*)foot, rois_per_img, pt, 0, tile_cnt,

@@ -433,6 +433,42 @@ def test_roi_align_bwd_tiles_full_size():
     assert np.all(g1[:, o:] == 0) and np.array_equal(g2[:, o:], b[:, o:])
 
 
+def test_roi_align_bwd_tiles_long_lists():
+    """Tile lists far beyond one 64-RoI staging chunk: all 512 RoIs of an image are slivers stacked on the same rows of P2 / P3 (every
+    tile of those rows lists hundreds of them, each RoI touches ~44 tiles) -- the chunked list staging of roi_align_bwd_tile_kernel and
+    the list capacity (sized so that it cannot overflow) against the float64 adjoint."""
+    ops = _ops()
+    rng = np.random.default_rng(21)
+    N, C, rpi = 1, 64, 512
+    sizes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    nlev = 4
+    geom = _geom(N, sizes)
+    ppi = geom.pix_per_img
+    y0 = rng.uniform(100, 140, rpi).astype(np.float32)
+    hh = rng.uniform(6, 9, rpi).astype(np.float32)
+    rois = np.stack([rng.uniform(0, 20, rpi), y0, rng.uniform(1300, 1344, rpi), y0 + hh], 1).astype(np.float32)
+    rois[256:, 3] = rois[256:, 1] + rng.uniform(10, 30, 256).astype(np.float32)      # sqrt(area) >= 112: P3
+    labels = np.ones(N * rpi, np.int32)
+    bidx = np.zeros(rpi, np.int64)
+    lev = orc.assign_roi_levels(rois, STRIDES[:nlev])
+    assert (lev == 0).sum() > 100 and (lev == 1).sum() > 100
+    gout = _bf16(rng.normal(0, 1, (N * rpi, 49, C)).astype(np.float32))
+    refg = orc.roi_align_backward(gout.float().numpy(), [(N, h, w, C) for h, w in sizes[:nlev]], rois, bidx, STRIDES[:nlev], 7, 7, 2)
+    ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(geom, rpi),), dtype=torch.uint8, device="cuda")
+    out = torch.full((N * ppi, C), 3.0, dtype=torch.bfloat16, device="cuda")
+    ops.roi_align_bwd_bf16(gout.cuda(), geom, nlev, STRIDES, C, _dev(rois), _dev(labels), rpi, (7, 7), 2, out, ws)
+    g1 = out.float().cpu().numpy().reshape(N, ppi, C)
+    o = 0
+    for l, (h, w) in enumerate(sizes[:nlev]):
+        ref_l = refg[l].reshape(N, h * w, C)
+        if np.abs(ref_l).max() > 0:
+            assert np.linalg.norm(g1[:, o:o + h * w] - ref_l) <= 2e-3 * np.linalg.norm(ref_l), l
+        else:
+            assert np.all(g1[:, o:o + h * w] == 0)
+        o += h * w
+    assert np.all(g1[:, o:] == 0)
+
+
 def test_roi_align_fwd_bwd():
     ops = _ops()
     rng = np.random.default_rng(5)
