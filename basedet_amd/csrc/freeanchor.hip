@@ -25,7 +25,7 @@ namespace {
 constexpr int FA_MAX_BUCKET = 64;
 constexpr int FA_NEG_ANCH = 64;          // anchors per negative-loss workgroup
 
-struct FaWs { size_t thresh2, bag_idx, bag_grad, pos_loss, neg_part, total; };
+struct FaWs { size_t thresh2, bag_idx, bag_grad, pos_loss, neg_part, maxiou, total; };
 inline FaWs fa_layout(int N, int Gmax, int bucket, int A) {
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     FaWs w{};
@@ -35,6 +35,7 @@ inline FaWs fa_layout(int N, int Gmax, int bucket, int A) {
     w.bag_grad = o; o = up(o + sizeof(float) * (size_t)N * Gmax * bucket * 5);
     w.pos_loss = o; o = up(o + sizeof(float) * N * Gmax);
     w.neg_part = o; o = up(o + sizeof(float) * (size_t)N * cdiv(A, FA_NEG_ANCH));
+    w.maxiou = o; o = up(o + sizeof(unsigned int) * N * Gmax);
     w.total = o;
     return w;
 }
@@ -54,17 +55,58 @@ __device__ __forceinline__ int total_fg(const int* num_gt, int N) {
     return s;
 }
 
+// (a) of fa_gt_kernel's job, round 5: max over all anchors of IoU(gt, decoded prediction) for EVERY gt of the image in one sweep -- a
+// prediction is decoded once (two exponentials) and met with all gts, instead of once per gt in that gt's workgroup; the maximum of
+// non-negative floats is the maximum of their bit patterns, whatever the order: atomicMax, same bits as the per-gt loop
+__global__ __launch_bounds__(256) void fa_maxiou_kernel(const bf16_raw* __restrict__ offsets, int box_ld, int apix, const float* __restrict__ anchors,
+                                                        int A, const float* __restrict__ gt, const int* __restrict__ num_gt, int Gmax,
+                                                        Coder coder, unsigned int* __restrict__ maxiou) {
+    __shared__ f32x4_t s_gt[256];
+    const int n = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    const int G = num_gt[n];
+    if (G <= 0) return;
+    Box p{0.f, 0.f, 0.f, 0.f};
+    float parea = 0.f;
+    if (a < A) {
+        const Box ab = ld_box(anchors + 4ll * a);
+        const f32x4_t pb = decode_dev(ab, ld_offsets(offsets, (long long)n * (A / apix), a, apix, box_ld), coder);
+        p = Box{pb[0], pb[1], pb[2], pb[3]};
+        parea = box_area(p);
+    }
+    for (int g0 = 0; g0 < G; g0 += 256) {          // the image's gts through LDS, 256 at a time (a scalar load per gt and wave cost 2 us each)
+    __syncthreads();
+    if (g0 + (int)threadIdx.x < G) {
+        const float* gp = gt + ((long long)n * Gmax + g0 + threadIdx.x) * 5;
+        s_gt[threadIdx.x] = (f32x4_t){gp[0], gp[1], gp[2], gp[3]};
+    }
+    __syncthreads();
+    const int g1 = G - g0 < 256 ? G : g0 + 256;
+    for (int g = g0; g < g1; ++g) {
+        const f32x4_t gv = s_gt[g - g0];
+        const Box gb{gv[0], gv[1], gv[2], gv[3]};
+        // 64 consecutive anchors sit on ~7 neighbouring pixels: for most gts no prediction of the wave has a positive-width intersection
+        // (IoU exactly 0, box_inter) -- decided on four min / max and a ballot, before areas, division, reduction and atomic
+        const bool hit = a < A && fminf(gb.x2, p.x2) > fmaxf(gb.x1, p.x1) && fminf(gb.y2, p.y2) > fmaxf(gb.y1, p.y1);
+        if (__ballot(hit) == 0ull) continue;
+        float u = hit ? box_iou_dev(gb, box_area(gb), p, parea) : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) u = fmaxf(u, __shfl_xor(u, o, 64));
+        if ((threadIdx.x & 63) == 0 && u > 0.f) atomicMax(&maxiou[n * Gmax + g], __float_as_uint(u));
+    }
+    }
+}
+
 __global__ __launch_bounds__(1024) void fa_gt_kernel(const bf16_raw* __restrict__ logits, const bf16_raw* __restrict__ offsets,
                                                      int box_ld, int apix, const float* __restrict__ anchors, int A, int K,
                                                      const float* __restrict__ gt, const int* __restrict__ num_gt, int N, int Gmax,
                                                      Coder coder, float iou_thresh, int bucket, float beta, float reg_weight,
-                                                     float alpha, float* __restrict__ thresh2, int* __restrict__ bag_idx,
-                                                     float* __restrict__ bag_grad, float* __restrict__ pos_loss) {
+                                                     float alpha, const unsigned int* __restrict__ maxiou, float* __restrict__ thresh2,
+                                                     int* __restrict__ bag_idx, float* __restrict__ bag_grad, float* __restrict__ pos_loss) {
     __shared__ unsigned int hist[256];
     __shared__ int sh[8];
     __shared__ int wcnt[16];
     __shared__ float red[16];
-    __shared__ int s_idx[FA_MAX_BUCKET];
+    __shared__ int s_idx[FA_MAX_BUCKET], s_eq[FA_MAX_BUCKET];
     __shared__ float s_p[FA_MAX_BUCKET], s_w[FA_MAX_BUCKET];
     __shared__ float s_bag[2];
     const int tid = threadIdx.x, g = blockIdx.x, n = blockIdx.y;
@@ -79,23 +121,8 @@ __global__ __launch_bounds__(1024) void fa_gt_kernel(const bf16_raw* __restrict_
     const int cls = (int)gp[4] - 1;
     const long long pix0 = (long long)n * (A / apix);
 
-    // (a) max IoU of the gt with the decoded predictions
-    float mx = 0.f;
-    for (int a = tid; a < A; a += 1024) {
-        const Box ab = ld_box(anchors + 4ll * a);
-        const f32x4_t pb = decode_dev(ab, ld_offsets(offsets, pix0, a, apix, box_ld), coder);
-        const Box p{pb[0], pb[1], pb[2], pb[3]};
-        mx = fmaxf(mx, box_iou_dev(gb, garea, p, box_area(p)));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    if (tid == 0) {
-        float m = red[0];
-        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-        thresh2[slot] = fminf(fmaxf(m, iou_thresh + 1e-7f), 1.f);
-    }
+    // (a) max IoU of the gt with the decoded predictions: fa_maxiou_kernel; here the clip (:58-63)
+    if (tid == 0) thresh2[slot] = fminf(fmaxf(__uint_as_float(maxiou[slot]), iou_thresh + 1e-7f), 1.f);
 
     // (b) the bag: `bucket` largest IoU(gt, anchor), ascending anchor index.  Nearly every anchor has IoU exactly 0 with a given gt:
     // counted into the radix histograms they would all hit one LDS bin (same-address atomics serialise), so the selection first runs
@@ -115,16 +142,30 @@ __global__ __launch_bounds__(1024) void fa_gt_kernel(const bf16_raw* __restrict_
         pos_only = false;
         r = radix_select_largest(A, bucket, 4, key, hist, sh);
     }
-    // members above the threshold: unordered collection; members equal to it: the first need_eq in index order
-    if (tid == 0) sh[4] = 0;
+    // members above the threshold: unordered collection; members equal to it: the first need_eq in index order.  Round 5: the same sweep
+    // also lists the anchors AT the threshold (IoUs are floats: almost always exactly need_eq = 1 of them) -- with at most 64 of them
+    // the ordered walk over all anchors below (two barriers per 1024 anchors, half of A on average) is not needed
+    if (tid == 0) { sh[4] = 0; sh[5] = 0; }
     __syncthreads();
     for (int i = tid; i < A; i += 1024) {
         bool valid; const unsigned int kv = key(i, valid);
         if (valid && (r.take_all || kv > r.T)) { const int q = atomicAdd(&sh[4], 1); if (q < FA_MAX_BUCKET) s_idx[q] = i; }
+        else if (valid && kv == r.T) { const int q = atomicAdd(&sh[5], 1); if (q < FA_MAX_BUCKET) s_eq[q] = i; }
     }
     __syncthreads();
     int base = sh[4];
-    if (!r.take_all && r.need_eq > 0) {
+    const int n_eq = sh[5];
+    if (!r.take_all && r.need_eq > 0 && n_eq <= FA_MAX_BUCKET) {
+        if (tid == 0) {
+            for (int x = 1; x < n_eq; ++x) {                         // ascending anchor index
+                const int v = s_eq[x]; int y = x - 1;
+                while (y >= 0 && s_eq[y] > v) { s_eq[y + 1] = s_eq[y]; --y; }
+                s_eq[y + 1] = v;
+            }
+            for (int x = 0; x < r.need_eq && x < n_eq; ++x) if (base + x < FA_MAX_BUCKET) s_idx[base + x] = s_eq[x];
+        }
+        base += r.need_eq;
+    } else if (!r.take_all && r.need_eq > 0) {
         int eq_base = 0;
         for (int c0 = 0; c0 < A && eq_base < r.need_eq; c0 += 1024) {       // eq_base is workgroup-uniform
             const int i = c0 + tid;
@@ -363,9 +404,13 @@ extern "C" int bd_freeanchor_loss_fwd_bwd(const void* logits, const void* offset
     hipStream_t st = (hipStream_t)stream;
     const int neg_blocks = cdiv(A, FA_NEG_ANCH);
     (void)hipMemsetAsync(d_offsets, 0, (size_t)N * (A / anchors_per_pix) * box_ld * sizeof(bf16_raw), st);
+    unsigned int* maxiou = (unsigned int*)(wb + w.maxiou);
+    (void)hipMemsetAsync(maxiou, 0, sizeof(unsigned int) * N * Gmax, st);
+    hipLaunchKernelGGL(fa_maxiou_kernel, dim3(cdiv(A, 256), N), dim3(256), 0, st, (const bf16_raw*)offsets, box_ld, anchors_per_pix, anchors, A,
+                       gt, num_gt, Gmax, coder, maxiou);
     hipLaunchKernelGGL(fa_gt_kernel, dim3(Gmax, N), dim3(1024), 0, st, (const bf16_raw*)logits, (const bf16_raw*)offsets, box_ld,
                        anchors_per_pix, anchors, A, K, gt, num_gt, N, Gmax, coder, iou_thresh, bucket, beta, reg_weight, alpha,
-                       thresh2, bag_idx, bag_grad, pos_loss);
+                       (const unsigned int*)maxiou, thresh2, bag_idx, bag_grad, pos_loss);
     hipLaunchKernelGGL(fa_neg_kernel, dim3(neg_blocks, N), dim3(256), (size_t)FA_NEG_ANCH * K * 8, st, (const bf16_raw*)logits,
                        (const bf16_raw*)offsets, box_ld, anchors_per_pix, anchors, A, K, gt, num_gt, N, Gmax, coder, iou_thresh,
                        bucket, alpha, gamma, thresh2, neg_part, (bf16_raw*)d_logits);

@@ -220,10 +220,22 @@ class FasterRCNN(FPNDetector):
         # profiles/r05_frcnn_ab.txt -- the persistent one-workgroup-per-CU convolution kernels keep the box chain's many small grids
         # waiting for a CU, and the box chain is the critical path; that schedule also failed the bench-batch parity test once.)
         side = self._tstream if (self.async_wgrad and self._tstream is not None) else None
+        S = m.RCNN.NUM_ROIS
+        key_ld = pl.rois.shape[1] + Gmax
+
+        def sample():
+            ops.rcnn_sample_targets(pl.rois, pl.num_rois, gt, num_gt, self._keys(inputs, "rcnn_fg", (N, key_ld)),
+                                    self._keys(inputs, "rcnn_bg", (N, key_ld)), S, int(S * m.RCNN.FG_RATIO), m.RCNN.FG_THRESHOLD,
+                                    m.RCNN.BG_THRESHOLD_HIGH, m.RCNN.BG_THRESHOLD_LOW, m.RCNN_BOX_REG.MEAN, m.RCNN_BOX_REG.STD,
+                                    pl.s_rois, pl.s_labels, pl.s_targets, pl.s_count, pl.s_total)
+
+        sample_on_side = bool(m.get("RCNN_SAMPLE_ON_SIDE", True))
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._proposals(pl, info)
+                if sample_on_side:        # the RoI sampling (one workgroup per image, 0.23 ms) right behind the proposals, under the RPN head's backward
+                    sample()
         else:
             self._proposals(pl, info)
         if early is not None:
@@ -244,12 +256,8 @@ class FasterRCNN(FPNDetector):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         # ---- RCNN: sampling, RoIAlign, box head, losses
-        S = m.RCNN.NUM_ROIS
-        key_ld = pl.rois.shape[1] + Gmax
-        ops.rcnn_sample_targets(pl.rois, pl.num_rois, gt, num_gt, self._keys(inputs, "rcnn_fg", (N, key_ld)),
-                                self._keys(inputs, "rcnn_bg", (N, key_ld)), S, int(S * m.RCNN.FG_RATIO), m.RCNN.FG_THRESHOLD,
-                                m.RCNN.BG_THRESHOLD_HIGH, m.RCNN.BG_THRESHOLD_LOW, m.RCNN_BOX_REG.MEAN, m.RCNN_BOX_REG.STD,
-                                pl.s_rois, pl.s_labels, pl.s_targets, pl.s_count, pl.s_total)
+        if side is None or not sample_on_side:
+            sample()
         self._box_head(pl)
         ops.rcnn_loss_fwd_bwd(pl.rcnn_raw, self.rcnn_ld, self.num_classes, self.num_classes + 1, pl.s_labels, pl.s_targets, pl.R,
                               m.LOSSES.RCNN_SMOOTH_L1_BETA, pl.s_total, pl.loss_buf[2:4], pl.d_rcnn_raw)

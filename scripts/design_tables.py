@@ -65,13 +65,19 @@ t.append("| workload | img/s (instrumented line) | dominant kernel, frac | confi
 gn = {n: per_step(kf, steps, (n,)) for n in ("gn_stats_partial", "gn_stats_final", "gn_apply", "gn_bwd_partial", "gn_bwd_final_kernel", "gn_bwd_final_c", "gn_bwd_apply")}
 t.append(f"| FCOS-R50-FPN, batch 16 | **{fcos['value']:.1f}** ({fcos['ms_per_step']:.2f} ms; round 4: 619.3 uninstrumented) | `{fcos['roofline']['kernel']}` {fcos['roofline']['frac']:.3f} | "
          f"GroupNorm **{sum(gn.values()):.2f}** (round 4: 3.08): " + ", ".join(f"`{k}` {v:.2f}" for k, v in gn.items()) + " |")
-box = {n: per_step(kr, steps, (n,)) for n in ("roi_align_bwd_sep", "f32_to_bf16", "roi_align_fwd", "rcnn_sample", "rcnn_loss", "sample_labels", "gt_rowmax", "retina_assign", "segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge")}
-main_chain = sum(box[n] for n in ("roi_align_bwd_sep", "f32_to_bf16", "roi_align_fwd", "rcnn_sample", "rcnn_loss"))
+box = {n: per_step(kr, steps, (n,)) for n in ("roi_align_bwd_tile", "roi_tile_list", "roi_tile_scan", "roi_foot", "conv1x1_thin_bwd", "conv1x1_thin_reduce",
+                                               "conv1x1_thin_fwd", "roi_align_fwd", "rcnn_sample", "rcnn_loss", "sample_labels", "gt_rowmax", "retina_assign",
+                                               "segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge")}
+roi_bwd = box["roi_align_bwd_tile"] + box["roi_tile_list"] + box["roi_tile_scan"] + box["roi_foot"]
+thin = box["conv1x1_thin_bwd"] + box["conv1x1_thin_reduce"] + box["conv1x1_thin_fwd"]
+main_chain = roi_bwd + sum(box[n] for n in ("roi_align_fwd", "rcnn_sample", "rcnn_loss"))
 prop = sum(box[n] for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge"))
 early = sum(box[n] for n in ("sample_labels", "gt_rowmax", "retina_assign"))
-t.append(f"| Faster R-CNN R50-FPN, batch 16 | **{frc['value']:.1f}** ({frc['ms_per_step']:.2f} ms) | `{frc['roofline']['kernel']}` {frc['roofline']['frac']:.3f} | "
-         f"box operators on the main chain **{main_chain:.2f}** (round 4: 4.7): " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("roi_align_bwd_sep", "f32_to_bf16", "roi_align_fwd", "rcnn_sample", "rcnn_loss")) +
-         f"; proposal chain on the side stream {prop:.2f} (round 4: 1.9: `nmsb_scan` 0.76, `nmsb_mask` 0.47, `nmsb_prepare` 0.26): " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge")) +
+t.append(f"| Faster R-CNN R50-FPN, batch 16 | **{frc['value']:.1f}** ({frc['ms_per_step']:.2f} ms; round 4: 526 instrumented / 560 plain) | `{frc['roofline']['kernel']}` {frc['roofline']['frac']:.3f} | "
+         f"box operators on the main chain **{main_chain:.2f}** (round 4: 4.7; before the tiled RoIAlign backward: 2.76): RoIAlign backward {roi_bwd:.2f} (`roi_align_bwd_tile` {box['roi_align_bwd_tile']:.2f} + its list kernels; "
+         f"was `roi_align_bwd_sep` 1.72 + `f32_to_bf16` 0.38), " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("roi_align_fwd", "rcnn_sample", "rcnn_loss")) +
+         f"; the RPN prediction layer on its own kernels {thin:.2f} (`conv1x1_thin_fwd` {box['conv1x1_thin_fwd']:.2f}, `conv1x1_thin_bwd` {box['conv1x1_thin_bwd']:.2f} + reduce; was 0.23 + 0.45 + 0.60 on the generic kernels)"
+         f"; proposal chain on the side stream {prop:.2f} (round 4: 1.9): " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge")) +
          f"; RPN targets under the forward pass {early:.2f}: " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("sample_labels", "gt_rowmax", "retina_assign")) + " |")
 t.append("")
 t.append("### Other workloads (`profiles/r05_workloads.txt`, one box, `--no-roofline`, 20–30 steps; builder-run)\n")
