@@ -70,14 +70,14 @@ box = {n: per_step(kr, steps, (n,)) for n in ("roi_align_bwd_tile", "roi_tile_li
                                                "segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge")}
 roi_bwd = box["roi_align_bwd_tile"] + box["roi_tile_list"] + box["roi_tile_scan"] + box["roi_foot"]
 thin = box["conv1x1_thin_bwd"] + box["conv1x1_thin_reduce"] + box["conv1x1_thin_fwd"]
-main_chain = roi_bwd + sum(box[n] for n in ("roi_align_fwd", "rcnn_sample", "rcnn_loss"))
-prop = sum(box[n] for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge"))
+main_chain = roi_bwd + sum(box[n] for n in ("roi_align_fwd", "rcnn_loss"))
+prop = sum(box[n] for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge", "rcnn_sample"))
 early = sum(box[n] for n in ("sample_labels", "gt_rowmax", "retina_assign"))
 t.append(f"| Faster R-CNN R50-FPN, batch 16 | **{frc['value']:.1f}** ({frc['ms_per_step']:.2f} ms; round 4: 526 instrumented / 560 plain) | `{frc['roofline']['kernel']}` {frc['roofline']['frac']:.3f} | "
          f"box operators on the main chain **{main_chain:.2f}** (round 4: 4.7; before the tiled RoIAlign backward: 2.76): RoIAlign backward {roi_bwd:.2f} (`roi_align_bwd_tile` {box['roi_align_bwd_tile']:.2f} + its list kernels; "
-         f"was `roi_align_bwd_sep` 1.72 + `f32_to_bf16` 0.38), " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("roi_align_fwd", "rcnn_sample", "rcnn_loss")) +
+         f"was `roi_align_bwd_sep` 1.72 + `f32_to_bf16` 0.38), " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("roi_align_fwd", "rcnn_loss")) +
          f"; the RPN prediction layer on its own kernels {thin:.2f} (`conv1x1_thin_fwd` {box['conv1x1_thin_fwd']:.2f}, `conv1x1_thin_bwd` {box['conv1x1_thin_bwd']:.2f} + reduce; was 0.23 + 0.45 + 0.60 on the generic kernels)"
-         f"; proposal chain on the side stream {prop:.2f} (round 4: 1.9): " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge")) +
+         f"; proposal chain + RoI sampling on the side stream {prop:.2f} (round 4: 1.9 + 0.23 on the main chain): " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge", "rcnn_sample")) +
          f"; RPN targets under the forward pass {early:.2f}: " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("sample_labels", "gt_rowmax", "retina_assign")) + " |")
 t.append("")
 t.append("### Other workloads (`profiles/r05_workloads.txt`, one box, `--no-roofline`, 20–30 steps; builder-run)\n")
