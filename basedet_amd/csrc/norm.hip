@@ -207,10 +207,10 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_raw* __r
 }
 
 // ab[(n*L + l)*32 + g] = (A, B) / count: one workgroup per (image, level), as gn_stats_final_kernel
-__global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restrict__ pg, GnLevels lv, int cpg, float* __restrict__ ab) {
-    __shared__ float red[8][32][2];
+__device__ __forceinline__ void gn_bwd_final_body(const float* __restrict__ pg, const GnLevels& lv, int cpg, float* __restrict__ ab, int l, int n,
+                                                  float (*red)[32][2]) {
     const int g = threadIdx.x & 31, q = threadIdx.x >> 5;
-    const int l = blockIdx.x, n = blockIdx.y, S = lv.slot0[lv.L];
+    const int S = lv.slot0[lv.L];
     float A = 0.f, B = 0.f;
     for (int c = lv.slot0[l] + q; c < lv.slot0[l + 1]; c += 8) {
         const float* o = pg + (((long long)n * S + c) * 32 + g) * 2;
@@ -227,14 +227,17 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restri
         ab[i * 2] = A * inv; ab[i * 2 + 1] = B * inv;
     }
 }
+__global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restrict__ pg, GnLevels lv, int cpg, float* __restrict__ ab) {
+    __shared__ float red[8][32][2];
+    gn_bwd_final_body(pg, lv, cpg, ab, blockIdx.x, blockIdx.y, red);
+}
 
 // dgamma[c], dbeta[c] (+)= sums over every (n, slot): a block owns 8 channels, 128 lanes walk the slots (each reads the 64 contiguous bytes
 // of its 8 channels), then a fixed-order LDS reduction in two steps -- reproducible, and no long serial chains (2 848 slots at batch 16)
-__global__ __launch_bounds__(1024) void gn_bwd_final_c_kernel(const float* __restrict__ pc, int slots, int C, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int accumulate) {
-    __shared__ float red[128][8][2];
+__device__ __forceinline__ void gn_bwd_final_c_body(const float* __restrict__ pc, int slots, int C, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int accumulate, int block, float (*red)[8][2]) {
     const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
+    const int c = block * 8 + cl;
     float dg = 0.f, db = 0.f;
     if (c < C)
         for (int s = sl; s < slots; s += 128) { dg += pc[((long long)s * C + c) * 2]; db += pc[((long long)s * C + c) * 2 + 1]; }
@@ -252,6 +255,26 @@ __global__ __launch_bounds__(1024) void gn_bwd_final_c_kernel(const float* __res
         dgamma[c] = accumulate ? dgamma[c] + a : a;
         dbeta[c] = accumulate ? dbeta[c] + b : b;
     }
+}
+__global__ __launch_bounds__(1024) void gn_bwd_final_c_kernel(const float* __restrict__ pc, int slots, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[128][8][2];
+    gn_bwd_final_c_body(pc, slots, C, dgamma, dbeta, accumulate, blockIdx.x, red);
+}
+// Round 5: both finals in ONE launch when the batch is not chunked (blocks [0, L * N): the per-(image, level, group) sums the apply pass waits
+// for; the rest: dgamma / dbeta) -- two small grids one after the other were 24 us per layer of an otherwise idle GPU on FCOS's main chain
+__global__ __launch_bounds__(1024) void gn_bwd_finals_kernel(const float* __restrict__ pg, GnLevels lv, int cpg, float* __restrict__ ab, int N,
+                                                             const float* __restrict__ pc, int slots, int C, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[128][8][2];
+    const int nb = lv.L * N;
+    if ((int)blockIdx.x < nb) {
+        // (the first four waves work; the other twelve end here -- a finished wave no longer counts at the barrier inside)
+        float (*r2)[32][2] = reinterpret_cast<float (*)[32][2]>(&red[0][0][0]);
+        if (threadIdx.x < 256) gn_bwd_final_body(pg, lv, cpg, ab, (int)blockIdx.x % lv.L, (int)blockIdx.x / lv.L, r2);
+        return;
+    }
+    gn_bwd_final_c_body(pc, slots, C, dgamma, dbeta, accumulate, (int)blockIdx.x - nb, red);
 }
 
 // dy = rstd * (dzm*gamma - B - xhat*A)
@@ -355,12 +378,15 @@ __global__ __launch_bounds__(256) void fcos_offsets_bwd_kernel(const bf16_raw* _
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void fcos_dscale_final_kernel(const float* __restrict__ partial, int nblocks, int L, float* __restrict__ dscale) {
-    const int l = threadIdx.x;
-    if (l >= L) return;
+// one wave per level: lane q adds blocks q, q + 64, ... in order, then the 64 partial sums go through a fixed butterfly (round 5: one thread
+// per level walking all 512 blocks was 51 us of an otherwise idle GPU on FCOS's main chain)
+__global__ __launch_bounds__(64 * MAXL) void fcos_dscale_final_kernel(const float* __restrict__ partial, int nblocks, int L, float* __restrict__ dscale) {
+    const int l = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * MAXL + l];
-    dscale[l] = s;
+    if (l < L)
+        for (int b = lane; b < nblocks; b += 64) s += partial[(long long)b * MAXL + l];
+    s = wave_sum(s);
+    if (l < L && lane == 0) dscale[l] = s;
 }
 
 inline GnLevels make_levels(int L, const int32_t* off, const int32_t* cnt) {
@@ -441,12 +467,16 @@ extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamm
         float* abc = ab + (size_t)n0 * L * 64;
         hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(S, nc), dim3(256), 0, st, dzc, yc, stc, gamma, beta, lv, (int)pix_per_img, C, relu,
                            pg + (size_t)n0 * S * 64, pc + (size_t)n0 * S * C * 2);
-        hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(L, nc), dim3(256), 0, st, (const float*)(pg + (size_t)n0 * S * 64), lv, C / 32, abc);
+        if (nc == N)
+            hipLaunchKernelGGL(gn_bwd_finals_kernel, dim3(L * N + cdiv(C, 8)), dim3(1024), 0, st, (const float*)pg, lv, C / 32, abc, N, (const float*)pc,
+                               N * S, C, dgamma, dbeta, accumulate);
+        else
+            hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(L, nc), dim3(256), 0, st, (const float*)(pg + (size_t)n0 * S * 64), lv, C / 32, abc);
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(egrid((long long)nc * pix_per_img * 32)), dim3(256), 0, st, dzc, yc, stc, (const float*)abc,
                            gamma, beta, lv, nc, (int)pix_per_img, relu, rev, (bf16_raw*)dy + eo);
     }
     // dgamma / dbeta over every (image, slot) of the batch, in slot order: independent of the chunking
-    hipLaunchKernelGGL(gn_bwd_final_c_kernel, dim3(cdiv(C, 8)), dim3(1024), 0, st, (const float*)pc, N * S, C, dgamma, dbeta, accumulate);
+    if (step < N) hipLaunchKernelGGL(gn_bwd_final_c_kernel, dim3(cdiv(C, 8)), dim3(1024), 0, st, (const float*)pc, N * S, C, dgamma, dbeta, accumulate);
     BD_CHECK_LAUNCH("bd_groupnorm_bwd");
     return BD_OK;
 }
@@ -479,7 +509,7 @@ extern "C" int bd_fcos_offsets_bwd(const void* raw, int ld, const float* scales,
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(fcos_offsets_bwd_kernel, dim3(OFF_BLOCKS), dim3(256), 0, st, (const bf16_raw*)raw, ld, scales, lv, N,
                        (int)pix_per_img, (const bf16_raw*)d_off, (const bf16_raw*)d_ctr, (bf16_raw*)d_raw, (float*)ws);
-    hipLaunchKernelGGL(fcos_dscale_final_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, OFF_BLOCKS, L, dscale);
+    hipLaunchKernelGGL(fcos_dscale_final_kernel, dim3(1), dim3(64 * MAXL), 0, st, (const float*)ws, OFF_BLOCKS, L, dscale);
     BD_CHECK_LAUNCH("bd_fcos_offsets_bwd");
     return BD_OK;
 }
