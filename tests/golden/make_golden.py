@@ -39,6 +39,102 @@ def functions_by_name(path, names, env):
     return [ns[n] for n in names]
 
 
+def methods_by_name(path, cls, names, env, nested_in=None):
+    """The named METHODS of class `cls` in a reference file whose module (or whose base class) cannot be imported: their definitions are
+    lifted out of the class body and compiled as plain functions taking `self` (the caller passes a stub object carrying the attributes
+    the body reads).  With `nested_in`, the named functions are instead the ones defined INSIDE that method's body (the helper closures
+    of AspectRatioGroupSampler.__init__).  Build container only; only the arrays the functions return are written anywhere."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    (cdef,) = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls]
+    body = cdef.body
+    if nested_in is not None:
+        (outer,) = [n for n in body if isinstance(n, ast.FunctionDef) and n.name == nested_in]
+        body = outer.body
+    picked = [n for n in body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in picked} == set(names), (path, cls, names)
+    ns = dict(env)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def batch_contract_fixtures():
+    """Outputs of the reference's own batch-contract code on seeded inputs:
+      * calculate_padding_shape and DetectionPadCollator.apply (data/collators/pad_collator.py:15-61): the method body runs with a stub
+        `self` that carries pad_value (its base class, megengine.data.Collator, is not installed);
+      * GroupedRandomSampler.batch (data/samplers/group_sampler.py:39-54): the grouping arithmetic -- an index joins its group's buffer,
+        a batch leaves when the buffer holds batch_size entries, unfilled buffers survive into the next pass -- on GIVEN permutations
+        (sample() / scatter() belong to megengine's RandomSampler and are inputs here), two passes in a row;
+      * the helper closures of AspectRatioGroupSampler.__init__ (:83-92): height / width ratios and their bisect-right group ids."""
+    import bisect
+    import types
+    from collections import defaultdict
+    cpath = os.path.join(REF, "basedet/data/collators/pad_collator.py")
+    (cps,) = functions_by_name(cpath, ["calculate_padding_shape"], {})
+    (apply,) = methods_by_name(cpath, "DetectionPadCollator", ["apply"], {"np": np, "defaultdict": defaultdict, "calculate_padding_shape": cps})
+    rng = np.random.default_rng(77)
+    out = {}
+    pads = [((3, 5, 7), (3, 8, 7)), ((2, 5), (4, 5)), ((3, 24, 31), (3, 24, 31)), ((0, 5), (3, 5)), ((7,), (9,))]
+    out["pad_n"] = np.int32(len(pads))
+    for i, (o, t) in enumerate(pads):
+        out[f"pad_orig_{i}"], out[f"pad_target_{i}"] = np.asarray(o, np.int64), np.asarray(t, np.int64)
+        out[f"pad_out_{i}"] = np.asarray(cps(o, t), np.int64)
+    cases = [  # (pad_value, [(H, W, boxes, image dtype)])
+        (0.0, [(20, 31, 3, np.uint8), (24, 17, 1, np.uint8)]),
+        (-1.0, [(20, 31, 0, np.uint8), (24, 17, 2, np.float64)]),                 # an image without boxes
+        (0.0, [(32, 32, 4, np.float32)]),                                         # a batch of one
+        (114.0, [(17, 40, 2, np.uint8), (40, 17, 5, np.uint8), (33, 33, 1, np.float32), (8, 8, 3, np.uint8)]),
+    ]
+    out["collate_n"] = np.int32(len(cases))
+    for c, (pv, imgs) in enumerate(cases):
+        inputs = []
+        for k, (H, W, g, dt) in enumerate(imgs):
+            img = rng.integers(0, 255, (3, H, W)).astype(dt) if dt == np.uint8 else rng.uniform(0, 255, (3, H, W)).astype(dt)
+            xy = rng.uniform(0, 10, (g, 2)); wh = rng.uniform(1, 12, (g, 2))
+            boxes = np.concatenate([xy, xy + wh], 1)                               # float64, as a reader hands them over
+            cat = rng.integers(1, 81, (g,)).astype(np.int64)
+            info = (int(H * 1.7), int(W * 1.7), k)
+            inputs.append((img, boxes, cat, info))
+            out[f"collate_{c}_img_{k}"], out[f"collate_{c}_boxes_{k}"], out[f"collate_{c}_cat_{k}"] = img, boxes, cat
+            out[f"collate_{c}_info_{k}"] = np.asarray(info, np.int64)
+        res = apply(types.SimpleNamespace(pad_value=pv), inputs)
+        assert sorted(res.keys()) == ["data", "gt_boxes", "im_info"]
+        out[f"collate_{c}_pad_value"], out[f"collate_{c}_count"] = np.float64(pv), np.int32(len(imgs))
+        for key in ("data", "gt_boxes", "im_info"):
+            out[f"collate_{c}_out_{key}"] = res[key]
+            assert res[key].dtype == np.float32
+    spath = os.path.join(REF, "basedet/data/samplers/group_sampler.py")
+    (batch,) = methods_by_name(spath, "GroupedRandomSampler", ["batch"], {"np": np})
+    car, quant = methods_by_name(spath, "AspectRatioGroupSampler", ["_compute_aspect_ratios", "_quantize"], {"bisect": bisect},
+                                 nested_in="__init__")
+    hw = [(480, 640)] * 13 + [(640, 480)] * 11 + [(500, 500)] * 3 + [(333, 500), (500, 333), (1, 3), (400, 401)]
+    class DS:
+        def __len__(self): return len(hw)
+        def get_img_info(self, i): return {"height": hw[i][0], "width": hw[i][1]}
+    out["sampler_hw"] = np.asarray(hw, np.int64)
+    ratios = car(DS())
+    out["sampler_ratios"] = np.asarray(ratios, np.float64)
+    for b, bins in enumerate(([1], [0.5, 1, 2], [2, 0.75], [1.0, 1.0])):
+        out[f"sampler_bins_{b}"] = np.asarray(bins, np.float64)
+        out[f"sampler_groups_{b}"] = np.asarray(quant(ratios, bins), np.int64)
+    out["sampler_bins_n"] = np.int32(4)
+    runs = [(4, [1]), (3, [0.5, 1, 2]), (1, [1]), (5, [1])]
+    out["sampler_runs_n"] = np.int32(len(runs))
+    for r, (bs, bins) in enumerate(runs):
+        gids = quant(ratios, bins)
+        perms = [rng.permutation(len(hw)) for _ in range(3)]
+        state = types.SimpleNamespace(world_size=1, group_ids=gids, batch_size=bs, buffer_per_group={k: [] for k in np.unique(gids).tolist()})
+        out[f"sampler_run_{r}_batch_size"], out[f"sampler_run_{r}_bins"] = np.int32(bs), np.asarray(bins, np.float64)
+        for e, perm in enumerate(perms):
+            state.sample = lambda perm=perm: perm.tolist()
+            got = [list(map(int, b)) for b in batch(state)]
+            out[f"sampler_run_{r}_perm_{e}"] = np.asarray(perm, np.int64)
+            out[f"sampler_run_{r}_flat_{e}"] = np.asarray([i for b in got for i in b], np.int64)
+            out[f"sampler_run_{r}_count_{e}"] = np.int32(len(got))
+    np.savez_compressed(os.path.join(HERE, "reference_batch_contract.npz"), **out)
+
+
 def nms_fixtures():
     """Keep lists of the reference's own numpy NMS (layers/common/post_processing.py:106-132 py_cpu_nms) on seeded random boxes with
     DISTINCT scores (its argsort()[::-1] is not stable, so ties have no reference answer)."""
@@ -135,6 +231,7 @@ def checkpoint_match_fixtures():
 def main():
     nms_fixtures()
     checkpoint_match_fixtures()
+    batch_contract_fixtures()
     # ---- 1. DummyLoader (basedet/utils/dummy.py:8-63) --------------------------------------
     dummy = load_by_path("ref_dummy", os.path.join(REF, "basedet/utils/dummy.py"))
     out = {}

@@ -55,3 +55,64 @@ def test_aspect_ratio_group_sampler():
     r1 = AspectRatioGroupSampler(ds, 2, seed=5, world_size=2, rank=1)
     i0 = {i for b in r0 for i in b}; i1 = {i for b in r1 for i in b}
     assert not (i0 & i1) or len(i0 & i1) <= 1          # at most the wrap-around padding element is shared
+
+
+# ---- fixtures produced by the reference's OWN code (tests/golden/make_golden.py batch_contract_fixtures: the bodies of
+# DetectionPadCollator.apply / GroupedRandomSampler.batch and the helper closures of AspectRatioGroupSampler.__init__ run in the build
+# container from the files where they lie; arrays only are committed) --------------------------------------------------------------------
+import os
+
+_GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_batch_contract.npz"))
+
+
+def test_calculate_padding_shape_matches_reference_outputs():
+    for i in range(int(_GOLD["pad_n"])):
+        got = calculate_padding_shape(tuple(_GOLD[f"pad_orig_{i}"].tolist()), tuple(_GOLD[f"pad_target_{i}"].tolist()))
+        assert np.array_equal(np.asarray(got, np.int64).reshape(-1, 2), _GOLD[f"pad_out_{i}"].reshape(-1, 2))
+
+
+def test_pad_collator_matches_reference_outputs():
+    for c in range(int(_GOLD["collate_n"])):
+        inputs = [(_GOLD[f"collate_{c}_img_{k}"], _GOLD[f"collate_{c}_boxes_{k}"], _GOLD[f"collate_{c}_cat_{k}"],
+                   tuple(_GOLD[f"collate_{c}_info_{k}"].tolist())) for k in range(int(_GOLD[f"collate_{c}_count"]))]
+        out = DetectionPadCollator(pad_value=float(_GOLD[f"collate_{c}_pad_value"])).apply(inputs)
+        assert set(out) == {"data", "gt_boxes", "im_info"}
+        for key in ("data", "gt_boxes", "im_info"):
+            want = _GOLD[f"collate_{c}_out_{key}"]
+            assert out[key].dtype == want.dtype == np.float32 and out[key].shape == want.shape, (c, key)
+            assert np.array_equal(out[key], want), (c, key)          # bit for bit: the contract is copies and exact casts
+
+
+class _HW:
+    def __init__(self, hw):
+        self.hw = hw
+
+    def __len__(self):
+        return len(self.hw)
+
+    def get_img_info(self, i):
+        return {"height": int(self.hw[i][0]), "width": int(self.hw[i][1])}
+
+
+def test_aspect_ratio_groups_match_reference_outputs():
+    ds = _HW(_GOLD["sampler_hw"])
+    for b in range(int(_GOLD["sampler_bins_n"])):
+        s = AspectRatioGroupSampler(ds, 2, aspect_grouping=_GOLD[f"sampler_bins_{b}"].tolist())
+        assert np.array_equal(np.asarray(s.group_ids, np.int64), _GOLD[f"sampler_groups_{b}"]), b
+    # the ratios themselves (height / width in float64)
+    got = np.array([h / w for h, w in _GOLD["sampler_hw"].tolist()], np.float64)
+    assert np.array_equal(got, _GOLD["sampler_ratios"])
+
+
+def test_grouped_batches_match_reference_outputs_over_three_passes():
+    """Same permutations in, same batches out -- including what the unfilled group buffers carry from one pass into the next."""
+    ds = _HW(_GOLD["sampler_hw"])
+    for r in range(int(_GOLD["sampler_runs_n"])):
+        bs = int(_GOLD[f"sampler_run_{r}_batch_size"])
+        s = AspectRatioGroupSampler(ds, bs, aspect_grouping=_GOLD[f"sampler_run_{r}_bins"].tolist())
+        for e in range(3):
+            perm = _GOLD[f"sampler_run_{r}_perm_{e}"]
+            s.sample = lambda perm=perm: perm
+            got = [list(b) for b in s.batch()]
+            assert len(got) == int(_GOLD[f"sampler_run_{r}_count_{e}"]) and all(len(b) == bs for b in got), (r, e)
+            assert [i for b in got for i in b] == _GOLD[f"sampler_run_{r}_flat_{e}"].tolist(), (r, e)
