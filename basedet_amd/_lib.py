@@ -125,7 +125,6 @@ SIGNATURES = {
     "bd_conv1x1_thin_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "bd_conv1x1_thin_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_roi_align_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "bd_roi_align_bwd_pk": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "bd_roi_align_bwd_bf16_workspace_bytes": (_Z, [_I, _I, _P, _P, _I]),
     "bd_roi_align_bwd_bf16": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "bd_subsample2x_fwd": (_I, [_P, _L, _L, _I, _I, _P, _L, _L, _I, _I, _P]),

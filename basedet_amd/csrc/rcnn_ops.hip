@@ -802,21 +802,13 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const bf16_raw* __re
 // workgroup-uniform 4x4 coefficient patch anchored at the top-left sample corner): one atomic per distinct pixel of the bin
 // (typically 9) instead of one per sample corner (16).  Bins whose samples spread over more than 4 rows / columns (very large
 // RoIs) take the direct path.
-// PK: the target is the bf16 gradient pyramid itself and two channels travel per atomic (global_atomic_pk_add_bf16): half the
-// atomic operations -- the kernel runs at the chip's atomic rate -- and no fp32 staging buffer / conversion pass.  The sums are then
-// rounded to bf16 at every add (a feature-map element receives ~2.5 contributions on average).  The thread block splits into
-// 256 / (C/2) groups that take alternate bins.
-typedef __attribute__((ext_vector_type(2))) short s16x2_t;
-__device__ __forceinline__ void pk_atomic_add(bf16_raw* p, float a, float b) {
-    const unsigned v = pack_bf2(a, b);
-    __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) s16x2_t*)p, __builtin_bit_cast(s16x2_t, v));
-}
-
-template <bool PK>
+// (Rounds 2-5 also carried a packed-bf16 variant -- global_atomic_pk_add_bf16 straight into the bf16 pyramid, running bf16 sums -- and a
+// separable 7 x 7 form of this scatter; round 5's tiled fixed-order sum, roi_align_bwd_tile_kernel below, replaced both.  This kernel stays
+// as the GENERAL form: any pooled size, any number of RoIs per image.)
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv,
                                                             const float* __restrict__ rois, const int* __restrict__ labels,
                                                             int rois_per_img, int PH, int PW, int S,
-                                                            void* __restrict__ gfeat_) {
+                                                            float* __restrict__ gfeat) {
     const int r = blockIdx.x;
     if (labels && labels[r] < 0) return;
     const int n = r / rois_per_img;
@@ -828,18 +820,10 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
     const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
     const float rw = (b.x2 * sc - 0.5f) - sw, rh = (b.y2 * sc - 0.5f) - sh_;
     const float bw = rw / (float)PW, bh = rh / (float)PH;
-    float* gp = reinterpret_cast<float*>(gfeat_) + ((long long)n * ppi + lv.pix_off[l]) * C;
-    bf16_raw* gpb = reinterpret_cast<bf16_raw*>(gfeat_) + ((long long)n * ppi + lv.pix_off[l]) * C;
+    float* gp = gfeat + ((long long)n * ppi + lv.pix_off[l]) * C;
     const bf16_raw* go = gout + (long long)r * nb * C;
     const float inv = 1.f / (float)(S * S);
-    // PK: thread -> (bin group, channel pair); the groups interleave over the bins
-    const int pairs = C >> 1;
-    const int groups = PK ? (pairs >= 256 ? 1 : 256 / pairs) : 1;
-    const int grp = PK ? (int)threadIdx.x / (pairs >= 256 ? 256 : pairs) : 0;
-    const int t0 = PK ? (int)threadIdx.x - grp * (pairs >= 256 ? 256 : pairs) : (int)threadIdx.x;
-    const int tstep = PK ? (pairs >= 256 ? 256 : pairs) : 256;
-    if (PK && grp >= groups) return;
-    for (int bin = grp; bin < nb; bin += groups) {
+    for (int bin = 0; bin < nb; ++bin) {
         const int ph = bin / PW, pw = bin - ph * PW;
         bool merged = S == 2;
         float coef[4][4];
@@ -881,19 +865,6 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
             }
         }
         if (merged) {
-            if (PK) {
-                for (int c2 = t0; c2 < pairs; c2 += tstep) {
-                    const unsigned gv = *reinterpret_cast<const unsigned*>(go + (long long)bin * C + 2 * c2);
-                    const float g0 = bf_lo(gv) * inv, g1 = bf_hi(gv) * inv;
-#pragma unroll
-                    for (int py = 0; py < 4; ++py)
-#pragma unroll
-                        for (int px = 0; px < 4; ++px)
-                            if (coef[py][px] != 0.f)                  // uniform over the bin group
-                                pk_atomic_add(gpb + ((long long)(Y0 + py) * W + X0 + px) * C + 2 * c2, coef[py][px] * g0, coef[py][px] * g1);
-                }
-                continue;
-            }
             for (int c = threadIdx.x; c < C; c += 256) {
                 const float g = bf2f(go[(long long)bin * C + c]) * inv;
 #pragma unroll
@@ -911,17 +882,6 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
                 const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)S;
                 const Bilinear bl = bilinear_setup(y, x, H, W);
                 if (!bl.ok) continue;
-                if (PK) {
-                    for (int c2 = t0; c2 < pairs; c2 += tstep) {
-                        const unsigned gv = *reinterpret_cast<const unsigned*>(go + (long long)bin * C + 2 * c2);
-                        const float g0 = bf_lo(gv) * inv, g1 = bf_hi(gv) * inv;
-                        pk_atomic_add(gpb + ((long long)bl.y0 * W + bl.x0) * C + 2 * c2, bl.w00 * g0, bl.w00 * g1);
-                        pk_atomic_add(gpb + ((long long)bl.y0 * W + bl.x1) * C + 2 * c2, bl.w01 * g0, bl.w01 * g1);
-                        pk_atomic_add(gpb + ((long long)bl.y1 * W + bl.x0) * C + 2 * c2, bl.w10 * g0, bl.w10 * g1);
-                        pk_atomic_add(gpb + ((long long)bl.y1 * W + bl.x1) * C + 2 * c2, bl.w11 * g0, bl.w11 * g1);
-                    }
-                    continue;
-                }
                 for (int c = threadIdx.x; c < C; c += 256) {
                     const float g = bf2f(go[(long long)bin * C + c]) * inv;
                     unsafeAtomicAdd(gp + ((long long)bl.y0 * W + bl.x0) * C + c, bl.w00 * g);
@@ -934,17 +894,9 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const bf16_raw* __re
     }
 }
 
-// Separable form of the scatter (round 3; the training default of rounds 3-4, since round 5 behind model.deterministic_roi_bwd = False: the
-// default is roi_align_bwd_tile_kernel below, which has no atomics), 7 x 7 bins.  A bilinear weight factors into a row and a column part and every sample of a bin
-// carries the same gradient, so the gradient of an RoI on its level is  dF = A^T (g / S^2) B  with A[ph][y] = sum of the row weights of bin
-// row ph's samples on pixel row y (B likewise for columns): ONE atomic per pixel of the RoI's footprint and channel -- an RoI on its own
-// level spans 7-14 pixels a side, ~80-260 pixels -- instead of one per distinct pixel of every bin (49 x ~9 = 441).  The scatter runs at the
-// chip's atomic rate (~250 G atomics / s, docs/HISTORY_r1_r2.md), so the atomics are what there is to save; the 49 gradients of a channel
-// sit in registers, A and B (block-uniform) in LDS.  Sample positions and validity are computed exactly as in roi_align_fwd_kernel.
-// Footprints beyond SEP_F pixels a side (RoIs clamped to the coarsest / finest level) take the per-sample path.
-constexpr int SEP_F = 24;
+// the row (or column) half of bilinear_setup: sample positions and validity exactly as in roi_align_fwd_kernel
 struct Lin1 { int i0, i1; float w0, w1; bool ok; };
-__device__ __forceinline__ Lin1 linear_setup(float y, int H) {             // the row (or column) half of bilinear_setup
+__device__ __forceinline__ Lin1 linear_setup(float y, int H) {
     Lin1 r;
     r.ok = !(y < -1.f || y > (float)H);
     if (y <= 0.f) y = 0.f;
@@ -954,103 +906,12 @@ __device__ __forceinline__ Lin1 linear_setup(float y, int H) {             // th
     return r;
 }
 
-// (The packed-bf16 variant stays on the per-bin kernel: pre-summed per RoI it is 1.5 % faster per step but no more accurate -- fewer, larger
-// addends, each rounded to bf16 before its atomic: 0.86 % against 0.80 % relative error on the densest level, scripts/exp/roi_pk_err.py.)
-__global__ __launch_bounds__(256) void roi_align_bwd_sep_kernel(const bf16_raw* __restrict__ gout, long long ppi, int C, RoiLevels lv,
-                                                                const float* __restrict__ rois, const int* __restrict__ labels,
-                                                                int rois_per_img, int S, float* __restrict__ gfeat) {
-    constexpr int P = 7;
-    __shared__ __attribute__((aligned(16))) float sA[SEP_F][8], sB[SEP_F][8];
-    const int r = blockIdx.x;
-    if (labels && labels[r] < 0) return;
-    const int n = r / rois_per_img;
-    const int tid = threadIdx.x;
-    const Box b = ld_box(rois + r * 4ll);
-    const int l = roi_level(b, lv);
-    const int H = lv.H[l], W = lv.W[l];
-    const float sc = lv.scale[l];
-    const float sw = b.x1 * sc - 0.5f, sh_ = b.y1 * sc - 0.5f;
-    const float rw = (b.x2 * sc - 0.5f) - sw, rh = (b.y2 * sc - 0.5f) - sh_;
-    const float bw = rw / (float)P, bh = rh / (float)P;
-    float* gp = gfeat + ((long long)n * ppi + lv.pix_off[l]) * C;
-    const bf16_raw* go = gout + (long long)r * (P * P) * C;
-    const float inv = 1.f / (float)(S * S);
-    // footprint of the valid samples (block-uniform; every thread walks the 2 x 7 S sample rows / columns)
-    int ymin = 1 << 30, ymax = -1, xmin = 1 << 30, xmax = -1;
-    for (int q = 0; q < P * S; ++q) {
-        const int pb = q / S, iq = q - pb * S;
-        const Lin1 ly = linear_setup(sh_ + (float)pb * bh + ((float)iq + 0.5f) * bh / (float)S, H);
-        const Lin1 lx = linear_setup(sw + (float)pb * bw + ((float)iq + 0.5f) * bw / (float)S, W);
-        if (ly.ok) { ymin = min(ymin, ly.i0); ymax = max(ymax, ly.i1); }
-        if (lx.ok) { xmin = min(xmin, lx.i0); xmax = max(xmax, lx.i1); }
-    }
-    if (ymax < 0 || xmax < 0) return;                       // no sample inside the map
-    const int FY = ymax - ymin + 1, FX = xmax - xmin + 1;
-    if (FY > SEP_F || FX > SEP_F) {                         // a very large RoI: per sample, four atomics each
-        for (int bin = 0; bin < P * P; ++bin) {
-            const int ph = bin / P, pw = bin - ph * P;
-            for (int iy = 0; iy < S; ++iy) {
-                const float y = sh_ + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)S;
-                for (int ix = 0; ix < S; ++ix) {
-                    const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)S;
-                    const Bilinear bl = bilinear_setup(y, x, H, W);
-                    if (!bl.ok) continue;
-                    for (int c = tid; c < C; c += 256) {
-                        const float g = bf2f(go[(long long)bin * C + c]) * inv;
-                        unsafeAtomicAdd(gp + ((long long)bl.y0 * W + bl.x0) * C + c, bl.w00 * g);
-                        unsafeAtomicAdd(gp + ((long long)bl.y0 * W + bl.x1) * C + c, bl.w01 * g);
-                        unsafeAtomicAdd(gp + ((long long)bl.y1 * W + bl.x0) * C + c, bl.w10 * g);
-                        unsafeAtomicAdd(gp + ((long long)bl.y1 * W + bl.x1) * C + c, bl.w11 * g);
-                    }
-                }
-            }
-        }
-        return;
-    }
-    for (int e = tid; e < SEP_F * 8; e += 256) { (&sA[0][0])[e] = 0.f; (&sB[0][0])[e] = 0.f; }
-    __syncthreads();
-    if (tid < P * S) {
-        const int pb = tid / S, iq = tid - pb * S;
-        const Lin1 ly = linear_setup(sh_ + (float)pb * bh + ((float)iq + 0.5f) * bh / (float)S, H);
-        if (ly.ok) { atomicAdd(&sA[ly.i0 - ymin][pb], ly.w0); atomicAdd(&sA[ly.i1 - ymin][pb], ly.w1); }
-    } else if (tid >= 64 && tid < 64 + P * S) {
-        const int q = tid - 64, pb = q / S, iq = q - pb * S;
-        const Lin1 lx = linear_setup(sw + (float)pb * bw + ((float)iq + 0.5f) * bw / (float)S, W);
-        if (lx.ok) { atomicAdd(&sB[lx.i0 - xmin][pb], lx.w0); atomicAdd(&sB[lx.i1 - xmin][pb], lx.w1); }
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float g[P * P];
-#pragma unroll
-        for (int k = 0; k < P * P; ++k) g[k] = bf2f(go[(long long)k * C + c]) * inv;
-        for (int py = 0; py < FY; ++py) {
-            const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(&sA[py][0]), a1 = *reinterpret_cast<const f32x4_t*>(&sA[py][4]);
-            const float a[P] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2]};
-            if (a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] == 0.f) continue;          // (weights are >= 0) a pixel row between two samples
-            float row[P];
-#pragma unroll
-            for (int pw = 0; pw < P; ++pw) {
-                float v = 0.f;
-#pragma unroll
-                for (int ph = 0; ph < P; ++ph) v += a[ph] * g[ph * P + pw];
-                row[pw] = v;
-            }
-            float* gr = gp + ((long long)(ymin + py) * W + xmin) * C + c;
-            for (int px = 0; px < FX; ++px) {
-                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(&sB[px][0]), b1 = *reinterpret_cast<const f32x4_t*>(&sB[px][4]);
-                if (b0[0] + b0[1] + b0[2] + b0[3] + b1[0] + b1[1] + b1[2] == 0.f) continue;
-                const float v = row[0] * b0[0] + row[1] * b0[1] + row[2] * b0[2] + row[3] * b0[3] + row[4] * b1[0] + row[5] * b1[1] + row[6] * b1[2];
-                unsafeAtomicAdd(gr + (long long)px * C, v);
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // deterministic RoIAlign backward (round 5: the training step's default).  The gradient pyramid is cut into 8x8-pixel tiles; every tile
 // gets the list of the RoIs whose sample footprint touches it, IN SLOT ORDER (one thread per tile walks its image's <= 512 footprints:
 // count, scan, fill -- no atomics anywhere), and one wave per (tile, 128-channel slice) sums the tile in registers:
-//     dF[y][x] += sum_ph A[y][ph] * (sum_pw B[x][pw] * g[ph][pw])          (the separable form of roi_align_bwd_sep_kernel above)
+//     dF[y][x] += sum_ph A[y][ph] * (sum_pw B[x][pw] * g[ph][pw])          (a bilinear weight factors into a row and a column part)
 // with A (8 rows x 7 bins) and B (8 columns x 7 bins) restricted to the tile, two channels per lane as packed fp32 pairs, the 49 pooled
 // gradients of the next RoI requested under the arithmetic of the current one.  The result is written ONCE as bf16 -- optionally added to
 // what the buffer holds (the RPN head's dL/dP): no fp32 pyramid to clear, no float atomics, no conversion pass, fixed summation order.
@@ -1615,30 +1476,9 @@ extern "C" int bd_roi_align_bwd(const void* gout, int64_t pix_per_img, int C, in
     if (R == 0) return BD_OK;
     RoiLevels lv{};
     BD_REQUIRE(fill_roi_levels(lv, L, lvl_pix_off_host, lvl_h_host, lvl_w_host, strides_host) == 0, "roi_align_bwd: strides must be powers of two");
-    static const int use_sep = bd_tune_env("BD_ROI_BWD_SEP", 1);       // 0: the per-bin scatter (A/B)
-    if (use_sep && PH == 7 && PW == 7 && 7 * sample_points <= 64)      // the separable kernel builds its row / column tables with 7 * S threads each
-        hipLaunchKernelGGL(roi_align_bwd_sep_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
-                           C, lv, rois, labels, rois_per_img, sample_points, gfeat);
-    else
-        hipLaunchKernelGGL(roi_align_bwd_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
-                           C, lv, rois, labels, rois_per_img, PH, PW, sample_points, (void*)gfeat);
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
+                       C, lv, rois, labels, rois_per_img, PH, PW, sample_points, gfeat);
     BD_CHECK_LAUNCH("bd_roi_align_bwd");
-    return BD_OK;
-}
-
-extern "C" int bd_roi_align_bwd_pk(const void* gout, int64_t pix_per_img, int C, int L, const int32_t* lvl_pix_off_host,
-                                   const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
-                                   const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
-                                   int sample_points, void* gfeat_bf16, bd_stream_t stream) {
-    BD_REQUIRE(gout && lvl_pix_off_host && lvl_h_host && lvl_w_host && strides_host && rois && gfeat_bf16, "roi_align_bwd_pk: null pointer");
-    BD_REQUIRE(L > 0 && L <= BD_MAX_SEGS && C > 0 && C % 2 == 0 && PH > 0 && PW > 0 && sample_points > 0 && rois_per_img > 0,
-               "roi_align_bwd_pk: bad sizes (C must be even)");
-    if (R == 0) return BD_OK;
-    RoiLevels lv{};
-    BD_REQUIRE(fill_roi_levels(lv, L, lvl_pix_off_host, lvl_h_host, lvl_w_host, strides_host) == 0, "roi_align_bwd_pk: strides must be powers of two");
-    hipLaunchKernelGGL(roi_align_bwd_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)gout, (long long)pix_per_img,
-                       C, lv, rois, labels, rois_per_img, PH, PW, sample_points, gfeat_bf16);
-    BD_CHECK_LAUNCH("bd_roi_align_bwd_pk");
     return BD_OK;
 }
 

@@ -73,13 +73,13 @@ class FasterRCNN(FPNDetector):
             self.base_anchors.append(torch.tensor(base, dtype=torch.float32, device=dev))
         self.pre_k = {True: m.RPN.TRAIN_PREV_NMS_TOPK, False: m.RPN.TEST_PREV_NMS_TOPK}
         self.post_k = {True: m.RPN.TRAIN_POST_NMS_TOPK, False: m.RPN.TEST_POST_NMS_TOPK}
-        # RoIAlign backward.  Default (round 5): the tiled fixed-order sum (bd_roi_align_bwd_bf16: per-tile RoI lists in slot order, sums in
-        # registers, written once on top of the RPN head's dL/dP) -- bitwise reproducible and the fastest of the three.
-        # deterministic_roi_bwd = False restores the fp32 atomic scatter + conversion pass of rounds 2-4; roi_bwd_pk = True (bench.py
-        # --roi-bwd-pk) the packed-bf16 atomics straight into the bf16 pyramid (running bf16 sums: rel-L2 0.6-0.9 % per level).
+        # RoIAlign backward: the tiled fixed-order sum (bd_roi_align_bwd_bf16: per-tile RoI lists in slot order, sums in registers, written
+        # once on top of the RPN head's dL/dP; bitwise reproducible) wherever its kernel's shape limits hold -- the configured 7 x 7 pooler,
+        # <= 512 RoIs per image, an even channel count; any other ROI_POOLER.SIZE / NUM_ROIS (the reference accepts them: roi_pool.py:35-78)
+        # takes the general fp32 scatter + conversion pass (bd_roi_align_bwd, the default of rounds 2-4).  deterministic_roi_bwd = False
+        # forces the scatter (tests: both forms against the oracle).
         self.deterministic_roi_bwd = True
         self.thin_rpn_bwd = bool(m.get("THIN_RPN_BWD", True))     # RPN prediction layer: fused one-pass backward (0: the generic weight / data gradient kernels)
-        self.roi_bwd_pk = False
         self._gen = torch.Generator(device=dev) if self.device.type == "cuda" else None
         if self._gen is not None:
             self._gen.manual_seed(0)
@@ -145,7 +145,9 @@ class FasterRCNN(FPNDetector):
         pl.g_fc1 = torch.empty((R, 1024), **bf)
         pl.g_pooled = torch.empty((R, fin), **bf)
         pl.g_feat32 = None                # (the fp32 scatter's staging pyramid, 1.5 GB at batch 16: allocated when that variant runs)
-        pl.roi_bwd_ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(pyr, S),), dtype=torch.uint8, device=dev)
+        pl.roi_bwd_tiled = self.pool == (7, 7) and S <= 512 and self.fpn_ch % 2 == 0       # the tiled kernel's limits (rcnn_ops.hip)
+        pl.roi_bwd_ws = (torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(pyr, S),), dtype=torch.uint8, device=dev)
+                         if pl.roi_bwd_tiled else None)
         pl.g_fc = ops.single(1, R, 1)
         pl.loss_buf = torch.zeros((4,), **f32)
 
@@ -189,14 +191,21 @@ class FasterRCNN(FPNDetector):
         Gmax = gt.shape[1]
         thr = m.MATCHER.THRESHOLDS
         nsa = m.RPN.NUM_SAMPLE_ANCHORS
+        S = m.RCNN.NUM_ROIS
+        key_ld = pl.rois.shape[1] + Gmax
+        # The four random-key tensors of a step (sampling.py:26 draws them where it needs them) are drawn HERE, on the main stream, in one
+        # fixed order: which side stream consumes them -- and whether the RPN targets run early -- no longer changes what a seed produces.
+        # The plan keeps them until the next step's draw (the side streams that read them have joined by then).
+        keys = {name: self._keys(inputs, name, shape) for name, shape in
+                (("rpn_pos", (N, pl.A_total)), ("rpn_neg", (N, pl.A_total)), ("rcnn_fg", (N, key_ld)), ("rcnn_bg", (N, key_ld)))}
+        pl.sample_keys = keys
 
         def rpn_targets():
             """RPN.get_ground_truth (rpn.py:215-240): anchors, ground truth and random keys in, labels / offsets out -- nothing of the network."""
             ops.rpn_assign_encode(pl.anchors, gt, num_gt, thr[0], thr[1], m.MATCHER.ALLOW_LOW_QUALITY, m.RPN_BOX_REG.MEAN,
                                   m.RPN_BOX_REG.STD, pl.rpn_labels, pl.rpn_match, pl.rpn_offsets, pl.rpn_num_fg, pl.assign_ws)
-            ops.sample_labels(pl.rpn_labels, self._keys(inputs, "rpn_pos", (N, pl.A_total)), self._keys(inputs, "rpn_neg", (N, pl.A_total)),
-                              int(m.RPN.POSITIVE_ANCHOR_RATIO * nsa), nsa, pl.rpn_num_valid)
-            if not (self.deterministic_roi_bwd or self.roi_bwd_pk):     # (the fp32 scatter only)
+            ops.sample_labels(pl.rpn_labels, keys["rpn_pos"], keys["rpn_neg"], int(m.RPN.POSITIVE_ANCHOR_RATIO * nsa), nsa, pl.rpn_num_valid)
+            if not (self.deterministic_roi_bwd and pl.roi_bwd_tiled):     # (the fp32 scatter only)
                 if pl.g_feat32 is None:
                     pl.g_feat32 = torch.empty((pl.pyr.pixels, self.fpn_ch), dtype=torch.float32, device=self.device)
                 pl.g_feat32.zero_()           # the fp32 pyramid RoIAlign's backward scatters into (1.5 GB at batch 16): cleared here, not in backward
@@ -220,12 +229,9 @@ class FasterRCNN(FPNDetector):
         # profiles/r05_frcnn_ab.txt -- the persistent one-workgroup-per-CU convolution kernels keep the box chain's many small grids
         # waiting for a CU, and the box chain is the critical path; that schedule also failed the bench-batch parity test once.)
         side = self._tstream if (self.async_wgrad and self._tstream is not None) else None
-        S = m.RCNN.NUM_ROIS
-        key_ld = pl.rois.shape[1] + Gmax
 
         def sample():
-            ops.rcnn_sample_targets(pl.rois, pl.num_rois, gt, num_gt, self._keys(inputs, "rcnn_fg", (N, key_ld)),
-                                    self._keys(inputs, "rcnn_bg", (N, key_ld)), S, int(S * m.RCNN.FG_RATIO), m.RCNN.FG_THRESHOLD,
+            ops.rcnn_sample_targets(pl.rois, pl.num_rois, gt, num_gt, keys["rcnn_fg"], keys["rcnn_bg"], S, int(S * m.RCNN.FG_RATIO), m.RCNN.FG_THRESHOLD,
                                     m.RCNN.BG_THRESHOLD_HIGH, m.RCNN.BG_THRESHOLD_LOW, m.RCNN_BOX_REG.MEAN, m.RCNN_BOX_REG.STD,
                                     pl.s_rois, pl.s_labels, pl.s_targets, pl.s_count, pl.s_total)
 
@@ -248,8 +254,8 @@ class FasterRCNN(FPNDetector):
         pl.rpn_bwd_done = False
         if side is not None:
             # the RPN head's backward needs nothing from the proposal chain: it runs now, under it, and leaves the FIRST contribution
-            # to dL/dP; the RoIAlign backward joins it later (head_backward: the fp32 pyramid through an accumulating conversion,
-            # the packed atomics directly on top)
+            # to dL/dP; the RoIAlign backward joins it later (head_backward: the tiled sums are added on top, the fp32 scatter's pyramid
+            # through an accumulating conversion)
             self._flush_wgrads()          # (partial sums left by a get_losses() that was never followed by backward(): reduce them now, free the arena)
             self._rpn_head_backward(pl, pl.wgrad_ws, pl.colsum_ws, first=True)
             pl.rpn_bwd_done = True
@@ -287,12 +293,7 @@ class FasterRCNN(FPNDetector):
         self._wgrad(self.fc1, pl.pooled, pl.g_fc1, g, g, ws, cws)
         self.fc1.dgrad(pl.g_fc1, g, g, pl.g_pooled)
         # first contribution to dL/dP: every pyramid level is written (zeros where no RoI sample lands, all of P6)
-        if self.roi_bwd_pk:
-            if not pl.rpn_bwd_done:
-                pl.g_P.zero_()
-            ops.roi_align_bwd_pk(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4), pl.s_labels.view(-1), S,
-                                 self.pool, 2, pl.g_P)
-        elif self.deterministic_roi_bwd:    # per-tile sums in registers, fixed order, written once (added to the RPN head's dL/dP when that ran first)
+        if self.deterministic_roi_bwd and pl.roi_bwd_tiled:    # per-tile sums in registers, fixed order, written once (added to the RPN head's dL/dP when that ran first)
             ops.roi_align_bwd_bf16(pl.g_pooled, pyr, self.rcnn_levels, self.strides, self.fpn_ch, pl.s_rois.view(-1, 4),
                                    pl.s_labels.view(-1), S, self.pool, 2, pl.g_P, pl.roi_bwd_ws, accumulate=pl.rpn_bwd_done)
         else:

@@ -507,13 +507,6 @@ def roi_align_bwd(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_im
                                pool[1], sample_points, ptr(gfeat), stream_ptr()), "bd_roi_align_bwd")
 
 
-def roi_align_bwd_pk(gout, geom: Geom, nlev, strides, Cn, rois, labels, rois_per_img, pool, sample_points, gfeat):
-    R = rois.shape[0]
-    check(L().bd_roi_align_bwd_pk(ptr(gout), geom.pix_per_img, Cn, nlev, i32arr(geom.off[:nlev]), i32arr(geom.H[:nlev]),
-                               i32arr(geom.W[:nlev]), i32arr(strides[:nlev]), ptr(rois), ptr(labels), R, rois_per_img, pool[0],
-                               pool[1], sample_points, ptr(gfeat), stream_ptr()), "bd_roi_align_bwd_pk")
-
-
 def roi_align_bwd_bf16_workspace_bytes(geom: Geom, rois_per_img):
     return int(L().bd_roi_align_bwd_bf16_workspace_bytes(geom.N, geom.nlev, i32arr(geom.H), i32arr(geom.W), rois_per_img))
 

@@ -479,10 +479,8 @@ def main():
     ap.add_argument("--main-priority", type=int, default=None,
                     help="ablation: -1 = run the step's main chain on a high-priority stream owned by the solver (round 2's default); "
                          "0 / unset = the caller's stream")
-    ap.add_argument("--roi-bwd-pk", action="store_true",
-                    help="Faster R-CNN: packed-bf16 atomic RoIAlign backward (running bf16 sums; default is the tiled fixed-order sum)")
     ap.add_argument("--roi-bwd-scatter", action="store_true",
-                    help="Faster R-CNN: the fp32 atomic scatter + conversion pass of rounds 2-4 as RoIAlign backward")
+                    help="Faster R-CNN: the general fp32 atomic scatter + conversion pass as RoIAlign backward (default: the tiled fixed-order sum)")
     ap.add_argument("--dense1x1", type=int, default=None, help="ablation: bd_conv_set_dense1x1 (0 = generic kernel for the dense 1x1 launches)")
     ap.add_argument("--no-mask-bits", action="store_true", help="ablation: bf16 activations instead of bit-packed ReLU gates as dgrad masks")
     ap.add_argument("--skip-s2-3x3-after-warmup", action="store_true",
@@ -602,8 +600,6 @@ def worker(args):
         ops.L().bd_wgrad_set_transpose_read(args.wgrad_knob)
     if args.no_mask_bits:
         model.use_mask_bits = False
-    if args.roi_bwd_pk:
-        model.roi_bwd_pk = True
     if args.roi_bwd_scatter:
         model.deterministic_roi_bwd = False
     if args.main_priority is not None:            # ablation: 0 = the step on the caller's (default-priority) stream

@@ -502,8 +502,9 @@ int bd_rcnn_sample_targets(const float* rois, const int32_t* num_rois, int post_
 /* roi_pool(..., "roi_align") (roi_pool.py:35-78): level = clamp(floor(4 + log2(sqrt(area)/224))) (:12-25), then
  * RoIAlign (average, sample_points^2 samples per bin, aligned) on that level of a pixel-major bf16 pyramid.
  * RoI r belongs to image r / rois_per_img; labels (optional) < 0 marks an empty slot (output row zeroed).
- * out: bf16 [R][PH*PW][C] (bin-major, channel-minor).  The backward scatters into an fp32 gradient pyramid of the
- * same pixel layout with atomic adds (the caller zeroes it). */
+ * out: bf16 [R][PH*PW][C] (bin-major, channel-minor).  bd_roi_align_bwd is the GENERAL backward (any pooled size, any number of RoIs
+ * per image): it scatters into an fp32 gradient pyramid of the same pixel layout with atomic adds (the caller zeroes it; summation
+ * order not fixed).  The 7 x 7 training default is bd_roi_align_bwd_bf16 below. */
 int bd_roi_align_fwd(const void* feat, int64_t pix_per_img, int C, int L, const int32_t* lvl_pix_off_host,
                      const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
                      const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
@@ -512,13 +513,6 @@ int bd_roi_align_bwd(const void* gout, int64_t pix_per_img, int C, int L, const 
                      const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
                      const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
                      int sample_points, float* gfeat, bd_stream_t stream);
-
-/* bd_roi_align_bwd with two channels per atomic (global_atomic_pk_add_bf16) straight into the ZEROED bf16 gradient pyramid: half the
- * atomic operations of the fp32 scatter, no fp32 staging buffer and no conversion pass; every add rounds to bf16.  C even. */
-int bd_roi_align_bwd_pk(const void* gout, int64_t pix_per_img, int C, int L, const int32_t* lvl_pix_off_host,
-                        const int32_t* lvl_h_host, const int32_t* lvl_w_host, const int32_t* strides_host,
-                        const float* rois, const int32_t* labels, int R, int rois_per_img, int PH, int PW,
-                        int sample_points, void* gfeat_bf16, bd_stream_t stream);
 
 /* Deterministic backward of bd_roi_align_fwd (the training step's default since round 5; roi_pool.py:35-78 under autograd): the gradient
  * pyramid is cut into 8x8-pixel tiles, every tile gets the list of the RoIs whose samples touch it in slot order (count, scan, fill: no

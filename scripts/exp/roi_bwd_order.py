@@ -46,10 +46,9 @@ def timeit(fn, it=5):
 for tag, r in (("random slot order", rois), ("sorted by level, y band, x", srt)):
     rd = torch.from_numpy(r).cuda()
     t32 = timeit(lambda: ops.roi_align_bwd(gout, geom, 4, STR, C, rd, labels, rpi, (7, 7), 2, gfeat))
-    tpk = timeit(lambda: ops.roi_align_bwd_pk(gout, geom, 4, STR, C, rd, labels, rpi, (7, 7), 2, gpk))
     ws = torch.empty((ops.roi_align_bwd_bf16_workspace_bytes(geom, rpi),), dtype=torch.uint8, device="cuda")
     tg = timeit(lambda: ops.roi_align_bwd_bf16(gout, geom, 4, STR, C, rd, labels, rpi, (7, 7), 2, gpk, ws))
     tga = timeit(lambda: ops.roi_align_bwd_bf16(gout, geom, 4, STR, C, rd, labels, rpi, (7, 7), 2, gpk, ws, accumulate=True))
     tz = timeit(lambda: gfeat.zero_())
     tc = timeit(lambda: ops.f32_to_bf16(gfeat, gpk))
-    print(f"{tag:30s}: fp32 scatter {t32:8.1f} us (+ zero fill {tz:6.1f} + convert {tc:6.1f})   packed bf16 {tpk:8.1f} us   deterministic tiles {tg:8.1f} us (accumulating: {tga:8.1f})", flush=True)
+    print(f"{tag:30s}: fp32 scatter {t32:8.1f} us (+ zero fill {tz:6.1f} + convert {tc:6.1f})   deterministic tiles {tg:8.1f} us (accumulating: {tga:8.1f})", flush=True)

@@ -19,7 +19,6 @@ python3 bench.py > $O/r04_bench.json 2> $O/bench.err
 for w in fcos_r50_800x1344 faster_rcnn_r50_800x1344 atss_r50_800x1344 ota_r50_800x1344 freeanchor_r50_800x1344 retinanet_r101_800x1344; do
   python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 done
-python3 bench.py --workload faster_rcnn_r50_800x1344 --roi-bwd-pk --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --ref-protocol-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('faster_rcnn pk', d['value'], d['ms_per_step'])" >> $O/workloads.txt
 python3 bench.py --workload retinanet_r101_800x1344 --fp8 --steps 20 --warmup 5 --no-cpu-baseline --ref-protocol-steps 0 > $O/r04_bench_r101_fp8.json 2>/dev/null
 python3 bench.py --workload retinanet_r101_800x1344 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline --ref-protocol-steps 0 > $O/r04_bench_r101_bf16_b32.json 2>/dev/null
 python3 bench.py --workload fcos_r50_800x1344 --steps 50 --warmup 10 --no-cpu-baseline --ref-protocol-steps 0 > $O/r04_bench_fcos_r50.json 2>/dev/null

@@ -146,7 +146,7 @@ def test_faster_rcnn_training_step_is_bitwise_reproducible_full_size():
     outs = []
     for _ in range(2):
         model = FasterRCNN(cfg, params=params)
-        assert model.deterministic_roi_bwd and not model.roi_bwd_pk
+        assert model.deterministic_roi_bwd
         model(b)
         model.backward()
         torch.cuda.synchronize()

@@ -4,10 +4,11 @@ sizes, configs/det_model/faster_rcnn_cfg.py).  bench.py's CPU-baseline leg runs 
 affordable; it sees what size-independent properties cannot: a tile that is consistently wrong at large grid indices.
 
 Per model: discrete targets (labels, matched anchors, RPN labels, sampled RoIs) bit-exact; losses <= 2e-2 and logits rel-L2 <= 2e-2
-against the plain fp32 oracle; EVERY parameter gradient against the plain fp32 oracle within a loose per-tensor bound (bf16 forward
-differences flip ReLU gates near zero, so this bound is not tight -- but a wrong small parameter cannot hide in a global cosine),
-and within 2e-2 against the oracle evaluated on the HIP run's own stored activations (identical gates: the backward pass is then the
-same linear map on both sides)."""
+against the plain fp32 oracle; EVERY parameter gradient against the plain fp32 oracle bounded in DIRECTION (per-parameter cosine and
+whole-model cosine, norm ratio: bf16 forward differences flip ReLU gates near zero, so a rel-L2 bound against the plain oracle would
+assert little -- but a wrong small parameter cannot hide in a global cosine), and within 2e-2 (Faster R-CNN: 3e-2) in rel-L2 against
+the oracle evaluated on the HIP run's own stored activations (identical gates: the backward pass is then the same linear map on both
+sides)."""
 import numpy as np
 import pytest
 import torch
@@ -21,6 +22,9 @@ N = 2
 MIN_COS_PARAM = 0.975       # RetinaNet-R50: observed worst parameter 0.9909 (layer2.1.conv1), whole model 0.99954, norm ratio 1.003
 MIN_COS_MODEL = 0.998
 FCOS_MIN_COS = (0.93, 0.99)  # FCOS-R50 (GroupNorm towers amplify the flipped gates): observed 0.9550 (layer2.3.conv1) / 0.99659
+# Faster R-CNN against the PLAIN oracle: the fp32 scores give (slightly) different proposals, so the keys sample different RoIs for the box
+# head -- its parameters and everything their gradient flows into see a different mini-batch of RoIs, not only flipped gates.
+FRCNN_MIN_COS = (0.50, 0.90)  # floors re-set from the first run's printed values (see the test)
 
 
 def _rel(a, b):
@@ -33,7 +37,7 @@ def _cos(a, b):
     return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
 
 
-def _check_grads(names, got, plain, injected, tag, min_cos_param=MIN_COS_PARAM, min_cos_model=MIN_COS_MODEL):
+def _check_grads(names, got, plain, injected, tag, min_cos_param=MIN_COS_PARAM, min_cos_model=MIN_COS_MODEL, inj_bound=2e-2):
     worst_plain, worst_inj, worst_cos = ("", 0.0), ("", 0.0), ("", 1.0)
     dot = na = nb = 0.0
     for n in names:
@@ -54,7 +58,7 @@ def _check_grads(names, got, plain, injected, tag, min_cos_param=MIN_COS_PARAM, 
     assert worst_cos[1] > min_cos_param, worst_cos
     assert model_cos > min_cos_model, model_cos
     assert 0.9 < np.sqrt(na / nb) < 1.1, np.sqrt(na / nb)
-    assert worst_inj[1] < 2e-2, worst_inj
+    assert worst_inj[1] < inj_bound, worst_inj
 
 
 def _check_forward_layers(orc, batch, fn, tag, bound=2e-2):
@@ -177,6 +181,7 @@ def test_faster_rcnn_r50_full_size_matches_oracle():
     # (1) plain fp32 oracle: the RPN targets do not depend on the network output -> bit-exact; RPN losses within bf16 tolerance
     orc = Oracle(params, P.oracle_arch(cfg), trainable=names)
     ref, aux = orc.faster_rcnn_losses(batch, keys)
+    ref_grads = orc.grads(ref["total_loss"])
     assert np.array_equal(dbg["rpn_labels"], aux["rpn_labels"])
     for k in ("rpn_cls_loss", "rpn_reg_loss"):
         got, want = float(out[k]), float(ref[k].detach())
@@ -203,11 +208,8 @@ def test_faster_rcnn_r50_full_size_matches_oracle():
     for k in ("rpn_cls_loss", "rpn_reg_loss", "rcnn_cls_loss", "rcnn_reg_loss", "total_loss"):
         got, want = float(out[k]), float(l2[k].detach())
         assert abs(got - want) / abs(want) < 2e-2, (k, got, want)
-    g2 = orc2.grads(l2["total_loss"])
-    got = model.reference_grads()
-    worst = ("", 0.0)
-    for n in names:
-        r = _rel(got[n], g2[n].detach())
-        worst = (n, r) if r > worst[1] else worst
-    print(f"[Faster R-CNN R50 2x800x1344, 2000/1000/512] worst per-parameter gradient rel-L2 vs the injected oracle: {worst}")
-    assert worst[1] < 3e-2, worst          # the packed-bf16 RoIAlign backward (running bf16 sums) sits on this path
+    # (3) every parameter gradient: direction against the plain oracle (as RetinaNet / FCOS above), rel-L2 against the injected one.  3e-2:
+    # the box head's gradients pass RoIAlign's backward (fp32 sums per 8 x 8 tile, ONE rounding to bf16 when the tile is written on top of
+    # the RPN head's bf16 dL/dP) and the bf16 FC layers; observed worst 1.6e-2.
+    _check_grads(names, model.reference_grads(), ref_grads, orc2.grads(l2["total_loss"]), "Faster R-CNN R50 2x800x1344, 2000/1000/512",
+                 *FRCNN_MIN_COS, inj_bound=3e-2)
