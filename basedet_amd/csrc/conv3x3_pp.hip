@@ -79,6 +79,12 @@ __device__ __forceinline__ int xpos(int chunk) { return (chunk >> 2) * 64 + ((((
 __device__ unsigned long long g_pp_stamp[64];
 __device__ unsigned long long g_pp_span[2048];      // [2 b], [2 b + 1]: s_memrealtime (100 MHz, chip-wide) at the start / end of workgroup b
 #endif
+// -DBD_PP_ABLATE=<bits> (diagnostic builds, TIMING ONLY -- the results are wrong; scripts/exp/pp_power.sh): bit 0 = the second K half of every
+// tap re-uses the first half's fragments (half of the loop's ds_read_b128 gone), bit 1 = no weight DMA inside the K loop (the ring keeps the
+// prologue's three taps).  Same MFMAs, same barriers: what moves is LDS / L2 traffic -- and with it launch time and the clock the chip holds.
+#ifndef BD_PP_ABLATE
+#define BD_PP_ABLATE 0
+#endif
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
@@ -249,7 +255,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     }
     const __amdgpu_buffer_rsrc_t w_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(p.w), 0, (unsigned)(p.CO * 9 * p.CK) * 2u, 0x00020000);
+    bool dma_on = true;          // (BD_PP_ABLATE bit 1 clears it behind the prologue)
     auto dma_piece = [&](int tap, int cb, int slot, int k) {       // buffer_load_dwordx4 ... offen lds: fixed VGPR offset + scalar offset
+        if ((BD_PP_ABLATE & 2) && !dma_on) return;
         unsigned char* l = wbuf + slot * W_SLOT + (wave + 8 * k) * 1024;
         int so = (tap * p.CK + cb * 64) * 2;
         asm volatile("" : "+s"(so));          // keep the tap offset in the scalar operand (else 36 hoisted per-tap VGPR offsets)
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     PP_BARRIER();
     PP_FENCE();
+    if (BD_PP_ABLATE & 2) dma_on = false;
 
     PP_STAMP();                    // 2: prologue done = K loop of tile 0 starts; then per tile: last K block (+ decode) starts, K loop done, epilogue issued, next K loop starts
     // Every tile enters its K loop with taps 0 and 1 of K block 0 complete in the ring and tap 2 requested (the prologue; for a following
@@ -347,13 +356,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 // busy 56 % of the time.
                 // ---------------- load segment ----------------
                 const int slot = t % 3;
+                if (!((BD_PP_ABLATE & 1) && kk == 1)) {
                 load_b(kk, t);
                 PP_FENCE();
                 load_a(kk, slot);
                 PP_FENCE();
+                }
                 if (kk == 1) {
                     // retire the pieces of tap t+1 (the last of them was issued in phase (t, 0)); piece 0 of tap t+2 stays in flight
-                    if (!cont && t >= 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (BD_PP_ABLATE & 2) { }           // (no DMA in flight: the counted waits would only catch the activation loads early)
+                    else if (!cont && t >= 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     else if (t >= 1 || cb > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                     if (t == 6) {
                         if (cont) load_x(nb);                      // consumed by the swap after tap 8

@@ -6,7 +6,7 @@ affordable; it sees what size-independent properties cannot: a tile that is cons
 Per model: discrete targets (labels, matched anchors, RPN labels, sampled RoIs) bit-exact; losses <= 2e-2 and logits rel-L2 <= 2e-2
 against the plain fp32 oracle; EVERY parameter gradient against the plain fp32 oracle bounded in DIRECTION (per-parameter cosine and
 whole-model cosine, norm ratio: bf16 forward differences flip ReLU gates near zero, so a rel-L2 bound against the plain oracle would
-assert little -- but a wrong small parameter cannot hide in a global cosine), and within 2e-2 (Faster R-CNN: 3e-2) in rel-L2 against
+assert little -- but a wrong small parameter cannot hide in a global cosine), and within 2e-2 (Faster R-CNN: 1e-2) in rel-L2 against
 the oracle evaluated on the HIP run's own stored activations (identical gates: the backward pass is then the same linear map on both
 sides)."""
 import numpy as np
@@ -22,9 +22,9 @@ N = 2
 MIN_COS_PARAM = 0.975       # RetinaNet-R50: observed worst parameter 0.9909 (layer2.1.conv1), whole model 0.99954, norm ratio 1.003
 MIN_COS_MODEL = 0.998
 FCOS_MIN_COS = (0.93, 0.99)  # FCOS-R50 (GroupNorm towers amplify the flipped gates): observed 0.9550 (layer2.3.conv1) / 0.99659
-# Faster R-CNN against the PLAIN oracle: the fp32 scores give (slightly) different proposals, so the keys sample different RoIs for the box
-# head -- its parameters and everything their gradient flows into see a different mini-batch of RoIs, not only flipped gates.
-FRCNN_MIN_COS = (0.50, 0.90)  # floors re-set from the first run's printed values (see the test)
+# Faster R-CNN against the PLAIN oracle (whose fp32 scores may order proposals differently): observed worst parameter 0.99798
+# (backbone.fpn_output4.weight), whole model 0.99989, norm ratio 0.996; against the injected oracle worst rel-L2 2.3e-3.
+FRCNN_MIN_COS = (0.99, 0.999)
 
 
 def _rel(a, b):
@@ -208,8 +208,8 @@ def test_faster_rcnn_r50_full_size_matches_oracle():
     for k in ("rpn_cls_loss", "rpn_reg_loss", "rcnn_cls_loss", "rcnn_reg_loss", "total_loss"):
         got, want = float(out[k]), float(l2[k].detach())
         assert abs(got - want) / abs(want) < 2e-2, (k, got, want)
-    # (3) every parameter gradient: direction against the plain oracle (as RetinaNet / FCOS above), rel-L2 against the injected one.  3e-2:
-    # the box head's gradients pass RoIAlign's backward (fp32 sums per 8 x 8 tile, ONE rounding to bf16 when the tile is written on top of
-    # the RPN head's bf16 dL/dP) and the bf16 FC layers; observed worst 1.6e-2.
+    # (3) every parameter gradient: direction against the plain oracle (as RetinaNet / FCOS above), rel-L2 against the injected one (the
+    # box head's gradients pass RoIAlign's tiled backward: fp32 sums per 8 x 8 tile, ONE rounding to bf16 when the tile is written on top
+    # of the RPN head's bf16 dL/dP; observed worst 2.3e-3 -- the bound of rounds 3-5, 3e-2, dated from the packed-bf16 atomics)
     _check_grads(names, model.reference_grads(), ref_grads, orc2.grads(l2["total_loss"]), "Faster R-CNN R50 2x800x1344, 2000/1000/512",
-                 *FRCNN_MIN_COS, inj_bound=3e-2)
+                 *FRCNN_MIN_COS, inj_bound=1e-2)
