@@ -44,12 +44,17 @@ SIGNATURES = {
     "bd_version": (_I, []),
     "bd_conv_last_kernel": (C.c_char_p, []),
     "bd_probe_mfma_rate": (_I, [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    "bd_probe_kernel_clock": (_I, [C.c_char_p, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bd_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_fwd_bits": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_fwd_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_dgrad_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_dgrad_bits": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
+    "bd_conv2d_ksplit_workspace_bytes": (_Z, []),
+    "bd_conv2d_ksplit_applies": (_I, [_D, _I]),
+    "bd_conv2d_fwd_ws": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
+    "bd_conv2d_dgrad_ws": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_conv_set_dense1x1": (_I, [_I]),
     "bd_conv2d_wgrad_workspace_bytes": (_Z, [_D]),
     "bd_conv2d_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _P, _Z, _P]),

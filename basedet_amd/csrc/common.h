@@ -56,6 +56,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- in-kernel clock probe (bd_probe_kernel_clock) -----------------------------------------------------------------------------------
+// The chip lowers its clock under MFMA-dense load (MI355X_MICROARCH.md, DVFS give-back), so a TFLOP/s figure is (in-cycle efficiency) x
+// (held clock).  The two dominant MFMA-bound kernels carry this probe in the SHIPPED build: lane 0 of workgroup 0 reads the shader-cycle
+// and the 100 MHz counters when it starts and when it ends (four scalar reads and two atomics per LAUNCH; a persistent workgroup lives as
+// long as the launch) and adds both differences to a pair of device counters nobody else reads; the host divides the sums.
+// No register lives across the kernel for it (conv3x3_pp_kernel has none to spare: a held stamp pair spilled four VGPRs into its K loop):
+// the START stamps are SUBTRACTED from the counters right away (mod 2^64), the END stamps added -- the sums are meaningful once the
+// launches have finished, which is when the host reads them.
+__device__ __forceinline__ void bd_clk_mark(unsigned long long* acc, bool end) {
+#ifdef BD_NO_CLK_PROBE          // (A/B build: what the probe costs -- profiles/r06_clk_probe_ab.txt)
+    return;
+#endif
+    const unsigned long long c = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+    atomicAdd(acc, end ? c : 0ull - c);
+    atomicAdd(acc + 1, end ? r : 0ull - r);
+}
+
 void bd_set_error(const char* fmt, ...);
 // bd_conv_last_kernel(): every convolution launch site names the kernel it dispatched to (a string literal; thread-local, host side only)
 void bd_note_kernel(const char* name);

@@ -85,6 +85,7 @@ __device__ unsigned long long g_pp_span[2048];      // [2 b], [2 b + 1]: s_memre
 #ifndef BD_PP_ABLATE
 #define BD_PP_ABLATE 0
 #endif
+__device__ unsigned long long g_pp_clk[2];           // bd_probe_kernel_clock("conv3x3_pp_kernel"): sums of workgroup 0's (shader cycles, 100 MHz ticks)
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                                    (p.CO + TAIL_CO - 1) / TAIL_CO);
         return;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bd_clk_mark(g_pp_clk, false);
     unsigned char* wbuf = smem;                                   // [3][W_SLOT]
     unsigned char* xbuf = smem + W_BYTES;                         // [X_BYTES]
     float* sbias = reinterpret_cast<float*>(smem + W_BYTES + X_BYTES);      // [256]
@@ -614,6 +616,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     PP_FENCE();
     PP_STAMP();                    // next K loop starts
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bd_clk_mark(g_pp_clk, true);
 #ifdef BD_PP_STAMP
     if (st_on) { g_pp_stamp[63] = __builtin_amdgcn_s_memrealtime(); g_pp_stamp[61] = __builtin_amdgcn_s_memtime(); }
     if (threadIdx.x == 0 && blockIdx.x < 1024) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_pp_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
@@ -692,6 +695,13 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     bd_note_kernel("conv3x3_pp_kernel");
     if (mode == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<0>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
     else hipLaunchKernelGGL((conv3x3_pp_kernel<1>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
+    return 0;
+}
+
+// (probe.hip) sums since the last reset; reset != 0 clears them afterwards
+int bd_pp_clk_read(unsigned long long* out2, int reset) {
+    if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_pp_clk), 16) != hipSuccess) return 1;
+    if (reset) { const unsigned long long z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pp_clk), z, 16) != hipSuccess) return 1; }
     return 0;
 }
 

@@ -62,6 +62,8 @@ struct RParams {
 __device__ unsigned long long g_rk_stamp[8][8];
 #endif
 
+__device__ unsigned long long g_rk_clk[2];           // bd_probe_kernel_clock("conv_wgrad3x3_ring_kernel")
+
 __device__ __forceinline__ void rk_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff, int soff = 0) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
 }
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 3, wo = wave >> 2;          // 16-ci group, 64-co group
+    if (blockIdx.x == 0 && threadIdx.x == 0) bd_clk_mark(g_rk_clk, false);
     int bid = blockIdx.x;
     {   // XCD-aware bijective remap: the tiles of one split share its patches -> consecutive ids on ONE XCD (one HBM fetch per XCD)
         const int nwg = gridDim.x;
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
         const int co = co0 + wo * 64 + wi * 16 + idx;
         if (co < p.Cout) p.csum[(size_t)split * p.Cout + co] = cacc[0];
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bd_clk_mark(g_rk_clk, true);
 }
 
 struct RPlan { int ci_tiles, co_tiles, tiles, splits, total, ppi, per; };
@@ -400,6 +404,12 @@ RPlan ring_plan(const bd_conv_desc* d) {
 }
 
 }  // namespace
+
+int bd_rk_clk_read(unsigned long long* out2, int reset) {          // (probe.hip)
+    if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_rk_clk), 16) != hipSuccess) return 1;
+    if (reset) { const unsigned long long z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rk_clk), z, 16) != hipSuccess) return 1; }
+    return 0;
+}
 
 #ifdef BD_RK_STAMP
 extern "C" int bd_debug_rk_stamp(unsigned long long* out64) {

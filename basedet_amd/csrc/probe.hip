@@ -94,3 +94,20 @@ extern "C" int bd_probe_mfma_rate(double seconds, double* tflops_out, double* cl
     if (rc != BD_OK) bd_set_error("bd_probe_mfma_rate: %s", hipGetErrorString(hipGetLastError()));
     return rc;
 }
+
+int bd_pp_clk_read(unsigned long long* out2, int reset);          // conv3x3_pp.hip
+int bd_rk_clk_read(unsigned long long* out2, int reset);          // conv_wgrad3x3_ring.hip
+
+// SYNCHRONOUS with the device (hipMemcpyFromSymbol): the clock the chip held, averaged over every launch of `kernel` since the last reset.
+extern "C" int bd_probe_kernel_clock(const char* kernel, int reset, double* clock_mhz_out, double* busy_ms_out) {
+    BD_REQUIRE(kernel && clock_mhz_out, "bd_probe_kernel_clock: null pointer");
+    unsigned long long v[2] = {0, 0};
+    int rc;
+    if (std::string(kernel) == "conv3x3_pp_kernel") rc = bd_pp_clk_read(v, reset);
+    else if (std::string(kernel) == "conv_wgrad3x3_ring_kernel") rc = bd_rk_clk_read(v, reset);
+    else { bd_set_error("bd_probe_kernel_clock: no probe in '%s' (conv3x3_pp_kernel, conv_wgrad3x3_ring_kernel)", kernel); return BD_EINVAL; }
+    if (rc != 0) { bd_set_error("bd_probe_kernel_clock: %s", hipGetErrorString(hipGetLastError())); return BD_ELAUNCH; }
+    *clock_mhz_out = v[1] ? (double)v[0] / (double)v[1] * 100.0 : 0.0;
+    if (busy_ms_out) *busy_ms_out = (double)v[1] * 1e-5;
+    return BD_OK;
+}

@@ -357,10 +357,14 @@ def measure_traffic(args, timeout_s=120):
         env.pop(k, None)
     res = {}
     try:
+        clocks = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
+            # GRBM_GUI_ACTIVE rides with WRITE_SIZE (2 of the 4 TCC slots; the GRBM block has its own two): the clock the chip held in each
+            # kernel of that pass = counter / 8 XCDs / dispatch time (MI355X_MICROARCH.md, DVFS give-back)
+            names = [counter, "GRBM_GUI_ACTIVE"] if counter == "WRITE_SIZE" else [counter]
             # own process group: on a timeout the profiler AND the profiled child (which holds the GPU) are ended together, by that exact group id
-            proc = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + tail, cwd="/tmp", env=env,
+            proc = subprocess.Popen([exe, "--pmc"] + names + ["--output-format", "csv", "-d", d, "--"] + tail, cwd="/tmp", env=env,
                                     stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 rc = proc.wait(timeout=timeout_s)
@@ -375,6 +379,11 @@ def measure_traffic(args, timeout_s=120):
             if rc != 0:
                 return {}, f"rocprofv3 --pmc {counter} exited with {rc}: traffic not measured"
             res[counter] = pmc_traffic.load(d, counter)
+            if counter == "WRITE_SIZE":
+                try:
+                    clocks = pmc_traffic.load_clock(d)
+                except Exception:                                   # noqa: BLE001 (the clock is an extra: never lose the traffic over it)
+                    clocks = {}
     except subprocess.TimeoutExpired:
         return {}, f"a rocprofv3 --pmc pass exceeded {timeout_s} s: traffic not measured"
     except Exception as e:                                          # noqa: BLE001 (a missing csv, a parse error: report, do not fail the bench)
@@ -383,6 +392,9 @@ def measure_traffic(args, timeout_s=120):
         shutil.rmtree(tmp, ignore_errors=True)
     (f, fc), (w, wc) = res["FETCH_SIZE"], res["WRITE_SIZE"]
     out = {k: {"hbm_bytes_per_launch": int((2 * f[k] / fc[k] + w.get(k, 0.0) / max(1, wc.get(k, 0))) * 1024)} for k in f}
+    for k, (mhz, us) in clocks.items():
+        if k in out:
+            out[k]["clock_mhz"], out[k]["pmc_dispatch_us"] = round(mhz, 0), round(us, 1)
     return out, ("traffic measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child processes after the timed region, "
                  "3 steps each, mean per launch), HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024")
 
@@ -612,6 +624,16 @@ def worker(args):
         from basedet_amd._lib import check as _check
         _check(ops.L().bd_conv_set_patch3x3((args.conv_knob if args.conv_knob is not None else 3) | 16),
                "--skip-s2-3x3-after-warmup (needs a -DBD_AB_SKIP diagnostic build of the library: BD_LIB_NAME / BD_EXTRA_FLAGS, BASEDET_HIP_LIB)")
+    def _kernel_clock(kern, reset):
+        """clock the chip held inside `kern` since the last reset (bd_probe_kernel_clock: workgroup 0 of every launch stamps its lifetime)"""
+        import ctypes as _C
+        mhz, busy = _C.c_double(0.0), _C.c_double(0.0)
+        if ops.L().bd_probe_kernel_clock(kern.encode(), int(reset), _C.byref(mhz), _C.byref(busy)) != 0 or not mhz.value:
+            return None
+        return {"clock_mhz": round(mhz.value, 0), "probe_busy_ms": round(busy.value, 2)}
+    CLOCKED = ("conv3x3_pp_kernel", "conv_wgrad3x3_ring_kernel")
+    for kern_ in CLOCKED:
+        _kernel_clock(kern_, True)               # (the device is idle: sync() above) the sums start with the timed region
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]       # step boundaries on the main stream (p50 / p95)
     if comm is not None:
         solver.comm_profile = []          # per step: (backward done on the main stream, last bucket's all-reduce done on the comm stream)
@@ -639,6 +661,7 @@ def worker(args):
     marks[args.steps].record()
     sync()
     elapsed = time.perf_counter() - t0
+    held_clock = {kern_: _kernel_clock(kern_, True) for kern_ in CLOCKED}          # over every launch of the timed region, all steps
     if timer:
         timer.enabled = False
         model.async_wgrad = not args.serial_wgrad
@@ -772,6 +795,23 @@ def worker(args):
                 if peak_meas and not hbm_bound and mfma_peak == PEAK_BF16_TFLOPS:
                     entries[-1]["peak_measured"] = peak_meas["tflops"]
                     entries[-1]["frac_of_measured"] = round(tf / peak_meas["tflops"], 4)
+                # frac = (in-cycle efficiency) x (held clock / 2400 MHz): the two factors, from the clock the chip held in this kernel's
+                # launches of the PMC pass (GRBM_GUI_ACTIVE / 8 / dispatch time; the vendor peak is 2500 TFLOP/s at 2400 MHz)
+                clk_pmc = pmc.get(kern, {}).get("clock_mhz")
+                held = held_clock.get(kern)
+                if not hbm_bound and (held or clk_pmc):
+                    if held:            # the kernel's own stamps over the WHOLE timed region (every step, concurrent side streams and all)
+                        entries[-1]["clock_mhz"] = held["clock_mhz"]
+                        entries[-1]["clock_src"] = ("in-kernel: workgroup 0 of every launch in the timed region adds d(s_memtime) and d(s_memrealtime) of its "
+                                                    f"lifetime to two device counters (bd_probe_kernel_clock; {held['probe_busy_ms']} ms of workgroup lifetime)")
+                    else:
+                        entries[-1]["clock_mhz"] = clk_pmc
+                        entries[-1]["clock_src"] = ("rocprofv3 --pmc GRBM_GUI_ACTIVE / 8 XCDs / dispatch time over this kernel's launches of the WRITE_SIZE pass "
+                                                    f"(mean dispatch {pmc[kern].get('pmc_dispatch_us')} us; serialised launches, reads high on dispatches under 0.3 ms)")
+                    if held and clk_pmc:
+                        entries[-1]["clock_mhz_pmc"] = clk_pmc
+                    # frac = frac_in_cycles x clock_mhz / 2400: what the kernel reaches of the matrix rate at the clock it was given
+                    entries[-1]["frac_in_cycles"] = round(tf / (mfma_peak * entries[-1]["clock_mhz"] / 2400.0), 4)
             entries.sort(key=lambda e: -e["ms_per_step"])
             out["roofline"] = entries[0]                 # the dominant kernel of the step
             out["roofline_others"] = entries[1:]

@@ -1,5 +1,5 @@
 """Dense 1x1 launches as plain GEMMs on well- and badly-quantised shapes: which bd_conv_set_dense1x1 mode runs them how fast.
-   python scripts/exp/gemm_probe.py [modes...]   (default 3 2 7)"""
+   python scripts/exp/gemm_probe.py [modes...]   (default 8 7: the default dispatch without / with the K-sliced kernel everywhere)"""
 import os
 import sys
 _here = os.path.dirname(os.path.abspath(__file__))
@@ -35,7 +35,7 @@ def timeit(run, iters=30):
 
 
 def main():
-    modes = [int(a) for a in sys.argv[1:]] or [3, 2]
+    modes = [int(a) for a in sys.argv[1:]] or [8, 7]
     print(f"{'shape':34s} " + " ".join(f"mode{m}: us / TF/s / kernel".rjust(44) for m in modes))
     for tag, M, K, CO in SHAPES:
         geo = ops.single(1, 1, M)

@@ -28,6 +28,26 @@ def load(d, counter):
     return tot, cnt
 
 
+def load_clock(d):
+    """Effective clock per kernel from a pass that collected GRBM_GUI_ACTIVE: the counter is summed over the 8 XCDs, so
+    MHz = sum(GRBM_GUI_ACTIVE) / 8 / sum(dispatch duration in us) (MI355X_MICROARCH.md, DVFS give-back: reads high on dispatches well under
+    0.3 ms, within 3 % of the in-kernel clock on long ones).  Returns {kernel: (mhz, mean dispatch us)}."""
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    assert files, d
+    gui, dur, n = collections.defaultdict(float), collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
+            continue
+        name = re.sub(r"^void ", "", r["Kernel_Name"])
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        m = re.match(r"conv_igemm_kernel<(\d+)", name)
+        name = f"conv_igemm_kernel<{m.group(1)}>" if m else re.split(r"[<(]", name)[0].strip()
+        gui[name] += float(r["Counter_Value"])
+        dur[name] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+        n[name] += 1
+    return {k: (gui[k] / 8.0 / dur[k], dur[k] / n[k]) for k in gui if dur[k] > 0}
+
+
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     f, fc = load(fetch_dir, "FETCH_SIZE")
