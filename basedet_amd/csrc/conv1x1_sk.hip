@@ -70,8 +70,9 @@ __device__ __forceinline__ f32x4_t sk_load_sc1(const float* p) {
 }
 // the compiler does not know that an inline-assembly load is asynchronous: the wait names the loaded registers as read-write operands, so
 // that every use of them is ordered behind it
-__device__ __forceinline__ void sk_wait_loads(f32x4_t (&ld)[4]) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]) : : "memory");
+__device__ __forceinline__ void sk_wait_loads(f32x4_t (&ld)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4]), "+v"(ld[5]), "+v"(ld[6]), "+v"(ld[7]) : : "memory");
 }
 
 __global__ __launch_bounds__(512, 1) void conv1x1_sk_kernel(const SkParams p) {
@@ -246,36 +247,39 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sk_kernel(const SkParams p) {
             while (__hip_atomic_load(written, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(n_sl - 1)) __builtin_amdgcn_s_sleep(4);
         }
         __syncthreads();
-        // sum in slice order, four accumulator quads at a time: prefix = s_0 + ... + s_{q-1} from the slabs, then + own, then + the rest
+        // sum in slice order, eight accumulator quads at a time -- four round trips per slice, the K loop's
+        // fragment registers are dead here: prefix = s_0 + ... + s_{q-1} from the slabs, then + own, then + the rest
+#ifndef BD_SK_ABLATE          // (-DBD_SK_ABLATE=1: timing only -- the last arriver skips the slab reads: what a free fix-up would be worth)
 #pragma unroll                 // (compile-time accumulator names: a run-time index would put the accumulators in scratch)
-        for (int b = 0; b < 8; ++b) {
-            f32x4_t pre[4];
+        for (int b = 0; b < 4; ++b) {
+            f32x4_t pre[8];
 #pragma unroll 1
             for (int q = 0; q < my_q; ++q) {
-                const float* in = p.slab + ((size_t)slot_of(g_first + q) * 8 + wave) * (32 * 256) + lane * 4 + b * 4 * 256;
-                f32x4_t ld[4];
+                const float* in = p.slab + ((size_t)slot_of(g_first + q) * 8 + wave) * (32 * 256) + lane * 4 + b * 8 * 256;
+                f32x4_t ld[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ld[e] = sk_load_sc1(in + e * 256);
+                for (int e = 0; e < 8; ++e) ld[e] = sk_load_sc1(in + e * 256);
                 sk_wait_loads(ld);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pre[e] = q == 0 ? ld[e] : pre[e] + ld[e];
+                for (int e = 0; e < 8; ++e) pre[e] = q == 0 ? ld[e] : pre[e] + ld[e];
             }
             if (my_q > 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[b][e] = pre[e] + acc[b][e];
+                for (int e = 0; e < 8; ++e) acc[2 * b + (e >> 2)][e & 3] = pre[e] + acc[2 * b + (e >> 2)][e & 3];
             }
 #pragma unroll 1
             for (int q = my_q + 1; q < n_sl; ++q) {
-                const float* in = p.slab + ((size_t)slot_of(g_first + q) * 8 + wave) * (32 * 256) + lane * 4 + b * 4 * 256;
-                f32x4_t ld[4];
+                const float* in = p.slab + ((size_t)slot_of(g_first + q) * 8 + wave) * (32 * 256) + lane * 4 + b * 8 * 256;
+                f32x4_t ld[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ld[e] = sk_load_sc1(in + e * 256);
+                for (int e = 0; e < 8; ++e) ld[e] = sk_load_sc1(in + e * 256);
                 sk_wait_loads(ld);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[b][e] = acc[b][e] + ld[e];
+                for (int e = 0; e < 8; ++e) acc[2 * b + (e >> 2)][e & 3] = acc[2 * b + (e >> 2)][e & 3] + ld[e];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         if (tid == 0) { *arrive = 0u; *written = 0u; }          // nobody touches them again in this launch: ready for the next one
     }
 

@@ -294,9 +294,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
         for (int j = 0; j < 4; ++j)
             fb[j] = *reinterpret_cast<const bf16x8_t*>(b_base + ((j + dy) * IW + dx) * X_PITCH + kk * 64);
     };
-    auto mfma_khalf = [&]() {
+    auto mfma_rows = [&](int i0, int i1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = i0; i < i1; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 // tied accumulator (D = C) in inline asm: under this register pressure the allocator otherwise rotates the 32
@@ -382,19 +382,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 // tap t+2.  The slot of tap t+2 was last read (tap t-1) in the load segment of phase (t-1, 1), one barrier before this
                 // group's (t, 0) -- by the other group, whose reads were issued before that barrier and return within ~100 cycles; the DMA
                 // data needs a memory round trip to arrive
-                if (kk == 0) {
-                    if (t + 1 < 9) { if (t > 1 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
-                    else if (cont) dma_piece(0, nb, 0, 3);
-                    if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, 0); }
-                    else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, 0);
-                } else {
+                auto issue_dma = [&]() {
+                    if (kk == 0) {
+                        if (t + 1 < 9) { if (t > 1 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
+                        else if (cont) dma_piece(0, nb, 0, 3);
+                        if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, 0); }
+                        else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, 0);
+                    } else {
 #pragma unroll
-                    for (int pc = 1; pc < 3; ++pc) {
-                        if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, pc); }
-                        else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, pc);
+                        for (int pc = 1; pc < 3; ++pc) {
+                            if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, pc); }
+                            else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, pc);
+                        }
+                        if (t == 8 && last_kb && more) dma_piece(1, 0, 1, 3);      // the next tile's tap 1 complete: see the head of the tile loop
                     }
-                    if (t == 8 && last_kb && more) dma_piece(1, 0, 1, 3);      // the next tile's tap 1 complete: see the head of the tile loop
-                }
+                };
+                // -DBD_PP_DMA_POS=<n> (experiment, profiles/r06_dma_pos.txt): the two pieces are requested behind the n-th row of four MFMAs of
+                // the MFMA segment instead of here in the load segment (same issue order, so the counted waits stand)
+#ifndef BD_PP_DMA_POS
+#define BD_PP_DMA_POS 0
+#endif
+                if (BD_PP_DMA_POS == 0) issue_dma();
                 PP_FENCE();
                 PP_BARRIER();
                 // ---------------- MFMA segment ----------------
@@ -406,7 +414,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
 #if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(1);
 #endif
-                mfma_khalf();
+                if (BD_PP_DMA_POS == 0) mfma_rows(0, 8);
+                else {
+                    mfma_rows(0, BD_PP_DMA_POS);
+                    PP_FENCE();
+                    issue_dma();
+                    PP_FENCE();
+                    mfma_rows(BD_PP_DMA_POS, 8);
+                }
 #if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(0);
 #endif

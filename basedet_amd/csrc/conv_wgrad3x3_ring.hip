@@ -269,9 +269,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
             xr[sx] = (i32x8_t){r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
         }
     };
-    auto mfma_half = [&]() {
+    auto mfma_taps = [&](int t0, int t1, bool with_bias) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = t0; t < t1; ++t) {
             const int r = t / 3, sx = t - 3 * (t / 3);
             const i32x4_t w = r == 0 ? __builtin_shufflevector(xr[sx], xr[sx], 0, 1, 2, 3)
                                      : (r == 1 ? __builtin_shufflevector(xr[sx], xr[sx], 2, 3, 4, 5) : __builtin_shufflevector(xr[sx], xr[sx], 4, 5, 6, 7));
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
             for (int j = 0; j < 4; ++j)
                 acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fb[j], acc[t][j], 0, 0, 0);
         }
-        if (do_cs) {                     // wave-uniform branches: no register copies, one MFMA
+        if (with_bias && do_cs) {                     // wave-uniform branches: no register copies, one MFMA
             if (wi == 0) cacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[0], cacc, 0, 0, 0);
             else if (wi == 1) cacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[1], cacc, 0, 0, 0);
             else if (wi == 2) cacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[2], cacc, 0, 0, 0);
@@ -323,15 +323,21 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
                 // ---------------- load segment ----------------
                 load_half(stage, kk);
                 RK_FENCE();
-                if (kk == 0) {
-                    issue_x(fill, dead);
-                } else {
+                // -DBD_RK_DMA_POS=<n> (experiment, profiles/r06_dma_pos.txt): the phase's two DMA requests are issued behind the n-th tap of the
+                // MFMA segment instead of here in the load segment (same issue order: the counted waits stand)
+#ifndef BD_RK_DMA_POS
+#define BD_RK_DMA_POS 0
+#endif
+                auto issue_dma = [&]() {
+                    if (kk == 0) issue_x(fill, dead);
+                    else { issue_g(fill, dead); advance(); }
+                };
+                if (kk == 1) {
                     // this wave's pieces of step t + 1 have landed; step t + 2 and the X pieces of step t + 3 stay in flight
                     if (two_x) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    issue_g(fill, dead);
-                    advance();
                 }
+                if (BD_RK_DMA_POS == 0) issue_dma();
                 RK_FENCE();
                 RK_T(0);
                 RK_BARRIER();
@@ -345,7 +351,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
 #if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(1);
 #endif
-                mfma_half();
+                if (BD_RK_DMA_POS == 0) mfma_taps(0, 9, true);
+                else {
+                    mfma_taps(0, BD_RK_DMA_POS, false);
+                    RK_FENCE();
+                    issue_dma();
+                    RK_FENCE();
+                    mfma_taps(BD_RK_DMA_POS, 9, true);
+                }
 #if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(0);
 #endif

@@ -970,9 +970,10 @@ def test_ksliced_dense1x1_matches_the_unsliced_kernels_and_fp64(M, K, CO, mode, 
         assert torch.isfinite(y.float()).all()
         err = (y.double() - r).norm() / r.norm()
         assert err < 3e-3, float(err)               # bf16 storage: 2^-9 relative per element
-    # sliced vs un-sliced: at most one bf16 rounding step apart, in few elements
+    # sliced vs un-sliced: at most one bf16 rounding step apart (+ the fp32 rounding of sums of this magnitude, which is all that is left
+    # of a result that cancels to ~0), in few elements
     diff = (ya.float() - y8_.float()).abs()
-    ulp = torch.maximum(ya.float().abs(), y8_.float().abs()) * 2 ** -7 + 1e-30
+    ulp = torch.maximum(ya.float().abs(), y8_.float().abs()) * 2 ** -7 + 1e-5 * scale
     assert (diff <= ulp).all(), float((diff / ulp).max())
     assert float((diff > 0).float().mean()) < 0.02
     if ba is not None:              # the gate bits agree wherever the two results have the same sign of life
