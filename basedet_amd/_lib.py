@@ -51,10 +51,6 @@ SIGNATURES = {
     "bd_conv2d_fwd_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_dgrad_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_dgrad_bits": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
-    "bd_conv2d_ksplit_workspace_bytes": (_Z, []),
-    "bd_conv2d_ksplit_applies": (_I, [_D, _I]),
-    "bd_conv2d_fwd_ws": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
-    "bd_conv2d_dgrad_ws": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_conv_set_dense1x1": (_I, [_I]),
     "bd_conv2d_wgrad_workspace_bytes": (_Z, [_D]),
     "bd_conv2d_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _P, _Z, _P]),

@@ -22,7 +22,6 @@ SOURCES = {
     "conv3x3_pp128.hip": [],
     "conv1x1.hip": [],
     "conv1x1_ring.hip": [],
-    "conv1x1_sk.hip": [],
     "conv1x1_thin.hip": [],
     "bottleneck_fused.hip": [],
     "conv_fp8.hip": [],

@@ -883,17 +883,12 @@ int g_conv1x1_wide_min_k = 0;   // BD_DENSE1X1_WIDE_K: smallest CK that takes th
 }  // namespace
 
 void bd_conv1x1_ring_everywhere(bool on);         // conv1x1_ring.hip
-void bd_conv1x1_sk_set_mode(int mode);            // conv1x1_sk.hip
 
 extern "C" int bd_conv_set_dense1x1(int depth) {
-    if (depth < 0 || depth > 8) {
-        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 8)", depth);
+    if (depth < 0 || depth > 6) {
+        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 6)", depth);
         return BD_EINVAL;
     }
-    // 7 = as 1 with the K-sliced 256 x 256 kernel (conv1x1_sk.hip) for every launch it can take, 8 = as 1 without it (default: the long-K
-    // launches whose tile count leaves much of the chip idle); only the *_ws entry points (a workspace) can reach that kernel at all
-    bd_conv1x1_sk_set_mode(depth == 7 ? 2 : (depth == 8 || depth == 0 ? 0 : 1));
-    if (depth == 7 || depth == 8) depth = 1;
     bd_conv1x1_ring_everywhere(depth == 5);          // 5 = as 1, with conv1x1_ring_kernel for every launch it can take (default: K <= 256 into >= 256 channels)
     // 6 = conv1x1_dense_kernel only (as 3) with its LDS-DMA ring variant for every K that allows it (default: 512 <= K <= 1024): test coverage
     g_conv1x1_dma_k = bd_tune_env("BD_DENSE1X1_DMA_K", depth == 6 ? 32 : 512);

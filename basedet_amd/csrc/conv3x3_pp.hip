@@ -382,27 +382,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 // tap t+2.  The slot of tap t+2 was last read (tap t-1) in the load segment of phase (t-1, 1), one barrier before this
                 // group's (t, 0) -- by the other group, whose reads were issued before that barrier and return within ~100 cycles; the DMA
                 // data needs a memory round trip to arrive
-                auto issue_dma = [&]() {
-                    if (kk == 0) {
-                        if (t + 1 < 9) { if (t > 1 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
-                        else if (cont) dma_piece(0, nb, 0, 3);
-                        if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, 0); }
-                        else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, 0);
-                    } else {
+                // (Round 6, measured and removed: the two pieces requested INSIDE the MFMA segment, behind its 2nd / 4th row of four MFMAs -- the
+                // guide prices a piece at ~60 cycles among bare MFMAs against 100 - 185 here -- made the step 2.0 % slower: a vector-memory
+                // instruction in the MFMA stream holds up the wave that owns the matrix pipe, here the partner's MFMAs run meanwhile;
+                // profiles/r06_dma_pos.txt)
+                if (kk == 0) {
+                    if (t + 1 < 9) { if (t > 1 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
+                    else if (cont) dma_piece(0, nb, 0, 3);
+                    if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, 0); }
+                    else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, 0);
+                } else {
 #pragma unroll
-                        for (int pc = 1; pc < 3; ++pc) {
-                            if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, pc); }
-                            else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, pc);
-                        }
-                        if (t == 8 && last_kb && more) dma_piece(1, 0, 1, 3);      // the next tile's tap 1 complete: see the head of the tile loop
+                    for (int pc = 1; pc < 3; ++pc) {
+                        if (t + 2 < 9) { if (t > 0 || cb > 0) dma_piece(t + 2, cb, (t + 2) % 3, pc); }
+                        else if (cont) dma_piece(t - 7, nb, (t + 2) % 3, pc);
                     }
-                };
-                // -DBD_PP_DMA_POS=<n> (experiment, profiles/r06_dma_pos.txt): the two pieces are requested behind the n-th row of four MFMAs of
-                // the MFMA segment instead of here in the load segment (same issue order, so the counted waits stand)
-#ifndef BD_PP_DMA_POS
-#define BD_PP_DMA_POS 0
-#endif
-                if (BD_PP_DMA_POS == 0) issue_dma();
+                    if (t == 8 && last_kb && more) dma_piece(1, 0, 1, 3);      // the next tile's tap 1 complete: see the head of the tile loop
+                }
                 PP_FENCE();
                 PP_BARRIER();
                 // ---------------- MFMA segment ----------------
@@ -414,14 +410,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
 #if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(1);
 #endif
-                if (BD_PP_DMA_POS == 0) mfma_rows(0, 8);
-                else {
-                    mfma_rows(0, BD_PP_DMA_POS);
-                    PP_FENCE();
-                    issue_dma();
-                    PP_FENCE();
-                    mfma_rows(BD_PP_DMA_POS, 8);
-                }
+                mfma_rows(0, 8);
 #if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(0);
 #endif

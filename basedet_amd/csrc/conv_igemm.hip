@@ -497,12 +497,6 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
 
 int bd_conv1x1_s2_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add, const void* mask,
                          const unsigned* maskbits, void* dst, int flags, hipStream_t stream);
-// conv1x1_sk.hip: the K-sliced 256 x 256 kernel (needs a workspace: the *_ws entry points)
-int bd_conv1x1_sk_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits, void* y,
-                         unsigned* ybits, long long M, int CK, int CO, int flags, void* ws, size_t ws_bytes, hipStream_t stream);
-size_t bd_conv1x1_sk_ws_bytes();
-bool bd_conv1x1_sk_applies(long long M, int CK, int CO);
-
 namespace {
 // 1x1 / stride 1 / pad 0 over one dense level: source pixel index == destination pixel index (conv1x1.hip)
 bool is_dense_1x1(const bd_conv_desc* d) {
@@ -512,18 +506,12 @@ bool is_dense_1x1(const bd_conv_desc* d) {
 }  // namespace
 
 static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
-                           unsigned* ybits, void* y8, float q_scale, int flags, bd_stream_t stream, void* ws = nullptr, size_t ws_bytes = 0) {
+                           unsigned* ybits, void* y8, float q_scale, int flags, bd_stream_t stream) {
     if (int e = check_desc(d)) return e;
     BD_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_fwd: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_fwd: Cout=%d must be a multiple of 8", d->Cout);
     BD_REQUIRE(!(flags & BD_EPI_MASK), "conv2d_fwd: BD_EPI_MASK is a dgrad-only flag");
-    if (ws && !y8 && is_dense_1x1(d) &&
-        bd_conv1x1_sk_launch(x, w_packed, bias, add, nullptr, nullptr, y, ybits, (long long)d->N * d->out_pix_per_img, d->Cin, d->Cout, flags,
-                             ws, ws_bytes, (hipStream_t)stream) == 0) {
-        BD_CHECK_LAUNCH("bd_conv2d_fwd(K-sliced 1x1)");
-        return BD_OK;
-    }
     if (is_dense_1x1(d) &&
         bd_conv1x1_dense_launch(x, w_packed, bias, add, nullptr, nullptr, y, ybits, y8, q_scale, 0, (long long)d->N * d->out_pix_per_img,
                                 d->Cin, d->Cout, flags, (hipStream_t)stream) == 0) {
@@ -597,20 +585,13 @@ extern "C" int bd_conv2d_fwd_bits(const bd_conv_desc* d, const void* x, const vo
 }
 
 static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
-                             const unsigned* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream, void* ws = nullptr,
-                             size_t ws_bytes = 0) {
+                             const unsigned* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream) {
     if (int e = check_desc(d)) return e;
     BD_REQUIRE(g && w_packed_t && dx, "conv2d_dgrad: null pointer");
     if (d->stride == 1) flags &= ~BD_EPI_SPARSE;          // every pixel of a stride-1 data gradient is reached
     BD_REQUIRE(d->Cout % 8 == 0, "conv2d_dgrad: Cout=%d must be a multiple of 8 (pad the gradient)", d->Cout);
     BD_REQUIRE(d->Cin % 8 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 8", d->Cin);
     BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad: BD_EPI_RELU is a forward-only flag");
-    if (ws && !dx8 && is_dense_1x1(d) &&
-        bd_conv1x1_sk_launch(g, w_packed_t, nullptr, add, mask, maskbits, dx, nullptr, (long long)d->N * d->in_pix_per_img, d->Cout, d->Cin, flags,
-                             ws, ws_bytes, (hipStream_t)stream) == 0) {
-        BD_CHECK_LAUNCH("bd_conv2d_dgrad(K-sliced 1x1)");
-        return BD_OK;
-    }
     if (is_dense_1x1(d) &&
         bd_conv1x1_dense_launch(g, w_packed_t, nullptr, add, mask, maskbits, dx, nullptr, dx8, q_scale, 1, (long long)d->N * d->in_pix_per_img,
                                 d->Cout, d->Cin, flags, (hipStream_t)stream) == 0) {
@@ -685,24 +666,6 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
     else launch_igemm<32>(p, (hipStream_t)stream);
     BD_CHECK_LAUNCH("bd_conv2d_dgrad");
     return BD_OK;
-}
-
-extern "C" size_t bd_conv2d_ksplit_workspace_bytes(void) { return bd_conv1x1_sk_ws_bytes(); }
-
-extern "C" int bd_conv2d_ksplit_applies(const bd_conv_desc* d, int dgrad) {
-    if (!d || check_desc(d) != 0 || !is_dense_1x1(d)) return 0;
-    return bd_conv1x1_sk_applies((long long)d->N * d->out_pix_per_img, dgrad ? d->Cout : d->Cin, dgrad ? d->Cin : d->Cout) ? 1 : 0;
-}
-
-extern "C" int bd_conv2d_fwd_ws(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
-                                uint32_t* ybits, int flags, void* ws, size_t ws_bytes, bd_stream_t stream) {
-    return conv2d_fwd_impl(d, x, w_packed, bias, add, y, ybits, nullptr, 1.f, flags, stream, ws, ws_bytes);
-}
-
-extern "C" int bd_conv2d_dgrad_ws(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
-                                  const uint32_t* maskbits, void* dx, int flags, void* ws, size_t ws_bytes, bd_stream_t stream) {
-    return conv2d_dgrad_impl(d, g, w_packed_t, add, maskbits ? nullptr : mask, maskbits, dx, nullptr, 1.f,
-                             maskbits ? (flags | BD_EPI_MASK) : flags, stream, ws, ws_bytes);
 }
 
 extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add,

@@ -323,21 +323,17 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
                 // ---------------- load segment ----------------
                 load_half(stage, kk);
                 RK_FENCE();
-                // -DBD_RK_DMA_POS=<n> (experiment, profiles/r06_dma_pos.txt): the phase's two DMA requests are issued behind the n-th tap of the
-                // MFMA segment instead of here in the load segment (same issue order: the counted waits stand)
-#ifndef BD_RK_DMA_POS
-#define BD_RK_DMA_POS 0
-#endif
-                auto issue_dma = [&]() {
-                    if (kk == 0) issue_x(fill, dead);
-                    else { issue_g(fill, dead); advance(); }
-                };
-                if (kk == 1) {
+                // (Round 6, measured and removed: the phase's requests issued behind tap 3 / tap 5 of the MFMA segment instead of here: the step
+                // 3.0 % slower, profiles/r06_dma_pos.txt -- see conv3x3_pp.hip)
+                if (kk == 0) {
+                    issue_x(fill, dead);
+                } else {
                     // this wave's pieces of step t + 1 have landed; step t + 2 and the X pieces of step t + 3 stay in flight
                     if (two_x) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    issue_g(fill, dead);
+                    advance();
                 }
-                if (BD_RK_DMA_POS == 0) issue_dma();
                 RK_FENCE();
                 RK_T(0);
                 RK_BARRIER();
@@ -351,14 +347,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
 #if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(1);
 #endif
-                if (BD_RK_DMA_POS == 0) mfma_taps(0, 9, true);
-                else {
-                    mfma_taps(0, BD_RK_DMA_POS, false);
-                    RK_FENCE();
-                    issue_dma();
-                    RK_FENCE();
-                    mfma_taps(BD_RK_DMA_POS, 9, true);
-                }
+                mfma_taps(0, 9, true);
 #if defined(BD_PP_PRIO) && BD_PP_PRIO == 0
                 __builtin_amdgcn_s_setprio(0);
 #endif

@@ -71,33 +71,12 @@ def L():
 
 
 # ---- dense path -------------------------------------------------------------------------------------------
-_KSPLIT_WS = {}          # (device, stream) -> workspace of the K-sliced dense 1x1 schedule (bd_conv2d_fwd_ws / _dgrad_ws)
-
-
-def ksplit_ws(d, dgrad):
-    """The calling stream's workspace if a launch of descriptor `d` would run K-sliced, else None.  One workspace per (device, stream): two
-    K-sliced launches sharing one must not overlap; zeroed once, the library leaves its counters at zero."""
-    if d.R != 1 or d.nseg != 1 or not L().bd_conv2d_ksplit_applies(C.byref(d), 1 if dgrad else 0):
-        return None
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    ws = _KSPLIT_WS.get(key)
-    if ws is None:
-        ws = torch.zeros((int(L().bd_conv2d_ksplit_workspace_bytes()),), dtype=torch.uint8, device="cuda")
-        _KSPLIT_WS[key] = ws
-    return ws
-
-
 def conv2d_fwd(d, x, w_packed, bias, y, add=None, flags=0, bits=None, y8=None, q_scale=1.0):
     """bits: optional uint32 [Cout/32][M] output, the bit-packed ReLU mask of y; y8: optional uint8 e4m3 twin of y (dense 1x1 launches
     only: bd_conv2d_fwd_bits / bd_conv2d_fwd_ex)."""
     if y8 is not None:
         check(L().bd_conv2d_fwd_ex(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), ptr(y8), float(q_scale), flags,
                                    stream_ptr()), "bd_conv2d_fwd_ex")
-        return y
-    ws = ksplit_ws(d, False)
-    if ws is not None:
-        check(L().bd_conv2d_fwd_ws(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), flags, ptr(ws), ws.numel(),
-                                   stream_ptr()), "bd_conv2d_fwd_ws")
         return y
     if bits is not None:
         check(L().bd_conv2d_fwd_bits(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), flags, stream_ptr()),
@@ -113,11 +92,6 @@ def conv2d_dgrad(d, g, w_packed_t, dx, add=None, mask=None, flags=0, maskbits=No
     if dx8 is not None:
         check(L().bd_conv2d_dgrad_ex(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(maskbits), ptr(dx), ptr(dx8),
                                      float(q_scale), flags, stream_ptr()), "bd_conv2d_dgrad_ex")
-        return dx
-    ws = ksplit_ws(d, True)
-    if ws is not None:
-        check(L().bd_conv2d_dgrad_ws(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(maskbits), ptr(dx), flags, ptr(ws), ws.numel(),
-                                     stream_ptr()), "bd_conv2d_dgrad_ws")
         return dx
     if maskbits is not None:
         check(L().bd_conv2d_dgrad_bits(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(maskbits), ptr(dx), flags, stream_ptr()),

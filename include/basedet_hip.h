@@ -115,27 +115,11 @@ int bd_conv2d_fwd_ex(const bd_conv_desc* d, const void* x, const void* w_packed,
  * and dx8 (may be NULL) = e5m2(clamp(dx * q_scale)), the gradient operand of a following bd_conv2d_dgrad_fp8. */
 int bd_conv2d_dgrad_ex(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
                        const uint32_t* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream);
-/* bd_conv2d_fwd_bits / bd_conv2d_dgrad_ex with a WORKSPACE: the long-K dense 1x1 launches whose 256 x 256 tile count leaves much of the
- * chip idle in its last round (res5's conv1 / conv3 gradients: 132 tiles for 256 CUs; res4's 263-tile layers; FPN lateral 4 / 5 --
- * models/cls/resnet.py:70-113, layers/backbone/fpn_backbone.py:61-76) then run K-SLICED: the flat (tile, K step) sequence is cut into one
- * equal range per CU, a tile cut by a range boundary is summed from fp32 slices IN SLICE ORDER by whichever slice arrives last (its own
- * from registers), so the result is bitwise reproducible.  ws: at least bd_conv2d_ksplit_workspace_bytes() bytes of device memory, ZERO
- * when first handed over (the library leaves its counters at zero after every launch); one workspace per STREAM that issues such launches
- * (two launches sharing a workspace must not overlap).  ws == NULL or too small, or any other descriptor: exactly bd_conv2d_fwd_bits /
- * bd_conv2d_dgrad_ex (ybits / maskbits may be NULL). */
-size_t bd_conv2d_ksplit_workspace_bytes(void);
-int bd_conv2d_ksplit_applies(const bd_conv_desc* d, int dgrad);      /* 1: a *_ws call with this descriptor would run K-sliced (so bring a workspace) */
-int bd_conv2d_fwd_ws(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
-                     uint32_t* ybits, int flags, void* ws, size_t ws_bytes, bd_stream_t stream);
-int bd_conv2d_dgrad_ws(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
-                       const uint32_t* maskbits, void* dx, int flags, void* ws, size_t ws_bytes, bd_stream_t stream);
 /* measurement knob: 1 (default) = the dense 1x1 kernels take every 1x1 / stride 1 launch over one dense level (conv1x1_ring.hip the
  * short-K launches into >= 256 channels, conv1x1.hip the rest), 0 = the generic kernel does (A/B; the *_bits / _ex entry points then
  * return BD_EINVAL); 2 = conv1x1.hip's 256 x 256 tile, 3 = its 128 x 128 tile only, 4 = its eight-wave 256-channel x 128-pixel tile
  * wherever legal, 5 = as 1 with conv1x1_ring.hip for every launch it can take, 6 = as 3 with the 128 x 128 tile's LDS-DMA ring variant for
- * every K that allows it (default: 512 <= K <= 1024) (all A/B: same results bit for bit); 7 = as 1 with the K-sliced kernel of the *_ws
- * entry points for every launch it can take, 8 = as 1 without it (A/B: within 2e-6 rel-L2 of the un-sliced kernels -- a cut tile is
- * summed from two to five fp32 slices). */
+ * every K that allows it (default: 512 <= K <= 1024) (all A/B: same results bit for bit). */
 int bd_conv_set_dense1x1(int depth);
 
 /* dw[Cout][R][S][Cin] (fp32) = sum over pixels g^T x, times row_scale[Cout] (NULL = 1); split over pixels with

@@ -1,5 +1,6 @@
 """Dense 1x1 launches as plain GEMMs on well- and badly-quantised shapes: which bd_conv_set_dense1x1 mode runs them how fast.
-   python scripts/exp/gemm_probe.py [modes...]   (default 8 7: the default dispatch without / with the K-sliced kernel everywhere)"""
+   python scripts/exp/gemm_probe.py [modes...]   (default 1 2: the default dispatch, conv1x1_big_kernel everywhere; modes 7 / 8 existed while the K-sliced kernel did:
+profiles/r06_dense1x1_sk.txt)"""
 import os
 import sys
 _here = os.path.dirname(os.path.abspath(__file__))
@@ -35,7 +36,7 @@ def timeit(run, iters=30):
 
 
 def main():
-    modes = [int(a) for a in sys.argv[1:]] or [8, 7]
+    modes = [int(a) for a in sys.argv[1:]] or [1, 2]
     print(f"{'shape':34s} " + " ".join(f"mode{m}: us / TF/s / kernel".rjust(44) for m in modes))
     for tag, M, K, CO in SHAPES:
         geo = ops.single(1, 1, M)

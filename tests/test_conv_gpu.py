@@ -885,132 +885,3 @@ def test_thin_1x1_backward_in_one_pass(M):
     assert rel_l2(outs[0][2].cpu(), torch.from_numpy(db_ref)) <= 1e-5
     assert np.all(outs[0][1].cpu().numpy()[real:] == 0) and np.all(outs[0][2].cpu().numpy()[real:] == 0)
 
-
-# ---- the K-sliced dense 1x1 schedule (conv1x1_sk.hip; bd_conv2d_fwd_ws / bd_conv2d_dgrad_ws) ---------------------------------------------
-def _ks_case(M, K, CO, mode, add, mask, bits, seed):
-    """inputs of one dense 1x1 launch over M pixels; returns (run(out) -> None, reference fp64 callable)"""
-    from basedet_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    geo = ops.single(1, 1, M)
-    cin, cout = (K, CO) if mode == "fwd" else (CO, K)
-    d = ops.conv_desc(geo, geo, cin, cout, 1, 1, 1, 0)
-    src = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-    w = (torch.randn(CO, 1, K, device="cuda", generator=g) * (K ** -0.5)).to(torch.bfloat16)
-    bias = torch.randn(CO, device="cuda", generator=g) if mode == "fwd" else None
-    addt = torch.randn(M, CO, device="cuda", generator=g).to(torch.bfloat16) if add else None
-    maskt = torch.randn(M, CO, device="cuda", generator=g).to(torch.bfloat16) if mask else None
-    mb = None
-    if mask and bits:           # the bit-packed form of the same gate: word (g, m) bit b = channel 32 g + b of pixel m is > 0
-        pos = (maskt.float() > 0).view(M, CO // 32, 32).to(torch.int64)
-        wv = (pos << torch.arange(32, device="cuda")).sum(-1)
-        mb = torch.where(wv >= 2 ** 31, wv - 2 ** 32, wv).to(torch.int32).t().contiguous()
-
-    def run(dst, ybits=None):
-        if mode == "fwd":
-            ops.conv2d_fwd(d, src, w, bias, dst, add=addt, flags=ops.EPI_RELU | (ops.EPI_ADD_BEFORE if add else 0), bits=ybits)
-        else:
-            fl = (ops.EPI_ADD_BEFORE if add else 0) | (ops.EPI_MASK if mask else 0)
-            ops.conv2d_dgrad(d, src, w, dst, add=addt, mask=None if mb is not None else maskt, maskbits=mb, flags=fl)
-
-    def ref():
-        r = src.double() @ w.view(CO, K).double().t()
-        if bias is not None:
-            r = r + bias.double()
-        if add:
-            r = r + addt.double()
-        if mode == "fwd":
-            r = r.clamp_min(0)
-        if mask:
-            r = r * (maskt.float() > 0).double()
-        return r
-    return run, ref
-
-
-KS_SHAPES = [  # (M, K, CO, mode, add, mask, bits)
-    (16800, 2048, 512, "fwd", 0, 0, 0),        # res5 conv1 forward: 132 tiles of 64 K steps -> every tile cut in two or three
-    (16800, 2048, 512, "dgrad", 0, 1, 0),      # res5 conv3 data gradient, bf16 gate
-    (16800, 2048, 256, "fwd", 0, 0, 0),        # lateral 5: 66 tiles, four to five slices each
-    (67200, 1024, 256, "fwd", 0, 0, 0),        # res4 conv1 forward: 263 tiles, whole tiles and cut ones in one range
-    (67200, 1024, 256, "dgrad", 0, 1, 0),
-    (16800, 512, 2048, "dgrad", 1, 1, 1),      # res5 conv1 data gradient: residual + bit-packed gate, 528 tiles of 16 steps
-    (16800, 512, 2048, "fwd", 1, 0, 0),        # ... with a residual and the bit-packed ReLU side output
-    (1000, 64, 256, "fwd", 0, 0, 0),           # four tiles of two steps: the grid shrinks to units / 2
-    (300, 4096, 264, "fwd", 1, 0, 0),          # ragged rows and a ragged second channel tile (264 = 256 + 8), 128 steps per tile
-]
-
-
-@pytest.mark.parametrize("M,K,CO,mode,add,mask,bits", KS_SHAPES)
-def test_ksliced_dense1x1_matches_the_unsliced_kernels_and_fp64(M, K, CO, mode, add, mask, bits):
-    """bd_conv_set_dense1x1(7) (the K-sliced 256 x 256 kernel for every launch it can take) against (8) (never): a cut tile is the sum of
-    two to five fp32 slices added in slice order, the un-sliced kernels keep one fp32 chain -- so the bf16 results may differ by one
-    rounding step in a few elements, never more; both against the float64 definition to the same tolerance; two launches bit-identical;
-    the workspace counters are back at zero."""
-    from basedet_amd import ops
-    run, ref = _ks_case(M, K, CO, mode, add, mask, bits, seed=M + K + CO)
-    want_bits = mode == "fwd" and add
-    out = {}
-    names = {}
-    for m in (8, 7, 7):
-        ops.L().bd_conv_set_dense1x1(m)
-        y = torch.full((M, CO), float("nan"), device="cuda", dtype=torch.bfloat16)
-        yb = torch.zeros((CO // 32, M), device="cuda", dtype=torch.int32) if want_bits and CO % 32 == 0 else None
-        run(y, yb)
-        torch.cuda.synchronize()
-        names.setdefault(m, ops.L().bd_conv_last_kernel().decode())
-        out.setdefault(m, []).append((y, yb))
-    ops.L().bd_conv_set_dense1x1(1)
-    assert names[7] == "conv1x1_sk_kernel" and names[8] != "conv1x1_sk_kernel", names
-    (y8_, b8_), (ya, ba), (yb_, bb_) = out[8][0], out[7][0], out[7][1]
-    assert torch.equal(ya, yb_), "two K-sliced launches differ"
-    if ba is not None:
-        assert torch.equal(ba, bb_)
-    r = ref()
-    scale = float(r.abs().max())
-    for y in (y8_, ya):
-        assert torch.isfinite(y.float()).all()
-        err = (y.double() - r).norm() / r.norm()
-        assert err < 3e-3, float(err)               # bf16 storage: 2^-9 relative per element
-    # sliced vs un-sliced: at most one bf16 rounding step apart (+ the fp32 rounding of sums of this magnitude, which is all that is left
-    # of a result that cancels to ~0), in few elements
-    diff = (ya.float() - y8_.float()).abs()
-    ulp = torch.maximum(ya.float().abs(), y8_.float().abs()) * 2 ** -7 + 1e-5 * scale
-    assert (diff <= ulp).all(), float((diff / ulp).max())
-    assert float((diff > 0).float().mean()) < 0.02
-    if ba is not None:              # the gate bits agree wherever the two results have the same sign of life
-        same = (ya.float() > 0) == (y8_.float() > 0)
-        pos = (ya.float() > 0).view(M, CO // 32, 32).to(torch.int64)
-        wv = (pos << torch.arange(32, device="cuda")).sum(-1)
-        want = torch.where(wv >= 2 ** 31, wv - 2 ** 32, wv).to(torch.int32).t().contiguous()
-        assert torch.equal(ba, want)
-        assert float(same.float().mean()) > 0.999
-    cnt = ops._KSPLIT_WS[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)][: 2 * 16384 * 4]
-    assert int(cnt.view(torch.int32).abs().max()) == 0, "the K-sliced kernel left a tile counter non-zero"
-
-
-def test_ksliced_dense1x1_is_reproducible_under_a_competing_stream():
-    """200 launches of the res5 conv1 shape while another stream keeps CUs busy (arrival order of the slices changes from launch to launch):
-    every result bit-identical -- the slices are added in slice order whoever arrives last."""
-    from basedet_amd import ops
-    M, K, CO = 16800, 2048, 512
-    run, _ = _ks_case(M, K, CO, "fwd", 0, 0, 0, seed=5)
-    ops.L().bd_conv_set_dense1x1(7)
-    try:
-        first = torch.empty((M, CO), device="cuda", dtype=torch.bfloat16)
-        run(first)
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        a = torch.randn(4096, 4096, device="cuda")
-        y = torch.empty_like(first)
-        bad = 0
-        for it in range(200):
-            if it % 3 == 0:
-                with torch.cuda.stream(side):
-                    a.mul_(1.0001)            # a bandwidth-bound kernel that takes CUs away for a while
-            run(y)
-            if it % 20 == 19:
-                torch.cuda.synchronize()
-                bad += int(not torch.equal(y, first))
-        torch.cuda.synchronize()
-        assert bad == 0 and torch.equal(y, first)
-    finally:
-        ops.L().bd_conv_set_dense1x1(1)
