@@ -27,6 +27,7 @@ class ConvDesc(C.Structure):
         ("Ho", C.c_int32 * BD_MAX_SEGS), ("Wo", C.c_int32 * BD_MAX_SEGS),
         ("in_off", C.c_int32 * BD_MAX_SEGS), ("out_off", C.c_int32 * BD_MAX_SEGS),
         ("in_pix_per_img", C.c_int32), ("out_pix_per_img", C.c_int32),
+        ("route", C.c_int32 * 4), ("sr_seed", C.c_uint32),        # per-call kernel routing / e5m2 rounding seed (0 = the library's choice)
     ]
 
 
@@ -51,7 +52,6 @@ SIGNATURES = {
     "bd_conv2d_fwd_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_dgrad_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_dgrad_bits": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
-    "bd_conv_set_dense1x1": (_I, [_I]),
     "bd_conv2d_wgrad_workspace_bytes": (_Z, [_D]),
     "bd_conv2d_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_conv2d_wgrad_bias_workspace_bytes": (_Z, [_D]),
@@ -101,14 +101,13 @@ SIGNATURES = {
     "bd_nms_workspace_bytes": (_Z, [_I]),
     "bd_batched_nms": (_I, [_P, _P, _P, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "bd_focal_loss_fwd_bwd": (_I, [_P, _P, _L, _I, _F, _F, _P, _I, _F, _P, _P, _P]),
-    "bd_focal_set_fast": (_I, [_I]),
+    "bd_focal_loss_fwd_bwd_general": (_I, [_P, _P, _L, _I, _F, _F, _P, _I, _F, _P, _P, _P]),
     "bd_smooth_l1_fwd_bwd": (_I, [_P, _P, _P, _L, _I, _I, _F, _P, _I, _F, _P, _P, _P]),
     "bd_giou_ltrb_fwd_bwd": (_I, [_P, _P, _P, _P, _L, _P, _F, _P, _P, _P]),
     "bd_bce_logits_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
     "bd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _L]),
     "bd_groupnorm_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _L, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "bd_groupnorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
-    "bd_groupnorm_set_chunks": (_I, [_I, _I]),
     "bd_fcos_offsets_fwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _L, _P, _P]),
     "bd_fcos_offsets_workspace_bytes": (_Z, []),
     "bd_fcos_offsets_bwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _Z, _P]),
@@ -119,7 +118,7 @@ SIGNATURES = {
     "bd_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "bd_rpn_proposals_workspace_bytes": (_Z, [_I, _I, _P, _I, _I, _I]),
     "bd_rpn_proposals": (_I, [_P, _I, _I, _I, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _I, _F, _I, _P, _P, _P, _Z, _P]),
-    "bd_rpn_set_nms_per_level": (_I, [_I]),
+    "bd_rpn_proposals_joint": (_I, [_P, _I, _I, _I, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "bd_rcnn_sample_targets": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bd_roi_align_fwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "bd_conv1x1_thin_bwd_workspace_bytes": (_Z, []),
@@ -146,10 +145,8 @@ SIGNATURES = {
     "bd_weight_pack_fp8": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "bd_conv2d_fwd_fp8": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     "bd_conv2d_fwd_fp8_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
-    "bd_conv_fp8_set_patch": (_I, [_I]),
-    "bd_quantize_bf8": (_I, [_P, _L, _F, _P, _P]),
+    "bd_quantize_bf8": (_I, [_P, _L, _F, _P, C.c_uint32, _P]),
     "bd_absmax_bf16": (_I, [_P, _L, _P, _P]),
-    "bd_fp8_set_stochastic_rounding": (_I, [C.c_uint32]),
     "bd_weight_pack_fp8_t": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "bd_conv2d_dgrad_fp8": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "bd_conv2d_wgrad_fp8_workspace_bytes": (_Z, [_D]),
@@ -174,8 +171,6 @@ SIGNATURES = {
     "bd_comm_allreduce_async_bf16": (_I, [_P, _P, _P, _Z, _I, C.POINTER(C.c_void_p), _I]),
     "bd_comm_wait": (_I, [_P, _P]),
     "bd_comm_destroy": (_I, [_P]),
-    "bd_wgrad_set_transpose_read": (_I, [_I]),
-    "bd_conv_set_patch3x3": (_I, [_I]),
 }
 
 _lib = None

@@ -22,12 +22,12 @@ __device__ __forceinline__ bf16_raw f2bf(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
     return __builtin_bit_cast(bf16_raw, b);
 }
-// ---- stochastic rounding of the e5m2 gradients (bd_fp8_set_stochastic_rounding) ----------------------------------------------------
+// ---- stochastic rounding of the e5m2 gradients (bd_conv_desc.sr_seed) ----------------------------------------------------
 // Round-to-nearest e5m2 (two mantissa bits) makes the SAME error on the same value every step; on a repeated batch those errors add up as a
 // bias and the run drifts.  With a seed set, the quantisers add a pseudo-random fraction below the kept bits before truncating
 // (v_cvt_sr_bf8_f32): unbiased, and -- the random word being a hash of (seed, element index) -- independent of which kernel variant or
 // tile writes the element.
-extern unsigned g_fp8_sr_seed;          // host side, conv_fp8.hip: 0 = round to nearest
+extern thread_local unsigned g_fp8_sr_seed;          // host side, conv_fp8.hip (set per call from bd_conv_desc.sr_seed / bd_quantize_bf8's argument): 0 = round to nearest
 __device__ __forceinline__ unsigned bd_mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
@@ -72,6 +72,21 @@ __device__ __forceinline__ void bd_clk_mark(unsigned long long* acc, bool end) {
     atomicAdd(acc, end ? c : 0ull - c);
     atomicAdd(acc + 1, end ? r : 0ull - r);
 }
+
+// ---- kernel routing is PER CALL -------------------------------------------------------------------------------------------------------
+// The routing knobs of rounds 1-5 (bd_conv_desc.route[0], bd_conv_desc.route[1], bd_conv_desc.route[2], bd_conv_desc.route[3],
+// bd_conv_desc.sr_seed) were process-global setters.  Round 6: a caller that wants a route says so in the descriptor of the call
+// (bd_conv_desc.route[], .sr_seed: include/basedet_hip.h); every entry point that takes a descriptor opens a BdRouteScope, which writes the
+// routing variables below from THAT descriptor (library defaults where a word is 0) -- nothing survives the call.  The variables are
+// thread_local: two host threads issuing calls with different routes do not see each other.
+#define BD_KNOB thread_local
+struct BdRouteScope {
+    int rc;                    // BD_OK, or BD_EINVAL (message set) for a route word out of range
+    explicit BdRouteScope(const bd_conv_desc* d);
+};
+#define BD_ROUTE(d)                                   \
+    BdRouteScope route_scope__(d);                    \
+    if (route_scope__.rc != BD_OK) return route_scope__.rc
 
 void bd_set_error(const char* fmt, ...);
 // bd_conv_last_kernel(): every convolution launch site names the kernel it dispatched to (a string literal; thread-local, host side only)

@@ -875,18 +875,19 @@ __global__ __launch_bounds__(512, 1) void conv1x1_big_kernel(const P1 p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-int g_conv1x1_dma_k = 512;      // BD_DENSE1X1_DMA_K: smallest CK that takes the LDS-DMA ring variant
-int g_conv1x1_depth = 1;        // bd_conv_set_dense1x1: 0 = off (generic kernel), 1 = the 128^2 tile (default), 2 = the 256^2 tile wherever legal (A/B), 3 = as 1,
+BD_KNOB int g_conv1x1_dma_k = 512;      // BD_DENSE1X1_DMA_K: smallest CK that takes the LDS-DMA ring variant
+BD_KNOB int g_conv1x1_depth = 1;        // bd_conv_desc.route[0]: 0 = off (generic kernel), 1 = the 128^2 tile (default), 2 = the 256^2 tile wherever legal (A/B), 3 = as 1,
                                 // 4 = the 256-channel x 128-pixel eight-wave tile wherever legal (A/B)
-int g_conv1x1_wide_min_k = 0;   // BD_DENSE1X1_WIDE_K: smallest CK that takes the eight-wave tile in mode 4
+BD_KNOB int g_conv1x1_wide_min_k = 0;   // BD_DENSE1X1_WIDE_K: smallest CK that takes the eight-wave tile in mode 4
 
 }  // namespace
 
 void bd_conv1x1_ring_everywhere(bool on);         // conv1x1_ring.hip
 
-extern "C" int bd_conv_set_dense1x1(int depth) {
+// bd_conv_desc.route[0] - 1 (BdRouteScope, conv_igemm.hip); the modes: include/basedet_hip.h
+int bd_route_dense1x1(int depth) {
     if (depth < 0 || depth > 6) {
-        bd_set_error("bd_conv_set_dense1x1: %d (0 .. 6)", depth);
+        bd_set_error("bd_conv_desc.route[0]: dense 1x1 mode %d (0 .. 6)", depth);
         return BD_EINVAL;
     }
     bd_conv1x1_ring_everywhere(depth == 5);          // 5 = as 1, with conv1x1_ring_kernel for every launch it can take (default: K <= 256 into >= 256 channels)
@@ -919,13 +920,13 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
 #ifdef BD_D1_STAMP
-    p.dbg = getenv("BD_D1_ABLATE") ? atoi(getenv("BD_D1_ABLATE")) : 0;
+    p.dbg = bd_tune_env("BD_D1_ABLATE", 0);          // (a -DBD_D1_STAMP build is also a -DBD_TUNING build: scripts/exp/d1_stamp.py)
 #endif
     {
         // the 256^2 tile: full 32-channel K steps and at least one full channel tile.  Measured (scripts/micro_1x1_step.py, the step's 16
         // launch classes): on par or slower than the 128^2 tile everywhere (6.2 - 6.5 vs 5.5 - 5.8 ms over the step's launches; its
         // one workgroup per CU quantises worse on the 263-tile res4 layers and its epilogue has 8 waves per CU to hide latency with,
-        // not 16), so it runs on request only (bd_conv_set_dense1x1(2): A/B)
+        // not 16), so it runs on request only (bd_conv_desc.route[0] mode 2: A/B)
         const int mt = (int)cdiv64(M, BG_T), nt = cdiv(CO, BG_T);
         const bool legal = CK % BG_BK == 0 && CO >= BG_T && g_conv1x1_depth != 3;
         if (legal && g_conv1x1_depth == 2) {
@@ -953,7 +954,7 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
     // 512 <= CK <= 1024 (res3 / res4 conv1 and conv3's data gradient, the laterals): the three-stage LDS-DMA ring (two K steps in flight
     // per workgroup, three workgroups per CU) is 3 - 11 % faster; shorter K (the epilogue is most of the tile) and the 16 800-pixel res5
     // layers (K = 2048: everything L2-resident, four workgroups per CU hide more) stay on the register-staged loop.  Measured per class
-    // with scripts/micro_1x1_step.py; BD_DENSE1X1_DMA_K (read by bd_conv_set_dense1x1) moves the lower bound for A/B.
+    // with scripts/micro_1x1_step.py; BD_DENSE1X1_DMA_K (read by bd_conv_desc.route[0]) moves the lower bound for A/B.
     static const int early = bd_tune_env("BD_DENSE1X1_EARLY", 0);     // measurement: epilogue operands requested before the K loop
     const bool has_ops = (add && (flags & (BD_EPI_ADD_BEFORE | BD_EPI_ADD_AFTER))) || ((flags & BD_EPI_MASK) && (mask || maskbits));
     if (CK % BK == 0 && CK >= g_conv1x1_dma_k && (CK <= 1024 || g_conv1x1_dma_k < 512)) {
@@ -980,7 +981,7 @@ int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, con
 // 1x1 / stride 2 / pad 0 over one dense level (the bottleneck shortcut convolutions) on the same kernel: mode 0 = forward (the source rows
 // are the (2y, 2x) pixels of the input), mode 1 = the data gradient ADDED IN PLACE at the pixels it reaches (BD_EPI_SPARSE with
 // BD_EPI_ADD_BEFORE and add == dx; the other pixels of dx keep what they hold).  Called from conv_igemm.hip; 0 = taken.
-int g_conv1x1_s2 = 1;        // bd_conv_set_patch3x3 bit 12 clears it (A/B against the generic kernel)
+BD_KNOB int g_conv1x1_s2 = 1;        // bd_conv_desc.route[1] bit 12 clears it (A/B against the generic kernel)
 int bd_conv1x1_s2_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add, const void* mask,
                          const unsigned* maskbits, void* dst, int flags, hipStream_t stream) {
     if (!g_conv1x1_s2 || g_conv1x1_depth == 0) return 1;
@@ -1018,6 +1019,7 @@ int bd_conv1x1_s2_launch(const bd_conv_desc* d, int mode, const void* src, const
 extern "C" int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, const void* wq, const float* wscale, const float* bias,
                               const void* add, const void* mask, const uint32_t* maskbits, void* y, uint32_t* ybits, void* y8, float q_scale,
                               int flags, bd_stream_t stream) {
+    BD_ROUTE(d);
     BD_REQUIRE(d && xq && wq && wscale && y, "conv1x1_fp8: null pointer");
     BD_REQUIRE(mode == 0 || mode == 1, "conv1x1_fp8: mode %d (0 forward, 1 data gradient)", mode);
     BD_REQUIRE(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->nseg == 1 && d->in_off[0] == 0 && d->out_off[0] == 0 &&

@@ -496,13 +496,13 @@ extern "C" int bd_debug_r1x_stamp(unsigned long long* out64) {
 }
 #endif
 
-static bool g_ring_everywhere = false;
-void bd_conv1x1_ring_everywhere(bool on) { g_ring_everywhere = on; }          // bd_conv_set_dense1x1(5): tests / A-B
+static BD_KNOB bool g_ring_everywhere = false;
+void bd_conv1x1_ring_everywhere(bool on) { g_ring_everywhere = on; }          // bd_conv_desc.route[0] mode 5: tests / A-B
 
 // Called by bd_conv1x1_dense_launch (conv1x1.hip) before its own kernels.  0 = taken.
 int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits, void* y,
                            unsigned* ybits, void* y8, long long M, int CK, int CO, int flags, hipStream_t stream) {
-    // BD_DENSE1X1_RING: 0 = every launch stays on conv1x1_dense_kernel (A/B), 2 = every legal launch comes here (also bd_conv_set_dense1x1(5))
+    // BD_DENSE1X1_RING: 0 = every launch stays on conv1x1_dense_kernel (A/B), 2 = every legal launch comes here (also bd_conv_desc.route[0] mode 5)
     static const int env_mode = bd_tune_env("BD_DENSE1X1_RING", 1);
     const int mode = g_ring_everywhere ? 2 : env_mode;
     if (!mode) return 1;

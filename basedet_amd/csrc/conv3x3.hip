@@ -392,17 +392,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const C3Params p)
 
 }  // namespace
 
-int g_patch_pp = 2;       // 2 = wherever the shape allows (default), 1 = only where the makespan estimate favours it (bit 7), 0 = never (bit 6): staggered 256-channel-tile instance (conv3x3_pp.hip) for CO > 128, CK % 8 == 0
+BD_KNOB int g_patch_pp = 2;       // 2 = wherever the shape allows (default), 1 = only where the makespan estimate favours it (bit 7), 0 = never (bit 6): staggered 256-channel-tile instance (conv3x3_pp.hip) for CO > 128, CK % 8 == 0
 int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                          const void* mask, void* dst, int flags, hipStream_t stream);
-int g_patch_pp128 = 0;    // staggered 128 / 64-channel-tile instances (conv3x3_pp128.hip): 0 = the 64-channel tile for Cout <= 64 (default: it
-                          // halves the matrix and LDS work of those layers), 1 = every remaining shape (bd_conv_set_patch3x3 bit 8: faster per
+BD_KNOB int g_patch_pp128 = 0;    // staggered 128 / 64-channel-tile instances (conv3x3_pp128.hip): 0 = the 64-channel tile for Cout <= 64 (default: it
+                          // halves the matrix and LDS work of those layers), 1 = every remaining shape (bd_conv_desc.route[1] bit 8: faster per
                           // launch, not per step -- see DESIGN.md), -1 = never (bit 9)
 int bd_conv3x3_pp128_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                             const void* mask, void* dst, int flags, hipStream_t stream);
-int g_patch_dma = 1;
+BD_KNOB int g_patch_dma = 1;
 static long long* g_patch_dbg = nullptr;
-extern "C" int bd_conv3x3_set_debug(long long* buf) { g_patch_dbg = buf; return 0; }      // bd_conv_set_patch3x3 bit 3 clears it (register-staged weights everywhere)
+extern "C" int bd_conv3x3_set_debug(long long* buf) { g_patch_dbg = buf; return 0; }      // bd_conv_desc.route[1] bit 3 clears it (register-staged weights everywhere)
 
 // called from conv_igemm.hip for 3x3 / stride 1 / pad 1 descriptors; mode 0 fwd (src = x, geometry in == out),
 // mode 1 dgrad (src = dY).  CK = reduction channels, CO = produced channels.

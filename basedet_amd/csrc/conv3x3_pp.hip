@@ -630,9 +630,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
 }  // namespace
 
 // 0 = launched, 1 = shape not handled here (caller falls back to conv3x3.hip)
-int g_pp_tail_split = 1;     // bd_conv_set_patch3x3 bit 13 clears it
-int g_pp_persistent = 1;     // bit 14 clears it: one workgroup per tile
-extern int g_patch_pp;       // 0 = never, 1 = where the makespan estimate favours it, 2 = wherever the shape allows (default)
+BD_KNOB int g_pp_tail_split = 1;     // bd_conv_desc.route[1] bit 13 clears it
+BD_KNOB int g_pp_persistent = 1;     // bit 14 clears it: one workgroup per tile
+extern BD_KNOB int g_patch_pp;       // 0 = never, 1 = where the makespan estimate favours it, 2 = wherever the shape allows (default)
 int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                          const void* mask, void* dst, int flags, hipStream_t stream) {
     PParams p{};

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp128_kernel(const PParams p) 
 }  // namespace
 
 // 0 = launched, 1 = shape not handled here (caller falls back to conv3x3.hip)
-extern int g_patch_pp128;     // 0 = the 64-channel tile for Cout <= 64 only (default), 1 = every shape, -1 = never
+extern BD_KNOB int g_patch_pp128;     // 0 = the 64-channel tile for Cout <= 64 only (default), 1 = every shape, -1 = never
 // patch range [patch_begin, patch_end) (patch_end < 0: all) on the tco-channel tile (0: by shape)
 int bd_conv3x3_pp128_launch_range(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
                                   const void* mask, void* dst, int flags, hipStream_t stream, int patch_begin, int patch_end, int tco) {

@@ -17,7 +17,7 @@
 
 using namespace igemm;
 
-unsigned g_fp8_sr_seed = 0;        // bd_fp8_set_stochastic_rounding: read by every e5m2 quantiser's launcher (common.h)
+BD_KNOB unsigned g_fp8_sr_seed = 0;        // bd_conv_desc.sr_seed: read by every e5m2 quantiser's launcher (common.h)
 
 namespace {
 
@@ -357,9 +357,9 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const F8Params fp) {
     }
 }
 
-int g_fp8_patch = 1;        // bd_conv_fp8_set_patch: 0 = every shape through the generic per-tap kernel (A/B)
-
 }  // namespace
+
+BD_KNOB int g_fp8_patch = 1;        // bd_conv_desc.route[3] - 1: 0 = every shape through the generic per-tap kernel (A/B)
 
 int bd_conv3x3_pp8_launch(const bd_conv_desc* d, int mode, const void* xq, const void* wq, const float* wscale, const float* bias,
                           const void* add, const void* mask, void* y, void* y8, float q_scale, int flags, hipStream_t stream);
@@ -387,21 +387,14 @@ int bd_weight_pack_fp8(const float* w, const float* row_scale, int Cout, int RS,
     return BD_OK;
 }
 
-int bd_conv_fp8_set_patch(int on) { g_fp8_patch = on ? 1 : 0; return BD_OK; }
-
-int bd_quantize_bf8(const void* x_bf16, int64_t n, float scale, void* q, bd_stream_t stream) {
+int bd_quantize_bf8(const void* x_bf16, int64_t n, float scale, void* q, uint32_t sr_seed, bd_stream_t stream) {
     BD_REQUIRE(x_bf16 && q, "quantize_bf8: null pointer");
     BD_REQUIRE(n % 16 == 0 && scale > 0.f, "quantize_bf8: n %% 16 != 0 or scale <= 0");
     if (n == 0) return BD_OK;
     const long long n16 = n / 16;
     const int grid = (int)std::min<long long>(cdiv64(n16, 256), 256 * 16);
-    hipLaunchKernelGGL(quantize_bf8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x_bf16, n16, scale, (u32x4_t*)q, g_fp8_sr_seed);
+    hipLaunchKernelGGL(quantize_bf8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x_bf16, n16, scale, (u32x4_t*)q, sr_seed);
     BD_CHECK_LAUNCH("bd_quantize_bf8");
-    return BD_OK;
-}
-
-int bd_fp8_set_stochastic_rounding(uint32_t seed) {
-    g_fp8_sr_seed = seed;
     return BD_OK;
 }
 
@@ -428,6 +421,7 @@ int bd_weight_pack_fp8_t(const float* w, const float* row_scale, int Cout, int R
 int bd_conv2d_dgrad_fp8(const bd_conv_desc* d, const void* g8, const void* wq_t, const float* wscale_t, const void* add, const void* mask,
                         void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream) {
     BD_REQUIRE(d && g8 && wq_t && wscale_t && dx, "conv2d_dgrad_fp8: null pointer");
+    BD_ROUTE(d);
     BD_REQUIRE(!(flags & BD_EPI_RELU), "conv2d_dgrad_fp8: BD_EPI_RELU is a forward-only flag");
     BD_REQUIRE(d->Cout % 16 == 0 && d->Cin % 8 == 0, "conv2d_dgrad_fp8: Cout %% 16 and Cin %% 8 must be 0 (got %d, %d)", d->Cout, d->Cin);
     if (bd_conv3x3_pp8_launch(d, 1, g8, wq_t, wscale_t, nullptr, add, mask, dx, dx8, q_scale, flags, (hipStream_t)stream) != 0) {
@@ -449,6 +443,7 @@ int bd_conv2d_fwd_fp8(const bd_conv_desc* d, const void* xq, const void* wq, con
 int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
                          void* y, void* y8, float q_scale, int flags, bd_stream_t stream) {
     BD_REQUIRE(d && xq && wq && wscale && y, "conv2d_fwd_fp8: null pointer");
+    BD_ROUTE(d);
     BD_REQUIRE(d->nseg >= 1 && d->nseg <= MAX_SUB && (d->stride == 1 || d->stride == 2) && d->R * d->S <= 32, "conv2d_fwd_fp8: bad descriptor");
     BD_REQUIRE(d->Cin % 16 == 0 && d->Cout % 8 == 0, "conv2d_fwd_fp8: Cin %% 16 and Cout %% 8 must be 0 (got %d, %d)", d->Cin, d->Cout);
     BD_REQUIRE(!(flags & (BD_EPI_MASK | BD_EPI_ADD_AFTER)), "conv2d_fwd_fp8: forward flags only");

@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
     }
 }
 
-int g_igemm_prefetch_epi = 1;      // bd_conv_set_patch3x3 bit 5 clears it
-int g_igemm_buf = 1;               // bd_conv_set_patch3x3 bit 11 clears it: 64-bit pointer staging instead of buffer loads
+BD_KNOB int g_igemm_prefetch_epi = 1;      // bd_conv_desc.route[1] bit 5 clears it
+BD_KNOB int g_igemm_buf = 1;               // bd_conv_desc.route[1] bit 11 clears it: 64-bit pointer staging instead of buffer loads
 
 template <int BK>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
@@ -439,19 +439,19 @@ bool is_3x3s1(const bd_conv_desc* d) {
         if (d->Hi[s] != d->Ho[s] || d->Wi[s] != d->Wo[s]) return false;
     return true;
 }
-int g_use_patch3x3 = 1;
+BD_KNOB int g_use_patch3x3 = 1;
 #ifdef BD_AB_SKIP                // diagnostic build only (BD_EXTRA_FLAGS=-DBD_AB_SKIP next to BD_LIB_NAME): the shipped library cannot skip a launch
-int g_skip_s2_3x3 = 0;          // bd_conv_set_patch3x3 bit 4: timing A/B only -- the stride-2 3x3 forward / data-gradient launches return at once
+BD_KNOB int g_skip_s2_3x3 = 0;          // bd_conv_desc.route[1] bit 4: timing A/B only -- the stride-2 3x3 forward / data-gradient launches return at once
 #endif
-int g_bk32_for_1x1 = 1;
+BD_KNOB int g_bk32_for_1x1 = 1;
 // Stride-2 3x3 layers stay on the generic kernel, and there the tiles are short (the data gradient visits 1 / 2 / 2 / 4 taps per
 // parity class) and bound by the latency of their few K steps: BK=32 tiles (32 KB of LDS instead of 80 KB: four workgroups per CU
 // instead of two) run them 10-35 % faster as long as the grid still fills the chip (P6's 70-tile forward keeps BK=64).
-// bd_conv_set_patch3x3 bit 10 clears it.
-int g_bk32_s2 = 1;
+// bd_conv_desc.route[1] bit 10 clears it.
+BD_KNOB int g_bk32_s2 = 1;
 // conv_igemm_wide.hip (round 5 experiment, measured no faster than this file's kernel on the stride-2 3x3 layers -- DESIGN.md): 0 = never
-// (default), 2 = every launch of this file that kernel can take (bd_conv_set_patch3x3 bit 16: tests / A-B)
-int g_igemm_wide = 0;
+// (default), 2 = every launch of this file that kernel can take (bd_conv_desc.route[1] bit 16: tests / A-B)
+BD_KNOB int g_igemm_wide = 0;
 
 }  // namespace
 
@@ -461,18 +461,19 @@ int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, co
                             const void* add, const void* mask, void* dst, int flags, hipStream_t stream);
 
 // debug/measurement knob: bit 0 clear forces the generic per-tap kernel for 3x3 stride-1 convolutions; bit 1: BK=32 tiles for 1x1
-extern int g_patch_dma;
-extern int g_patch_pp;
-extern int g_patch_pp128;
-extern int g_conv1x1_s2;
-extern int g_pp_tail_split;
-extern int g_pp_persistent;
-extern "C" int bd_conv_set_patch3x3(int enable) {
+extern BD_KNOB int g_patch_dma;
+extern BD_KNOB int g_patch_pp;
+extern BD_KNOB int g_patch_pp128;
+extern BD_KNOB int g_conv1x1_s2;
+extern BD_KNOB int g_pp_tail_split;
+extern BD_KNOB int g_pp_persistent;
+// bd_conv_desc.route[1] - 1: the bit mask documented in include/basedet_hip.h
+static int bd_route_patch3x3(int enable) {
 #ifdef BD_AB_SKIP
     g_skip_s2_3x3 = (enable >> 4) & 1;
 #else
     if ((enable >> 4) & 1) {         // (checked before anything is changed)
-        bd_set_error("bd_conv_set_patch3x3: bit 4 (skip the 3x3 / stride-2 launches: a timing A/B that leaves stale outputs) exists in "
+        bd_set_error("bd_conv_desc.route[1]: bit 4 (skip the 3x3 / stride-2 launches: a timing A/B that leaves stale outputs) exists in "
                      "-DBD_AB_SKIP diagnostic builds only");
         return BD_EINVAL;
     }
@@ -489,6 +490,25 @@ extern "C" int bd_conv_set_patch3x3(int enable) {
     g_pp_persistent = ((enable >> 14) & 1) ^ 1;
     g_igemm_wide = ((enable >> 16) & 1) ? 2 : 0;
     return BD_OK;
+}
+
+int bd_route_dense1x1(int depth);          // conv1x1.hip
+int bd_route_wgrad(int use_tr);            // conv_wgrad.hip
+extern BD_KNOB int g_fp8_patch;            // conv_fp8.hip
+
+// Every entry point that takes a descriptor: the routing variables are written from THAT descriptor, defaults where a word is 0
+BdRouteScope::BdRouteScope(const bd_conv_desc* d) : rc(BD_OK) {
+    const int r0 = d ? d->route[0] : 0, r1 = d ? d->route[1] : 0, r2 = d ? d->route[2] : 0, r3 = d ? d->route[3] : 0;
+    if (r0 < 0 || r1 < 0 || r2 < 0 || r3 < 0) {
+        bd_set_error("bd_conv_desc.route: negative word (0 = the library's choice, otherwise the route + 1)");
+        rc = BD_EINVAL;
+        return;
+    }
+    if ((rc = bd_route_dense1x1(r0 ? r0 - 1 : 1)) != BD_OK) return;
+    if ((rc = bd_route_patch3x3(r1 ? r1 - 1 : 3)) != BD_OK) return;
+    if ((rc = bd_route_wgrad(r2 ? r2 - 1 : 1)) != BD_OK) return;
+    g_fp8_patch = r3 ? (r3 - 1 != 0) : 1;
+    g_fp8_sr_seed = d ? d->sr_seed : 0u;
 }
 
 int bd_conv1x1_dense_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits,
@@ -570,16 +590,19 @@ static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_p
 
 extern "C" int bd_conv2d_fwd(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* add, void* y, int flags, bd_stream_t stream) {
+    BD_ROUTE(d);
     return conv2d_fwd_impl(d, x, w_packed, bias, add, y, nullptr, nullptr, 1.f, flags, stream);
 }
 
 extern "C" int bd_conv2d_fwd_ex(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
                                 uint32_t* ybits, void* y8, float q_scale, int flags, bd_stream_t stream) {
+    BD_ROUTE(d);
     return conv2d_fwd_impl(d, x, w_packed, bias, add, y, ybits, y8, q_scale, flags, stream);
 }
 
 extern "C" int bd_conv2d_fwd_bits(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* add, void* y,
                                   uint32_t* ybits, int flags, bd_stream_t stream) {
+    BD_ROUTE(d);
     BD_REQUIRE(ybits != nullptr, "conv2d_fwd_bits: null ybits");
     return conv2d_fwd_impl(d, x, w_packed, bias, add, y, ybits, nullptr, 1.f, flags, stream);
 }
@@ -670,17 +693,20 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
 
 extern "C" int bd_conv2d_dgrad(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add,
                                const void* mask, void* dx, int flags, bd_stream_t stream) {
+    BD_ROUTE(d);
     return conv2d_dgrad_impl(d, g, w_packed_t, add, mask, nullptr, dx, nullptr, 1.f, flags, stream);
 }
 
 extern "C" int bd_conv2d_dgrad_ex(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
                                   const uint32_t* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream) {
+    BD_ROUTE(d);
     return conv2d_dgrad_impl(d, g, w_packed_t, add, maskbits ? nullptr : mask, maskbits, dx, dx8, q_scale,
                              maskbits ? (flags | BD_EPI_MASK) : flags, stream);
 }
 
 extern "C" int bd_conv2d_dgrad_bits(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const uint32_t* maskbits,
                                     void* dx, int flags, bd_stream_t stream) {
+    BD_ROUTE(d);
     BD_REQUIRE(maskbits != nullptr, "conv2d_dgrad_bits: null maskbits");
     return conv2d_dgrad_impl(d, g, w_packed_t, add, nullptr, maskbits, dx, nullptr, 1.f, flags | BD_EPI_MASK, stream);
 }

@@ -1,5 +1,5 @@
 // Implicit-GEMM convolution forward / data gradient, WIDE wave tile -- a round-5 EXPERIMENT for the stride-2 3x3 family (res3.0 / res4.0 /
-// res5.0 conv2), opt-in (bd_conv_set_patch3x3 bit 16), NOT on the default path: on those layers it runs exactly as fast as conv_igemm.hip's
+// res5.0 conv2), opt-in (bd_conv_desc.route[1] bit 16), NOT on the default path: on those layers it runs exactly as fast as conv_igemm.hip's
 // kernel, with either K order (forward 137 / 138 / 142 us against 140 / 126 / 123; data gradient 222 / 173 / 156 against 214 / 169 / 145:
 // profiles/r05_s2_micro.txt), and 20-35 % slower than conv1x1.hip on the dense 1x1 launches (profiles/r05_dense1x1_wide.txt).  What both
 // kernels share is what bounds them: ~96 KB of gathered operand bytes in flight per CU (LDS holds no more beside the tiles) over a loaded

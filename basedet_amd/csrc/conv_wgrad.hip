@@ -311,9 +311,9 @@ BdRedEntry plain_entry(const float* slab, int splits, long long n, int row_len, 
 struct Plan { int ci_tiles, co_tiles, splits, steps_per_split, total_steps; long long M; };
 
 constexpr int BKP_DEFAULT = 64;
-int g_wgrad_use_tr = 1;
-int g_wgrad_use_3x3 = 1;
-int g_wgrad_use_ring = 1;       // conv_wgrad3x3_ring.hip for the wide stride-1 3x3 layers (bd_wgrad_set_transpose_read bit 2 set = off)
+BD_KNOB int g_wgrad_use_tr = 1;
+BD_KNOB int g_wgrad_use_3x3 = 1;
+BD_KNOB int g_wgrad_use_ring = 1;       // conv_wgrad3x3_ring.hip for the wide stride-1 3x3 layers (bd_conv_desc.route[2] bit 2 set = off)
 
 // 3x3 / pad 1 with stride 1 or 2: served by the nine-tap patch kernel (conv_wgrad3x3.hip)
 bool is_3x3s1(const bd_conv_desc* d) {
@@ -363,7 +363,8 @@ void bd_wgrad1x1r_entry(const bd_conv_desc* d, BdRedEntry* e);
 // bit 1 (value 2) additionally disables the nine-tap 3x3 kernels (forces the generic per-tap kernel);
 // bit 2 (value 4) disables the ring-staged kernels only (conv_wgrad3x3_ring.hip, conv_wgrad1x1_ring.hip; their shapes then take
 // conv_wgrad3x3.hip / conv_wgrad1x1.hip).
-extern "C" int bd_wgrad_set_transpose_read(int use_tr) {
+// bd_conv_desc.route[2] - 1 (BdRouteScope, conv_igemm.hip)
+int bd_route_wgrad(int use_tr) {
     g_wgrad_use_tr = use_tr & 1;
     g_wgrad_use_3x3 = (use_tr & 2) ? 0 : 1;
     g_wgrad_use_ring = (use_tr & 4) ? 0 : 1;
@@ -379,6 +380,8 @@ void bd_wgrad_reduce_launch(const float* slab, int splits, long long n, int row_
 }
 
 extern "C" size_t bd_conv2d_wgrad_workspace_bytes(const bd_conv_desc* d) {
+    BdRouteScope rs__(d);
+    if (rs__.rc != BD_OK) return 0;
     if (!d || d->nseg < 1 || d->nseg > BD_MAX_SEGS) return 0;
     const Plan pl = make_plan(d);
     size_t splits = (size_t)pl.splits;
@@ -414,6 +417,8 @@ static int wgrad_impl(const bd_conv_desc* d, const void* x, const void* g, const
                       int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream, bd_wgrad_queue* q);
 
 extern "C" size_t bd_conv2d_wgrad_bias_workspace_bytes(const bd_conv_desc* d) {
+    BdRouteScope rs__(d);
+    if (rs__.rc != BD_OK) return 0;
     const size_t w = bd_conv2d_wgrad_workspace_bytes(d);
     if (!w) return 0;
     size_t extra = bd_colsum_workspace_bytes(d->Cout);
@@ -432,6 +437,7 @@ extern "C" size_t bd_conv2d_wgrad_bias_workspace_bytes(const bd_conv_desc* d) {
 
 extern "C" int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
                                     float* dbias, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_ROUTE(d);
     BD_REQUIRE(dbias, "conv2d_wgrad_bias: null bias gradient");
     BD_REQUIRE(d && d->Cout <= 2048, "conv2d_wgrad_bias: Cout must be <= 2048");
     const size_t need = bd_conv2d_wgrad_bias_workspace_bytes(d);
@@ -444,6 +450,7 @@ extern "C" int bd_conv2d_wgrad_bias(const bd_conv_desc* d, const void* x, const 
 
 extern "C" int bd_conv2d_wgrad(const bd_conv_desc* d, const void* x, const void* g, const float* row_scale,
                                float* dw, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_ROUTE(d);
     return wgrad_impl(d, x, g, row_scale, dw, nullptr, accumulate, ws, ws_bytes, stream, nullptr);
 }
 
@@ -460,6 +467,7 @@ extern "C" int bd_wgrad_queue_destroy(bd_wgrad_queue_t q) {
 extern "C" int bd_wgrad_queue_pending(bd_wgrad_queue_t q) { return q ? (int)q->entries.size() : 0; }
 extern "C" int bd_conv2d_wgrad_queued(bd_wgrad_queue_t q, const bd_conv_desc* d, const void* x, const void* g, const float* row_scale, float* dw,
                                       float* dbias, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_ROUTE(d);
     BD_REQUIRE(q != nullptr, "bd_conv2d_wgrad_queued: null queue");
     if (dbias) {
         BD_REQUIRE(d && d->Cout <= 2048, "conv2d_wgrad_queued: Cout must be <= 2048");

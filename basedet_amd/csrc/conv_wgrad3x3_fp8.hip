@@ -279,12 +279,15 @@ void bd_wgrad_reduce_launch(const float* slab, int splits, long long n, int row_
                             hipStream_t stream);       // conv_wgrad.hip
 
 extern "C" size_t bd_conv2d_wgrad_fp8_workspace_bytes(const bd_conv_desc* d) {
+    BdRouteScope rs__(d);
+    if (rs__.rc != BD_OK) return 0;
     if (!d || !f8_ok(d)) return 0;
     return (size_t)f8_splits(d) * d->Cout * 9 * d->Cin * sizeof(float);
 }
 
 extern "C" int bd_conv2d_wgrad_fp8(const bd_conv_desc* d, const void* x8, const void* g8, float inv_scale, const float* row_scale,
                                    float* dw, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {
+    BD_ROUTE(d);
     BD_REQUIRE(d && x8 && g8 && dw && ws, "conv2d_wgrad_fp8: null pointer");
     BD_REQUIRE(f8_ok(d), "conv2d_wgrad_fp8: 3x3 / stride 1 / pad 1 with Cin %% 16 == 0 and Cout %% 16 == 0 only (tensors < 2 GB)");
     const size_t need = bd_conv2d_wgrad_fp8_workspace_bytes(d);

@@ -434,16 +434,12 @@ inline int loss_grid(long long n) {
 
 }  // namespace
 
-static int g_focal_fast = 1;
-extern "C" int bd_focal_set_fast(int on) { g_focal_fast = on ? 1 : 0; return BD_OK; }      // 0: the general-gamma kernel also for gamma = 2 (A/B)
-
-extern "C" int bd_focal_loss_fwd_bwd(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha, float gamma,
-                                     const void* norm, int norm_is_float, float grad_scale, float* loss_sum, void* dlogits,
-                                     bd_stream_t stream) {
+static int focal_launch(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha, float gamma, const void* norm,
+                        int norm_is_float, float grad_scale, float* loss_sum, void* dlogits, bool general, bd_stream_t stream) {
     BD_REQUIRE(logits && labels && norm && loss_sum && dlogits, "focal_loss: null pointer");
     BD_REQUIRE(K > 0 && K % 8 == 0, "focal_loss: K=%d must be a multiple of 8", K);
     if (rows == 0) return BD_OK;
-    if (gamma == 2.f && g_focal_fast)
+    if (gamma == 2.f && !general)
         hipLaunchKernelGGL(focal_g2_kernel, dim3(loss_grid(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_raw*)logits, labels, (long long)rows, K, alpha, norm, norm_is_float, grad_scale, loss_sum,
                            (bf16_raw*)dlogits);
@@ -453,6 +449,19 @@ extern "C" int bd_focal_loss_fwd_bwd(const void* logits, const int32_t* labels, 
                            loss_sum, (bf16_raw*)dlogits);
     BD_CHECK_LAUNCH("bd_focal_loss_fwd_bwd");
     return BD_OK;
+}
+
+extern "C" int bd_focal_loss_fwd_bwd(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha, float gamma,
+                                     const void* norm, int norm_is_float, float grad_scale, float* loss_sum, void* dlogits,
+                                     bd_stream_t stream) {
+    return focal_launch(logits, labels, rows, K, alpha, gamma, norm, norm_is_float, grad_scale, loss_sum, dlogits, false, stream);
+}
+
+// the general-gamma kernel whatever gamma is (the gamma == 2 instance of bd_focal_loss_fwd_bwd is checked against it)
+extern "C" int bd_focal_loss_fwd_bwd_general(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha, float gamma,
+                                             const void* norm, int norm_is_float, float grad_scale, float* loss_sum, void* dlogits,
+                                             bd_stream_t stream) {
+    return focal_launch(logits, labels, rows, K, alpha, gamma, norm, norm_is_float, grad_scale, loss_sum, dlogits, true, stream);
 }
 
 extern "C" int bd_smooth_l1_fwd_bwd(const void* pred, const float* target, const int32_t* labels, int64_t pixels, int A,

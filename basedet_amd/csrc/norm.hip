@@ -209,14 +209,17 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_raw* __r
 // ab[(n*L + l)*32 + g] = (A, B) / count: one workgroup per (image, level), as gn_stats_final_kernel
 __device__ __forceinline__ void gn_bwd_final_body(const float* __restrict__ pg, const GnLevels& lv, int cpg, float* __restrict__ ab, int l, int n,
                                                   float (*red)[32][2]) {
+    // (every thread of the block reaches the barrier; threads past the first 256 -- gn_bwd_finals_kernel launches 1024 -- carry nothing)
     const int g = threadIdx.x & 31, q = threadIdx.x >> 5;
     const int S = lv.slot0[lv.L];
     float A = 0.f, B = 0.f;
-    for (int c = lv.slot0[l] + q; c < lv.slot0[l + 1]; c += 8) {
-        const float* o = pg + (((long long)n * S + c) * 32 + g) * 2;
-        A += o[0]; B += o[1];
+    if (q < 8) {
+        for (int c = lv.slot0[l] + q; c < lv.slot0[l + 1]; c += 8) {
+            const float* o = pg + (((long long)n * S + c) * 32 + g) * 2;
+            A += o[0]; B += o[1];
+        }
+        red[q][g][0] = A; red[q][g][1] = B;
     }
-    red[q][g][0] = A; red[q][g][1] = B;
     __syncthreads();
     if (q == 0) {
         A = 0.f; B = 0.f;
@@ -269,9 +272,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_finals_kernel(const float* __rest
     __shared__ float red[128][8][2];
     const int nb = lv.L * N;
     if ((int)blockIdx.x < nb) {
-        // (the first four waves work; the other twelve end here -- a finished wave no longer counts at the barrier inside)
         float (*r2)[32][2] = reinterpret_cast<float (*)[32][2]>(&red[0][0][0]);
-        if (threadIdx.x < 256) gn_bwd_final_body(pg, lv, cpg, ab, (int)blockIdx.x % lv.L, (int)blockIdx.x / lv.L, r2);
+        gn_bwd_final_body(pg, lv, cpg, ab, (int)blockIdx.x % lv.L, (int)blockIdx.x / lv.L, r2);        // (all 1024 threads: one barrier inside)
         return;
     }
     gn_bwd_final_c_body(pc, slots, C, dgamma, dbeta, accumulate, (int)blockIdx.x - nb, red);
@@ -400,15 +402,12 @@ inline GnLevels make_levels(int L, const int32_t* off, const int32_t* cnt) {
 inline int egrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 constexpr int OFF_BLOCKS = 512;
 
-// images per chunk of the forward / backward (0 = the whole batch in one chunk): bd_groupnorm_set_chunks
-int g_gn_chunk_fwd = 0, g_gn_chunk_bwd = 0;
+// (Rounds 4-5 could run the forward / backward in chunks of images -- bd_groupnorm_set_chunks: statistics of a chunk, then its apply pass
+// re-reading the chunk from the Infinity Cache -- or walk the apply pass from the END: measured slower at every chunk size
+// (profiles/r05_gn_chunks.txt); round 6 removed the switch.  The loops below run once, over the whole batch.)
+constexpr int GN_CHUNK = 0;
 
 }  // namespace
-
-extern "C" int bd_groupnorm_set_chunks(int fwd_images, int bwd_images) {
-    g_gn_chunk_fwd = fwd_images; g_gn_chunk_bwd = bwd_images;       // < 0: the whole batch at once, the apply pass walking it from the END
-    return BD_OK;
-}
 
 // slots per image <= pix_per_img / 128 + L
 extern "C" size_t bd_groupnorm_workspace_bytes(int N, int L, int C, int64_t pix_per_img) {
@@ -426,8 +425,8 @@ extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* 
     const GnLevels lv = make_levels(L, lvl_off_host, lvl_cnt_host);
     const int S = lv.slot0[L];
     hipStream_t st = (hipStream_t)stream;
-    const int step = g_gn_chunk_fwd > 0 ? g_gn_chunk_fwd : N;
-    const int rev = g_gn_chunk_fwd < 0;
+    const int step = GN_CHUNK > 0 ? GN_CHUNK : N;
+    const int rev = 0;
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nc = n0 + step <= N ? step : N - n0;
         const bf16_raw* yc = (const bf16_raw*)y + (long long)n0 * pix_per_img * C;
@@ -456,8 +455,8 @@ extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamm
     float* pg = (float*)ws;
     float* pc = pg + (size_t)N * S * 32 * 2;
     float* ab = pc + (size_t)N * S * C * 2;
-    const int step = g_gn_chunk_bwd > 0 ? g_gn_chunk_bwd : N;
-    const int rev = g_gn_chunk_bwd < 0;
+    const int step = GN_CHUNK > 0 ? GN_CHUNK : N;
+    const int rev = 0;
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nc = n0 + step <= N ? step : N - n0;
         const long long eo = (long long)n0 * pix_per_img * C;

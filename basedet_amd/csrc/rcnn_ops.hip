@@ -1263,7 +1263,6 @@ inline NmslLayout nmsl_layout(int N, int L, int C, int post_k) {
     return l;
 }
 
-int g_rpn_nms_per_level = 1;       // bd_rpn_set_nms_per_level(0): the joint batched NMS of rounds 1-4 (A/B; same proposals bit for bit)
 
 struct RpnWs { size_t tk_idx, tk_score, tk_cnt, boxes, scores, levels, keep, nms, total; };
 inline RpnWs rpn_ws_layout(int N, int C, int L, int k, int post_k) {
@@ -1339,11 +1338,11 @@ extern "C" size_t bd_rpn_proposals_workspace_bytes(int N, int L, const int32_t* 
     return rpn_ws_layout(N, rpn_capacity(L, lvl_pixels_host, A, pre_k), L, pre_k, post_k).total;
 }
 
-extern "C" int bd_rpn_proposals(const void* raw, int ldc, int A, int cls_off, int box_off, int N, int64_t pix_per_img, int L,
-                                const int32_t* lvl_pix_off_host, const int32_t* lvl_pixels_host, const float* anchors,
-                                const float* im_info, int info_ld, const float* mean4_host, const float* std4_host, int pre_k,
-                                float nms_thresh, int post_k, float* rois, int32_t* num_rois, void* ws, size_t ws_bytes,
-                                bd_stream_t stream) {
+static int rpn_proposals_impl(const void* raw, int ldc, int A, int cls_off, int box_off, int N, int64_t pix_per_img, int L,
+                              const int32_t* lvl_pix_off_host, const int32_t* lvl_pixels_host, const float* anchors,
+                              const float* im_info, int info_ld, const float* mean4_host, const float* std4_host, int pre_k,
+                              float nms_thresh, int post_k, float* rois, int32_t* num_rois, void* ws, size_t ws_bytes,
+                              bool nms_per_level, bd_stream_t stream) {
     BD_REQUIRE(raw && lvl_pix_off_host && lvl_pixels_host && anchors && im_info && rois && num_rois && ws, "rpn_proposals: null pointer");
     BD_REQUIRE(N > 0 && L > 0 && L <= BD_MAX_SEGS && A > 0 && pre_k > 0 && pre_k <= TOPK_MAX && post_k > 0, "rpn_proposals: bad sizes");
     BD_REQUIRE(cls_off >= 0 && box_off >= 0 && cls_off + A <= ldc && box_off + 4 * A <= ldc, "rpn_proposals: bad channel layout");
@@ -1382,7 +1381,7 @@ extern "C" int bd_rpn_proposals(const void* raw, int ldc, int A, int cls_off, in
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(C, 256), N), dim3(256), 0, st, (const bf16_raw*)raw, (long long)pix_per_img, ldc,
                        A, box_off, anchors, lv, pre_k, tk_idx, tk_score, tk_cnt, im_info, info_ld, make_coder(mean4_host, std4_host),
                        C, boxes, scores, levels);
-    if (g_rpn_nms_per_level) {
+    if (nms_per_level) {
         const NmslLayout nl = nmsl_layout(N, L, C, post_k);
         unsigned char* nb = wb + w.nms;
         float* sboxes = (float*)(nb + nl.sboxes);
@@ -1403,7 +1402,24 @@ extern "C" int bd_rpn_proposals(const void* raw, int ldc, int A, int cls_off, in
     return BD_OK;
 }
 
-extern "C" int bd_rpn_set_nms_per_level(int on) { g_rpn_nms_per_level = on != 0; return BD_OK; }
+extern "C" int bd_rpn_proposals(const void* raw, int ldc, int A, int cls_off, int box_off, int N, int64_t pix_per_img, int L,
+                                const int32_t* lvl_pix_off_host, const int32_t* lvl_pixels_host, const float* anchors,
+                                const float* im_info, int info_ld, const float* mean4_host, const float* std4_host, int pre_k,
+                                float nms_thresh, int post_k, float* rois, int32_t* num_rois, void* ws, size_t ws_bytes,
+                                bd_stream_t stream) {
+    return rpn_proposals_impl(raw, ldc, A, cls_off, box_off, N, pix_per_img, L, lvl_pix_off_host, lvl_pixels_host, anchors, im_info, info_ld,
+                              mean4_host, std4_host, pre_k, nms_thresh, post_k, rois, num_rois, ws, ws_bytes, true, stream);
+}
+
+// the batched NMS as ONE problem per image (rounds 1-4) instead of level by level + merge: the same proposals bit for bit (tests)
+extern "C" int bd_rpn_proposals_joint(const void* raw, int ldc, int A, int cls_off, int box_off, int N, int64_t pix_per_img, int L,
+                                      const int32_t* lvl_pix_off_host, const int32_t* lvl_pixels_host, const float* anchors,
+                                      const float* im_info, int info_ld, const float* mean4_host, const float* std4_host, int pre_k,
+                                      float nms_thresh, int post_k, float* rois, int32_t* num_rois, void* ws, size_t ws_bytes,
+                                      bd_stream_t stream) {
+    return rpn_proposals_impl(raw, ldc, A, cls_off, box_off, N, pix_per_img, L, lvl_pix_off_host, lvl_pixels_host, anchors, im_info, info_ld,
+                              mean4_host, std4_host, pre_k, nms_thresh, post_k, rois, num_rois, ws, ws_bytes, false, stream);
+}
 
 extern "C" int bd_sample_labels(int32_t* labels, const float* keys_pos, const float* keys_neg, int N, int A, int num_pos_max,
                                 int num_total, int32_t* num_valid, bd_stream_t stream) {
@@ -1572,7 +1588,8 @@ extern "C" int bd_roi_align_bwd_bf16(const void* gout, int64_t pix_per_img, int 
     for (int l = 0; l < L_all; ++l) {
         pt.pix_off[l] = lvl_pix_off_host[l]; pt.H[l] = lvl_h_host[l]; pt.W[l] = lvl_w_host[l];
         pt.tiles_x[l] = cdiv(lvl_w_host[l], RT);
-        BD_REQUIRE(pt.tiles_x[l] < 65536 && cdiv(lvl_h_host[l], RT) < 65536, "roi_align_bwd_bf16: level too large");
+        // (tile coordinates are packed two to a SIGNED int and unpacked with an arithmetic shift: 15 bits each)
+        BD_REQUIRE(pt.tiles_x[l] < 32768 && cdiv(lvl_h_host[l], RT) < 32768, "roi_align_bwd_bf16: level too large");
         pt.tile_start[l] = ts;
         ts += pt.tiles_x[l] * cdiv(lvl_h_host[l], RT);
     }

@@ -209,7 +209,7 @@ class FPNDetector:
             for c in self.convs.values():             # one scale everywhere at the start (a twin's producer reads it off the consumer's layer object)
                 c.grad_scale = float(m.get("FP8_GRAD_SCALE", fp8_scale0))
         self.fp8_delayed_scaling = bool(m.get("FP8_DELAYED_SCALING", True)) and bool(self._fp8_grad_layers) and self.device.type == "cuda"
-        # Stochastic rounding of those gradients (bd_fp8_set_stochastic_rounding): round-to-nearest e5m2 repeats the same error on the
+        # Stochastic rounding of those gradients (bd_conv_desc.sr_seed): round-to-nearest e5m2 repeats the same error on the
         # same value every step, which a repeated batch turns into a drift (the long repeated-batch runs)
         self.fp8_stochastic_rounding = bool(m.get("FP8_STOCHASTIC_ROUNDING", True)) and bool(self._fp8_grad_layers) and self.device.type == "cuda"
         self.fp8_amax_interval = int(m.get("FP8_AMAX_INTERVAL", 10))

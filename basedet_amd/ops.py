@@ -70,19 +70,45 @@ def L():
     return _lib.load()
 
 
+# ---- per-call kernel routing (bd_conv_desc.route / .sr_seed) ---------------------------------------------------------------------------
+# The library keeps no routing state (round 6: the bd_*_set_* knobs are gone).  A test or an A/B harness that wants a route sets it HERE;
+# every wrapper below that takes a descriptor stamps the current words into it right before the call.  Production code never touches this.
+_ROUTE = [0, 0, 0, 0]          # (route + 1) words: dense 1x1 mode, 3x3 / generic bit mask, weight-gradient bit mask, fp8 forward patch kernel
+_SR_SEED = [0]                 # e5m2 stochastic-rounding seed of the calls made from now on (the fp8 model sets it per step)
+_ROUTE_NAMES = {"dense1x1": 0, "patch3x3": 1, "wgrad": 2, "fp8_patch": 3}
+
+
+def set_route(**kw):
+    """set_route(dense1x1=mode, patch3x3=mask, wgrad=mask, fp8_patch=0|1); a value of None returns that word to the library's default.
+    The meanings: include/basedet_hip.h, bd_conv_desc.route."""
+    for k, v in kw.items():
+        _ROUTE[_ROUTE_NAMES[k]] = 0 if v is None else int(v) + 1
+
+
+def reset_route():
+    _ROUTE[:] = [0, 0, 0, 0]
+    _SR_SEED[0] = 0
+
+
+def _stamp(d):
+    d.route[0], d.route[1], d.route[2], d.route[3] = _ROUTE
+    d.sr_seed = _SR_SEED[0]
+    return d
+
+
 # ---- dense path -------------------------------------------------------------------------------------------
 def conv2d_fwd(d, x, w_packed, bias, y, add=None, flags=0, bits=None, y8=None, q_scale=1.0):
     """bits: optional uint32 [Cout/32][M] output, the bit-packed ReLU mask of y; y8: optional uint8 e4m3 twin of y (dense 1x1 launches
     only: bd_conv2d_fwd_bits / bd_conv2d_fwd_ex)."""
     if y8 is not None:
-        check(L().bd_conv2d_fwd_ex(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), ptr(y8), float(q_scale), flags,
+        check(L().bd_conv2d_fwd_ex(C.byref(_stamp(d)), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), ptr(y8), float(q_scale), flags,
                                    stream_ptr()), "bd_conv2d_fwd_ex")
         return y
     if bits is not None:
-        check(L().bd_conv2d_fwd_bits(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), flags, stream_ptr()),
+        check(L().bd_conv2d_fwd_bits(C.byref(_stamp(d)), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), ptr(bits), flags, stream_ptr()),
               "bd_conv2d_fwd_bits")
         return y
-    check(L().bd_conv2d_fwd(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), flags, stream_ptr()), "bd_conv2d_fwd")
+    check(L().bd_conv2d_fwd(C.byref(_stamp(d)), ptr(x), ptr(w_packed), ptr(bias), ptr(add), ptr(y), flags, stream_ptr()), "bd_conv2d_fwd")
     return y
 
 
@@ -90,14 +116,14 @@ def conv2d_dgrad(d, g, w_packed_t, dx, add=None, mask=None, flags=0, maskbits=No
     """maskbits: the ReLU mask as written by conv2d_fwd(bits=...) instead of the bf16 activation `mask` (bd_conv2d_dgrad_bits);
     dx8: optional uint8 e5m2 twin of dx * q_scale (dense 1x1 launches only: bd_conv2d_dgrad_ex)."""
     if dx8 is not None:
-        check(L().bd_conv2d_dgrad_ex(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(maskbits), ptr(dx), ptr(dx8),
+        check(L().bd_conv2d_dgrad_ex(C.byref(_stamp(d)), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(maskbits), ptr(dx), ptr(dx8),
                                      float(q_scale), flags, stream_ptr()), "bd_conv2d_dgrad_ex")
         return dx
     if maskbits is not None:
-        check(L().bd_conv2d_dgrad_bits(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(maskbits), ptr(dx), flags, stream_ptr()),
+        check(L().bd_conv2d_dgrad_bits(C.byref(_stamp(d)), ptr(g), ptr(w_packed_t), ptr(add), ptr(maskbits), ptr(dx), flags, stream_ptr()),
               "bd_conv2d_dgrad_bits")
         return dx
-    check(L().bd_conv2d_dgrad(C.byref(d), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(dx), flags, stream_ptr()), "bd_conv2d_dgrad")
+    check(L().bd_conv2d_dgrad(C.byref(_stamp(d)), ptr(g), ptr(w_packed_t), ptr(add), ptr(mask), ptr(dx), flags, stream_ptr()), "bd_conv2d_dgrad")
     return dx
 
 
@@ -114,20 +140,21 @@ def weight_pack_fp8(w, row_scale, Cout, RS, Cin, act_scale, wq, wscale):
 
 def conv2d_fwd_fp8(d, xq, wq, wscale, bias, y, add=None, flags=0, y8=None, q_scale=1.0):
     """y8: optional uint8 twin of y (e4m3(y * q_scale)) for a following fp8 convolution."""
-    check(L().bd_conv2d_fwd_fp8_ex(C.byref(d), ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(y), ptr(y8), float(q_scale), flags,
+    check(L().bd_conv2d_fwd_fp8_ex(C.byref(_stamp(d)), ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(y), ptr(y8), float(q_scale), flags,
                                    stream_ptr()), "bd_conv2d_fwd_fp8")
     return y
 
 
 def quantize_bf8(x, scale, q):
-    """q (uint8) = e5m2(clamp(x * scale)) of a bf16 tensor (gradients)."""
-    check(L().bd_quantize_bf8(ptr(x), x.numel(), float(scale), ptr(q), stream_ptr()), "bd_quantize_bf8")
+    """q (uint8) = e5m2(clamp(x * scale)) of a bf16 tensor (gradients); rounding: fp8_set_stochastic_rounding."""
+    check(L().bd_quantize_bf8(ptr(x), x.numel(), float(scale), ptr(q), _SR_SEED[0], stream_ptr()), "bd_quantize_bf8")
     return q
 
 
 def fp8_set_stochastic_rounding(seed):
-    """seed != 0: the e5m2 quantisers launched from now on round stochastically (hash of seed and element index); 0: to nearest."""
-    check(L().bd_fp8_set_stochastic_rounding(int(seed) & 0xFFFFFFFF), "bd_fp8_set_stochastic_rounding")
+    """seed != 0: the e5m2 quantisers CALLED from now on round stochastically (hash of seed and element index); 0: to nearest.  Python-side
+    state: the seed travels with every call (bd_conv_desc.sr_seed, bd_quantize_bf8's argument)."""
+    _SR_SEED[0] = int(seed) & 0xFFFFFFFF
 
 
 def absmax_bf16(x, out):
@@ -141,25 +168,25 @@ def weight_pack_fp8_t(w, row_scale, Cout, RS, Cin, grad_scale, wq_t, wscale_t):
 
 
 def conv2d_dgrad_fp8(d, g8, wq_t, wscale_t, dx, add=None, mask=None, flags=0, dx8=None, q_scale=1.0):
-    check(L().bd_conv2d_dgrad_fp8(C.byref(d), ptr(g8), ptr(wq_t), ptr(wscale_t), ptr(add), ptr(mask), ptr(dx), ptr(dx8), float(q_scale),
+    check(L().bd_conv2d_dgrad_fp8(C.byref(_stamp(d)), ptr(g8), ptr(wq_t), ptr(wscale_t), ptr(add), ptr(mask), ptr(dx), ptr(dx8), float(q_scale),
                                   flags, stream_ptr()), "bd_conv2d_dgrad_fp8")
     return dx
 
 
 def conv1x1_fp8(d, mode, xq, wq, wscale, bias, y, add=None, mask=None, maskbits=None, bits=None, y8=None, q_scale=1.0, flags=0):
     """Dense 1x1 launch on one-byte operands: mode 0 forward (xq e4m3), mode 1 data gradient (xq = e5m2 gradient)."""
-    check(L().bd_conv1x1_fp8(C.byref(d), mode, ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(mask), ptr(maskbits), ptr(y),
+    check(L().bd_conv1x1_fp8(C.byref(_stamp(d)), mode, ptr(xq), ptr(wq), ptr(wscale), ptr(bias), ptr(add), ptr(mask), ptr(maskbits), ptr(y),
                              ptr(bits), ptr(y8), float(q_scale), flags, stream_ptr()), "bd_conv1x1_fp8")
     return y
 
 
 def conv2d_wgrad_fp8_workspace_bytes(d):
-    return int(L().bd_conv2d_wgrad_fp8_workspace_bytes(C.byref(d)))
+    return int(L().bd_conv2d_wgrad_fp8_workspace_bytes(C.byref(_stamp(d))))
 
 
 def conv2d_wgrad_fp8(d, x8, g8, inv_scale, dw, ws, row_scale=None, accumulate=False):
     """Weight gradient of a 3x3 / stride-1 convolution from the one-byte twins (x8 e4m3, g8 e5m2); dw fp32 [Cout][9][Cin]."""
-    check(L().bd_conv2d_wgrad_fp8(C.byref(d), ptr(x8), ptr(g8), float(inv_scale), ptr(row_scale), ptr(dw), int(accumulate), ptr(ws),
+    check(L().bd_conv2d_wgrad_fp8(C.byref(_stamp(d)), ptr(x8), ptr(g8), float(inv_scale), ptr(row_scale), ptr(dw), int(accumulate), ptr(ws),
                                   ws.numel() * ws.element_size(), stream_ptr()), "bd_conv2d_wgrad_fp8")
     return dw
 
@@ -184,22 +211,22 @@ def dense_1x1_bits_ok(d):
 
 
 def conv2d_wgrad_workspace_bytes(d):
-    return int(L().bd_conv2d_wgrad_workspace_bytes(C.byref(d)))
+    return int(L().bd_conv2d_wgrad_workspace_bytes(C.byref(_stamp(d))))
 
 
 def conv2d_wgrad(d, x, g, dw, ws, row_scale=None, accumulate=False):
-    check(L().bd_conv2d_wgrad(C.byref(d), ptr(x), ptr(g), ptr(row_scale), ptr(dw), int(accumulate), ptr(ws),
+    check(L().bd_conv2d_wgrad(C.byref(_stamp(d)), ptr(x), ptr(g), ptr(row_scale), ptr(dw), int(accumulate), ptr(ws),
                               ws.numel() * ws.element_size(), stream_ptr()), "bd_conv2d_wgrad")
     return dw
 
 
 def conv2d_wgrad_bias_workspace_bytes(d):
-    return int(L().bd_conv2d_wgrad_bias_workspace_bytes(C.byref(d)))
+    return int(L().bd_conv2d_wgrad_bias_workspace_bytes(C.byref(_stamp(d))))
 
 
 def conv2d_wgrad_bias(d, x, g, dw, dbias, ws, row_scale=None, accumulate=False):
     """Weight and bias gradient in one call (the 3x3 patch kernel sums g's columns while staging them)."""
-    check(L().bd_conv2d_wgrad_bias(C.byref(d), ptr(x), ptr(g), ptr(row_scale), ptr(dw), ptr(dbias), int(accumulate), ptr(ws),
+    check(L().bd_conv2d_wgrad_bias(C.byref(_stamp(d)), ptr(x), ptr(g), ptr(row_scale), ptr(dw), ptr(dbias), int(accumulate), ptr(ws),
                                    ws.numel() * ws.element_size(), stream_ptr()), "bd_conv2d_wgrad_bias")
     return dw
 
@@ -461,12 +488,15 @@ def rpn_proposals_workspace_bytes(N, lvl_pixels, A, pre_k, post_k):
     return int(L().bd_rpn_proposals_workspace_bytes(N, len(lvl_pixels), i32arr(lvl_pixels), A, pre_k, post_k))
 
 
-def rpn_proposals(raw, ldc, A, cls_off, box_off, geom: Geom, anchors, im_info, mean, std, pre_k, nms_thresh, post_k, rois, num_rois, ws):
+def rpn_proposals(raw, ldc, A, cls_off, box_off, geom: Geom, anchors, im_info, mean, std, pre_k, nms_thresh, post_k, rois, num_rois, ws,
+                  joint_nms=False):
+    """joint_nms: the batched NMS as one problem per image (bd_rpn_proposals_joint: rounds 1-4) instead of level by level + merge."""
     lvl_pixels = [h * w for h, w in zip(geom.H, geom.W)]
-    check(L().bd_rpn_proposals(ptr(raw), ldc, A, cls_off, box_off, geom.N, geom.pix_per_img, geom.nlev, i32arr(geom.off),
-                               i32arr(lvl_pixels), ptr(anchors), ptr(im_info), im_info.shape[1], f32arr(mean), f32arr(std),
-                               int(pre_k), float(nms_thresh), int(post_k), ptr(rois), ptr(num_rois), ptr(ws),
-                               ws.numel() * ws.element_size(), stream_ptr()), "bd_rpn_proposals")
+    fn = L().bd_rpn_proposals_joint if joint_nms else L().bd_rpn_proposals
+    check(fn(ptr(raw), ldc, A, cls_off, box_off, geom.N, geom.pix_per_img, geom.nlev, i32arr(geom.off),
+             i32arr(lvl_pixels), ptr(anchors), ptr(im_info), im_info.shape[1], f32arr(mean), f32arr(std),
+             int(pre_k), float(nms_thresh), int(post_k), ptr(rois), ptr(num_rois), ptr(ws),
+             ws.numel() * ws.element_size(), stream_ptr()), "bd_rpn_proposals")
 
 
 def rcnn_sample_targets(rois, num_rois, gt_boxes, num_gt, keys_fg, keys_bg, num_samples, num_fg_max, fg_thresh, bg_hi, bg_lo,
@@ -570,10 +600,11 @@ def det_finalize(boxes, scores, labels, keep, num_keep, max_out, im_info, out_bo
 
 
 # ---- losses -----------------------------------------------------------------------------------------------
-def focal_loss_fwd_bwd(logits, labels, rows, K, alpha, gamma, norm, grad_scale, loss_sum, dlogits):
-    check(L().bd_focal_loss_fwd_bwd(ptr(logits), ptr(labels), rows, K, float(alpha), float(gamma), ptr(norm),
-                                    int(norm.dtype == torch.float32), float(grad_scale), ptr(loss_sum), ptr(dlogits),
-                                    stream_ptr()), "bd_focal_loss_fwd_bwd")
+def focal_loss_fwd_bwd(logits, labels, rows, K, alpha, gamma, norm, grad_scale, loss_sum, dlogits, general=False):
+    """general: the general-gamma kernel also for gamma == 2 (bd_focal_loss_fwd_bwd_general)"""
+    fn = L().bd_focal_loss_fwd_bwd_general if general else L().bd_focal_loss_fwd_bwd
+    check(fn(ptr(logits), ptr(labels), rows, K, float(alpha), float(gamma), ptr(norm),
+             int(norm.dtype == torch.float32), float(grad_scale), ptr(loss_sum), ptr(dlogits), stream_ptr()), "bd_focal_loss_fwd_bwd")
 
 
 def smooth_l1_fwd_bwd(pred, target, labels, pixels, A, ld, beta, norm, weight, loss_sum, dpred):
@@ -649,7 +680,7 @@ class WgradQueue:
         check(L().bd_wgrad_queue_create(C.byref(self._h)), "bd_wgrad_queue_create")
 
     def wgrad(self, d, x, g, dw, dbias, ws, row_scale=None, accumulate=False):
-        check(L().bd_conv2d_wgrad_queued(self._h, C.byref(d), ptr(x), ptr(g), ptr(row_scale), ptr(dw), ptr(dbias), int(accumulate), ptr(ws),
+        check(L().bd_conv2d_wgrad_queued(self._h, C.byref(_stamp(d)), ptr(x), ptr(g), ptr(row_scale), ptr(dw), ptr(dbias), int(accumulate), ptr(ws),
                                          ws.numel() * ws.element_size(), stream_ptr()), "bd_conv2d_wgrad_queued")
 
     def pending(self):

@@ -251,6 +251,17 @@ class KernelTimer:
         nb = sum(m[8] for m in self.meta[kind])
         return dict(launches=len(rec), ms=ms, flops=fl, bytes=nb)
 
+    def by_launch_class(self, kind, ridge):
+        """The kernel's launches split by EACH LAUNCH's own arithmetic intensity against the machine balance `ridge` (FLOP per byte): a
+        kernel whose average launch is HBM-bound can hold launches that sit above the ridge (res5's conv1: 400 FLOP/B) -- they are graded
+        against the MFMA roof, the others against HBM.  {"mfma": {...}, "hbm": {...}} with launches, ms, flops, bytes per class."""
+        out = {}
+        for (s, e, f), m in zip(self.records[kind], self.meta[kind]):
+            cls = "mfma" if (m[8] > 0 and f / m[8] >= ridge) else "hbm"
+            a = out.setdefault(cls, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1; a["ms"] += s.elapsed_time(e); a["flops"] += f; a["bytes"] += m[8]
+        return out
+
 
 def _cpu_model():
     try:
@@ -493,17 +504,15 @@ def main():
                          "0 / unset = the caller's stream")
     ap.add_argument("--roi-bwd-scatter", action="store_true",
                     help="Faster R-CNN: the general fp32 atomic scatter + conversion pass as RoIAlign backward (default: the tiled fixed-order sum)")
-    ap.add_argument("--dense1x1", type=int, default=None, help="ablation: bd_conv_set_dense1x1 (0 = generic kernel for the dense 1x1 launches)")
+    ap.add_argument("--dense1x1", type=int, default=None, help="ablation: bd_conv_desc.route[0], the dense 1x1 mode of every call (0 = generic kernel for the dense 1x1 launches)")
     ap.add_argument("--no-mask-bits", action="store_true", help="ablation: bf16 activations instead of bit-packed ReLU gates as dgrad masks")
     ap.add_argument("--skip-s2-3x3-after-warmup", action="store_true",
                     help="timing A/B only: after the warm-up steps the 3x3 / stride-2 forward and data-gradient launches become no-ops (their "
                          "outputs keep the last warm-up step's values): the step-time difference is what those launches cost")
     ap.add_argument("--wgrad-knob", type=int, default=None,
-                    help="ablation: bd_wgrad_set_transpose_read bit mask (5 = the ring-staged weight-gradient kernels off: rounds 1-3 kernels)")
-    ap.add_argument("--gn-chunks", default=None, metavar="F,B",
-                    help="ablation (FCOS family): bd_groupnorm_set_chunks -- images per chunk of the GroupNorm forward / backward (0 = whole batch)")
+                    help="ablation: bd_conv_desc.route[2], the weight-gradient bit mask (5 = the ring-staged weight-gradient kernels off: rounds 1-3 kernels)")
     ap.add_argument("--conv-knob", type=int, default=None,
-                    help="ablation: bd_conv_set_patch3x3 bit mask (include/basedet_hip.h) applied before the run")
+                    help="ablation: bd_conv_desc.route[1] bit mask (include/basedet_hip.h) of every call of the run")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -590,7 +599,7 @@ def worker(args):
         "im_info": torch.from_numpy(host_batch["im_info"]).cuda(),
     }
     if os.environ.get("BD_PATCH3X3"):
-        ops.L().bd_conv_set_patch3x3(int(os.environ["BD_PATCH3X3"]))
+        ops.set_route(patch3x3=int(os.environ["BD_PATCH3X3"]))
     timer = None if args.no_roofline else KernelTimer(ops)
 
     def sync():
@@ -603,13 +612,11 @@ def worker(args):
     if args.serial_wgrad:
         model.async_wgrad = False
     if args.conv_knob is not None:
-        ops.L().bd_conv_set_patch3x3(args.conv_knob)
+        ops.set_route(patch3x3=args.conv_knob)
     if args.dense1x1 is not None:
-        ops.L().bd_conv_set_dense1x1(args.dense1x1)
-    if args.gn_chunks is not None:
-        ops.L().bd_groupnorm_set_chunks(*[int(v) for v in args.gn_chunks.split(",")])
+        ops.set_route(dense1x1=args.dense1x1)
     if args.wgrad_knob is not None:
-        ops.L().bd_wgrad_set_transpose_read(args.wgrad_knob)
+        ops.set_route(wgrad=args.wgrad_knob)
     if args.no_mask_bits:
         model.use_mask_bits = False
     if args.roi_bwd_scatter:
@@ -621,9 +628,9 @@ def worker(args):
         last = solver.minimize(model, batch)
     sync()
     if args.skip_s2_3x3_after_warmup:             # (A/B only: see the flag's help; the result line says so)
-        from basedet_amd._lib import check as _check
-        _check(ops.L().bd_conv_set_patch3x3((args.conv_knob if args.conv_knob is not None else 3) | 16),
-               "--skip-s2-3x3-after-warmup (needs a -DBD_AB_SKIP diagnostic build of the library: BD_LIB_NAME / BD_EXTRA_FLAGS, BASEDET_HIP_LIB)")
+        # (needs a -DBD_AB_SKIP diagnostic build of the library -- BD_LIB_NAME / BD_EXTRA_FLAGS, BASEDET_HIP_LIB: the shipped one answers the
+        # first convolution call with BD_EINVAL)
+        ops.set_route(patch3x3=(args.conv_knob if args.conv_knob is not None else 3) | 16)
     def _kernel_clock(kern, reset):
         """clock the chip held inside `kern` since the last reset (bd_probe_kernel_clock: workgroup 0 of every launch stamps its lifetime)"""
         import ctypes as _C
@@ -797,6 +804,17 @@ def worker(args):
                     entries[-1]["frac_of_measured"] = round(tf / peak_meas["tflops"], 4)
                 # frac = (in-cycle efficiency) x (held clock / 2400 MHz): the two factors, from the clock the chip held in this kernel's
                 # launches of the PMC pass (GRBM_GUI_ACTIVE / 8 / dispatch time; the vendor peak is 2500 TFLOP/s at 2400 MHz)
+                # ... and per LAUNCH CLASS: a kernel's average hides launches on the other side of the ridge
+                cls = timer.by_launch_class(kern, mfma_peak * 1e12 / (PEAK_HBM_GBS * 1e9))
+                if len(cls) > 1 or ("mfma" in cls) == hbm_bound:
+                    entries[-1]["by_launch_class"] = {
+                        c: {"launches_per_step": v["launches"] // sampled, "ms_per_step": round(v["ms"] / sampled, 3),
+                            "flop_per_byte": round(v["flops"] / max(v["bytes"], 1.0), 1),
+                            **({"achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                                "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak, 4)} if c == "mfma" else
+                               {"achieved": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})}
+                        for c, v in cls.items()}
                 clk_pmc = pmc.get(kern, {}).get("clock_mhz")
                 held = held_clock.get(kern)
                 if not hbm_bound and (held or clk_pmc):

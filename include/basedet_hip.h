@@ -58,6 +58,24 @@ typedef struct bd_conv_desc {
     int32_t Ho[BD_MAX_SEGS], Wo[BD_MAX_SEGS];   /* output size per level */
     int32_t in_off[BD_MAX_SEGS], out_off[BD_MAX_SEGS]; /* pixel offset of the level inside one image */
     int32_t in_pix_per_img, out_pix_per_img;    /* pixel stride between images */
+    /* Kernel ROUTING of this call, for parity tests and A/B harnesses (production callers leave all of it 0 = the library's choice).
+     * Round 6: these words replace the process-global bd_*_set_* knobs of rounds 1-5 -- the library keeps NO routing state between calls.
+     * A word holds (route + 1):
+     *   route[0]  dense 1x1 launches (1x1 / stride 1 over one dense level), mode 0 .. 6: 1 (default) = conv1x1_ring.hip takes the short-K
+     *             launches into >= 256 channels, conv1x1.hip the rest; 0 = the generic kernel (the *_bits / _ex entry points then return
+     *             BD_EINVAL); 2 = conv1x1.hip's 256 x 256 tile, 3 = its 128 x 128 tile only, 4 = its eight-wave 256-channel x 128-pixel
+     *             tile wherever legal, 5 = as 1 with conv1x1_ring.hip for every launch it can take, 6 = as 3 with the 128 x 128 tile's
+     *             LDS-DMA ring variant for every K that allows it (all: the same results bit for bit);
+     *   route[1]  3x3 / generic path, a bit mask (default 3): see "route[1] bits" below;
+     *   route[2]  weight gradients, a bit mask (default 1): bit 0 = operand transposes through ds_read_b64_tr_b16 (clear: scalar 16-bit
+     *             LDS reads, the slow reference path that validates the transposing read); bit 1 set = no nine-tap / 1x1 kernels (generic
+     *             weight-gradient kernel); bit 2 set = no ring-staged kernels (conv_wgrad3x3_ring.hip, conv_wgrad1x1_ring.hip);
+     *   route[3]  fp8 forward (bd_conv2d_fwd_fp8*): 1 (default) = conv3x3_pp8.hip where the shape allows, 0 = the generic per-tap kernel.
+     * sr_seed != 0: the e5m2 twins this call writes (the dx8 outputs of bd_conv2d_dgrad_ex / bd_conv2d_dgrad_fp8 / bd_conv1x1_fp8 mode 1)
+     * are rounded STOCHASTICALLY -- a hash of (seed, element index) below the kept bits -- instead of to nearest (a training
+     * hyper-parameter of the fp8 configuration, not a route). */
+    int32_t route[4];
+    uint32_t sr_seed;
 } bd_conv_desc;
 
 const char* bd_last_error_string(void);
@@ -115,12 +133,6 @@ int bd_conv2d_fwd_ex(const bd_conv_desc* d, const void* x, const void* w_packed,
  * and dx8 (may be NULL) = e5m2(clamp(dx * q_scale)), the gradient operand of a following bd_conv2d_dgrad_fp8. */
 int bd_conv2d_dgrad_ex(const bd_conv_desc* d, const void* g, const void* w_packed_t, const void* add, const void* mask,
                        const uint32_t* maskbits, void* dx, void* dx8, float q_scale, int flags, bd_stream_t stream);
-/* measurement knob: 1 (default) = the dense 1x1 kernels take every 1x1 / stride 1 launch over one dense level (conv1x1_ring.hip the
- * short-K launches into >= 256 channels, conv1x1.hip the rest), 0 = the generic kernel does (A/B; the *_bits / _ex entry points then
- * return BD_EINVAL); 2 = conv1x1.hip's 256 x 256 tile, 3 = its 128 x 128 tile only, 4 = its eight-wave 256-channel x 128-pixel tile
- * wherever legal, 5 = as 1 with conv1x1_ring.hip for every launch it can take, 6 = as 3 with the 128 x 128 tile's LDS-DMA ring variant for
- * every K that allows it (default: 512 <= K <= 1024) (all A/B: same results bit for bit). */
-int bd_conv_set_dense1x1(int depth);
 
 /* dw[Cout][R][S][Cin] (fp32) = sum over pixels g^T x, times row_scale[Cout] (NULL = 1); split over pixels with
  * fp32 partial slabs in ws, reduced in a fixed order (bitwise reproducible).  accumulate != 0 adds to dw. */
@@ -149,7 +161,7 @@ int bd_conv2d_wgrad_queued(bd_wgrad_queue_t q, const bd_conv_desc* d, const void
                            float* dbias, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
 int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream);
 
-/* debug/measurement knob, bit mask (default 3): bit 0 = 3x3/stride-1 forward and dgrad use the patch kernel
+/* bd_conv_desc.route[1] bits (the word holds mask + 1; default mask 3): bit 0 = 3x3/stride-1 forward and dgrad use the patch kernel
  * (conv3x3.hip); bit 1 = BK=32 tiles for 1x1 convs in the generic kernel; bit 2 = unused.
  * 0 = everything through the generic per-tap implicit GEMM (conv_igemm.hip).
  * Ablation bits (set = feature OFF unless noted): bit 3 = register-staged instead of LDS-DMA weights in the patch kernel;
@@ -172,11 +184,7 @@ int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream);
  * bit 16 = (set = ON) conv_igemm_wide.hip (round 5 experiment: 128-channel x 256-pixel workgroup tile, 128 x 64 wave tiles, both operands
  * by LDS-DMA, K-block pairs outermost) for EVERY launch of the generic path it can take (tests / A-B: measured no faster than the generic
  * kernel on the stride-2 3x3 layers, which stay there). */
-int bd_conv_set_patch3x3(int enable);
 
-/* debug/measurement knob: 1 (default) = operand transposes through ds_read_b64_tr_b16, 0 = scalar 16-bit LDS reads
- * (slow reference path used by the parity tests to validate the transposing read). */
-int bd_wgrad_set_transpose_read(int use_tr);
 
 /* ResNet stem: 7x7/2 pad 3 conv (3->64) + folded FrozenBN + ReLU (models/cls/resnet.py:142-146,238-240).
  * x_halo: bf16 [N][H+6][W+8][4] as written by bd_pad_normalize (zero halo, channel 3 = 0);
@@ -384,8 +392,11 @@ int bd_batched_nms(const float* boxes, const float* scores, const int32_t* idxs,
 int bd_focal_loss_fwd_bwd(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha,
                           float gamma, const void* norm, int norm_is_float, float grad_scale,
                           float* loss_sum, void* dlogits, bd_stream_t stream);
-/* measurement knob: 1 (default) = the gamma == 2 instance (one sigmoid / log per logit, the positive class patched in), 0 = general kernel. */
-int bd_focal_set_fast(int on);
+/* gamma == 2 takes its own instance (one sigmoid / log per logit, the positive class patched in); bd_focal_loss_fwd_bwd_general runs the
+ * general-gamma kernel whatever gamma is (the instance is checked against it). */
+int bd_focal_loss_fwd_bwd_general(const void* logits, const int32_t* labels, int64_t rows, int K, float alpha,
+                                  float gamma, const void* norm, int norm_is_float, float grad_scale,
+                                  float* loss_sum, void* dlogits, bd_stream_t stream);
 
 /* smooth_l1_loss (layers/losses/smooth_l1_loss.py:7-34) over rows with label > 0 (retinanet.py:158-162).
  * Row r = pixel*A + a; pred/dpred are bf16 with `ld` channels per pixel (ld >= 4*A, ld % 4 == 0), element
@@ -424,10 +435,6 @@ int bd_groupnorm_fwd(const void* y, const float* gamma, const float* beta, int N
 int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamma, const float* beta, const float* stats, int N, int L,
                      const int32_t* lvl_off_host, const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, int relu,
                      void* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream);
-/* measurement knob: images per chunk of bd_groupnorm_fwd / _bwd (0 = the whole batch at once: the default, 0 / 0).  A chunk's statistics
- * pass is followed at once by its apply pass, which then re-reads the chunk from the 256 MB Infinity Cache instead of HBM -- measured
- * slower at every chunk size (csrc/norm.hip); results do not depend on it (bit for bit). */
-int bd_groupnorm_set_chunks(int fwd_images, int bwd_images);
 
 /* offsets = relu(bbox_pred * scale_l) * stride_l (point_head.py:143).  raw: bf16 [pixels][ld = 8] (channels 0-3 =
  * bbox_pred, 4 = ctrness logit, 5-7 = 0), scales: device fp32 [L]; out: bf16 [pixels][4]. */
@@ -488,10 +495,14 @@ int bd_rpn_proposals(const void* raw, int ldc, int A, int cls_off, int box_off, 
                      const float* im_info, int info_ld, const float* mean4_host, const float* std4_host, int pre_k,
                      float nms_thresh, int post_k, float* rois, int32_t* num_rois, void* ws, size_t ws_bytes,
                      bd_stream_t stream);
-/* measurement knob: 1 (default, round 5) = bd_rpn_proposals runs its batched NMS level by level (N x L independent problems of <= pre_k
- * boxes, then a merge into the joint order), 0 = as one problem per image (rounds 1-4).  The proposals are the same bit for bit: boxes of
+/* bd_rpn_proposals runs its batched NMS level by level (N x L independent problems of <= pre_k boxes, then a merge into the joint order:
+ * round 5); bd_rpn_proposals_joint runs it as one problem per image (rounds 1-4).  The proposals are the same bit for bit: boxes of
  * different levels never overlap after batched_nms's shift (post_processing.py:44-45), which both forms apply. */
-int bd_rpn_set_nms_per_level(int on);
+int bd_rpn_proposals_joint(const void* raw, int ldc, int A, int cls_off, int box_off, int N, int64_t pix_per_img, int L,
+                           const int32_t* lvl_pix_off_host, const int32_t* lvl_pixels_host, const float* anchors,
+                           const float* im_info, int info_ld, const float* mean4_host, const float* std4_host, int pre_k,
+                           float nms_thresh, int post_k, float* rois, int32_t* num_rois, void* ws, size_t ws_bytes,
+                           bd_stream_t stream);
 
 /* RCNN.get_ground_truth (rcnn.py:95-147) per image: candidates = proposals + gt boxes, IoU max/argmax over the gts,
  * fg (>= fg_thresh) / bg ([bg_lo, bg_hi)) masks, random subsampling with caller-supplied keys (see
@@ -621,20 +632,17 @@ int bd_conv2d_fwd_fp8(const bd_conv_desc* d, const void* xq, const void* wq, con
                       void* y, int flags, bd_stream_t stream);
 /* ... and also writes y8 (may be NULL) = e4m3(clamp(y * q_scale)), the input of a following fp8 convolution (saves its cast pass).
  * 3x3 / stride 1 launches with Cout > 128 take the fp8 instance of the staggered patch kernel (conv3x3_pp8.hip), the rest the
- * generic per-tap kernel (conv_fp8.hip); bd_conv_fp8_set_patch(0) forces the generic kernel (measurement knob). */
+ * generic per-tap kernel (conv_fp8.hip); bd_conv_desc.route[3] = 1 forces the generic kernel (A/B). */
 int bd_conv2d_fwd_fp8_ex(const bd_conv_desc* d, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
                          void* y, void* y8, float q_scale, int flags, bd_stream_t stream);
-int bd_conv_fp8_set_patch(int on);
 /* fp8 DATA GRADIENT of a 3x3 / stride 1 / pad 1 convolution with Cin > 128 (the patch kernel's mirrored-tap mode): the gradient operand
  * g8 is e5m2 ("bf8": the format fp8 training uses for gradients) = bd_quantize_bf8(g, grad_scale) or the dx8 twin of the producing
  * launch; wq_t [Cin][RS][Cout] e4m3 with one scale per INPUT channel and wscale_t[ci] = s_ci / grad_scale from bd_weight_pack_fp8_t.
  * dx (bf16) = epi(conv_transpose(g8, wq_t) * wscale_t [+ add]); add / mask / flags as bd_conv2d_dgrad; dx8 (may be NULL) =
  * e5m2(clamp(dx * q_scale)). */
-int bd_quantize_bf8(const void* x_bf16, int64_t n, float scale, void* q, bd_stream_t stream);
-/* seed != 0: every e5m2 quantiser launched from now on (bd_quantize_bf8, the dx8 twins of bd_conv2d_dgrad_ex / bd_conv2d_dgrad_fp8 /
- * bd_conv1x1_fp8 mode 1) rounds stochastically -- a hash of (seed, element index) below the kept bits -- instead of to nearest; 0
- * restores round-to-nearest.  Host-side state read at launch time. */
-int bd_fp8_set_stochastic_rounding(uint32_t seed);
+/* sr_seed != 0: stochastic rounding (a hash of (seed, element index) below the kept bits) instead of round-to-nearest -- the same rule
+ * as bd_conv_desc.sr_seed for the dx8 twins of the convolution entry points. */
+int bd_quantize_bf8(const void* x_bf16, int64_t n, float scale, void* q, uint32_t sr_seed, bd_stream_t stream);
 /* out[0] = max(out[0], max |x|) over a bf16 tensor (n % 8 == 0; NaNs skipped; zero out[0] first): the statistic behind the delayed scaling of
  * the e5m2 gradients (the reference's loss-scale hook, solver/default_solver.py:66-76: GradScaler of the AMP path). */
 int bd_absmax_bf16(const void* x_bf16, int64_t n, float* out, bd_stream_t stream);

@@ -1,4 +1,4 @@
-"""conv1x1_big_kernel (256 x 256 tile, bd_conv_set_dense1x1(2)) and the default dispatch on balanced grids (one or two tiles per CU) at growing K:
+"""conv1x1_big_kernel (256 x 256 tile, bd_conv_desc.route[0] mode 2) and the default dispatch on balanced grids (one or two tiles per CU) at growing K:
 the slope is the cost of a 64-channel K block per CU, the intercept prologue + epilogue.   python scripts/exp/gemm_kslope.py"""
 import os
 import sys
@@ -35,7 +35,7 @@ def main():
             y = torch.empty(M, CO, device="cuda", dtype=torch.bfloat16)
             row = []
             for m in modes:
-                ops.L().bd_conv_set_dense1x1(m)
+                ops.set_route(dense1x1=m)
                 us = timeit(lambda: ops.conv2d_fwd(d, x, w, None, y, flags=ops.EPI_RELU))
                 name = ops.L().bd_conv_last_kernel().decode()
                 dk = ""
@@ -46,7 +46,7 @@ def main():
                 row.append(f"mode {m} {name:22s} {us:7.1f} us {2.0 * M * K * CO / us / 1e6:6.0f} TF/s {(2.0 * M * (K + CO) + 2.0 * K * CO) / us / 1e3:6.0f} GB/s{dk}")
             print(f"   K {K:5d}: " + " | ".join(row), flush=True)
             del x, w, y
-    ops.L().bd_conv_set_dense1x1(1)
+    ops.set_route(dense1x1=1)
 
 
 if __name__ == "__main__":

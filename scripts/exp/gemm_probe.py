@@ -1,4 +1,4 @@
-"""Dense 1x1 launches as plain GEMMs on well- and badly-quantised shapes: which bd_conv_set_dense1x1 mode runs them how fast.
+"""Dense 1x1 launches as plain GEMMs on well- and badly-quantised shapes: which bd_conv_desc.route[0] mode runs them how fast.
    python scripts/exp/gemm_probe.py [modes...]   (default 1 2: the default dispatch, conv1x1_big_kernel everywhere; modes 7 / 8 existed while the K-sliced kernel did:
 profiles/r06_dense1x1_sk.txt)"""
 import os
@@ -47,7 +47,7 @@ def main():
         row = []
         ref = None
         for m in modes:
-            ops.L().bd_conv_set_dense1x1(m)
+            ops.set_route(dense1x1=m)
             run = lambda: ops.conv2d_fwd(d, x, w, None, y, flags=ops.EPI_RELU)
             us = timeit(run)
             name = ops.L().bd_conv_last_kernel().decode()
@@ -60,7 +60,7 @@ def main():
             row.append(f"{us:7.1f} / {2.0 * M * K * CO / us / 1e6:6.0f} / {name}{same}")
         print(f"{tag:34s} " + " ".join(r.rjust(44) for r in row), flush=True)
         del x, w, y
-    ops.L().bd_conv_set_dense1x1(1)
+    ops.set_route(dense1x1=1)
 
 
 if __name__ == "__main__":

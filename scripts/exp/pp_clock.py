@@ -10,7 +10,7 @@ from basedet_amd import ops
 
 N, C = 16, 256
 if len(sys.argv) > 1:
-    ops.L().bd_conv_set_patch3x3(int(sys.argv[1]))
+    ops.set_route(patch3x3=int(sys.argv[1]))
 sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
 geo = ops.Geom(N, [h for h, _ in sizes], [w for _, w in sizes])
 d = ops.conv_desc(geo, geo, C, C, 3, 3, 1, 1)

@@ -1,4 +1,4 @@
-"""1x1 / stride-2 shortcut launches: the dense kernel with strided row mapping vs the generic kernel (bd_conv_set_patch3x3 bit 12), forward and
+"""1x1 / stride-2 shortcut launches: the dense kernel with strided row mapping vs the generic kernel (bd_conv_desc.route[1] bit 12), forward and
 the in-place sparse data gradient, same box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -27,9 +27,9 @@ for (h, w, cin, cout) in ((200, 336, 256, 512), (100, 168, 512, 1024), (50, 84, 
     act = torch.relu(torch.randn(gin.pixels, cin, device="cuda")).to(torch.bfloat16)
     res = []
     for knob in (1 | 4096, 1):
-        ops.L().bd_conv_set_patch3x3(knob)
+        ops.set_route(patch3x3=knob)
         tf = timeit(lambda: ops.conv2d_fwd(d, x, wf, None, y))
         td = timeit(lambda: ops.conv2d_dgrad(d, g, wt, dx, add=dx, mask=act, flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK | ops.EPI_SPARSE))
         res.append((tf, td))
-    ops.L().bd_conv_set_patch3x3(1)
+    ops.set_route(patch3x3=1)
     print(f"{h}x{w} {cin}->{cout} s2: fwd generic {res[0][0]:7.1f} us -> dense {res[1][0]:7.1f} us   sparse dgrad generic {res[0][1]:7.1f} us -> dense {res[1][1]:7.1f} us", flush=True)

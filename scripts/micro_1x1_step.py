@@ -1,4 +1,4 @@
-"""The dense 1x1 launches of one RetinaNet-R50 step (800x1344, batch 16) with their epilogue operands, timed per bd_conv_set_dense1x1
+"""The dense 1x1 launches of one RetinaNet-R50 step (800x1344, batch 16) with their epilogue operands, timed per bd_conv_desc.route[0]
 mode (0 = the generic kernel, 1 = default choice, 2 = the 256^2 LDS-DMA tile wherever legal, 3 = the 128^2 tile only, 5 = conv1x1_ring_kernel wherever legal): algorithmic GB/s
 per launch class.   python scripts/micro_1x1_step.py [modes...]"""
 import os
@@ -70,14 +70,14 @@ def timeit(run, iters=20):
 def main():
     depths = [int(a) for a in sys.argv[1:]] or [3, 2]
     if os.environ.get("BD_KNOB"):          # e.g. 65536 with mode 0: the dense 1x1 launches on conv_igemm_wide_kernel (round 5 A/B)
-        ops.L().bd_conv_set_patch3x3(int(os.environ["BD_KNOB"]))
+        ops.set_route(patch3x3=int(os.environ["BD_KNOB"]))
     tot = {(dp, b): 0.0 for dp in depths for b in (0, 1)}
     print(f"{'launch':40s} " + " ".join(f"d{dp}{'b' if b else ' '}:us/GB/s" .rjust(16) for dp in depths for b in ((0, 1) if dp else (0,))))
     for tag, H, W, Cin, Cout, mode, add, mask, cnt in L:
         row = []
         for dp in depths:
             for b in ((0, 1) if dp else (0,)):
-                ops.L().bd_conv_set_dense1x1(dp)
+                ops.set_route(dense1x1=dp)
                 run, nb, fl = make(H, W, Cin, Cout, mode, add, mask, b)
                 us = timeit(run)
                 tot[(dp, b)] += us * cnt
@@ -86,7 +86,7 @@ def main():
                 torch.cuda.empty_cache()
         print(f"{tag:40s} " + " ".join(r.rjust(16) for r in row), flush=True)
     print("sum over the step's launches (ms): " + ", ".join(f"d{dp}{'b' if b else ''}={v / 1e3:.3f}" for (dp, b), v in tot.items() if dp or not b))
-    ops.L().bd_conv_set_dense1x1(1)
+    ops.set_route(dense1x1=1)
 
 
 if __name__ == "__main__":

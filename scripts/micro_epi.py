@@ -1,5 +1,5 @@
 """1x1 data gradients with their epilogue operands (ReLU mask + accumulated gradient), as the bottleneck blocks issue them:
-time per launch and algorithmic HBM rate.  BD_KNOB = bd_conv_set_patch3x3 mask, BD_PRE_KSTEPS = prefetch threshold."""
+time per launch and algorithmic HBM rate.  BD_KNOB = bd_conv_desc.route[1] mask, BD_PRE_KSTEPS = prefetch threshold."""
 import os
 import sys
 _here = os.path.dirname(os.path.abspath(__file__))
@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(_here))
 import torch
 from basedet_amd import ops
 if os.environ.get("BD_KNOB"):
-    ops.L().bd_conv_set_patch3x3(int(os.environ["BD_KNOB"]))
+    ops.set_route(patch3x3=int(os.environ["BD_KNOB"]))
 
 
 def bench(N, H, W, Cin, Cout, epi, iters=20):

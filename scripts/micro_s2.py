@@ -7,7 +7,7 @@ sys.path.insert(0, _here)
 from micro_conv import bench
 from basedet_amd import ops
 if os.environ.get('BD_KNOB'):
-    ops.L().bd_conv_set_patch3x3(int(os.environ['BD_KNOB']))
+    ops.set_route(patch3x3=int(os.environ['BD_KNOB']))
 for rep in range(2):
     for mode in sys.argv[1:] or ("dgrad",):
         for (h, w, cin, cout) in ((200, 336, 128, 128), (100, 168, 256, 256), (50, 84, 512, 512), (25, 42, 2048, 256)):

@@ -40,11 +40,11 @@ for name, h, w, cin, cout in SHAPES:
     res, t = {}, {1: [], 5: []}
     for r in range(rounds):
         for knob in (1, 5):
-            ops.L().bd_wgrad_set_transpose_read(knob)
+            ops.set_route(wgrad=knob)
             t[knob].append(timed(lambda: ops.conv2d_wgrad(d, x, g, dw, ws)))
             if r == 0:
                 res[knob] = dw.clone()
-    ops.L().bd_wgrad_set_transpose_read(1)
+    ops.set_route(wgrad=1)
     rel = float((res[1] - res[5]).norm() / res[5].norm())
     med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
     print(f"{name:32s} ring {med[1]:7.1f} us {nbytes / med[1] / 1e3:7.0f} GB/s (min {min(t[1]):7.1f}) | staged {med[5]:7.1f} us {nbytes / med[5] / 1e3:7.0f} GB/s "

@@ -48,11 +48,11 @@ for name, hw, cin, cout in SHAPES:
     t = {1: [], 5: []}
     for r in range(rounds):
         for knob in (1, 5):
-            ops.L().bd_wgrad_set_transpose_read(knob)
+            ops.set_route(wgrad=knob)
             t[knob].append(timed(lambda: ops.conv2d_wgrad_bias(d, x, g, dw, db, ws)))
             if r == 0:
                 res[knob] = (dw.clone(), db.clone())
-    ops.L().bd_wgrad_set_transpose_read(1)
+    ops.set_route(wgrad=1)
     rel = float((res[1][0] - res[5][0]).norm() / res[5][0].norm())
     relb = float((res[1][1] - res[5][1]).norm() / res[5][1].norm())
     med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}

@@ -18,10 +18,10 @@ for (N, H, W, Cin, Cout) in shapes:
     x = torch.randn(gin.pixels, Cin, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(Cout, 9, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
     b = torch.randn(Cout, device="cuda", generator=g)
-    ops.L().bd_conv_set_patch3x3(3 | 64 | 512)
+    ops.set_route(patch3x3=3 | 64 | 512)
     ref = torch.empty((gin.pixels, Cout), device="cuda", dtype=torch.bfloat16)
     ops.conv2d_fwd(d, x, w, b, ref, flags=ops.EPI_RELU)
-    ops.L().bd_conv_set_patch3x3(3)
+    ops.set_route(patch3x3=3)
     # a competing stream keeps the memory system busy (DMA latencies vary)
     side = torch.cuda.Stream()
     junk = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
@@ -36,6 +36,6 @@ for (N, H, W, Cin, Cout) in shapes:
     torch.cuda.synchronize()
     print(f"N={N} {H}x{W} {Cin}->{Cout}: {nbad} / {iters} launches differ", flush=True)
     bad += nbad
-ops.L().bd_conv_set_patch3x3(3)
+ops.set_route(patch3x3=3)
 print("RACE SCREEN", "FAILED" if bad else "clean", flush=True)
 sys.exit(1 if bad else 0)

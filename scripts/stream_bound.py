@@ -14,7 +14,7 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters
 
 import os as _os
-ops.L().bd_conv_set_patch3x3(int(_os.environ.get("BD_PATCH3X3", "3")))
+ops.set_route(patch3x3=int(_os.environ.get("BD_PATCH3X3", "3")))
 for (H, W, Cin, Cout, with_add) in ((200, 336, 64, 256, True), (100, 168, 128, 512, True), (50, 84, 256, 1024, True), (50, 84, 1024, 256, False),
                                     (100, 168, 512, 128, False), (200, 336, 256, 64, False)):
     N = 16

@@ -17,19 +17,13 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-# The library's measurement knobs are process-global (include/basedet_hip.h: bd_conv_set_patch3x3, bd_conv_set_dense1x1,
-# bd_wgrad_set_transpose_read, bd_focal_set_fast, bd_conv_fp8_set_patch).  A test that flips one and then fails would leave it flipped
-# for every later test of the run: every GPU test ends with the defaults restored, whatever happened inside it.
-_KNOB_DEFAULTS = (("bd_conv_set_patch3x3", (3,)), ("bd_conv_set_dense1x1", (1,)), ("bd_wgrad_set_transpose_read", (1,)), ("bd_focal_set_fast", (1,)),
-                  ("bd_conv_fp8_set_patch", (1,)), ("bd_groupnorm_set_chunks", (0, 0)), ("bd_rpn_set_nms_per_level", (1,)))
-
-
+# Kernel routing is per call since round 6 (bd_conv_desc.route: the library keeps no state); what a test sets is the PYTHON shim's
+# current route (basedet_amd.ops.set_route), stamped into every descriptor it passes on.  A test that sets one and then fails would leave
+# it set for every later test of the run: every GPU test ends with the shim's words back at "library default".
 @pytest.fixture(autouse=True)
-def _restore_library_knobs(request):
+def _restore_route(request):
     yield
     if request.node.get_closest_marker("gpu") is None:
         return
-    from basedet_amd import _lib
-    lib = _lib.load()
-    for name, value in _KNOB_DEFAULTS:
-        assert getattr(lib, name)(*value) == 0, name
+    from basedet_amd import ops
+    ops.reset_route()

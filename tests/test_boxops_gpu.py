@@ -201,10 +201,8 @@ def test_focal_and_l1_losses():
     valid = labels >= 0
     # the gamma == 2 instance (default), the general kernel on the same inputs, and a non-integer gamma through the general kernel
     for fast, alpha, gamma in ((1, 0.25, 2.0), (0, 0.25, 2.0), (1, 0.25, 1.5), (1, -1.0, 2.0)):
-        ops.L().bd_focal_set_fast(fast)
         loss.zero_()
-        ops.focal_loss_fwd_bwd(x.cuda(), _dev(labels), rows, K, alpha, gamma, norm, 1.0, loss, dl)
-        ops.L().bd_focal_set_fast(1)
+        ops.focal_loss_fwd_bwd(x.cuda(), _dev(labels), rows, K, alpha, gamma, norm, 1.0, loss, dl, general=not fast)
         ref_loss = ob.sigmoid_focal_loss(xf[valid], t[valid], alpha, gamma).sum() / max(1, nfg)
         assert abs(float(loss.item()) - ref_loss) / ref_loss < 2e-3, (fast, alpha, gamma)
         got = dl.float().cpu().numpy()

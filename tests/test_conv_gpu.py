@@ -42,7 +42,7 @@ def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel;
     # 2: specialised kernels without any staggered instance (bits 6 + 9); 3: the staggered 128 / 64-channel instances everywhere (bits 6 + 8);
     # 4: no patch kernels, and conv_igemm_wide.hip for every launch of the generic path it can take (bit 16: 3x3 / stride 1 and 2, P6)
-    ops.L().bd_conv_set_patch3x3({0: 0, 1: 3, 2: 3 | 64 | 512, 3: 3 | 64 | 256, 4: 1 << 16}[patch3x3])
+    ops.set_route(patch3x3={0: 0, 1: 3, 2: 3 | 64 | 512, 3: 3 | 64 | 256, 4: 1 << 16}[patch3x3])
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -86,14 +86,14 @@ def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ws = torch.empty((ops.conv2d_wgrad_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
     scale = torch.rand(Cout, generator=g) + 0.5
     for use_tr in (0, 1):
-        ops.L().bd_wgrad_set_transpose_read(use_tr)
+        ops.set_route(wgrad=use_tr)
         dw = torch.full((Cout, R, R, Cin), 7.0, dtype=torch.float32, device="cuda")
         ops.conv2d_wgrad(d, xp, nchw_to_pm(gy), dw, ws)
         assert rel_l2(dw.cpu(), ref_dw) < 2e-3, f"use_tr={use_tr}"
         ops.conv2d_wgrad(d, xp, nchw_to_pm(gy), dw, ws, row_scale=scale.cuda(), accumulate=True)
         assert rel_l2(dw.cpu(), ref_dw * (1 + scale.view(-1, 1, 1, 1))) < 2e-3
-    ops.L().bd_wgrad_set_transpose_read(1)
-    ops.L().bd_conv_set_patch3x3(3)
+    ops.set_route(wgrad=1)
+    ops.set_route(patch3x3=3)
 
 
 @pytest.mark.parametrize("chans", [(64, 72), (192, 256)])
@@ -101,7 +101,7 @@ def test_conv_multilevel_head_layout(chans):
     """Five pyramid levels through one launch (RetinaNetHead weight sharing, retina_head.py:103-112).  (192, 256): the staggered
     256-channel patch instance on a multi-segment descriptor, forward and dgrad."""
     ops = _ops()
-    ops.L().bd_conv_set_patch3x3(3)
+    ops.set_route(patch3x3=3)
     N, (C, Cout) = 2, chans
     Hs, Ws = [12, 6, 3, 2, 1], [20, 10, 5, 3, 2]
     g = torch.Generator().manual_seed(7)
@@ -142,7 +142,7 @@ def test_conv_multilevel_head_layout(chans):
         got = dxv[:, geo.off[i]: geo.off[i] + Hs[i] * Ws[i]].reshape(N, Hs[i], Ws[i], C).permute(0, 3, 1, 2)
         assert rel_l2(got, xr.grad) < TOL, f"dgrad level {i}"
     assert rel_l2(dw.cpu(), oihw_to_ohwi(ref_dw)) < 2e-3
-    ops.L().bd_conv_set_patch3x3(3)
+    ops.set_route(patch3x3=3)
 
 
 def test_stem_conv_and_pad_normalize():
@@ -314,7 +314,7 @@ def test_patch_instances_agree_bitwise(shape):
     gate[::5, 1::4] = -1.5
     outs = []
     for knob in (3 | 64 | 512, 3, 3 | 64 | 256):
-        ops.L().bd_conv_set_patch3x3(knob)
+        ops.set_route(patch3x3=knob)
         y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
         dx = torch.full((gin.pixels, Cin), 3.0, device="cuda", dtype=torch.bfloat16)
         ops.conv2d_fwd(d, x, w, b, y, add=res, flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE)
@@ -331,7 +331,7 @@ def test_patch_instances_agree_bitwise(shape):
             ops.conv2d_dgrad(d, gy, wt, dx3)
         torch.cuda.synchronize()
         outs.append((y.clone(), dx.clone(), y2, y3, dx2, dx3))
-    ops.L().bd_conv_set_patch3x3(3)
+    ops.set_route(patch3x3=3)
     for k in (1, 2):          # both staggered instances against the plain 128-channel kernel
         for a, b_ in zip(outs[0], outs[k]):
             assert torch.equal(a, b_)
@@ -386,13 +386,13 @@ def test_wgrad_bias_multilevel(chans):
 
 @pytest.mark.parametrize("depth", [1, 0, 2, 3, 4, 6])
 def test_dense_1x1_kernel_and_mask_bits(depth):
-    """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_set_dense1x1: 0 = the generic kernel,
+    """conv1x1.hip (every 1x1 / stride 1 launch over one dense level) in each variant (bd_conv_desc.route[0]: 0 = the generic kernel,
     1 = the default choice, 2 = 256^2 wherever legal, 3 = 128^2 only, 4 = the eight-wave 256-channel x 128-pixel tile wherever legal): forward with
     residual + ReLU and the data gradient with accumulate + mask against torch-CPU fp32; the bit-packed ReLU mask written by the
     forward launch equals (y > 0) bit for bit, and a data gradient gated by it equals the one gated by the bf16 activation."""
     ops = _ops()
     # 6: the 128^2 tile's LDS-DMA ring variant for every K that allows it (default: 512 <= K <= 1024 only)
-    assert ops.L().bd_conv_set_dense1x1(depth) == 0
+    ops.set_route(dense1x1=depth)
     try:
         for (N, Cin, Cout, H, W) in ((2, 256, 64, 23, 37), (1, 64, 256, 50, 41), (2, 200, 192, 9, 13), (1, 1024, 256, 20, 21), (1, 32, 544, 7, 9),
                                      (1, 320, 448, 13, 19), (3, 512, 512, 17, 31)):
@@ -437,7 +437,7 @@ def test_dense_1x1_kernel_and_mask_bits(depth):
                 if depth in (2, 3, 4, 6):
                     tw = {}
                     for dd in (2, 3, 4):
-                        ops.L().bd_conv_set_dense1x1(dd)
+                        ops.set_route(dense1x1=dd)
                         y8 = torch.zeros((M, Cout), dtype=torch.uint8, device="cuda")
                         y2 = torch.empty_like(y)
                         ops.conv2d_fwd(d, nchw_to_pm(x), wf, bias.cuda(), y2, add=nchw_to_pm(res), flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE,
@@ -447,20 +447,20 @@ def test_dense_1x1_kernel_and_mask_bits(depth):
                         ops.conv2d_dgrad(d, nchw_to_pm(gy), wd, dx3, add=dx3, mask=nchw_to_pm(act), flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK,
                                          dx8=dx8, q_scale=64.0)
                         tw[dd] = (y2.clone(), y8.clone(), dx3.clone(), dx8.clone())
-                    ops.L().bd_conv_set_dense1x1(depth)
+                    ops.set_route(dense1x1=depth)
                     for a, b, c in zip(tw[2], tw[3], tw[4]):
                         assert torch.equal(a, b) and torch.equal(a, c)
                     assert torch.equal(tw[2][0], y) and torch.equal(tw[2][2], dx)
     finally:
-        ops.L().bd_conv_set_dense1x1(1)
+        ops.set_route(dense1x1=1)
 
 
 @pytest.mark.parametrize("case", [(4, 60, 70, 128, 512), (4, 60, 70, 512, 128), (2, 50, 84, 256, 1024), (2, 50, 84, 1024, 256), (16, 25, 42, 64, 256),
                                   (1, 33, 47, 192, 200), (3, 40, 50, 320, 320), (1, 11, 9, 2048, 512), (2, 37, 41, 128, 64)])
 def test_conv1x1_ring_kernel_gives_the_dense_kernels_bits(case):
     """conv1x1_ring.hip (persistent workgroups, eight-stage LDS-DMA ring that runs across tile boundaries, epilogue operands requested a
-    tile ahead, every wait an exact vmcnt; bd_conv_set_dense1x1(5): every launch it can take) against conv1x1_dense_kernel
-    (bd_conv_set_dense1x1(3)): the same bits for every epilogue the step uses -- K of 2 .. 32 ring steps (fewer / more than the ring is deep),
+    tile ahead, every wait an exact vmcnt; bd_conv_desc.route[0] mode 5: every launch it can take) against conv1x1_dense_kernel
+    (bd_conv_desc.route[0] mode 3): the same bits for every epilogue the step uses -- K of 2 .. 32 ring steps (fewer / more than the ring is deep),
     several tiles per workgroup, ragged pixel and channel tiles."""
     ops = _ops()
     N, H, W, Cin, Cout = case
@@ -481,7 +481,7 @@ def test_conv1x1_ring_kernel_gives_the_dense_kernels_bits(case):
     out = {}
     try:
         for mode in (3, 5):
-            assert ops.L().bd_conv_set_dense1x1(mode) == 0
+            ops.set_route(dense1x1=mode)
             r = []
             # forward: residual + ReLU (+ gate bits out); bias only; residual added after the (absent) gate
             y = torch.full((M, Cout), 7.0, dtype=torch.bfloat16, device="cuda")
@@ -507,7 +507,7 @@ def test_conv1x1_ring_kernel_gives_the_dense_kernels_bits(case):
             torch.cuda.synchronize()
             out[mode] = r
     finally:
-        ops.L().bd_conv_set_dense1x1(1)
+        ops.set_route(dense1x1=1)
     for k, (a, b) in enumerate(zip(out[3], out[5])):
         assert (a is None and b is None) or torch.equal(a, b), (case, k)
     # and against fp32 (the ring path by itself)
@@ -576,7 +576,7 @@ def test_pp_tail_split_same_bits(shape, knob):
     gate = torch.relu(torch.randn(gin.pixels, Cin, device="cuda", generator=g)).to(torch.bfloat16)
     outs = []
     for kb in (knob | 8192 | 16384, knob):
-        ops.L().bd_conv_set_patch3x3(kb)
+        ops.set_route(patch3x3=kb)
         y = torch.full((gin.pixels, Cout), 3.0, device="cuda", dtype=torch.bfloat16)
         y2 = torch.full_like(y, 3.0)
         dx = torch.full((gin.pixels, Cin), 3.0, device="cuda", dtype=torch.bfloat16)
@@ -587,7 +587,7 @@ def test_pp_tail_split_same_bits(shape, knob):
         ops.conv2d_dgrad(d, gy, wt, dx2)
         torch.cuda.synchronize()
         outs.append((y, y2, dx, dx2))
-    ops.L().bd_conv_set_patch3x3(3)
+    ops.set_route(patch3x3=3)
     for a, b_ in zip(*outs):
         assert torch.equal(a, b_)
     # and against fp32 on a strip that lies in the tail tiles (the last image)
@@ -635,7 +635,7 @@ def test_pp_persistent_launches_on_two_streams_same_bits():
 @pytest.mark.parametrize("case", [(2, 256, 256, 50, 84), (1, 128, 720, 37, 41), (3, 200, 136, 11, 19), (2, 64, 96, 8, 8), (1, 64, 128, 3, 5)])
 def test_wgrad_ring_kernel_agrees_with_the_register_staged_kernel(case):
     """conv_wgrad3x3_ring.hip (LDS-DMA ring, 64 ci x 128 co tile, persistent workgroups) against conv_wgrad3x3.hip (bit 2 of
-    bd_wgrad_set_transpose_read routes its shapes back there): the same products summed in another order -> fp32 rounding only; the
+    bd_conv_desc.route[2] routes its shapes back there): the same products summed in another order -> fp32 rounding only; the
     bias column sums likewise; and two launches of the ring kernel are bit-identical (fixed-order reduce)."""
     ops = _ops()
     N, Cin, Cout, H, W = case
@@ -647,13 +647,13 @@ def test_wgrad_ring_kernel_agrees_with_the_register_staged_kernel(case):
     ws = torch.empty((ops.conv2d_wgrad_bias_workspace_bytes(d) // 4 + 4,), dtype=torch.float32, device="cuda")
     outs = []
     for knob in (1, 5, 1):
-        ops.L().bd_wgrad_set_transpose_read(knob)
+        ops.set_route(wgrad=knob)
         dw = torch.full((Cout, 3, 3, Cin), 3.0, dtype=torch.float32, device="cuda")
         db = torch.full((Cout,), 3.0, dtype=torch.float32, device="cuda")
         ops.conv2d_wgrad_bias(d, x, gy, dw, db, ws)
         torch.cuda.synchronize()
         outs.append((dw.cpu(), db.cpu()))
-    ops.L().bd_wgrad_set_transpose_read(1)
+    ops.set_route(wgrad=1)
     assert rel_l2(outs[0][0], outs[1][0]) < 2e-6 and rel_l2(outs[0][1], outs[1][1]) < 2e-6
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
     assert rel_l2(outs[0][1], gy.float().sum(0).cpu()) < 1e-4
@@ -662,7 +662,7 @@ def test_wgrad_ring_kernel_agrees_with_the_register_staged_kernel(case):
 @pytest.mark.parametrize("case", [(2, 1024, 256, 50, 84), (2, 128, 512, 40, 56), (1, 512, 2048, 13, 21), (2, 256, 64, 30, 40), (1, 72, 200, 9, 11),
                                   (1, 64, 64, 2, 3)])
 def test_wgrad1x1_ring_kernel_agrees_with_the_register_staged_kernel(case):
-    """conv_wgrad1x1_ring.hip (LDS-DMA ring, persistent workgroups) against conv_wgrad1x1.hip (bit 2 of bd_wgrad_set_transpose_read routes
+    """conv_wgrad1x1_ring.hip (LDS-DMA ring, persistent workgroups) against conv_wgrad1x1.hip (bit 2 of bd_conv_desc.route[2] routes
     its shapes back there) and against the fp32 definition dW = G^T X: same products in another order -> fp32 rounding only; two launches
     of the ring kernel are bit-identical; row scale and accumulate go through the ring reduce."""
     ops = _ops()
@@ -678,14 +678,14 @@ def test_wgrad1x1_ring_kernel_agrees_with_the_register_staged_kernel(case):
     scale = (torch.rand(Cout, generator=gen) + 0.5).cuda()
     outs = []
     for knob in (1, 5, 1):
-        ops.L().bd_wgrad_set_transpose_read(knob)
+        ops.set_route(wgrad=knob)
         dw = torch.full((Cout, 1, 1, Cin), 3.0, dtype=torch.float32, device="cuda")
         ops.conv2d_wgrad(d, xd, gd, dw, ws)
         first = dw.cpu()
         ops.conv2d_wgrad(d, xd, gd, dw, ws, row_scale=scale, accumulate=True)
         torch.cuda.synchronize()
         outs.append((first, dw.cpu()))
-    ops.L().bd_wgrad_set_transpose_read(1)
+    ops.set_route(wgrad=1)
     assert rel_l2(outs[0][0], ref) < 1e-5
     assert rel_l2(outs[0][0], outs[1][0]) < 2e-6
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
@@ -814,7 +814,7 @@ def test_igemm_wide_agrees_with_the_generic_kernel(case):
     res, addt, maskt = bf(gout.pixels, Cout), bf(gin.pixels, Cin), bf(gin.pixels, Cin)
     outs = {}
     for name, knob in (("generic", 0), ("wide", 1 << 16), ("wide2", 1 << 16)):
-        assert ops.L().bd_conv_set_patch3x3(knob) == 0
+        ops.set_route(patch3x3=knob)
         y1 = torch.empty((gout.pixels, Cout), dtype=torch.bfloat16, device="cuda")
         y2 = torch.empty_like(y1)
         ops.conv2d_fwd(d, x, wf, bias, y1, add=res, flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE)
@@ -832,7 +832,7 @@ def test_igemm_wide_agrees_with_the_generic_kernel(case):
         assert k1 in want, (name, k1)
         if not (name.startswith("wide") and Cout % 32):       # (a data gradient whose K = Cout is no multiple of 32 stays on the generic kernel)
             assert k2 in want, (name, k2)
-    ops.L().bd_conv_set_patch3x3(3)
+    ops.set_route(patch3x3=3)
     for i, (a, b, c) in enumerate(zip(outs["generic"], outs["wide"], outs["wide2"])):
         assert rel_l2(b.float().cpu(), a.float().cpu()) < 1e-3, i
         assert torch.equal(b, c), i

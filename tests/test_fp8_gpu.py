@@ -69,9 +69,9 @@ def fp8_kernel(request):
     """1: 3x3 / stride 1 / Cout > 128 launches take the fp8 instance of the staggered patch kernel (conv3x3_pp8.hip); 0: every shape
     through the generic per-tap kernel (conv_fp8.hip)."""
     ops = _ops()
-    ops.L().bd_conv_fp8_set_patch(request.param)
+    ops.set_route(fp8_patch=request.param)
     yield request.param
-    ops.L().bd_conv_fp8_set_patch(1)
+    ops.set_route(fp8_patch=1)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -617,7 +617,7 @@ def test_absmax_and_delayed_gradient_scale():
 
 
 def test_e5m2_stochastic_rounding():
-    """bd_fp8_set_stochastic_rounding: (1) unbiased -- the mean of the dequantised values over many seeds approaches the input where
+    """bd_conv_desc.sr_seed: (1) unbiased -- the mean of the dequantised values over many seeds approaches the input where
     round-to-nearest is off by up to an eighth; (2) every result is one of the two e5m2 neighbours of the value; (3) a function of (seed,
     element index) only: the same bytes twice, other bytes with another seed; (4) seed 0 restores round-to-nearest exactly."""
     ops = _ops()

@@ -71,7 +71,7 @@ def test_training_step_is_bitwise_reproducible_full_size():
 def test_training_step_is_bit_identical_with_either_dense_1x1_kernel_full_size():
     """conv1x1_ring_kernel (round 4) gives conv1x1_dense_kernel's bits launch by launch (tests/test_conv_gpu.py), so a whole RetinaNet-R50
     step at 4 x 800 x 1344 -- forward, targets, backward through every bottleneck -- must not change by a bit when the ring kernel takes
-    every launch it can (bd_conv_set_dense1x1(5)), only the default ones (1), or none (3)."""
+    every launch it can (bd_conv_desc.route[0] mode 5), only the default ones (1), or none (3)."""
     from basedet_amd import ops
     from basedet_amd.configs import RetinaNetConfig
     from basedet_amd.models import RetinaNet, params as P
@@ -85,14 +85,14 @@ def test_training_step_is_bit_identical_with_either_dense_1x1_kernel_full_size()
     outs = {}
     try:
         for mode in (3, 5, 1):
-            assert ops.L().bd_conv_set_dense1x1(mode) == 0
+            ops.set_route(dense1x1=mode)
             model = RetinaNet(cfg, params=params)
             model(batch)
             model.backward()
             torch.cuda.synchronize()
             outs[mode] = (model.arena.g.clone(), model._cur.labels.clone())
     finally:
-        ops.L().bd_conv_set_dense1x1(1)
+        ops.set_route(dense1x1=1)
     for mode in (5, 1):
         assert torch.equal(outs[3][1], outs[mode][1])
         assert torch.equal(outs[3][0], outs[mode][0]), mode          # every gradient of the arena, bit for bit

@@ -98,15 +98,14 @@ def test_retinanet_r101_bf16_full_size_matches_oracle(r101):
                           "RetinaNet-R101 2x800x1344", bound=3e-2)
 
 
-_FP8_COS = {}          # results of the parametrised runs below, in order: (True, 2) is compared with (True, 0)
-
-
-@pytest.mark.parametrize("dgrad,wgrad", [(False, 0), (True, 0), (True, 2)])
-def test_retinanet_r101_fp8_full_size_tolerance(r101, dgrad, wgrad):
-    """WEIGHT_DTYPE = fp8_e4m3 on R101: forward only (dgrad False), with e5m2 data gradients under per-group delayed scales, and with the
-    3x3 weight gradients from the one-byte twins as well (FP8_WGRAD = 2: conv_wgrad3x3_fp8_kernel, the default since round 4)."""
+def _fp8_run(r101, dgrad, wgrad):
+    """One fp8 forward + backward of the R101 fixture's batch (cached in the fixture: the (True, 2) case is judged against (True, 0) and
+    computes it itself when it has not run -- under -k, xdist or any other order)."""
+    cache = r101.setdefault("_fp8", {})
+    if (dgrad, wgrad) in cache:
+        return cache[(dgrad, wgrad)]
     from basedet_amd.models import RetinaNet
-    cfg, names, ref, aux, b16 = r101["cfg"], r101["names"], r101["ref"], r101["aux"], r101["bf16"]
+    cfg, names, b16 = r101["cfg"], r101["names"], r101["bf16"]
     cfg.MODEL.WEIGHT_DTYPE = "fp8_e4m3"
     cfg.MODEL.FP8_DGRAD = dgrad
     cfg.MODEL.FP8_WGRAD = wgrad
@@ -123,29 +122,41 @@ def test_retinanet_r101_fp8_full_size_tolerance(r101, dgrad, wgrad):
     m8.backward()
     torch.cuda.synchronize()
     g8 = m8.reference_grads()
-    assert np.array_equal(m8._cur.labels.cpu().numpy(), aux["labels"])
-    for k in ("cls_loss", "reg_loss", "total_loss"):
-        v8, v16, vr = float(out8[k]), b16["losses"][k], ref[k]
-        print(f"{k}: fp8 {v8:.5f} bf16 {v16:.5f} fp32 oracle {vr:.5f}")
-        assert abs(v8 - vr) / abs(vr) < 5e-2, (k, v8, vr)
     a = torch.cat([g8[n].double().reshape(-1) for n in names])
     b = torch.cat([b16["grads"][n].double().reshape(-1) for n in names])
-    assert bool(torch.isfinite(a).all())
-    cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-    print(f"R101 gradient cosine fp8 (dgrad={dgrad}, wgrad={wgrad}) vs bf16: {cos:.5f}")
-    # floors with real margin (observed 0.9814-0.9818 with e5m2 data gradients), and the one-byte weight gradients are
-    # judged AGAINST the same run without them: what they may cost is a delta, not a coincidence with an absolute number
-    assert cos >= 0.975, cos
-    _FP8_COS[(dgrad, wgrad)] = cos
-    if wgrad and (dgrad, 0) in _FP8_COS:
-        assert cos >= _FP8_COS[(dgrad, 0)] - 0.003, (cos, _FP8_COS[(dgrad, 0)])          # observed: -0.0004
-    # ... and layer by layer over the 3x3 weights (what the one-byte weight-gradient kernel produces when wgrad is on): a two-image batch at
-    # the pre-probe scales; the lowest layer is a thin backbone conv2 or, with fp8 weight gradients, the deepest conv of the classification tower
     worst = min((float(torch.dot(g8[n].double().reshape(-1), b16["grads"][n].double().reshape(-1)) /
                        (g8[n].double().norm() * b16["grads"][n].double().norm())), n)
                 for n in names if n.endswith(".weight") and g8[n].dim() == 4 and g8[n].shape[-1] == 3)
+    res = dict(losses={k: float(v) for k, v in out8.items()}, labels=m8._cur.labels.cpu().numpy().copy(), finite=bool(torch.isfinite(a).all()),
+               cos=float(torch.dot(a, b) / (a.norm() * b.norm())), worst=worst)
+    del m8
+    torch.cuda.empty_cache()
+    cache[(dgrad, wgrad)] = res
+    return res
+
+
+@pytest.mark.parametrize("dgrad,wgrad", [(False, 0), (True, 0), (True, 2)])
+def test_retinanet_r101_fp8_full_size_tolerance(r101, dgrad, wgrad):
+    """WEIGHT_DTYPE = fp8_e4m3 on R101: forward only (dgrad False), with e5m2 data gradients under per-group delayed scales, and with the
+    3x3 weight gradients from the one-byte twins as well (FP8_WGRAD = 2: conv_wgrad3x3_fp8_kernel, the default since round 4)."""
+    ref, aux, b16 = r101["ref"], r101["aux"], r101["bf16"]
+    got = _fp8_run(r101, dgrad, wgrad)
+    assert np.array_equal(got["labels"], aux["labels"])
+    for k in ("cls_loss", "reg_loss", "total_loss"):
+        v8, v16, vr = got["losses"][k], b16["losses"][k], ref[k]
+        print(f"{k}: fp8 {v8:.5f} bf16 {v16:.5f} fp32 oracle {vr:.5f}")
+        assert abs(v8 - vr) / abs(vr) < 5e-2, (k, v8, vr)
+    assert got["finite"]
+    cos, worst = got["cos"], got["worst"]
+    print(f"R101 gradient cosine fp8 (dgrad={dgrad}, wgrad={wgrad}) vs bf16: {cos:.5f}")
+    # ADVICE round 4: floors with real margin (observed 0.9814-0.9818 with e5m2 data gradients), and the one-byte weight gradients are
+    # judged AGAINST the same run without them (ADVICE round 5: computed here if that case has not run): what they may cost is a delta
+    assert cos >= 0.975, cos
+    # ... and layer by layer over the 3x3 weights (what the one-byte weight-gradient kernel produces when wgrad is on): a two-image batch at
+    # the pre-probe scales; the lowest layer is a thin backbone conv2 or, with fp8 weight gradients, the deepest conv of the classification tower
     print(f"worst 3x3 weight-gradient cosine (dgrad={dgrad}, wgrad={wgrad}):", worst)
     assert worst[0] >= 0.84, worst            # observed: 0.910 forward only (layer2.0.conv2), 0.895 with e5m2 data gradients, 0.869 with fp8 weight gradients
-    _FP8_COS[("worst", dgrad, wgrad)] = worst[0]
-    if wgrad and ("worst", dgrad, 0) in _FP8_COS:
-        assert worst[0] >= _FP8_COS[("worst", dgrad, 0)] - 0.05, (worst, _FP8_COS[("worst", dgrad, 0)])      # observed: -0.026
+    if wgrad:
+        base = _fp8_run(r101, dgrad, 0)
+        assert cos >= base["cos"] - 0.003, (cos, base["cos"])          # observed: -0.0004
+        assert worst[0] >= base["worst"][0] - 0.05, (worst, base["worst"])      # observed: -0.026

@@ -149,14 +149,13 @@ def test_rpn_proposals(pre_k, post_k, per_level, ties):
     rois = torch.empty((N, post_k, 4), dtype=torch.float32, device="cuda")
     num = torch.empty((N,), dtype=torch.int32, device="cuda")
     ws = torch.empty((ops.rpn_proposals_workspace_bytes(N, [h * w for h, w in sizes], A, pre_k, post_k),), dtype=torch.uint8, device="cuda")
-    assert ops.L().bd_rpn_set_nms_per_level(per_level) == 0
-    ops.rpn_proposals(raw_dev, ldc, A, 0, A, geom, _dev(anc_all), _dev(im_info), [0, 0, 0, 0], [1, 1, 1, 1], pre_k, thr, post_k, rois, num, ws)
+    ops.rpn_proposals(raw_dev, ldc, A, 0, A, geom, _dev(anc_all), _dev(im_info), [0, 0, 0, 0], [1, 1, 1, 1], pre_k, thr, post_k, rois, num, ws,
+                      joint_nms=not per_level)
     gr, gn = rois.cpu().numpy(), num.cpu().numpy()
     if per_level:            # ... and the joint form gives the same proposals bit for bit
         rois0, num0 = torch.empty_like(rois), torch.empty_like(num)
-        ops.L().bd_rpn_set_nms_per_level(0)
-        ops.rpn_proposals(raw_dev, ldc, A, 0, A, geom, _dev(anc_all), _dev(im_info), [0, 0, 0, 0], [1, 1, 1, 1], pre_k, thr, post_k, rois0, num0, ws)
-        ops.L().bd_rpn_set_nms_per_level(1)
+        ops.rpn_proposals(raw_dev, ldc, A, 0, A, geom, _dev(anc_all), _dev(im_info), [0, 0, 0, 0], [1, 1, 1, 1], pre_k, thr, post_k, rois0, num0, ws,
+                          joint_nms=True)
         assert torch.equal(num, num0) and torch.equal(rois, rois0)
     for n in range(N):
         sc, of = [], []
