@@ -16,7 +16,6 @@ SOURCES = {
     "image_ops.hip": [],
     "h2d.hip": [],
     "conv_igemm.hip": [],
-    "conv_igemm_wide.hip": [],
     "conv3x3.hip": [],
     "conv3x3_pp.hip": [],
     "conv3x3_pp128.hip": [],

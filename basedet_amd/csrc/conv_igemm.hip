@@ -449,13 +449,11 @@ BD_KNOB int g_bk32_for_1x1 = 1;
 // instead of two) run them 10-35 % faster as long as the grid still fills the chip (P6's 70-tile forward keeps BK=64).
 // bd_conv_desc.route[1] bit 10 clears it.
 BD_KNOB int g_bk32_s2 = 1;
-// conv_igemm_wide.hip (round 5 experiment, measured no faster than this file's kernel on the stride-2 3x3 layers -- DESIGN.md): 0 = never
-// (default), 2 = every launch of this file that kernel can take (bd_conv_desc.route[1] bit 16: tests / A-B)
-BD_KNOB int g_igemm_wide = 0;
+// (Round 5 built conv_igemm_wide.hip -- a 128-channel x 256-pixel tile, 128 x 64 wave tiles, both operands by LDS-DMA -- for the stride-2 3x3
+// layers and measured it no faster than this file's kernel; round 6 closed the family and deleted it: profiles/r06_s2_phase_major.txt.)
 
 }  // namespace
 
-int bd_conv_igemm_wide_launch(igemm::IgemmParams p, bool everywhere, hipStream_t stream);
 
 int bd_conv3x3_patch_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias,
                             const void* add, const void* mask, void* dst, int flags, hipStream_t stream);
@@ -488,7 +486,10 @@ static int bd_route_patch3x3(int enable) {
     g_conv1x1_s2 = ((enable >> 12) & 1) ^ 1;
     g_pp_tail_split = ((enable >> 13) & 1) ^ 1;
     g_pp_persistent = ((enable >> 14) & 1) ^ 1;
-    g_igemm_wide = ((enable >> 16) & 1) ? 2 : 0;
+    if ((enable >> 16) & 1) {
+        bd_set_error("bd_conv_desc.route[1]: bit 16 (conv_igemm_wide.hip) is gone since round 6");
+        return BD_EINVAL;
+    }
     return BD_OK;
 }
 
@@ -576,10 +577,6 @@ static int conv2d_fwd_impl(const bd_conv_desc* d, const void* x, const void* w_p
     p.M = (int)m;
     p.src_pix_per_img = d->in_pix_per_img; p.dst_pix_per_img = d->out_pix_per_img;
     set_buffer_sizes(p, d->N);
-    if (g_igemm_wide && bd_conv_igemm_wide_launch(p, g_igemm_wide == 2, (hipStream_t)stream) == 0) {
-        BD_CHECK_LAUNCH("bd_conv2d_fwd(wide)");
-        return BD_OK;
-    }
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
         launch_igemm<64>(p, (hipStream_t)stream);
@@ -679,10 +676,6 @@ static int conv2d_dgrad_impl(const bd_conv_desc* d, const void* g, const void* w
     p.M = (int)m;
     p.src_pix_per_img = d->out_pix_per_img; p.dst_pix_per_img = d->in_pix_per_img;
     set_buffer_sizes(p, d->N);
-    if (g_igemm_wide && bd_conv_igemm_wide_launch(p, g_igemm_wide == 2, (hipStream_t)stream) == 0) {
-        BD_CHECK_LAUNCH("bd_conv2d_dgrad(wide)");
-        return BD_OK;
-    }
     p.m_tiles = cdiv(p.M, TILE_P); p.n_tiles = cdiv(p.CO, TILE_C);
     if (p.CK > 32 && !(g_bk32_for_1x1 && p.R * p.S == 1) && !(g_bk32_s2 && p.stride == 2 && p.m_tiles * p.n_tiles >= 512))
         launch_igemm<64>(p, (hipStream_t)stream);

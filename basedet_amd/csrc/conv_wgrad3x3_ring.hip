@@ -62,6 +62,12 @@ struct RParams {
 __device__ unsigned long long g_rk_stamp[8][8];
 #endif
 
+// -DBD_RK_ABLATE=<bits> (diagnostic builds, TIMING ONLY -- the results are wrong; scripts/exp/rk_power.sh): bit 0 = the second K half of a step
+// re-uses the first half's fragments (half of the loop's transposing reads gone), bit 1 = no operand DMA inside the loop, bit 2 = only the X
+// pieces 0 - 7 of 13 are requested (what a smaller input halo could save at most: -38 % of the X bytes).  Same MFMAs, same barriers.
+#ifndef BD_RK_ABLATE
+#define BD_RK_ABLATE 0
+#endif
 __device__ unsigned long long g_rk_clk[2];           // bd_probe_kernel_clock("conv_wgrad3x3_ring_kernel")
 
 __device__ __forceinline__ void rk_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff, int soff = 0) {
@@ -163,7 +169,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
     };
     // request the cursor's patch into ring stage `stage`, X pieces and G pieces separately (dead: past the end of this workgroup's range --
     // the DMAs are still issued, with every lane out of range, so that each wave's vmcnt arithmetic is the same on every step)
+    bool in_loop = false;
     auto issue_x = [&](int stage, bool dead) {
+        if ((BD_RK_ABLATE & 2) && in_loop) return;
         const unsigned Xs = lds0 + stage * STAGE + wave * 1024;            // LDS byte address of this wave's first piece
         const int ys = c_by * 8 - 1, xs = c_bx * 8 - 1;
         const int xorg = ((c_n * p.in_ppi + sg.in_off + ys * sg.Wi + xs) * p.Cin + ci0) * 2;       // may be negative; valid sums are not
@@ -172,19 +180,20 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
         if (!dead && ys >= 0 && xs >= 0 && ys + XW <= sg.Hi && xs + XW <= sg.Wi) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                if (k == 1 && !two_x) break;
+                if (k == 1 && (!two_x || (BD_RK_ABLATE & 4))) break;
                 rk_dma16(x_rsrc, Xs + k * 8192, x_in[k], xorg);
             }
             return;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (k == 1 && !two_x) break;
+            if (k == 1 && (!two_x || (BD_RK_ABLATE & 4))) break;
             const bool ok = !dead & x_ok[k] & ((unsigned)(ys + x_iy[k]) < (unsigned)sg.Hi) & ((unsigned)(xs + x_ix[k]) < (unsigned)sg.Wi);
             rk_dma16(x_rsrc, Xs + k * 8192, ok ? (unsigned)(xorg + x_vec[k]) : X_NONE);
         }
     };
     auto issue_g = [&](int stage, bool dead) {
+        if ((BD_RK_ABLATE & 2) && in_loop) return;
         const unsigned Gs = lds0 + stage * STAGE + X_BYTES + wave * 1024;
         const int y0 = c_by * 8, x0 = c_bx * 8;
         const int gorg = ((c_n * p.out_ppi + sg.out_off + y0 * sg.W + x0) * p.Cout + co0) * 2;
@@ -306,6 +315,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
         RK_BARRIER();
         if (wo == 1) RK_BARRIER();                 // stagger: the second group runs one barrier behind
         RK_FENCE();
+        in_loop = true;
         int stage = 0, fill = DEPTH;               // stage of step t; stage the requests of step t + DEPTH go to
 #ifdef BD_RK_STAMP
         unsigned long long st[4] = {0, 0, 0, 0};
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 // ---------------- load segment ----------------
-                load_half(stage, kk);
+                if (!((BD_RK_ABLATE & 1) && kk == 1)) load_half(stage, kk);
                 RK_FENCE();
                 // (Round 6, measured and removed: the phase's requests issued behind tap 3 / tap 5 of the MFMA segment instead of here: the step
                 // 3.0 % slower, profiles/r06_dma_pos.txt -- see conv3x3_pp.hip)
@@ -329,7 +339,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_ring_kernel(const RParams p
                     issue_x(fill, dead);
                 } else {
                     // this wave's pieces of step t + 1 have landed; step t + 2 and the X pieces of step t + 3 stay in flight
-                    if (two_x) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    if (BD_RK_ABLATE & 6) { }                // (fewer / no requests in flight: the counts below would wait for younger ones)
+                    else if (two_x) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     issue_g(fill, dead);
                     advance();

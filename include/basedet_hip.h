@@ -180,10 +180,7 @@ int bd_wgrad_queue_flush(bd_wgrad_queue_t q, bd_stream_t stream);
  * 256-channel workgroups for r tiles; same bits);
  * bit 14 = one workgroup per tile in conv3x3_pp.hip instead of the persistent grid (by default one workgroup per CU walks up to 16 tiles
  * and requests the next tile's operands inside the current tile's last K block; same bits);
- * bit 15 = unused;
- * bit 16 = (set = ON) conv_igemm_wide.hip (round 5 experiment: 128-channel x 256-pixel workgroup tile, 128 x 64 wave tiles, both operands
- * by LDS-DMA, K-block pairs outermost) for EVERY launch of the generic path it can take (tests / A-B: measured no faster than the generic
- * kernel on the stride-2 3x3 layers, which stay there). */
+ * bits 15, 16 = unused (16 routed to round 5's conv_igemm_wide.hip, deleted in round 6: BD_EINVAL). */
 
 
 /* ResNet stem: 7x7/2 pad 3 conv (3->64) + folded FrozenBN + ReLU (models/cls/resnet.py:142-146,238-240).

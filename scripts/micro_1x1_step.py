@@ -69,7 +69,7 @@ def timeit(run, iters=20):
 
 def main():
     depths = [int(a) for a in sys.argv[1:]] or [3, 2]
-    if os.environ.get("BD_KNOB"):          # e.g. 65536 with mode 0: the dense 1x1 launches on conv_igemm_wide_kernel (round 5 A/B)
+    if os.environ.get("BD_KNOB"):          # a route[1] bit mask for the run
         ops.set_route(patch3x3=int(os.environ["BD_KNOB"]))
     tot = {(dp, b): 0.0 for dp in depths for b in (0, 1)}
     print(f"{'launch':40s} " + " ".join(f"d{dp}{'b' if b else ' '}:us/GB/s" .rjust(16) for dp in depths for b in ((0, 1) if dp else (0,))))

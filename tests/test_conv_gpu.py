@@ -35,14 +35,13 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("patch3x3", [1, 0, 2, 3, 4])
+@pytest.mark.parametrize("patch3x3", [1, 0, 2, 3])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd_dgrad_wgrad(case, patch3x3):
     ops = _ops()
     # patch3x3 = 1: specialised kernels (3x3 patch, streaming 1x1); 0: everything through the generic kernel;
     # 2: specialised kernels without any staggered instance (bits 6 + 9); 3: the staggered 128 / 64-channel instances everywhere (bits 6 + 8);
-    # 4: no patch kernels, and conv_igemm_wide.hip for every launch of the generic path it can take (bit 16: 3x3 / stride 1 and 2, P6)
-    ops.set_route(patch3x3={0: 0, 1: 3, 2: 3 | 64 | 512, 3: 3 | 64 | 256, 4: 1 << 16}[patch3x3])
+    ops.set_route(patch3x3={0: 0, 1: 3, 2: 3 | 64 | 512, 3: 3 | 64 | 256}[patch3x3])
     N, Cin, Cout, H, W, R, stride, pad = case
     g = torch.Generator().manual_seed(1234 + Cin + Cout + H)
     x = bf16_round(torch.randn(N, Cin, H, W, generator=g))
@@ -784,59 +783,6 @@ def test_conv_last_kernel_names_the_dispatched_kernel_for_the_bench_descriptors(
     assert sc == {"fwd": "conv1x1_dense_kernel", "wgrad": "conv_wgrad1x1_kernel"}, sc
     # narrow 3x3 (res2-sized conv2 of a trainable layer1 would be 64 -> 64): the 64-channel staggered tile
     assert run(g3, g3, 64, 64, 3, 1, 1, ("fwd",)) == {"fwd": "conv3x3_pp128_kernel"}
-
-
-@pytest.mark.parametrize("case", [
-    # N, Cin, Cout, H, W, R, stride, pad
-    (2, 128, 128, 38, 52, 3, 2, 1),      # res3.0 conv2 (scaled down): one channel tile
-    (2, 256, 256, 27, 31, 3, 2, 1),      # res4.0 conv2 on odd sizes: two channel tiles, ragged pixel tile
-    (1, 512, 512, 14, 20, 3, 2, 1),      # res5.0 conv2: four channel tiles, 16 K blocks per tap
-    (1, 2048, 256, 25, 42, 3, 2, 1),     # P6
-    (2, 64, 136, 21, 17, 3, 1, 1),       # stride 1 through the same kernel (bit 16), ragged channel tile (136 = 128 + 8)
-    (3, 96, 64, 9, 11, 5, 1, 2),         # 5x5 filter, 25 taps, three K blocks
-])
-def test_igemm_wide_agrees_with_the_generic_kernel(case):
-    """conv_igemm_wide_kernel (round 5 experiment, opt-in: 128 x 256 workgroup tile, 128 x 64 wave tiles, LDS-DMA ring) computes the generic kernel's GEMM with the
-    same MFMA and fp32 accumulation in ANOTHER K order (K-block pairs outermost, taps inside: L2 re-use): forward and data gradient --
-    every epilogue -- agree with conv_igemm_kernel to fp32 summation order (a bf16 result may round the other way: rel-L2 <= 1e-3), two
-    launches are bit-identical, and the torch reference holds within the bf16 tolerance (test_conv_fwd_dgrad_wgrad, knob 4)."""
-    ops = _ops()
-    N, Cin, Cout, H, W, R, stride, pad = case
-    g = torch.Generator().manual_seed(77 + Cin + H)
-    gin = ops.single(N, H, W)
-    gout = gin.conv_out(R, stride, pad)
-    d = ops.conv_desc(gin, gout, Cin, Cout, R, R, stride, pad)
-    bf = lambda *shape: bf16_round(torch.randn(*shape, generator=g)).to(torch.bfloat16).cuda()
-    x, gy = bf(gin.pixels, Cin), bf(gout.pixels, Cout)
-    wf = (bf(Cout, R * R, Cin).float() / np.sqrt(Cin * R * R)).to(torch.bfloat16)
-    wd = (bf(Cin, R * R, Cout).float() / np.sqrt(Cout * R * R)).to(torch.bfloat16)
-    bias = torch.randn(Cout, generator=g).cuda()
-    res, addt, maskt = bf(gout.pixels, Cout), bf(gin.pixels, Cin), bf(gin.pixels, Cin)
-    outs = {}
-    for name, knob in (("generic", 0), ("wide", 1 << 16), ("wide2", 1 << 16)):
-        ops.set_route(patch3x3=knob)
-        y1 = torch.empty((gout.pixels, Cout), dtype=torch.bfloat16, device="cuda")
-        y2 = torch.empty_like(y1)
-        ops.conv2d_fwd(d, x, wf, bias, y1, add=res, flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE)
-        k1 = ops.L().bd_conv_last_kernel().decode()
-        ops.conv2d_fwd(d, x, wf, None, y2)
-        dx1 = torch.empty((gin.pixels, Cin), dtype=torch.bfloat16, device="cuda")
-        dx2, dx3 = torch.empty_like(dx1), torch.empty_like(dx1)
-        ops.conv2d_dgrad(d, gy, wd, dx1, add=addt, mask=maskt, flags=ops.EPI_ADD_BEFORE | ops.EPI_MASK)
-        k2 = ops.L().bd_conv_last_kernel().decode()
-        ops.conv2d_dgrad(d, gy, wd, dx2, add=addt, mask=maskt, flags=ops.EPI_ADD_AFTER | ops.EPI_MASK)
-        ops.conv2d_dgrad(d, gy, wd, dx3)
-        torch.cuda.synchronize()
-        outs[name] = (y1, y2, dx1, dx2, dx3)
-        want = ("conv_igemm_wide_kernel",) if name.startswith("wide") else ("conv_igemm_kernel<32>", "conv_igemm_kernel<64>")
-        assert k1 in want, (name, k1)
-        if not (name.startswith("wide") and Cout % 32):       # (a data gradient whose K = Cout is no multiple of 32 stays on the generic kernel)
-            assert k2 in want, (name, k2)
-    ops.set_route(patch3x3=3)
-    for i, (a, b, c) in enumerate(zip(outs["generic"], outs["wide"], outs["wide2"])):
-        assert rel_l2(b.float().cpu(), a.float().cpu()) < 1e-3, i
-        assert torch.equal(b, c), i
-    assert float(outs["wide"][0].float().abs().max()) > 0 and float(outs["wide"][4].float().abs().max()) > 0
 
 
 @pytest.mark.parametrize("M", [16 * 700 + 5, 16 * 256 * 7 + 16, 37])
