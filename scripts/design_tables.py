@@ -1,12 +1,12 @@
-"""Regenerates the measurement tables of DESIGN.md section 5 (between the R5_TABLES markers) from profiles/r05_*.
+"""Regenerates the measurement tables of DESIGN.md section 5 (between the R6_TABLES markers) from profiles/r06_*.
 python scripts/design_tables.py"""
 import csv, json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda n: os.path.join(ROOT, "profiles", n)
-d = json.load(open(P("r05_bench.json")))
+d = json.load(open(P("r06_bench.json")))
 rows = [d["roofline"]] + d["roofline_others"]
-sq = json.load(open(P("r05_pmc_sq.json")))["kernels"]
-ks = list(csv.DictReader(open(P("r05_bench_kernel_stats.csv"))))
+sq = json.load(open(P("r06_pmc_sq.json")))["kernels"]
+ks = list(csv.DictReader(open(P("r06_bench_kernel_stats.csv"))))
 
 
 def rocprof_avg(name, table=ks):
@@ -26,16 +26,16 @@ def per_step(table, steps, pats):
 
 
 W = []
-for l in open(P("r05_workloads.txt")).read().strip().splitlines():
+for l in open(P("r06_workloads.txt")).read().strip().splitlines():
     k, v, ms = l.rsplit(" ", 2)
     W.append((k.strip(), float(v), float(ms)))
-r101 = json.load(open(P("r05_bench_r101_fp8.json"))); r101b = json.load(open(P("r05_bench_r101_bf16_b32.json")))
-fcos = json.load(open(P("r05_bench_fcos_r50.json"))); frc = json.load(open(P("r05_bench_faster_rcnn_r50.json")))
+r101 = json.load(open(P("r06_bench_r101_fp8.json"))); r101b = json.load(open(P("r06_bench_r101_bf16_b32.json")))
+fcos = json.load(open(P("r06_bench_fcos_r50.json"))); frc = json.load(open(P("r06_bench_faster_rcnn_r50.json")))
 pm = d.get("mfma_peak_measured") or {}
 t = []
-t.append("### Headline and protocol legs (`profiles/r05_bench.json`: the default `python bench.py`, 100 timed steps after 20 warm-up)\n")
+t.append("### Headline and protocol legs (`profiles/r06_bench.json`: the default `python bench.py`, 100 timed steps after 20 warm-up)\n")
 t.append("| leg | img/s | ms/step (mean; p50 / p95) | note |\n|---|---|---|---|")
-t.append(f"| RetinaNet-R50-FPN, inputs resident in HBM (**`value`**) | **{d['value']:.1f}** (round 4: 632.1; driver-run 629.6) | {d['ms_per_step']:.2f}; {d['step_ms_p50']:.2f} / {d['step_ms_p95']:.2f} | `whole_step_mfma_frac` {d['config']['whole_step_mfma_frac']:.3f} |")
+t.append(f"| RetinaNet-R50-FPN, inputs resident in HBM (**`value`**) | **{d['value']:.1f}** (round 5: 638.5; driver-run 635.9) | {d['ms_per_step']:.2f}; {d['step_ms_p50']:.2f} / {d['step_ms_p95']:.2f} | `whole_step_mfma_frac` {d['config']['whole_step_mfma_frac']:.3f} |")
 rp = d["reference_protocol"]
 t.append(f"| same step, the reference harness's protocol (`tools/benchmark.py:125-133`: float64 host batch → fp32 → H2D inside the step, device sync around every step) — PCIe-inclusive, never `value` | **{rp['images_per_sec']:.0f}** | {rp['ms_per_step_mean']:.1f}; {rp['ms_p50']:.1f} / {rp['ms_p95']:.1f} | `bd_h2d_submit`: threaded conversion into pinned chunks, per-chunk DMA |")
 cb = d["cpu_baseline"]
@@ -44,12 +44,13 @@ t.append(f"| CPU baseline, oracle (`kind: \"port\"`), {cb['cpu']}, {cb['cores']}
 if pm:
     t.append(f"| what the matrix pipes of this device sustain on the kernels' register-level pattern (`bd_probe_mfma_rate`, in the same run; `roofline.peak_measured`) | — | — | **{pm['tflops']:.0f} TFLOP/s** at an in-kernel clock of {pm['clock_mhz']:.0f} MHz (vendor peak 2 500 at 2 400 MHz) |")
 t.append("")
-t.append("### Per kernel (HIP events on one step in 25; `traffic` = PMC `FETCH_SIZE` / `WRITE_SIZE` child passes of the same run; kernel names from `bd_conv_last_kernel`; rocprofv3 `--kernel-trace --stats` of `bench.py --steps 10 --warmup 3 --serial-wgrad` in `profiles/r05_bench_kernel_stats.csv`)\n")
-t.append("| kernel | ms / step | launches | roof | achieved | frac (of the measured MFMA peak) | HBM traffic vs algorithmic per launch | avg launch: events vs rocprofv3 | MFMA busy / wait_any (SQ) |\n|---|---|---|---|---|---|---|---|---|")
+t.append("### Per kernel (HIP events on one step in 25; `traffic` = PMC `FETCH_SIZE` / `WRITE_SIZE` child passes of the same run; kernel names from `bd_conv_last_kernel`; rocprofv3 `--kernel-trace --stats` of `bench.py --steps 10 --warmup 3 --serial-wgrad` in `profiles/r06_bench_kernel_stats.csv`)\n")
+t.append("| kernel | ms / step | launches | roof | achieved | frac (of the measured MFMA peak) | clock held in the step → frac in cycles | HBM traffic vs algorithmic per launch | avg launch: events vs rocprofv3 | MFMA busy / wait_any (SQ) |\n|---|---|---|---|---|---|---|---|---|---|")
 for i, r in enumerate(rows):
     k = r["kernel"]; s = sq.get(k, {}); ra = rocprof_avg(k)
     fm = f" ({r['frac_of_measured']:.3f})" if r.get("frac_of_measured") else ""
-    t.append(f"| `{k}`{' (**dominant: `roofline`**)' if i == 0 else ''} | {r['ms_per_step']:.2f} | {r['launches_per_step']} | {r['bound'].upper()} | {r['achieved']:.0f} {r['unit']} | **{r['frac']:.3f}**{fm} | "
+    t.append(f"| `{k}`{' (**dominant: `roofline`**)' if i == 0 else ''} | {r['ms_per_step']:.2f} | {r['launches_per_step']} | {r['bound'].upper()} | {r['achieved']:.0f} {r['unit']} | **{r['frac']:.3f}**{fm} | " +
+             (f"{r['clock_mhz']:.0f} MHz → {r['frac_in_cycles']:.3f}" if r.get("clock_mhz") else "—") + " | " +
              f"{(r['traffic'] or 0) / 1e6:.0f} vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB | {r['avg_launch_us']:.1f}" + (f" vs {ra:.1f} µs" if ra else " µs") +
              f" | {s.get('mfma_busy_frac_of_simd_cycles', '—')} / {s.get('wait_any_frac', '—')} |")
 t.append("")
@@ -57,14 +58,14 @@ t.append("The weight-gradient rows time the whole `bd_conv2d_wgrad` call with ev
          "their `traffic` is the kernel's (slab writes included).  `conv_wgrad1x1_kernel` (the stride-2 shortcuts): the algorithmic bytes now count the quarter of the input it reads (round 4 charged all of it: 0.486 → "
          f"{[r for r in rows if r['kernel'] == 'conv_wgrad1x1_kernel'][0]['frac']:.3f}).\n")
 # FCOS / Faster R-CNN
-kf = list(csv.DictReader(open(P("r05_fcos_r50_800x1344_kernel_stats.csv"))))
-kr = list(csv.DictReader(open(P("r05_faster_rcnn_r50_800x1344_kernel_stats.csv"))))
+kf = list(csv.DictReader(open(P("r06_fcos_r50_800x1344_kernel_stats.csv"))))
+kr = list(csv.DictReader(open(P("r06_faster_rcnn_r50_800x1344_kernel_stats.csv"))))
 steps = 13
-t.append("### C3 / C4 (builder-run; `profiles/r05_bench_fcos_r50.json`, `r05_bench_faster_rcnn_r50.json`: 50 timed steps with `roofline`; kernel sums from `profiles/r05_{fcos,faster_rcnn}_r50_800x1344_kernel_stats.csv`, 13 steps)\n")
+t.append("### C3 / C4 (builder-run; `profiles/r06_bench_fcos_r50.json`, `r06_bench_faster_rcnn_r50.json`: 50 timed steps with `roofline`; kernel sums from `profiles/r06_{fcos,faster_rcnn}_r50_800x1344_kernel_stats.csv`, 13 steps)\n")
 t.append("| workload | img/s (instrumented line) | dominant kernel, frac | config-specific kernels, ms per step (rocprofv3) |\n|---|---|---|---|")
 gn = {n: per_step(kf, steps, (n,)) for n in ("gn_stats_partial", "gn_stats_final", "gn_apply", "gn_bwd_partial", "gn_bwd_final_kernel", "gn_bwd_final_c", "gn_bwd_apply")}
-t.append(f"| FCOS-R50-FPN, batch 16 | **{fcos['value']:.1f}** ({fcos['ms_per_step']:.2f} ms; round 4: 619.3 uninstrumented) | `{fcos['roofline']['kernel']}` {fcos['roofline']['frac']:.3f} | "
-         f"GroupNorm **{sum(gn.values()):.2f}** (round 4: 3.08): " + ", ".join(f"`{k}` {v:.2f}" for k, v in gn.items()) + " |")
+t.append(f"| FCOS-R50-FPN, batch 16 | **{fcos['value']:.1f}** ({fcos['ms_per_step']:.2f} ms; round 5: 645.8) | `{fcos['roofline']['kernel']}` {fcos['roofline']['frac']:.3f} | "
+         f"GroupNorm **{sum(gn.values()):.2f}** (round 5: 2.35): " + ", ".join(f"`{k}` {v:.2f}" for k, v in gn.items()) + " |")
 box = {n: per_step(kr, steps, (n,)) for n in ("roi_align_bwd_tile", "roi_tile_list", "roi_tile_scan", "roi_foot", "conv1x1_thin_bwd", "conv1x1_thin_reduce",
                                                "conv1x1_thin_fwd", "roi_align_fwd", "rcnn_sample", "rcnn_loss", "sample_labels", "gt_rowmax", "retina_assign",
                                                "segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge")}
@@ -73,23 +74,22 @@ thin = box["conv1x1_thin_bwd"] + box["conv1x1_thin_reduce"] + box["conv1x1_thin_
 main_chain = roi_bwd + sum(box[n] for n in ("roi_align_fwd", "rcnn_loss"))
 prop = sum(box[n] for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge", "rcnn_sample"))
 early = sum(box[n] for n in ("sample_labels", "gt_rowmax", "retina_assign"))
-t.append(f"| Faster R-CNN R50-FPN, batch 16 | **{frc['value']:.1f}** ({frc['ms_per_step']:.2f} ms; round 4: 526 instrumented / 560 plain) | `{frc['roofline']['kernel']}` {frc['roofline']['frac']:.3f} | "
-         f"box operators on the main chain **{main_chain:.2f}** (round 4: 4.7; before the tiled RoIAlign backward: 2.76): RoIAlign backward {roi_bwd:.2f} (`roi_align_bwd_tile` {box['roi_align_bwd_tile']:.2f} + its list kernels; "
-         f"was `roi_align_bwd_sep` 1.72 + `f32_to_bf16` 0.38), " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("roi_align_fwd", "rcnn_loss")) +
-         f"; the RPN prediction layer on its own kernels {thin:.2f} (`conv1x1_thin_fwd` {box['conv1x1_thin_fwd']:.2f}, `conv1x1_thin_bwd` {box['conv1x1_thin_bwd']:.2f} + reduce; was 0.23 + 0.45 + 0.60 on the generic kernels)"
-         f"; proposal chain + RoI sampling on the side stream {prop:.2f} (round 4: 1.9 + 0.23 on the main chain): " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge", "rcnn_sample")) +
+t.append(f"| Faster R-CNN R50-FPN, batch 16 | **{frc['value']:.1f}** ({frc['ms_per_step']:.2f} ms; round 5: 648.3) | `{frc['roofline']['kernel']}` {frc['roofline']['frac']:.3f} | "
+         f"box operators on the main chain **{main_chain:.2f}** (round 5: 0.85): RoIAlign backward {roi_bwd:.2f} (`roi_align_bwd_tile` {box['roi_align_bwd_tile']:.2f} + its list kernels), " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("roi_align_fwd", "rcnn_loss")) +
+         f"; the RPN prediction layer on its own kernels {thin:.2f} (`conv1x1_thin_fwd` {box['conv1x1_thin_fwd']:.2f}, `conv1x1_thin_bwd` {box['conv1x1_thin_bwd']:.2f} + reduce)"
+         f"; proposal chain + RoI sampling on the side stream {prop:.2f} (round 5: 1.27): " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("segment_topk", "nmsl_prepare", "nmsl_mask", "nmsl_scan", "nmsl_merge", "rcnn_sample")) +
          f"; RPN targets under the forward pass {early:.2f}: " + ", ".join(f"`{n}` {box[n]:.2f}" for n in ("sample_labels", "gt_rowmax", "retina_assign")) + " |")
 t.append("")
-t.append("### Other workloads (`profiles/r05_workloads.txt`, one box, `--no-roofline`, 20–30 steps; builder-run)\n")
+t.append("### Other workloads (`profiles/r06_workloads.txt`, one box, `--no-roofline`, 20–30 steps; builder-run)\n")
 t.append("| workload | img/s | ms/step |\n|---|---|---|")
 for k, v, ms in W:
     t.append(f"| `{k}` | {v:.1f} | {ms:.2f} |")
 t.append("")
-t.append(f"BASELINE config 5 on one GPU (`profiles/r05_bench_r101_fp8.json`, batch 32): **{r101['value']:.1f} img/s**, {r101['ms_per_step']:.1f} ms/step "
+t.append(f"BASELINE config 5 on one GPU (`profiles/r06_bench_r101_fp8.json`, batch 32): **{r101['value']:.1f} img/s**, {r101['ms_per_step']:.1f} ms/step "
          f"(fp8 forward + e5m2 data gradients + one-byte 3×3 weight gradients under per-group delayed scales, the default) against bf16 {r101b['value']:.1f} ({r101b['ms_per_step']:.1f} ms); "
-         f"dominant kernel `{r101['roofline']['kernel']}` {r101['roofline']['ms_per_step']:.1f} ms at {r101['roofline']['frac']:.3f} of the {r101['roofline']['peak']:.0f} {r101['roofline']['unit']} roof.  Not worked on this round.\n")
+         f"dominant kernel `{r101['roofline']['kernel']}` {r101['roofline']['ms_per_step']:.1f} ms at {r101['roofline']['frac']:.3f} of the {r101['roofline']['peak']:.0f} {r101['roofline']['unit']} roof.  Not worked on in rounds 5-6 (what bounds the two fp8 kernels: section 8).\n")
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
-s = re.sub(r"<!-- R5_TABLES_BEGIN -->.*<!-- R5_TABLES_END -->", "<!-- R5_TABLES_BEGIN -->\n" + "\n".join(t).replace("\\", "\\\\") + "\n<!-- R5_TABLES_END -->", s, flags=re.S)
+s = re.sub(r"<!-- R6_TABLES_BEGIN -->.*<!-- R6_TABLES_END -->", "<!-- R6_TABLES_BEGIN -->\n" + "\n".join(t).replace("\\", "\\\\") + "\n<!-- R6_TABLES_END -->", s, flags=re.S)
 open(path, "w").write(s)
 print("DESIGN.md section 5 tables regenerated")
