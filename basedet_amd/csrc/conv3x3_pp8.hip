@@ -212,10 +212,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
 
     // one tap = four phases = the four 32-channel quarters of the wave's 128 output channels (A fragments i0, i0 + 1), K = 128 each;
     // the tap's four B fragments (the four patch rows) are read in its first phase
-    i32x8_t fa[2], fb[4];
+    // PP8_ROWS = 16-row channel fragments per phase: 4 (round 6) = TWO phases of 16 MFMAs per tap, as conv3x3_pp.hip since round 2; 2 = the
+    // four phases of 8 of rounds 2-5 (-DBD_PP8_ROWS=2: A/B).  A phase pays its two barriers and its lgkmcnt wait whatever it holds: ~100
+    // cycles beside 256 (8 MFMAs of 32 cycles) or beside 512.
+#ifndef BD_PP8_ROWS
+#define BD_PP8_ROWS 4
+#endif
+    constexpr int PP8_ROWS = BD_PP8_ROWS;
+    static_assert(PP8_ROWS == 2 || PP8_ROWS == 4, "two or four fragment rows per phase");
+    i32x8_t fa[PP8_ROWS], fb[4];
     auto load_a = [&](int i0, int slot) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PP8_ROWS; ++i) {
             const unsigned char* lo = slot == 2 ? a_hi[0] : a_base[0] + slot * W_SLOT;
             const unsigned char* hi = slot == 2 ? a_hi[1] : a_base[1] + slot * W_SLOT;
             const u32x4_t l = *reinterpret_cast<const u32x4_t*>(lo + (i0 + i) * 2048), h = *reinterpret_cast<const u32x4_t*>(hi + (i0 + i) * 2048);
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
     asm volatile("" : "+v"(one));
     auto mfma_quarter = [&](int i0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < PP8_ROWS; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 // tied accumulator (D = C) in inline asm, as in the bf16 kernel
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; q += PP8_ROWS / 2) {          // (q = the first 32-row quarter of the phase)
                 // ---------------- load segment ----------------
                 const int slot = t % 3;
                 if (q == 0) { load_b(t); PP_FENCE(); }
@@ -287,21 +295,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp8_kernel(const PParams p) {
                 }
                 // weight DMA, one piece per phase: (t, 1..3) and (t+1, 0) fill the slot of tap t+2 -- its previous tenant, tap t-1, was
                 // last read in phase (t-1, 3), two barriers before (t, 1)
-                if (q == 0) {
-                    if (t + 1 < 9) { if (t > 0 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
-                    else if (!last_kb) dma_piece(0, cb + 1, 0, 3);
-                } else {
-                    if (t + 2 < 9) dma_piece(t + 2, cb, (t + 2) % 3, q - 1);
-                    else if (!last_kb) dma_piece(t - 7, cb + 1, (t + 2) % 3, q - 1);
+#pragma unroll
+                for (int qq = q; qq < q + PP8_ROWS / 2; ++qq) {          // (the pieces of the quarters this phase covers, in the old order)
+                    if (qq == 0) {
+                        if (t + 1 < 9) { if (t > 0 || cb > 0) dma_piece(t + 1, cb, (t + 1) % 3, 3); }
+                        else if (!last_kb) dma_piece(0, cb + 1, 0, 3);
+                    } else {
+                        if (t + 2 < 9) dma_piece(t + 2, cb, (t + 2) % 3, qq - 1);
+                        else if (!last_kb) dma_piece(t - 7, cb + 1, (t + 2) % 3, qq - 1);
+                    }
                 }
                 PP_FENCE();
                 PP_BARRIER();
                 // ---------------- MFMA segment ----------------
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PP_FENCE();
-                __builtin_amdgcn_s_setprio(1);
+                if (PP8_ROWS == 2) __builtin_amdgcn_s_setprio(1);
                 mfma_quarter(q * 2);
-                __builtin_amdgcn_s_setprio(0);
+                if (PP8_ROWS == 2) __builtin_amdgcn_s_setprio(0);
                 PP_FENCE();
                 PP_BARRIER();
                 PP_FENCE();

@@ -50,7 +50,7 @@ for i, r in enumerate(rows):
     k = r["kernel"]; s = sq.get(k, {}); ra = rocprof_avg(k)
     fm = f" ({r['frac_of_measured']:.3f})" if r.get("frac_of_measured") else ""
     t.append(f"| `{k}`{' (**dominant: `roofline`**)' if i == 0 else ''} | {r['ms_per_step']:.2f} | {r['launches_per_step']} | {r['bound'].upper()} | {r['achieved']:.0f} {r['unit']} | **{r['frac']:.3f}**{fm} | " +
-             (f"{r['clock_mhz']:.0f} MHz → {r['frac_in_cycles']:.3f}" if r.get("clock_mhz") else "—") + " | " +
+             (f"{r['clock_mhz']:.0f} MHz{' (PMC pass, serialised: reads high)' if str(r.get('clock_src', '')).startswith('rocprofv3') else ''} → {r['frac_in_cycles']:.3f}" if r.get("clock_mhz") else "—") + " | " +
              f"{(r['traffic'] or 0) / 1e6:.0f} vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB | {r['avg_launch_us']:.1f}" + (f" vs {ra:.1f} µs" if ra else " µs") +
              f" | {s.get('mfma_busy_frac_of_simd_cycles', '—')} / {s.get('wait_any_frac', '—')} |")
 t.append("")
@@ -63,7 +63,7 @@ kr = list(csv.DictReader(open(P("r06_faster_rcnn_r50_800x1344_kernel_stats.csv")
 steps = 13
 t.append("### C3 / C4 (builder-run; `profiles/r06_bench_fcos_r50.json`, `r06_bench_faster_rcnn_r50.json`: 50 timed steps with `roofline`; kernel sums from `profiles/r06_{fcos,faster_rcnn}_r50_800x1344_kernel_stats.csv`, 13 steps)\n")
 t.append("| workload | img/s (instrumented line) | dominant kernel, frac | config-specific kernels, ms per step (rocprofv3) |\n|---|---|---|---|")
-gn = {n: per_step(kf, steps, (n,)) for n in ("gn_stats_partial", "gn_stats_final", "gn_apply", "gn_bwd_partial", "gn_bwd_final_kernel", "gn_bwd_final_c", "gn_bwd_apply")}
+gn = {n: per_step(kf, steps, (n,)) for n in ("gn_stats_partial", "gn_stats_final", "gn_apply", "gn_bwd_partial", "gn_bwd_finals", "gn_bwd_apply")}
 t.append(f"| FCOS-R50-FPN, batch 16 | **{fcos['value']:.1f}** ({fcos['ms_per_step']:.2f} ms; round 5: 645.8) | `{fcos['roofline']['kernel']}` {fcos['roofline']['frac']:.3f} | "
          f"GroupNorm **{sum(gn.values()):.2f}** (round 5: 2.35): " + ", ".join(f"`{k}` {v:.2f}" for k, v in gn.items()) + " |")
 box = {n: per_step(kr, steps, (n,)) for n in ("roi_align_bwd_tile", "roi_tile_list", "roi_tile_scan", "roi_foot", "conv1x1_thin_bwd", "conv1x1_thin_reduce",
