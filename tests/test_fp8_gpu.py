@@ -654,3 +654,83 @@ def test_e5m2_stochastic_rounding():
         assert err_sr < 0.2 * err_rn, (err_sr, err_rn)
     finally:
         ops.fp8_set_stochastic_rounding(0)
+
+
+@pytest.mark.parametrize("mode", ["fwd", "dgrad"])
+def test_fp8_patch_kernel_persistent_walk_matches_the_generic_kernel(mode):
+    """conv3x3_pp8_kernel as a PERSISTENT grid (round 6: one workgroup per CU walks its tiles, the next tile's image and taps requested inside
+    the current tile's last K block, an 8-tile geometry table): 22 images x five pyramid levels x 264 produced channels = 4 224 tiles --
+    three grid rounds of 256 workgroups on an MI355X, five / six tiles each, a ragged second channel tile, a last tile that is mostly
+    padding.  Exact-structure operands (every product and partial sum exact in fp32): the forward launch must agree with the generic
+    per-tap fp8 kernel (bd_conv_desc.route[3] = generic) up to the tie direction of the bf16 store; the data gradient (which only the
+    patch kernel serves) must be bit-identical over two launches and reproduce a float64 evaluation at sampled pixels."""
+    ops = _ops()
+    N, C, CO = 22, 256, 264
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    geo = ops.Geom(N, [h for h, _ in sizes], [w for _, w in sizes])
+    g = torch.Generator(device="cuda").manual_seed(99)
+    if mode == "fwd":
+        d = ops.conv_desc(geo, geo, C, CO, 3, 3, 1, 1)
+        vals = torch.tensor([0.0, 0.25, 0.5, 1.0, 1.5, -0.5, -1.0, 2.0, 3.0, -0.125], device="cuda")
+        x = vals[torch.randint(0, len(vals), (geo.pixels, C), generator=g, device="cuda")].to(torch.bfloat16)
+        wv = torch.tensor([0.0, 0.875, -0.875, 1.75, -3.5, 0.4375], device="cuda")
+        w = wv[torch.randint(0, len(wv), (CO, 9, C), generator=g, device="cuda")].contiguous()
+        w[:, 0, 0] = 7.0
+        xq = torch.empty((x.numel(),), dtype=torch.uint8, device="cuda")
+        ops.quantize_fp8(x, 1.0, xq)
+        wq = torch.empty((CO, 9, C), dtype=torch.uint8, device="cuda")
+        ws = torch.empty((CO,), dtype=torch.float32, device="cuda")
+        ops.weight_pack_fp8(w, None, CO, 9, C, 1.0, wq, ws)
+        bias = torch.randn(CO, generator=g, device="cuda")
+        outs = {}
+        for route in (1, 0, 1):
+            ops.set_route(fp8_patch=route)
+            y = torch.full((geo.pixels, CO), float("nan"), dtype=torch.bfloat16, device="cuda")
+            ops.conv2d_fwd_fp8(d, xq, wq, ws, bias, y, flags=ops.EPI_RELU)
+            name = ops.L().bd_conv_last_kernel().decode()
+            assert (name == "conv3x3_pp8_kernel") == (route == 1), (route, name)
+            outs.setdefault(route, []).append(y)
+        ops.set_route(fp8_patch=None)
+        a, b, gen = outs[1][0], outs[1][1], outs[0][0]
+        assert torch.equal(a, b), "two launches of the persistent kernel differ"
+        assert bool(torch.isfinite(a.float()).all())
+        diff = (a.float() - gen.float()).abs()
+        assert float((diff > 0).float().mean()) < 1e-3
+        assert bool((diff <= gen.float().abs() * 2.0 ** -7 + 1e-6).all()), float(diff.max())
+        assert float(a.float().abs().max()) > 1.0
+    else:
+        d = ops.conv_desc(geo, geo, CO, C, 3, 3, 1, 1)          # the data gradient produces Cin = 264 channels from Cout = 256
+        GS = 2.0 ** 12
+        gv = torch.tensor([0.0, 1.0, -1.0, 1.5, 0.5, -0.75, 2.0, -3.0, 0.25], device="cuda") / GS
+        gy = gv[torch.randint(0, len(gv), (geo.pixels, C), generator=g, device="cuda")].to(torch.bfloat16)
+        wv = torch.tensor([0.0, 0.875, -0.875, 1.75, -3.5, 0.4375], device="cuda")
+        w = wv[torch.randint(0, len(wv), (C, 9, CO), generator=g, device="cuda")].contiguous()          # [Cout][tap][Cin]
+        w[0, 0, :] = 7.0
+        g8 = torch.empty((gy.numel(),), dtype=torch.uint8, device="cuda")
+        ops.quantize_bf8(gy, GS, g8)
+        wq = torch.empty((CO, 9, C), dtype=torch.uint8, device="cuda")
+        ws = torch.empty((CO,), dtype=torch.float32, device="cuda")
+        ops.weight_pack_fp8_t(w, None, C, 9, CO, GS, wq, ws)
+        outs = []
+        for _ in range(2):
+            dx = torch.full((geo.pixels, CO), float("nan"), dtype=torch.bfloat16, device="cuda")
+            ops.conv2d_dgrad_fp8(d, g8, wq, ws, dx, q_scale=GS)
+            assert ops.L().bd_conv_last_kernel().decode() == "conv3x3_pp8_kernel"
+            outs.append(dx)
+        assert torch.equal(outs[0], outs[1])
+        assert bool(torch.isfinite(outs[0].float()).all())
+        # float64 evaluation at sampled pixels of every level and of the first / last images: dx[n, y, x, ci] = sum g[n, y + 1 - r, x + 1 - s, co] w[co][r][s][ci]
+        gyf, wf = gy.double().view(N, geo.pix_per_img, C), w.double().view(C, 3, 3, CO)
+        rng = np.random.default_rng(4)
+        for n in (0, N - 1, 7):
+            for (h, wd), off in zip(sizes, geo.off):
+                for _ in range(6):
+                    yy, xx = int(rng.integers(0, h)), int(rng.integers(0, wd))
+                    acc = torch.zeros(CO, dtype=torch.float64, device="cuda")
+                    for r in range(3):
+                        for s_ in range(3):
+                            sy, sx = yy + 1 - r, xx + 1 - s_
+                            if 0 <= sy < h and 0 <= sx < wd:
+                                acc += gyf[n, off + sy * wd + sx] @ wf[:, r, s_, :]
+                    got = outs[0].double().view(N, geo.pix_per_img, CO)[n, off + yy * wd + xx]
+                    assert bool(((got - acc).abs() <= acc.abs() * 2.0 ** -7 + 1e-9).all()), (n, h, yy, xx, float((got - acc).abs().max()))
