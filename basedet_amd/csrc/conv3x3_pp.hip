@@ -273,7 +273,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     const unsigned char* a_base[2];          // K half kk: row wm*128 + frow of slot 0; + slot * W_SLOT + i * 2048 at compile time
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) a_base[kk] = wbuf + swz(wm * 128 + frow, kk * 4 + fchunk);
-    const unsigned char* a_hi[2] = {a_base[0] + 2 * W_SLOT, a_base[1] + 2 * W_SLOT};     // slot 2 (ds_read offsets are 16 bit)
+    // slot 2 sits past the 16-bit ds_read offset: its base is a register of its own -- an OPAQUE 32-bit LDS address, or the compiler folds it back
+    // into a_base + 0x10000 + i * 2048 and keeps one address register per (fragment row, K half): 16 VGPRs live through the K loop (round 6)
+    typedef __attribute__((address_space(3))) const unsigned char lds_u8_t;
+    typedef __attribute__((address_space(3))) const bf16x8_t lds_bf16x8_t;
+    unsigned a_hi[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        a_hi[kk] = (unsigned)(size_t)(lds_u8_t*)(a_base[kk]) + 2 * W_SLOT;
+        asm volatile("" : "+v"(a_hi[kk]));
+    }
     const unsigned char* b_base = xbuf + (wp * (IH * IW) + colperm(frow)) * X_PITCH + xpos(fchunk);
 
     // one tap = four phases: (A rows 0-63, K half 0) (A rows 64-127, K half 0) (rows 0-63, half 1) (rows 64-127, half 1); the B
@@ -283,8 +292,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     auto load_a = [&](int kk, int slot) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const unsigned char* base = slot == 2 ? a_hi[kk] : a_base[kk] + slot * W_SLOT;
-            fa[i] = *reinterpret_cast<const bf16x8_t*>(base + i * 2048);
+            if (slot == 2) fa[i] = *(lds_bf16x8_t*)(size_t)(a_hi[kk] + i * 2048);
+            else fa[i] = *reinterpret_cast<const bf16x8_t*>(a_base[kk] + slot * W_SLOT + i * 2048);
         }
     };
     auto load_b = [&](int kk, int t) {
