@@ -43,6 +43,52 @@ __device__ __forceinline__ unsigned bd_pack4_e5m2_sr(float a, float b, float c, 
     return (unsigned)v;
 }
 
+// ---- one-byte twins written by the 1x1 epilogues (conv1x1.hip, conv1x1_ring.hip) ---------------------------------------------------------
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+__device__ __forceinline__ unsigned pack4_e5m2(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -57344.f), 57344.f); b = fminf(fmaxf(b, -57344.f), 57344.f);
+    c = fminf(fmaxf(c, -57344.f), 57344.f); d = fminf(fmaxf(d, -57344.f), 57344.f);
+    int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+// eight consecutive channels (element index idx, a multiple of 8) -> eight e5m2 bytes; seed != 0: stochastic rounding (common.h)
+__device__ __forceinline__ u32x2_t e5m2_pair(const float* v, float qs, unsigned seed, long long idx) {
+    u32x2_t o8;
+    if (seed) {
+        const unsigned g0 = (unsigned)(idx >> 2);
+        const unsigned r0 = bd_mix32(seed ^ g0);           // one full hash per eight elements; the second word by a multiply-add
+        o8[0] = bd_pack4_e5m2_sr(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, r0);
+        o8[1] = bd_pack4_e5m2_sr(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs, r0 * 0x9e3779b1u + 0x7f4a7c15u);
+    } else {
+        o8[0] = pack4_e5m2(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
+        o8[1] = pack4_e5m2(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs);
+    }
+    return o8;
+}
+
+// One-byte twin of a pixel's 64 wave-channels: lane group cg holds 8 bytes of each 32-channel half; the lane pairs (cg, cg ^ 1) swap one
+// piece so that every lane stores 16 contiguous bytes (64-byte runs per pixel and instruction instead of 32-byte ones): even cg ends up
+// with bytes [8 cg, 8 cg + 16) of half 0, odd cg with bytes [8 (cg - 1), 8 (cg - 1) + 16) of half 1.  `keep` = this lane's piece of the
+// half it stores, `send` = its piece of the other half.  Returns the 16 bytes; *off = byte offset inside the pixel's 64-byte run.
+__device__ __forceinline__ u32x4_t twin_pair(u32x2_t h0, u32x2_t h1, int cg, int* off) {
+    const bool odd = cg & 1;
+    const u32x2_t send = odd ? h0 : h1;
+    u32x2_t recv;
+    recv[0] = (unsigned)__shfl_xor((int)send[0], 16, 64);
+    recv[1] = (unsigned)__shfl_xor((int)send[1], 16, 64);
+    *off = odd ? 32 + 8 * (cg - 1) : 8 * cg;
+    return odd ? (u32x4_t){recv[0], recv[1], h1[0], h1[1]} : (u32x4_t){h0[0], h0[1], recv[0], recv[1]};
+}
+
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }

@@ -58,57 +58,12 @@ __device__ __forceinline__ int s2_big_row(const P1& p, int m) {
     return n * p.bHW + 2 * y * p.bW + 2 * x;
 }
 
-__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
-    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
-    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
-    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-    return (unsigned)v;
-}
-
-__device__ __forceinline__ unsigned pack4_e5m2(float a, float b, float c, float d) {
-    a = fminf(fmaxf(a, -57344.f), 57344.f); b = fminf(fmaxf(b, -57344.f), 57344.f);
-    c = fminf(fmaxf(c, -57344.f), 57344.f); d = fminf(fmaxf(d, -57344.f), 57344.f);
-    int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
-    v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
-    return (unsigned)v;
-}
-
-// eight consecutive channels (element index idx, a multiple of 8) -> eight e5m2 bytes; seed != 0: stochastic rounding (common.h)
-__device__ __forceinline__ u32x2_t e5m2_pair(const float* v, float qs, unsigned seed, long long idx) {
-    u32x2_t o8;
-    if (seed) {
-        const unsigned g0 = (unsigned)(idx >> 2);
-        const unsigned r0 = bd_mix32(seed ^ g0);           // one full hash per eight elements; the second word by a multiply-add
-        o8[0] = bd_pack4_e5m2_sr(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, r0);
-        o8[1] = bd_pack4_e5m2_sr(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs, r0 * 0x9e3779b1u + 0x7f4a7c15u);
-    } else {
-        o8[0] = pack4_e5m2(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
-        o8[1] = pack4_e5m2(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs);
-    }
-    return o8;
-}
-
 typedef __attribute__((address_space(3))) void lds_void_1x1_t;
 
 // 16 bytes per lane straight into LDS.  (A plain function: called with template-dependent arguments from inside the kernel template, the
 // target builtin made the HOST pass drop the instantiation without a diagnostic -- undefined kernel stubs at link time.)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_1x1_t*)lds, 16, voff, soff, 0, 0);
-}
-
-// One-byte twin of a pixel's 64 wave-channels: lane group cg holds 8 bytes of each 32-channel half; the lane pairs (cg, cg ^ 1) swap one
-// piece so that every lane stores 16 contiguous bytes (64-byte runs per pixel and instruction instead of 32-byte ones): even cg ends up
-// with bytes [8 cg, 8 cg + 16) of half 0, odd cg with bytes [8 (cg - 1), 8 (cg - 1) + 16) of half 1.  `keep` = this lane's piece of the
-// half it stores, `send` = its piece of the other half.  Returns the 16 bytes; *off = byte offset inside the pixel's 64-byte run.
-__device__ __forceinline__ u32x4_t twin_pair(u32x2_t h0, u32x2_t h1, int cg, int* off) {
-    const bool odd = cg & 1;
-    const u32x2_t send = odd ? h0 : h1;
-    u32x2_t recv;
-    recv[0] = (unsigned)__shfl_xor((int)send[0], 16, 64);
-    recv[1] = (unsigned)__shfl_xor((int)send[1], 16, 64);
-    *off = odd ? 32 + 8 * (cg - 1) : 8 * cg;
-    return odd ? (u32x4_t){recv[0], recv[1], h1[0], h1[1]} : (u32x4_t){h0[0], h0[1], recv[0], recv[1]};
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
@@ -902,6 +857,9 @@ int bd_route_dense1x1(int depth) {
 
 int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, const void* add, const void* mask, const unsigned* maskbits, void* y,
                            unsigned* ybits, void* y8, long long M, int CK, int CO, int flags, hipStream_t stream);      // conv1x1_ring.hip
+int bd_conv1x1_ring_fp8_launch(int mode, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
+                               const unsigned* maskbits, void* y, unsigned* ybits, void* y8, float q_scale, unsigned sr_seed, long long M, int CK,
+                               int CO, int flags, hipStream_t stream);                                                   // conv1x1_ring.hip
 
 // Called by bd_conv2d_fwd / bd_conv2d_dgrad (conv_igemm.hip) for 1x1 / stride 1 / pad 0 launches over one dense level.
 // Returns 0 when the launch was taken, 1 when the shape is left to the generic kernel.
@@ -1038,6 +996,13 @@ extern "C" int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, c
     p.M = (int)M; p.CK = CK; p.CO = CO; p.flags = flags | (maskbits ? BD_EPI_MASK : 0);
     p.x_bytes = (unsigned)(M * CK); p.w_bytes = (unsigned)((long long)CO * CK);
     p.m_tiles = (int)cdiv64(M, TP); p.n_tiles = cdiv(CO, TC);
+    // round 6: the ring kernel's one-byte form for the launch classes its bf16 form takes (bd_conv_desc.route[0]: 1 default, 5 = every legal
+    // launch, 3 = never); bf16 gates stay here
+    if (g_conv1x1_depth == 1 && !p.mask &&
+        bd_conv1x1_ring_fp8_launch(mode, xq, wq, wscale, bias, add, maskbits, y, ybits, y8, q_scale, p.sr_seed, M, CK, CO, p.flags, (hipStream_t)stream) == 0) {
+        BD_CHECK_LAUNCH("bd_conv1x1_fp8");
+        return BD_OK;
+    }
     const int grid = p.m_tiles * p.n_tiles;
     BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fp8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * F8_TILE);

@@ -53,6 +53,12 @@ struct PR {
     int M, CK, CO;
     unsigned x_bytes, w_bytes, y_bytes, bits_bytes;
     int n_tiles, tiles, nsteps;
+    // one-byte operands (F8 != 0): per-produced-channel epilogue multiplier, optional one-byte twin of y (y * q_scale: e4m3 forward, e5m2 data
+    // gradient, rounded stochastically when sr_seed != 0)
+    const float* wscale;
+    unsigned char* y8;
+    float q_scale;
+    unsigned sr_seed, y8_bytes;
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -85,6 +91,7 @@ struct ESet {                // epilogue operands and addresses of one tile, per
     u32x4_t aux[NU];         // residual
     unsigned bits[NU];       // this lane's gate byte
     unsigned yv[NU / 2];     // byte offset of unit (j, 0) in y / add (unit (j, 1): + 64, as the instruction offset)
+    unsigned tv[NU / 2];     // F8: byte offset of this lane's 16 bytes of pixel j in the one-byte twin (twin_pair, common.h)
     unsigned bv[2];          // byte offset of this lane's byte of unit (0, half) in the gate words (unit (j, half): + 64 j)
     bool full;               // whole tile in range: the offsets as they stand; else checked per unit
     int m, c;                // first pixel / channel of the lane
@@ -126,7 +133,12 @@ template <int J> using IC = std::integral_constant<int, J>;
 // XRES (K = 128 or 256, i.e. 2 or 4 K steps): the pixel rows of a pixel tile stay in the pixel halves of the four stages while the workgroup
 // walks that pixel tile's channel tiles -- only the weights stream -- and the rows of the pixel tile after (K = 256) / after next (K = 128)
 // are requested into a slot as soon as the last channel tile has consumed it.  A third less through the CU's vector memory pipe per tile.
-template <int EPI, int BK, bool XRES>
+// F8 (round 6): 0 = bf16 operands; 1 / 2 = ONE-BYTE operands (BASELINE config 5: e4m3 weights with e4m3 activations / e5m2 gradients): the same
+// 128-byte rows carry 128 channels, a K step is one v_mfma_scale_f32_16x16x128_f8f6f4 per fragment pair (all block scales 2^0; 2 declares the
+// pixel operand e5m2), the epilogue multiplies by the per-channel weight scale and runs in fp32 like conv1x1_fp8_kernel's (conv1x1.hip) --
+// same K order, same arithmetic: the same bits -- and ALWAYS issues the NU / 2 stores of the one-byte twin (beyond num_records when the caller
+// wants none: the instruction counts behind the vmcnt waits stay compile-time constants).
+template <int EPI, int BK, bool XRES, int F8 = 0>
 __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(const PR p) {
     constexpr int NW = 8;
     using S = Shape<NW, BK>;
@@ -134,7 +146,8 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
     constexpr int WPX = S::WPX, FJ = S::FJ, PK = S::PK, NP = S::NP, NU = S::NU, NSTAGE = S::NSTAGE, DEPTH = S::DEPTH, RING_BYTES = S::RING_BYTES;
     constexpr bool ADD = EPI & E_ADD, RELU = EPI & E_RELU, MASK = EPI & E_MASK, YBITS = EPI & E_YBITS;
     constexpr int NLOAD = (ADD ? NU : 0) + (MASK ? NU : 0);     // vector-memory instructions of one epilogue: the NEXT tile's operands ...
-    constexpr int NSTORE = NU + (YBITS ? NU : 0);               // ... then this tile's stores
+    constexpr int NSTORE = NU + (YBITS ? NU : 0) + (F8 ? NU / 2 : 0);      // ... then this tile's stores
+    constexpr unsigned ES = F8 ? 1u : 2u;                       // bytes per operand element
     constexpr int NE = NLOAD + NSTORE;
     typedef ESet<NU> E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -162,10 +175,15 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
     const __amdgpu_buffer_rsrc_t mb_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(MASK ? p.maskbits : (const unsigned*)p.y), 0, MASK ? p.bits_bytes : 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t yb_rsrc = __builtin_amdgcn_make_buffer_rsrc(YBITS ? p.ybits : (unsigned*)p.y, 0, YBITS ? p.bits_bytes : 4, 0x00020000);
+    const bool twin = F8 && p.y8;
+    const __amdgpu_buffer_rsrc_t y8_rsrc = __builtin_amdgcn_make_buffer_rsrc(twin ? p.y8 : (unsigned char*)p.y, 0, twin ? p.y8_bytes : 4, 0x00020000);
 
     // ---- the bias vector, padded with zeros to whole channel tiles, behind the ring
     float* bias_lds = reinterpret_cast<float*>(smem + RING_BYTES);
     for (int i = tid; i < n_tiles * TC; i += 64 * NW) bias_lds[i] = (p.bias && i < p.CO) ? p.bias[i] : 0.f;
+    float* scale_lds = bias_lds + n_tiles * TC;                  // F8: the weight scales behind the bias vector
+    if constexpr (F8 != 0)
+        for (int i = tid; i < n_tiles * TC; i += 64 * NW) scale_lds[i] = i < p.CO ? p.wscale[i] : 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // written before this wave's first barrier (the barriers below are bare s_barrier)
 
     // ---- producer: K step (ptile, pstep) -> ring stage `fill`; this wave owns pieces wave + NW k (8 rows x 128 B each) of both operands
@@ -177,10 +195,10 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
         const int ch = (lane % CPR) ^ ((lrow[k] >> 1) & (CPR - 1));     // lds_off on the source side
         const int rho = lrow[k] & 15;
         wperm[k] = (lrow[k] & 64) + 32 * ((lrow[k] >> 5) & 1) + 8 * (rho >> 2) + 4 * ((lrow[k] >> 4) & 1) + (rho & 3);      // LDS row -> channel of the tile
-        a_lane[k] = (unsigned)(wperm[k] * p.CK + ch * 8) * 2u;
-        b_lane[k] = (unsigned)(lrow[k] * p.CK + ch * 8) * 2u;
+        a_lane[k] = (unsigned)(wperm[k] * p.CK) * ES + (unsigned)ch * 16u;
+        b_lane[k] = (unsigned)(lrow[k] * p.CK) * ES + (unsigned)ch * 16u;
     }
-    const unsigned tile_stride = (unsigned)(128 * p.CK) * 2u;           // bytes between the first rows of neighbouring tiles (either operand)
+    const unsigned tile_stride = (unsigned)(128 * p.CK) * ES;           // bytes between the first rows of neighbouring tiles (either operand)
     unsigned a_src[PK], b_src[PK];
     int ptile = t_begin, pstep = 0;
     int ptm = t_begin / n_tiles, ptn = t_begin - ptm * n_tiles;
@@ -229,7 +247,15 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
 #pragma unroll
         for (int j = 0; j < FJ; ++j) e.yv[j] = y0 + (unsigned)(32 * p.CO) * j;
         e.bv[0] = b0; e.bv[1] = b0 + (unsigned)(4 * p.M);
+        if constexpr (F8 != 0) {
+            // twin_pair: even cg stores bytes [8 cg, 8 cg + 16) of the wave's first 32 channels, odd cg bytes [8 (cg - 1), + 16) of the second 32
+            const int toff = (cg & 1) ? 32 + 8 * (cg - 1) : 8 * cg;
+            const unsigned t0 = (unsigned)(e.m * p.CO + tn * TC + wc * 64 + toff);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) e.tv[j] = twin ? t0 + (unsigned)(16 * p.CO) * j : X_NONE;
+        }
     };
+    auto twin_ok = [&](const E& e, int j) { return e.m + 16 * j < p.M && (int)(e.c - 8 * cg) + ((cg & 1) ? 32 + 8 * (cg - 1) : 8 * cg) < p.CO; };
     // edge tiles: unit (j, half) in range = pixel m + 16 j and channels c + 32 half .. + 7 (CO % 8 == 0)
     auto unit_ok = [&](const E& e, int j, int half) { return e.m + 16 * j < p.M && e.c + 32 * half < p.CO; };
     auto request = [&](E& e, int tm, int tn, bool live) {             // NLOAD instructions
@@ -284,6 +310,32 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[kh][i], f.b[kh][j], acc[i][j], 0, 0, 0);
     };
+    // F8: one MFMA consumes a whole 128-channel row segment; a lane's fragment = the 32 bytes at k = 32 (lane >> 4) = chunks 2 frag_chunk and
+    // 2 frag_chunk + 1 of its row (operand map: scripts/exp/mfma_fp8_layout.hip) -- under the swizzle the second one sits at (offset ^ 16)
+    static_assert(F8 == 0 || BK == 64, "one-byte operands: 128-byte rows");
+    typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+    struct Frags8 { i32x8_t a[4], b[FJ]; };
+    const int a_off8 = S::lds_off(wc * 64 + frag_row, 2 * frag_chunk), b_off8 = A_BYTES + S::lds_off(wp * (16 * FJ) + frag_row, 2 * frag_chunk);
+    auto read_frags8 = [&](Frags8& f, const unsigned char* st, const unsigned char* stx) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(st + a_off8 + i * 16 * RB), hi = *reinterpret_cast<const u32x4_t*>(st + (a_off8 ^ 16) + i * 16 * RB);
+            f.a[i] = (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(stx + b_off8 + j * 16 * RB), hi = *reinterpret_cast<const u32x4_t*>(stx + (b_off8 ^ 16) + j * 16 * RB);
+            f.b[j] = (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+    };
+    auto mfmas8 = [&](const Frags8& f) {
+        const int one = 0x7f7f7f7f;                  // E8M0 block scales 2^0
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f.a[i], f.b[j], acc[i][j], 0, F8 == 2 ? 1 : 0, 0, one, 0, one);
+    };
 
     // one 16-byte unit: 8 channels of one pixel.  The arithmetic after the fp32 sums runs on the packed bf16 pairs: ReLU = max with 0 as
     // int16 (a negative bf16 is a negative int16), the gate = AND with a mask spread from the gate byte, the gate bits written = (int16 > 0)
@@ -326,32 +378,94 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
         }
         out = (u32x4_t){o[0], o[1], o[2], o[3]};
     };
-    auto epilogue = [&](const E& e) {          // NSTORE instructions
-        f32x4_t bias[4];
+    // F8: the unit in fp32, in conv1x1_fp8_kernel's order of operations (scale and bias, residual, ReLU, gate, round) -- the same bits -- plus
+    // the unit's eight bytes of the one-byte twin
+    auto unit8 = [&](const E& e, int q, const f32x4_t (&bias)[4], const f32x4_t (&scl)[4], u32x4_t& out, unsigned& byte, u32x2_t& o8) {
+        const int j = q >> 1, half = q & 1;
+        const f32x4_t lo = acc[2 * half][j] * scl[2 * half] + bias[2 * half], hi = acc[2 * half + 1][j] * scl[2 * half + 1] + bias[2 * half + 1];
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if constexpr (ADD) {
+            const u32x4_t av = e.aux[q];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) bias[qq] = *reinterpret_cast<const f32x4_t*>(bias_lds + e.c + 32 * (qq >> 1) + 4 * (qq & 1));
+            for (int k = 0; k < 4; ++k) { v[2 * k] += bf_lo(av[k]); v[2 * k + 1] += bf_hi(av[k]); }
+        }
+        if constexpr (RELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if constexpr (MASK) {
+            const unsigned gate = e.bits[q];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (!((gate >> k) & 1u)) v[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+        if constexpr (YBITS) {
+            byte = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) byte |= (v[k] > 0.f ? 1u : 0u) << k;
+        }
+        if (twin) {
+            if constexpr (F8 == 2) o8 = e5m2_pair(v, p.q_scale, p.sr_seed, (long long)(e.m + 16 * j) * p.CO + e.c + 32 * half);
+            else {
+                o8[0] = pack4_e4m3(v[0] * p.q_scale, v[1] * p.q_scale, v[2] * p.q_scale, v[3] * p.q_scale);
+                o8[1] = pack4_e4m3(v[4] * p.q_scale, v[5] * p.q_scale, v[6] * p.q_scale, v[7] * p.q_scale);
+            }
+        }
+    };
+    auto epilogue = [&](const E& e) {          // NSTORE instructions
+        f32x4_t bias[4], scl[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            bias[qq] = *reinterpret_cast<const f32x4_t*>(bias_lds + e.c + 32 * (qq >> 1) + 4 * (qq & 1));
+            if constexpr (F8 != 0) scl[qq] = *reinterpret_cast<const f32x4_t*>(scale_lds + e.c + 32 * (qq >> 1) + 4 * (qq & 1));
+        }
         if (e.full) {
             auto one = [&](auto J) {
                 constexpr int j = decltype(J)::value;
                 if constexpr (j < FJ) {
                     u32x4_t o0, o1;
                     unsigned y0 = 0u, y1 = 0u;
-                    unit(e, 2 * j, bias, o0, y0);
-                    unit(e, 2 * j + 1, bias, o1, y1);
-                    store16<0>(o0, y_rsrc, e.yv[j]); store16<64>(o1, y_rsrc, e.yv[j]);
+                    if constexpr (F8 != 0) {
+                        u32x2_t h0 = {0u, 0u}, h1 = {0u, 0u};
+                        unit8(e, 2 * j, bias, scl, o0, y0, h0);
+                        unit8(e, 2 * j + 1, bias, scl, o1, y1, h1);
+                        int off;
+                        const u32x4_t t16 = twin_pair(h0, h1, cg, &off);
+                        store16<0>(o0, y_rsrc, e.yv[j]); store16<64>(o1, y_rsrc, e.yv[j]);
+                        store16<0>(t16, y8_rsrc, e.tv[j]);
+                    } else {
+                        unit(e, 2 * j, bias, o0, y0);
+                        unit(e, 2 * j + 1, bias, o1, y1);
+                        store16<0>(o0, y_rsrc, e.yv[j]); store16<64>(o1, y_rsrc, e.yv[j]);
+                    }
                     if constexpr (YBITS) { store1<64 * j>(y0, yb_rsrc, e.bv[0]); store1<64 * j>(y1, yb_rsrc, e.bv[1]); }
                 }
             };
             one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{});
         } else {
+            u32x2_t h0 = {0u, 0u};
 #pragma unroll
             for (int q = 0; q < NU; ++q) {
                 const int j = q >> 1, half = q & 1;
                 const bool ok = unit_ok(e, j, half);
                 u32x4_t o;
                 unsigned yb = 0u;
-                unit(e, q, bias, o, yb);
-                store16<0>(o, y_rsrc, ok ? e.yv[j] + 64u * half : X_NONE);
+                if constexpr (F8 != 0) {
+                    u32x2_t h = {0u, 0u};
+                    unit8(e, q, bias, scl, o, yb, h);
+                    store16<0>(o, y_rsrc, ok ? e.yv[j] + 64u * half : X_NONE);
+                    if (half == 0) h0 = h;
+                    else {
+                        int off;
+                        const u32x4_t t16 = twin_pair(h0, h, cg, &off);
+                        store16<0>(t16, y8_rsrc, twin_ok(e, j) ? e.tv[j] : X_NONE);
+                    }
+                } else {
+                    unit(e, q, bias, o, yb);
+                    store16<0>(o, y_rsrc, ok ? e.yv[j] + 64u * half : X_NONE);
+                }
                 if constexpr (YBITS) store1<0>(yb, yb_rsrc, ok ? e.bv[half] + 64u * j : X_NONE);
             }
         }
@@ -422,9 +536,15 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
 #ifdef BD_R1X_STAMP
         R1X_T(0);        // (diagnostic build: slot 0 = the DMA requests + producer bookkeeping, slot 3 = fragment reads + MFMAs)
 #endif
-        Frags f;
-        read_frags(f, stage, XRES ? smem + xslot * STAGE : stage);
-        mfmas(f);
+        if constexpr (F8 != 0) {
+            Frags8 f;
+            read_frags8(f, stage, XRES ? smem + xslot * STAGE : stage);
+            mfmas8(f);
+        } else {
+            Frags f;
+            read_frags(f, stage, XRES ? smem + xslot * STAGE : stage);
+            mfmas(f);
+        }
         stage = stage + STAGE == smem + RING_BYTES ? smem : stage + STAGE;
         ends = (ends << 1) | (tile_end ? 1u : 0u);
         if constexpr (XRES) { p_last = last_co; p_tm = tm; p_s = s; p_slot = xslot; }
@@ -449,7 +569,8 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
         if constexpr (NLOAD > 0) {
             if (first) wait_vm<(DEPTH - 1) * NPW>();
             else if (nsteps >= DEPTH) wait_vm<NSTORE + DEPTH * NPW>();
-            else wait_vm<NSTORE + 2 * NPW>();
+            else if (nsteps >= 2) wait_vm<NSTORE + 2 * NPW>();
+            else wait_vm<NSTORE + NPW>();                                   // one K step per tile (K = 64 bf16 / 128 one-byte channels)
             settle(cur);
         }
         R1X_T(4);
@@ -476,16 +597,17 @@ __global__ __launch_bounds__(512, (Shape<8, BK>::WGS)) void conv1x1_ring_kernel(
 #endif
 }
 
-template <int EPI, int BK, bool XRES>
+template <int EPI, int BK, bool XRES, int F8 = 0>
 void launch_ring(PR p, hipStream_t stream) {
     using S = Shape<8, BK>;
-    p.nsteps = p.CK / BK;
-    const int lds = S::RING_BYTES + p.n_tiles * TC * 4;
-    BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ring_kernel<EPI, BK, XRES>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::RING_BYTES + MAX_CO * 4));
+    constexpr int VECS = F8 ? 2 : 1;                             // bias (+ weight scales) behind the ring
+    p.nsteps = p.CK / (F8 ? 2 * BK : BK);
+    const int lds = S::RING_BYTES + p.n_tiles * TC * 4 * VECS;
+    BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ring_kernel<EPI, BK, XRES, F8>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::RING_BYTES + MAX_CO * 4 * VECS));
     const int slots = S::WGS * bd_num_cus();
-    bd_note_kernel("conv1x1_ring_kernel");
-    hipLaunchKernelGGL((conv1x1_ring_kernel<EPI, BK, XRES>), dim3(p.tiles < slots ? p.tiles : slots), dim3(512), lds, stream, p);
+    bd_note_kernel(F8 ? "conv1x1_ring_fp8_kernel" : "conv1x1_ring_kernel");
+    hipLaunchKernelGGL((conv1x1_ring_kernel<EPI, BK, XRES, F8>), dim3(p.tiles < slots ? p.tiles : slots), dim3(512), lds, stream, p);
 }
 
 }  // namespace
@@ -511,7 +633,7 @@ int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, cons
     // gradient: 14 - 16 %); the other launches at 67 200 / 16 800 pixels have 2 - 8 tiles per CU -- one persistent workgroup per CU pays the
     // rounding (5 tiles against 4.1) that three to four small workgroups per CU even out -- and stay on conv1x1_dense_kernel (2 - 6 % slower here)
     if (mode != 2 && !(M >= 131072 || (CK <= 256 && CO >= 256 && M >= 32768))) return 1;
-    if (y8 || CK % 64 != 0 || CK < 128 || CO % 8 != 0 || CO > MAX_CO) return 1;
+    if (y8 || CK % 64 != 0 || CK < (g_ring_everywhere ? 64 : 128) || CO % 8 != 0 || CO > MAX_CO) return 1;      // (K = 64, one step per tile: legal, measured below)
     if ((flags & BD_EPI_MASK) && mask && !maskbits) return 1;                   // bf16 gates: the older kernel
     if ((maskbits || ybits) && CO % 32 != 0) return 1;
     if ((flags & BD_EPI_SPARSE) || ((flags & BD_EPI_ADD_AFTER) && add)) return 1;
@@ -538,6 +660,41 @@ int bd_conv1x1_ring_launch(const void* x, const void* w, const float* bias, cons
         BD_R1X_CASE(0) BD_R1X_CASE(1) BD_R1X_CASE(2) BD_R1X_CASE(3) BD_R1X_CASE(4) BD_R1X_CASE(5) BD_R1X_CASE(6) BD_R1X_CASE(7)
         BD_R1X_CASE(8) BD_R1X_CASE(9) BD_R1X_CASE(10) BD_R1X_CASE(11) BD_R1X_CASE(12) BD_R1X_CASE(13) BD_R1X_CASE(14) BD_R1X_CASE(15)
 #undef BD_R1X_CASE
+    }
+    return 0;
+}
+
+// One-byte form (BASELINE config 5), called by bd_conv1x1_fp8 (conv1x1.hip) before conv1x1_fp8_kernel.  0 = taken.  mode 0: xq e4m3
+// activations, no gates; mode 1: xq = e5m2 gradient, no ReLU.  Same launch classes as the bf16 rule above with K counted in 128-byte steps.
+int bd_conv1x1_ring_fp8_launch(int mode, const void* xq, const void* wq, const float* wscale, const float* bias, const void* add,
+                               const unsigned* maskbits, void* y, unsigned* ybits, void* y8, float q_scale, unsigned sr_seed, long long M, int CK,
+                               int CO, int flags, hipStream_t stream) {
+    // measured per launch class of R101 at batch 32 (scripts/exp/fp8_1x1_shapes.py, profiles/r06_fp8_1x1_ring.txt): up to four K steps this form is
+    // 11 - 25 % faster than conv1x1_fp8_kernel (res4 conv3 forward 195 -> 156 us, its conv1 data gradient 187 -> 167, res3's K = 512 launches
+    // 135 -> 102 / 119 -> 98); at eight and sixteen steps (K = 1 024 / 2 048) it is 3 - 9 % slower and those launches stay there
+    if (!g_ring_everywhere && !(CK <= 512 && (M >= 131072 || (CO >= 256 && M >= 32768)))) return 1;
+    if (CK % 128 != 0 || CO % 32 != 0 || CO > MAX_CO) return 1;          // (K = 128: one step per tile -- res3 conv3 forward 353 -> 314 us)
+    if ((flags & BD_EPI_SPARSE) || ((flags & BD_EPI_ADD_AFTER) && add)) return 1;
+    const long long xb = M * CK, wb = (long long)CO * CK, yb = M * CO * 2, bb = (long long)(CO / 32) * M * 4;
+    if (xb >= 0x7fffffffll || wb >= 0x7fffffffll || yb >= 0x7fffffffll || M >= (1ll << 24)) return 1;
+    PR p{};
+    p.x = (const bf16_raw*)xq; p.w = (const bf16_raw*)wq; p.bias = bias; p.add = (const bf16_raw*)add; p.maskbits = maskbits;
+    p.y = (bf16_raw*)y; p.ybits = ybits;
+    p.wscale = wscale; p.y8 = (unsigned char*)y8; p.q_scale = q_scale; p.sr_seed = sr_seed; p.y8_bytes = (unsigned)(M * CO);
+    p.M = (int)M; p.CK = CK; p.CO = CO;
+    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; p.y_bytes = (unsigned)yb; p.bits_bytes = (unsigned)bb;
+    p.n_tiles = cdiv(CO, TC);
+    p.tiles = (int)cdiv64(M, TP) * p.n_tiles;
+    const int epi = (((flags & BD_EPI_ADD_BEFORE) && add) ? E_ADD : 0) | ((flags & BD_EPI_RELU) ? E_RELU : 0) |
+                    (((flags & BD_EPI_MASK) && maskbits) ? E_MASK : 0) | (ybits ? E_YBITS : 0);
+    if (mode == 0 ? (epi & E_MASK) : (epi & E_RELU)) return 1;
+    const bool xres = (CK == 256 || CK == 512) && p.n_tiles >= 2;         // K of exactly 2 or 4 steps: the pixel rows stay resident
+    switch (epi | (mode << 4)) {
+#define BD_R1X8_CASE(n, f8) case (n | ((f8 - 1) << 4)): if (xres) launch_ring<n, 64, true, f8>(p, stream); else launch_ring<n, 64, false, f8>(p, stream); break;
+        BD_R1X8_CASE(0, 1) BD_R1X8_CASE(1, 1) BD_R1X8_CASE(2, 1) BD_R1X8_CASE(3, 1) BD_R1X8_CASE(8, 1) BD_R1X8_CASE(9, 1) BD_R1X8_CASE(10, 1) BD_R1X8_CASE(11, 1)
+        BD_R1X8_CASE(0, 2) BD_R1X8_CASE(1, 2) BD_R1X8_CASE(4, 2) BD_R1X8_CASE(5, 2) BD_R1X8_CASE(8, 2) BD_R1X8_CASE(9, 2) BD_R1X8_CASE(12, 2) BD_R1X8_CASE(13, 2)
+#undef BD_R1X8_CASE
+        default: return 1;
     }
     return 0;
 }

@@ -163,8 +163,9 @@ class KernelTimer:
                 nbytes = 1.0 * m * K + 1.0 * K * CO + 2.0 * m * CO * (1 + (add is not None) + (mask is not None and maskbits is None)) \
                     + (m * CO / 8.0 if maskbits is not None else 0.0) + (m * CO / 8.0 if bits is not None else 0.0) \
                     + (1.0 * m * CO if y8 is not None else 0.0)
-                self.records.setdefault("conv1x1_fp8_kernel", []).append((s, e, flops(d)))
-                self.meta.setdefault("conv1x1_fp8_kernel", []).append(("conv1x1_fp8 " + ("fwd" if mode == 0 else "dgrad"), d.Cin, d.Cout, 1, 1, 1, d.Ho[0], d.Wo[0], nbytes))
+                kern = ops.L().bd_conv_last_kernel().decode() or "conv1x1_fp8_kernel"      # conv1x1_fp8_kernel or conv1x1_ring_fp8_kernel (round 6)
+                self.records.setdefault(kern, []).append((s, e, flops(d)))
+                self.meta.setdefault(kern, []).append(("conv1x1_fp8 " + ("fwd" if mode == 0 else "dgrad"), d.Cin, d.Cout, 1, 1, 1, d.Ho[0], d.Wo[0], nbytes))
                 return r
             return inner
 

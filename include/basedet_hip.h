@@ -65,7 +65,7 @@ typedef struct bd_conv_desc {
      *             launches into >= 256 channels, conv1x1.hip the rest; 0 = the generic kernel (the *_bits / _ex entry points then return
      *             BD_EINVAL); 2 = conv1x1.hip's 256 x 256 tile, 3 = its 128 x 128 tile only, 4 = its eight-wave 256-channel x 128-pixel
      *             tile wherever legal, 5 = as 1 with conv1x1_ring.hip for every launch it can take, 6 = as 3 with the 128 x 128 tile's
-     *             LDS-DMA ring variant for every K that allows it (all: the same results bit for bit);
+     *             LDS-DMA ring variant for every K that allows it (all: the same results bit for bit); bd_conv1x1_fp8 honours 1 / 3 / 5;
      *   route[1]  3x3 / generic path, a bit mask (default 3): see "route[1] bits" below;
      *   route[2]  weight gradients, a bit mask (default 1): bit 0 = operand transposes through ds_read_b64_tr_b16 (clear: scalar 16-bit
      *             LDS reads, the slow reference path that validates the transposing read); bit 1 set = no nine-tap / 1x1 kernels (generic
@@ -666,7 +666,9 @@ int bd_conv1x1_thin_bwd(const void* x, const void* g, const float* w, int64_t M,
  * wscale from bd_weight_pack_fp8 (RS = 1); mode 1 = data gradient: xq = e5m2 twin of the output gradient (g * grad_scale), wq / wscale
  * from bd_weight_pack_fp8_t.  y (bf16) = epi(conv(xq, wq) * wscale[c] + bias [+ add]) with the side inputs / outputs of
  * bd_conv2d_fwd_ex / bd_conv2d_dgrad_ex: mask or maskbits (mode 1), ybits (mode 0), y8 = e4m3 (mode 0) / e5m2 (mode 1) of y * q_scale;
- * each may be NULL. */
+ * each may be NULL.  Two kernels, the same bits: conv1x1_fp8_kernel (conv1x1.hip) and, round 6, the one-byte form of conv1x1_ring_kernel
+ * (conv1x1_ring.hip) for launches of up to four 128-channel K steps over many pixels or into >= 256 channels; bd_conv_desc.route[0] applies
+ * as for the bf16 launches (3 = the first kernel only, 5 = the ring form wherever legal). */
 int bd_conv1x1_fp8(const bd_conv_desc* d, int mode, const void* xq, const void* wq, const float* wscale, const float* bias,
                    const void* add, const void* mask, const uint32_t* maskbits, void* y, uint32_t* ybits, void* y8, float q_scale,
                    int flags, bd_stream_t stream);

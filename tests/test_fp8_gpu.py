@@ -476,6 +476,92 @@ def test_fp8_dense_1x1_tolerance_on_random_data():
     assert reld < 1.2e-1, reld
 
 
+R1X8_SHAPES = [
+    # pixels (ragged against the 128-pixel tile), K, produced channels
+    (2 * 37 * 53, 256, 256),          # two K steps, two channel tiles: the pixel rows stay resident (XRES)
+    (1 * 41 * 29, 512, 544),          # four K steps, produced-channel tail (544 = 4 x 128 + 32), XRES
+    (3 * 19 * 23, 1024, 128),         # eight K steps, one channel tile
+    (1 * 30 * 17, 384, 1024),         # three K steps (no XRES), eight channel tiles
+    (5 * 31 * 17, 128, 512),          # ONE K step per tile: every ring step closes a tile
+]
+
+
+@pytest.mark.parametrize("mode", ["fwd", "dgrad"])
+@pytest.mark.parametrize("shape", R1X8_SHAPES)
+def test_fp8_ring_1x1_kernel_is_bit_identical_to_the_dense_fp8_kernel(shape, mode):
+    """conv1x1_ring_kernel's one-byte form (round 6; bd_conv_desc.route[0] = 5: every legal launch) against conv1x1_fp8_kernel (route[0] = 3) on
+    random data, every epilogue the fp8 model issues: the bf16 result, the gate bits and the one-byte twin (to nearest and stochastically
+    rounded) must be the same BITS -- same K order, same fp32 epilogue arithmetic."""
+    ops = _ops()
+    M, K, CO = shape
+    g = torch.Generator(device="cuda").manual_seed(5 + M + K + CO)
+    H, W = 1, M
+    geo = ops.single(1, H, W)
+    if mode == "fwd":
+        d = ops.conv_desc(geo, geo, K, CO, 1, 1, 1, 0)
+        x = torch.relu(torch.randn(M, K, generator=g, device="cuda")).to(torch.bfloat16)
+        xq = torch.empty((M * K,), dtype=torch.uint8, device="cuda")
+        ops.quantize_fp8(x, 1.0, xq)
+        w = (torch.randn(CO, 1, K, generator=g, device="cuda") / np.sqrt(K)).contiguous()
+        wq = torch.empty((CO, 1, K), dtype=torch.uint8, device="cuda")
+        ws = torch.empty((CO,), dtype=torch.float32, device="cuda")
+        ops.weight_pack_fp8(w, None, CO, 1, K, 1.0, wq, ws)
+        bias = torch.randn(CO, generator=g, device="cuda")
+        res = torch.randn(M, CO, generator=g, device="cuda").to(torch.bfloat16)
+        variants = [dict(bias=None, add=None, flags=0, bits=False, twin=False),
+                    dict(bias=bias, add=None, flags=ops.EPI_RELU, bits=True, twin=True),
+                    dict(bias=bias, add=res, flags=ops.EPI_RELU | ops.EPI_ADD_BEFORE, bits=True, twin=True),
+                    dict(bias=None, add=res, flags=ops.EPI_ADD_BEFORE, bits=False, twin=True)]
+        for v in variants:
+            outs = {}
+            for route in (3, 5):
+                ops.set_route(dense1x1=route)
+                y = torch.full((M, CO), float("nan"), dtype=torch.bfloat16, device="cuda")
+                yb = torch.full((CO // 32, M), -1, dtype=torch.int32, device="cuda") if v["bits"] else None
+                y8 = torch.full((M, CO), 0x7f, dtype=torch.uint8, device="cuda") if v["twin"] else None
+                ops.conv1x1_fp8(d, 0, xq, wq, ws, v["bias"], y, add=v["add"], bits=yb, y8=y8, q_scale=0.75, flags=v["flags"])
+                name = ops.L().bd_conv_last_kernel().decode()
+                assert name == ("conv1x1_ring_fp8_kernel" if route == 5 else "conv1x1_fp8_kernel"), (route, name)
+                outs[route] = (y, yb, y8)
+            ops.set_route(dense1x1=None)
+            assert bool(torch.isfinite(outs[5][0].float()).all())
+            for a, b, what in zip(outs[3], outs[5], ("y", "ybits", "twin")):
+                assert (a is None and b is None) or torch.equal(a, b), (v["flags"], what)
+    else:
+        d = ops.conv_desc(geo, geo, CO, K, 1, 1, 1, 0)          # the data gradient contracts over Cout = K and produces Cin = CO channels
+        GS = 2.0 ** 10
+        gy = (torch.randn(M, K, generator=g, device="cuda") * 2.0 ** -9).to(torch.bfloat16)
+        g8 = torch.empty((M * K,), dtype=torch.uint8, device="cuda")
+        ops.quantize_bf8(gy, GS, g8)
+        w = (torch.randn(K, 1, CO, generator=g, device="cuda") / np.sqrt(K)).contiguous()          # [Cout][1][Cin]
+        wq = torch.empty((CO, 1, K), dtype=torch.uint8, device="cuda")
+        ws = torch.empty((CO,), dtype=torch.float32, device="cuda")
+        ops.weight_pack_fp8_t(w, None, K, 1, CO, GS, wq, ws)
+        acc0 = (torch.randn(M, CO, generator=g, device="cuda") * 0.1).to(torch.bfloat16)
+        gate = torch.randint(-2 ** 31, 2 ** 31 - 1, (CO // 32, M), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+        variants = [dict(acc=False, gate=False, twin=False, seed=0),
+                    dict(acc=True, gate=True, twin=True, seed=0),
+                    dict(acc=False, gate=True, twin=True, seed=0),
+                    dict(acc=True, gate=True, twin=True, seed=12345)]
+        for v in variants:
+            outs = {}
+            for route in (3, 5):
+                ops.set_route(dense1x1=route)
+                ops.fp8_set_stochastic_rounding(v["seed"])
+                dx = acc0.clone() if v["acc"] else torch.full((M, CO), float("nan"), dtype=torch.bfloat16, device="cuda")
+                dx8 = torch.full((M, CO), 0x7f, dtype=torch.uint8, device="cuda") if v["twin"] else None
+                ops.conv1x1_fp8(d, 1, g8, wq, ws, None, dx, add=dx if v["acc"] else None, maskbits=gate if v["gate"] else None, y8=dx8, q_scale=GS,
+                                flags=ops.EPI_ADD_BEFORE if v["acc"] else 0)
+                name = ops.L().bd_conv_last_kernel().decode()
+                assert name == ("conv1x1_ring_fp8_kernel" if route == 5 else "conv1x1_fp8_kernel"), (route, name)
+                outs[route] = (dx, dx8)
+            ops.set_route(dense1x1=None)
+            ops.fp8_set_stochastic_rounding(0)
+            assert bool(torch.isfinite(outs[5][0].float()).all())
+            for a, b, what in zip(outs[3], outs[5], ("dx", "twin")):
+                assert (a is None and b is None) or torch.equal(a, b), (v, what)
+
+
 # ---- the 3x3 weight gradient on one-byte operands (csrc/conv_wgrad3x3_fp8.hip) -----------------------------------------------------------
 WG_CASES = [
     # N, Cin, Cout, sizes
