@@ -107,6 +107,9 @@ SIGNATURES = {
     "bd_bce_logits_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
     "bd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _L]),
     "bd_groupnorm_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _L, _I, _F, _I, _P, _P, _P, _Z, _P]),
+    "bd_conv2d_fwd_gnstats_bytes": (_Z, [_D]),
+    "bd_conv2d_fwd_gnstats": (_I, [_D, _P, _P, _P, _P, _P, _Z, _P]),
+    "bd_groupnorm_fwd_parts": (_I, [_D, _P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "bd_groupnorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "bd_fcos_offsets_fwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _L, _P, _P]),
     "bd_fcos_offsets_workspace_bytes": (_Z, []),

@@ -57,6 +57,7 @@ struct PParams {
     int tail_end;            // the 64-channel tile of conv3x3_pp128_body.h over patches [total_patches, tail_end)
     float inv_ppi;           // 1 / patches_per_img (the patch indices are < 2^24: exact quotients by a float multiply and one correction)
     PSeg seg[MAX_SEG];
+    float* gn_part;          // GNS instance only: per (patch, group of 8 channels) the (sum, sum of squares) of the fp32 results, [patch][32][2]
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -89,7 +90,13 @@ __device__ unsigned long long g_pp_clk[2];           // bd_probe_kernel_clock("c
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-template <int MODE>
+// GNS (round 6): the forward instance that also leaves GroupNorm's statistics (layers/head/point_head.py:47-58: conv -> GroupNorm(32) -> ReLU in
+// FCOS's towers): a lane's 8 channels of a pixel ARE one group of GroupNorm(32, 256), so the epilogue adds its fp32 results (before the bf16
+// rounding) and their squares per channel group over the patch's pixels inside the image, the 16 lanes of a row are summed by a fixed butterfly,
+// and lane 0 of the row stores the pair -- gn_stats_final_kernel (norm.hip) then sums a level's patches exactly as it sums 128-pixel slots.
+// A separate instantiation: the plain forward / data-gradient instances are untouched.  (Round 5 built this on the 253-register kernel: the
+// sums spilled INSIDE the K loop and the launch lost what the statistics pass saved; the 16 address registers found in round 6 made room.)
+template <int MODE, bool GNS = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= p.main_grid) {       // tail tiles of a grid of 256 k + r pixel tiles (see bd_conv3x3_pp_launch): 4 r short workgroups
@@ -447,10 +454,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
     int lq = lane;                            // (opaque copy: the epilogue's per-lane constants are not kept across the MFMA loop)
     asm volatile("" : "+v"(lq));
     const int cg = lq >> 4, erow = lq & 15;
-    const bool do_relu = p.flags & BD_EPI_RELU;
-    const bool add_before = (p.flags & BD_EPI_ADD_BEFORE) && p.add;
-    const bool add_after = (p.flags & BD_EPI_ADD_AFTER) && p.add;
-    const bool do_mask = (p.flags & BD_EPI_MASK) && p.mask;
+    // (the GNS instance is launched without residual, gate or ReLU -- GroupNorm follows: compile-time constants, so that the 64 gate registers
+    // and the general path below do not exist in it)
+    const bool do_relu = !GNS && (p.flags & BD_EPI_RELU);
+    const bool add_before = !GNS && (p.flags & BD_EPI_ADD_BEFORE) && p.add;
+    const bool add_after = !GNS && (p.flags & BD_EPI_ADD_AFTER) && p.add;
+    const bool do_mask = !GNS && (p.flags & BD_EPI_MASK) && p.mask;
     const int cbase = co0 + wm * 128 + 8 * cg;          // + 32 h
     const int oy0 = c_oy0, ox = c_px0 + colperm(erow), H = c_H, W = c_W, dbase = c_dst;
     // Fast paths (no residual operand): the epilogue of a one-workgroup-per-CU kernel is pure issue time -- the general loop below, with
@@ -494,6 +503,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
             for (int k = 0; k < 4; ++k) dma_piece(2, 0, 2, k);
         }
         PP_FENCE();
+        float gsum[4] = {0.f, 0.f, 0.f, 0.f}, gsq[4] = {0.f, 0.f, 0.f, 0.f};          // GNS: this lane's (sum, sum of squares) per channel group h
         auto unit = [&](int h, int j, const f32x4_t b0, const f32x4_t b1) {
             u32x4_t o;
 #pragma unroll
@@ -502,6 +512,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 const f32x4_t bb = (k >> 1) ? b1 : b0;
                 f32x2_e v = {a[2 * (k & 1)], a[2 * (k & 1) + 1]};
                 v += (f32x2_e){bb[2 * (k & 1)], bb[2 * (k & 1) + 1]};
+                if constexpr (GNS) {
+                    if (okj[j]) { gsum[h] += v[0] + v[1]; gsq[h] += v[0] * v[0] + v[1] * v[1]; }
+                }
                 i16x2_e w = __builtin_bit_cast(i16x2_e, __builtin_convertvector(v, bf16x2_e));
                 if (do_mask) {          // keep where the stored activation is > 0: sat(0 - m) >> 15 is all ones exactly for m > 0 (-0.0 = 0x8000 saturates to 32767)
                     // (written as the two packed instructions: the vector-builtin form of this gate was compiled into selects that
@@ -542,6 +555,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 for (int j = 0; j < 4; ++j) {
                     const u32x4_t o = unit(h, j, b0, b1);
                     if (okh && okj[j]) *reinterpret_cast<u32x4_t*>(drow[j] + 32 * h) = o;
+                }
+            }
+        }
+        if constexpr (GNS) {
+            // the 16 lanes of a row (same channel groups, 16 pixel columns): butterfly over lane bits 3..0 -- a fixed order; lane 0 of the row
+            // stores the four (sum, sum of squares) pairs of the wave's patch: part[(patch * 32 + group) * 2], group = channel / 8
+            const int pid = pt * NPATCH + wp;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float a = gsum[h], b = gsq[h];
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+                if (erow == 0 && pid < p.total_patches && cbase + 32 * h < p.CO) {
+                    float* o = p.gn_part + ((long long)pid * 32 + ((cbase + 32 * h) >> 3)) * 2;
+                    *reinterpret_cast<f32x2_t*>(o) = (f32x2_t){a, b};
                 }
             }
         }
@@ -642,9 +670,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
 BD_KNOB int g_pp_tail_split = 1;     // bd_conv_desc.route[1] bit 13 clears it
 BD_KNOB int g_pp_persistent = 1;     // bit 14 clears it: one workgroup per tile
 extern BD_KNOB int g_patch_pp;       // 0 = never, 1 = where the makespan estimate favours it, 2 = wherever the shape allows (default)
-int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
-                         const void* mask, void* dst, int flags, hipStream_t stream) {
+static int pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
+                     const void* mask, void* dst, int flags, float* gn_part, hipStream_t stream) {
     PParams p{};
+    p.gn_part = gn_part;
     p.CK = mode == 0 ? d->Cin : d->Cout;
     p.CO = mode == 0 ? d->Cout : d->Cin;
     p.src_ppi = mode == 0 ? d->in_pix_per_img : d->out_pix_per_img;
@@ -678,7 +707,7 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
     int px_tiles = cdiv(p.total_patches, NPATCH);
     p.tail_end = p.total_patches;
     const int num_cus = bd_num_cus();
-    if (g_pp_tail_split && p.n_tiles == 1 && px_tiles > num_cus) {
+    if (g_pp_tail_split && !gn_part && p.n_tiles == 1 && px_tiles > num_cus) {          // (the tail body leaves no GroupNorm statistics)
         const int r = px_tiles % num_cus;
         if (r > 0 && r * (TILE_CO / TAIL_CO) <= num_cus) {
             px_tiles -= r;
@@ -700,13 +729,16 @@ int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const
         // worse (one workgroup per CU, 256 CUs).  Mode 1 takes the instance with the shorter estimated makespan; the default takes
         // this one regardless: equal time on the small grids in isolation, fewer LDS and HBM bytes, and 0.2 % faster steps.
         const int grid128 = cdiv(p.total_patches, NPATCH) * cdiv(p.CO, 128);
-        if (g_patch_pp < 2 && 3 * cdiv(grid, 256) >= 2 * cdiv(grid128, 256)) return 1;
+        if (!gn_part && g_patch_pp < 2 && 3 * cdiv(grid, 256) >= 2 * cdiv(grid128, 256)) return 1;
     }
     BD_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     bd_note_kernel("conv3x3_pp_kernel");
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<0>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
+    if (gn_part) {
+        BD_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        hipLaunchKernelGGL((conv3x3_pp_kernel<0, true>), dim3(p.main_grid), dim3(512), LDS_BYTES, stream, p);
+    } else if (mode == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<0>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
     else hipLaunchKernelGGL((conv3x3_pp_kernel<1>), dim3(p.main_grid + tail_wgs), dim3(512), LDS_BYTES, stream, p);
     return 0;
 }
@@ -726,3 +758,41 @@ extern "C" int bd_debug_pp_span(unsigned long long* out2048) {
     return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_pp_span), 2048 * 8) == hipSuccess ? 0 : 1;
 }
 #endif
+
+int bd_conv3x3_pp_launch(const bd_conv_desc* d, int mode, const void* src, const void* w, const float* bias, const void* add,
+                         const void* mask, void* dst, int flags, hipStream_t stream) {
+    return pp_launch(d, mode, src, w, bias, add, mask, dst, flags, nullptr, stream);
+}
+
+// The patch layout of this kernel over a multi-level output, for the consumers of the GNS instance's statistics (norm.hip): starts[l] = first
+// patch of level l inside one image, starts[nseg] = patches per image.
+int bd_conv3x3_pp_patch_starts(const bd_conv_desc* d, int* starts) {
+    int ps = 0;
+    for (int s = 0; s < d->nseg; ++s) { starts[s] = ps; ps += cdiv(d->Ho[s], PH) * cdiv(d->Wo[s], PW); }
+    starts[d->nseg] = ps;
+    return ps;
+}
+
+extern "C" size_t bd_conv2d_fwd_gnstats_bytes(const bd_conv_desc* d) {
+    if (!d || d->nseg < 1 || d->nseg > BD_MAX_SEGS) return 0;
+    int starts[BD_MAX_SEGS + 1];
+    return (size_t)d->N * bd_conv3x3_pp_patch_starts(d, starts) * 32 * 2 * sizeof(float);
+}
+
+extern "C" int bd_conv2d_fwd_gnstats(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y, float* part,
+                                     size_t part_bytes, bd_stream_t stream) {
+    BD_ROUTE(d);
+    BD_REQUIRE(d && x && w_packed && y && part, "conv2d_fwd_gnstats: null pointer");
+    BD_REQUIRE(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Cout == 256 && d->Cin % 64 == 0,
+               "conv2d_fwd_gnstats: 3x3 / stride 1 / pad 1 into 256 channels (GroupNorm(32, 256)) only; got %dx%d s%d p%d %d -> %d", d->R, d->S,
+               d->stride, d->pad, d->Cin, d->Cout);
+    for (int s = 0; s < d->nseg; ++s)
+        BD_REQUIRE(d->Hi[s] == d->Ho[s] && d->Wi[s] == d->Wo[s], "conv2d_fwd_gnstats: level %d changes size", s);
+    if (part_bytes < bd_conv2d_fwd_gnstats_bytes(d)) { bd_set_error("conv2d_fwd_gnstats: statistics buffer too small"); return BD_EWORKSPACE; }
+    if (pp_launch(d, 0, x, w_packed, bias, nullptr, nullptr, y, 0, part, (hipStream_t)stream) != 0) {
+        bd_set_error("conv2d_fwd_gnstats: shape not taken by conv3x3_pp_kernel (tensor too large for 32-bit offsets?)");
+        return BD_EINVAL;
+    }
+    BD_CHECK_LAUNCH("bd_conv2d_fwd_gnstats");
+    return BD_OK;
+}

@@ -442,6 +442,29 @@ extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* 
     return BD_OK;
 }
 
+int bd_conv3x3_pp_patch_starts(const bd_conv_desc* d, int* starts);          // conv3x3_pp.hip
+
+// GroupNorm forward from the per-patch statistics the producing convolution left (bd_conv2d_fwd_gnstats): the finalize kernel sums a level's
+// patches exactly as it sums 128-pixel slots (8 lanes per group in patch order, then the eight partial sums in lane order: a fixed order),
+// then the unchanged apply pass.  d = that convolution's descriptor (its output levels are the tensor's levels).
+extern "C" int bd_groupnorm_fwd_parts(const bd_conv_desc* d, const void* y, const float* part, const float* gamma, const float* beta, float eps,
+                                      int relu, float* stats, void* z, bd_stream_t stream) {
+    BD_REQUIRE(d && y && part && gamma && beta && stats && z, "groupnorm_fwd_parts: null pointer");
+    BD_REQUIRE(d->Cout == 256 && d->nseg >= 1 && d->nseg <= MAXL && d->N >= 1, "groupnorm_fwd_parts: 256 channels, 1 .. %d levels", MAXL);
+    GnLevels lv{};
+    lv.L = d->nseg;
+    int starts[BD_MAX_SEGS + 1];
+    const int S = bd_conv3x3_pp_patch_starts(d, starts);
+    for (int i = 0; i < d->nseg; ++i) { lv.off[i] = d->out_off[i]; lv.cnt[i] = d->Ho[i] * d->Wo[i]; lv.slot0[i] = starts[i]; }
+    for (int i = d->nseg; i <= MAXL; ++i) lv.slot0[i] = S;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(d->nseg, d->N), dim3(256), 0, st, part, lv, 8, eps, stats);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(egrid((long long)d->N * d->out_pix_per_img * 32)), dim3(256), 0, st, (const bf16_raw*)y, (const float*)stats,
+                       gamma, beta, lv, d->N, (int)d->out_pix_per_img, relu, 0, (bf16_raw*)z);
+    BD_CHECK_LAUNCH("bd_groupnorm_fwd_parts");
+    return BD_OK;
+}
+
 extern "C" int bd_groupnorm_bwd(const void* dz, const void* y, const float* gamma, const float* beta, const float* stats, int N, int L,
                                 const int32_t* lvl_off_host, const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, int relu,
                                 void* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, bd_stream_t stream) {

@@ -186,6 +186,14 @@ class ConvLayer:
         return ops.conv2d_fwd(self.desc(gin, gout), x, self.w_fwd, self.b, y, add=add, flags=flags, bits=bits,
                               y8=y8 if (y8 is not None and ops.dense_1x1_bits_ok(self.desc(gin, gout))) else None, q_scale=q_scale)
 
+    def gnstats_ok(self):
+        """True when forward_gnstats serves this layer: a bf16 3x3 / stride-1 convolution into GroupNorm(32, 256)'s 256 channels."""
+        return (not self.fp8) and self.k == 3 and self.stride == 1 and self.pad == 1 and self.cout == 256 and self.cin % 64 == 0
+
+    def forward_gnstats(self, x, gin, gout, y, part):
+        """forward() of a tower convolution that also leaves GroupNorm's per-patch statistics in `part` (ops.conv2d_fwd_gnstats)."""
+        return ops.conv2d_fwd_gnstats(self.desc(gin, gout), x, self.w_fwd, self.b, y, part)
+
     def dgrad(self, g, gin, gout, dx, first=True, mask=None, add_after=None, maskbits=None, g8=None, dx8=None, q_scale=1.0,
               add_before=None, sparse=False):
         """dx (+)= conv^T(g); returns True when the launch also wrote the e5m2 twin dx8 (= dx * q_scale, q_scale = the CONSUMER's

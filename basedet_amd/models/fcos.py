@@ -96,6 +96,10 @@ class FCOS(FPNDetector):
         pl.loss_buf = torch.zeros((3,), **f32)
         pl.gn_ws = torch.empty((ops.groupnorm_workspace_bytes(N, L, ch, pl.pyr.pix_per_img) // 4 + 16,), **f32)
         pl.off_ws = torch.empty((ops.fcos_offsets_workspace_bytes() // 4,), **f32)
+        # MODEL.FUSE_GN_STATS (default on): GroupNorm's statistics from the tower convolutions' epilogues instead of a pass over their outputs
+        tower_convs = self.towers["cls_subnet"][0] + self.towers["bbox_subnet"][0]
+        fuse = bool(self.cfg.MODEL.get("FUSE_GN_STATS", True)) and dev.type == "cuda" and all(c.gnstats_ok() for c in tower_convs)
+        pl.gn_part = (torch.empty((ops.conv2d_fwd_gnstats_bytes(tower_convs[0].desc(pl.pyr, pl.pyr)) // 4,), **f32) if fuse else None)
 
     # ---- forward -----------------------------------------------------------------------------------------
     def head_forward(self, pl):
@@ -105,8 +109,14 @@ class FCOS(FPNDetector):
             t = pl.P
             bufs = pl.tw[tower]
             for i, c in enumerate(convs):
-                c.forward(t, pyr, pyr, bufs["y"][i])
-                ops.groupnorm_fwd(bufs["y"][i], gammas[i].w, betas[i].w, pyr, ch, GN_EPS, True, bufs["stats"][i], bufs["z"][i], pl.gn_ws)
+                if pl.gn_part is not None:
+                    # the statistics pass rides in the convolution's epilogue (round 6: bd_conv2d_fwd_gnstats / bd_groupnorm_fwd_parts)
+                    c.forward_gnstats(t, pyr, pyr, bufs["y"][i], pl.gn_part)
+                    ops.groupnorm_fwd_parts(c.desc(pyr, pyr), bufs["y"][i], pl.gn_part, gammas[i].w, betas[i].w, GN_EPS, True, bufs["stats"][i],
+                                            bufs["z"][i])
+                else:
+                    c.forward(t, pyr, pyr, bufs["y"][i])
+                    ops.groupnorm_fwd(bufs["y"][i], gammas[i].w, betas[i].w, pyr, ch, GN_EPS, True, bufs["stats"][i], bufs["z"][i], pl.gn_ws)
                 t = bufs["z"][i]
             if tower == "cls_subnet":
                 self.cls_score.forward(t, pyr, pyr, pl.logits)

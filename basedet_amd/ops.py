@@ -639,6 +639,24 @@ def groupnorm_fwd(y, gamma, beta, geom: Geom, Cn, eps, relu, stats, z, ws):
     return z
 
 
+def conv2d_fwd_gnstats_bytes(d):
+    return int(L().bd_conv2d_fwd_gnstats_bytes(C.byref(d)))
+
+
+def conv2d_fwd_gnstats(d, x, w_packed, bias, y, part):
+    """3x3 / stride-1 convolution into 256 channels that also leaves GroupNorm's per-patch statistics in `part` (fp32, conv2d_fwd_gnstats_bytes)."""
+    check(L().bd_conv2d_fwd_gnstats(C.byref(_stamp(d)), ptr(x), ptr(w_packed), ptr(bias), ptr(y), ptr(part), part.numel() * part.element_size(),
+                                    stream_ptr()), "bd_conv2d_fwd_gnstats")
+    return y
+
+
+def groupnorm_fwd_parts(d, y, part, gamma, beta, eps, relu, stats, z):
+    """GroupNorm(32, 256) (+ReLU) from the statistics conv2d_fwd_gnstats left: stats (mean, rstd) [N][L][32][2] out, z out."""
+    check(L().bd_groupnorm_fwd_parts(C.byref(d), ptr(y), ptr(part), ptr(gamma), ptr(beta), float(eps), int(relu), ptr(stats), ptr(z), stream_ptr()),
+          "bd_groupnorm_fwd_parts")
+    return z
+
+
 def groupnorm_bwd(dz, y, gamma, beta, stats, geom: Geom, Cn, relu, dy, dgamma, dbeta, ws, accumulate=False):
     """The ReLU gate (relu=True) is recomputed from y, stats, gamma, beta: the forward's output z is not an operand."""
     off, cnt = _lvl_arrays(geom)

@@ -426,6 +426,17 @@ size_t bd_groupnorm_workspace_bytes(int N, int L, int C, int64_t pix_per_img);
 int bd_groupnorm_fwd(const void* y, const float* gamma, const float* beta, int N, int L, const int32_t* lvl_off_host,
                      const int32_t* lvl_cnt_host, int64_t pix_per_img, int C, float eps, int relu, float* stats,
                      void* z, void* ws, size_t ws_bytes, bd_stream_t stream);
+/* The tower step conv -> GroupNorm(32) -> ReLU (point_head.py:47-58) with the statistics pass FUSED into the convolution (round 6):
+ * bd_conv2d_fwd_gnstats = bd_conv2d_fwd of a 3x3 / stride 1 / pad 1 convolution into 256 channels (bias, no residual / ReLU) that also leaves,
+ * per 4 x 16-pixel output patch and group of 8 channels, the (sum, sum of squares) of its fp32 results in `part` (bd_conv2d_fwd_gnstats_bytes;
+ * the layout is the kernel's own and only bd_groupnorm_fwd_parts reads it); bd_groupnorm_fwd_parts = bd_groupnorm_fwd without its statistics
+ * pass: it sums a level's patches in a fixed order into stats (mean, rstd) and applies.  The statistics come from the UNROUNDED results
+ * (within 2e-3 of the separate pass, which reads the bf16 tensor); reproducible bit for bit.  d = the convolution's descriptor for both calls. */
+size_t bd_conv2d_fwd_gnstats_bytes(const bd_conv_desc* d);
+int bd_conv2d_fwd_gnstats(const bd_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y, float* part,
+                          size_t part_bytes, bd_stream_t stream);
+int bd_groupnorm_fwd_parts(const bd_conv_desc* d, const void* y, const float* part, const float* gamma, const float* beta, float eps,
+                           int relu, float* stats, void* z, bd_stream_t stream);
 /* dz = gradient w.r.t. the (ReLU'd) output z; relu != 0 gates it with z > 0, RECOMPUTED from y, stats, gamma and beta with the forward's
  * own arithmetic (round 5: z is no longer read -- two of the backward's seven tensor passes).  dy: gradient w.r.t. the conv output y;
  * dgamma/dbeta fp32 [C] (accumulate != 0 adds). */

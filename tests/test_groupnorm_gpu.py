@@ -79,3 +79,59 @@ def test_groupnorm_fwd_bwd_matches_torch_and_is_reproducible(N, sizes):
     dg2, db2 = dg.clone(), db.clone()
     ops.groupnorm_bwd(dzd, yd, gd, bd, stats, geom, C, True, dy, dg2, db2, ws, accumulate=True)
     assert torch.allclose(dg2, 2 * dg, rtol=1e-6) and torch.allclose(db2, 2 * db, rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,sizes", [(3, [(25, 42), (13, 21), (7, 11)]), (16, [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)])])
+def test_groupnorm_statistics_from_the_convolution_epilogue(N, sizes):
+    """Round 6: conv -> GroupNorm -> ReLU with the statistics pass fused into the convolution (bd_conv2d_fwd_gnstats + bd_groupnorm_fwd_parts)
+    against the separate form (bd_conv2d_fwd + bd_groupnorm_fwd).  The convolution's output is the same bits; the statistics -- summed from the
+    fp32 results before the bf16 rounding instead of from the rounded tensor -- agree to 2e-3 (mean: of the group's standard deviation; rstd:
+    relative); z agrees to a bf16 rounding step of |z| + 1; mean and rstd also match the definition on the fp32 convolution result; two
+    launches agree bit for bit.  The second case is the benchmark's pyramid (1 536 tiles, six per workgroup, patches that overhang the image)."""
+    from basedet_amd import ops
+    from tests.util import pack_weights
+    geom = ops.Geom(N, [h for h, _ in sizes], [w for _, w in sizes])
+    gen = torch.Generator().manual_seed(23 + N)
+    x = torch.randn(geom.pixels, C, generator=gen).to(torch.bfloat16).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=gen) / np.sqrt(9 * C)).to(torch.bfloat16).float()
+    bias = (torch.randn(C, generator=gen) * 0.5).cuda()
+    gamma = (torch.rand(C, generator=gen) + 0.5).cuda()
+    beta = (torch.randn(C, generator=gen) * 0.3).cuda()
+    wf, _ = pack_weights(ops, w)
+    d = ops.conv_desc(geom, geom, C, C, 3, 3, 1, 1)
+    ws = torch.empty((ops.groupnorm_workspace_bytes(N, geom.nlev, C, geom.pix_per_img) // 4 + 16,), dtype=torch.float32, device="cuda")
+    y0 = torch.empty((geom.pixels, C), dtype=torch.bfloat16, device="cuda")
+    ops.conv2d_fwd(d, x, wf, bias, y0)
+    st0 = torch.empty((N, geom.nlev, 32, 2), dtype=torch.float32, device="cuda")
+    z0 = torch.empty_like(y0)
+    ops.groupnorm_fwd(y0, gamma, beta, geom, C, 1e-5, True, st0, z0, ws)
+    outs = []
+    for rep in range(2):
+        part = torch.full((ops.conv2d_fwd_gnstats_bytes(d) // 4,), float("nan"), dtype=torch.float32, device="cuda")
+        y1 = torch.full((geom.pixels, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+        ops.conv2d_fwd_gnstats(d, x, wf, bias, y1, part)
+        assert ops.L().bd_conv_last_kernel().decode() == "conv3x3_pp_kernel"
+        st1 = torch.full((N, geom.nlev, 32, 2), float("nan"), dtype=torch.float32, device="cuda")
+        z1 = torch.full((geom.pixels, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+        ops.groupnorm_fwd_parts(d, y1, part, gamma, beta, 1e-5, True, st1, z1)
+        torch.cuda.synchronize()
+        outs.append((y1, st1, z1, part))
+    y1, st1, z1, part = outs[0]
+    assert torch.equal(y1, y0), "the fused launch's convolution output differs"
+    assert bool(torch.isfinite(part).all()) and bool(torch.isfinite(st1).all())
+    std0 = 1.0 / st0[..., 1]
+    assert float(((st1[..., 0] - st0[..., 0]).abs() / std0).max()) < 2e-3
+    assert float(((st1[..., 1] - st0[..., 1]).abs() / st0[..., 1]).max()) < 2e-3
+    dz = (z1.float() - z0.float()).abs()
+    assert bool((dz <= (z0.float().abs() + 1.0) * 2.0 ** -7).all()), float(dz.max())
+    assert rel_l2(z1.float().cpu(), z0.float().cpu()) < 2e-3
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # against the definition, on the first level of image 0 (fp32 convolution of the same bf16 operands)
+    H, W = sizes[0]
+    xi = x[: H * W].float().cpu().view(1, H, W, C).permute(0, 3, 1, 2)
+    yi = TF.conv2d(xi, w, bias.cpu(), padding=1)[0].permute(1, 2, 0).reshape(H * W, 32, 8)
+    mean = yi.mean(dim=(0, 2))
+    rstd = 1.0 / torch.sqrt(yi.var(dim=(0, 2), unbiased=False) + 1e-5)
+    assert torch.allclose(st1[0, 0, :, 0].cpu(), mean, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(st1[0, 0, :, 1].cpu(), rstd, rtol=1e-3, atol=1e-4)
