@@ -78,16 +78,18 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const bf16_raw* _
     }
 }
 
-// stats[(n*L + l)*32 + g] = (mean, rstd).  One workgroup per (image, level): 8 lanes per group walk the level's slots (lane q: slots q,
-// q + 8, ...), then the eight partial sums are added in lane order -- a fixed order; a single thread per (n, l, g) summing the 132 slots
-// of the largest level one after the other took 37 us per launch (rocprofv3, first form of this round).
-__global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __restrict__ partial, GnLevels lv, int cpg, float eps,
-                                                             float* __restrict__ stats) {
-    __shared__ float red[8][32][2];
+// stats[(n*L + l)*32 + g] = (mean, rstd).  One workgroup per (image, level): GN_FQ lanes per group walk the level's slots (lane q: slots q,
+// q + GN_FQ, ...), then the partial sums are added in lane order -- a fixed order; a single thread per (n, l, g) summing the 132 slots
+// of the largest level one after the other took 37 us per launch (rocprofv3, first form of round 5).  Round 6: 32 lanes per group instead of 8 --
+// the slots of the fused form are the convolution's 4 x 16-pixel patches (275 on the largest level at 800 x 1344): 16 -> 6 us per launch (rocprofv3).
+constexpr int GN_FQ = 32;
+__global__ __launch_bounds__(32 * GN_FQ) void gn_stats_final_kernel(const float* __restrict__ partial, GnLevels lv, int cpg, float eps,
+                                                                    float* __restrict__ stats) {
+    __shared__ float red[GN_FQ][32][2];
     const int g = threadIdx.x & 31, q = threadIdx.x >> 5;
     const int l = blockIdx.x, n = blockIdx.y, S = lv.slot0[lv.L];
     float s = 0.f, ss = 0.f;
-    for (int c = lv.slot0[l] + q; c < lv.slot0[l + 1]; c += 8) {
+    for (int c = lv.slot0[l] + q; c < lv.slot0[l + 1]; c += GN_FQ) {
         const float* o = partial + (((long long)n * S + c) * 32 + g) * 2;
         s += o[0]; ss += o[1];
     }
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
     if (q == 0) {
         s = 0.f; ss = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { s += red[k][g][0]; ss += red[k][g][1]; }
+        for (int k = 0; k < GN_FQ; ++k) { s += red[k][g][0]; ss += red[k][g][1]; }
         const float inv = 1.f / ((float)lv.cnt[l] * (float)cpg);
         const float mean = s * inv;
         const float var = fmaxf(ss * inv - mean * mean, 0.f);
@@ -434,7 +436,7 @@ extern "C" int bd_groupnorm_fwd(const void* y, const float* gamma, const float* 
         float* part = (float*)ws + (size_t)n0 * S * 64;
         float* stc = stats + (size_t)n0 * L * 64;
         hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, nc), dim3(256), 0, st, yc, lv, (int)pix_per_img, C, part);
-        hipLaunchKernelGGL(gn_stats_final_kernel, dim3(L, nc), dim3(256), 0, st, (const float*)part, lv, C / 32, eps, stc);
+        hipLaunchKernelGGL(gn_stats_final_kernel, dim3(L, nc), dim3(32 * GN_FQ), 0, st, (const float*)part, lv, C / 32, eps, stc);
         hipLaunchKernelGGL(gn_apply_kernel, dim3(egrid((long long)nc * pix_per_img * 32)), dim3(256), 0, st, yc, (const float*)stc, gamma, beta,
                            lv, nc, (int)pix_per_img, relu, rev, zc);
     }
@@ -458,7 +460,7 @@ extern "C" int bd_groupnorm_fwd_parts(const bd_conv_desc* d, const void* y, cons
     for (int i = 0; i < d->nseg; ++i) { lv.off[i] = d->out_off[i]; lv.cnt[i] = d->Ho[i] * d->Wo[i]; lv.slot0[i] = starts[i]; }
     for (int i = d->nseg; i <= MAXL; ++i) lv.slot0[i] = S;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(d->nseg, d->N), dim3(256), 0, st, part, lv, 8, eps, stats);
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(d->nseg, d->N), dim3(32 * GN_FQ), 0, st, part, lv, 8, eps, stats);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(egrid((long long)d->N * d->out_pix_per_img * 32)), dim3(256), 0, st, (const bf16_raw*)y, (const float*)stats,
                        gamma, beta, lv, d->N, (int)d->out_pix_per_img, relu, 0, (bf16_raw*)z);
     BD_CHECK_LAUNCH("bd_groupnorm_fwd_parts");
