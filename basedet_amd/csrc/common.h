@@ -157,7 +157,7 @@ void bd_note_kernel(const char* name);
 
 // Measurement switches from the ENVIRONMENT (tile targets, staging depths, A/B routes of scripts/) exist in -DBD_TUNING diagnostic builds
 // only (BD_LIB_NAME / BD_EXTRA_FLAGS of basedet_amd/build.py): the shipped library reads no environment variable except BD_RCCL_LIB (where
-// RCCL lives: deployment, not behaviour).  What is left process-global are the documented bd_*_set_* knobs of include/basedet_hip.h.
+// RCCL lives: deployment, not behaviour).  Nothing is process-global since round 6: kernel routing travels in bd_conv_desc.route[] per call.
 #ifdef BD_TUNING
 #include <stdlib.h>
 static inline int bd_tune_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }

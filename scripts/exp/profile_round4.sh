@@ -1,3 +1,6 @@
+# ROUND-4 collection script, kept for the record of how profiles/r04_* were made.  Its BD_DENSE1X1_* environment prefixes act only on a
+# -DBD_TUNING build of the library (BD_EXTRA_FLAGS=-DBD_TUNING python -m basedet_amd.build): on the shipped library they are ignored and those
+# lines measure the default twice.  The current script is scripts/profile_round6.sh.
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
