@@ -80,7 +80,7 @@ __device__ __forceinline__ int xpos(int chunk) { return (chunk >> 2) * 64 + ((((
 __device__ unsigned long long g_pp_stamp[64];
 __device__ unsigned long long g_pp_span[2048];      // [2 b], [2 b + 1]: s_memrealtime (100 MHz, chip-wide) at the start / end of workgroup b
 #endif
-// -DBD_PP_ABLATE=<bits> (diagnostic builds, TIMING ONLY -- the results are wrong; scripts/exp/pp_power.sh): bit 0 = the second K half of every
+// -DBD_PP_ABLATE=<bits> (diagnostic builds, TIMING ONLY -- the results are wrong; scripts/exp/pp_power.sh; bit 2 = no stores in the fast-path epilogue): bit 0 = the second K half of every
 // tap re-uses the first half's fragments (half of the loop's ds_read_b128 gone), bit 1 = no weight DMA inside the K loop (the ring keeps the
 // prologue's three taps).  Same MFMAs, same barriers: what moves is LDS / L2 traffic -- and with it launch time and the clock the chip holds.
 #ifndef BD_PP_ABLATE
@@ -548,13 +548,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const PParams p) {
                 PP_STAMP();            // ... and everything older than the next tile's tap 2 has landed
                 PP_FENCE();
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (okh && okj[j]) *reinterpret_cast<u32x4_t*>(drow[j]) = o0[j];
+                for (int j = 0; j < 4; ++j) {
+                    if (BD_PP_ABLATE & 4) asm volatile("" :: "v"(o0[j]));           // (bit 2, timing only: the fast path converts but does not store)
+                    else if (okh && okj[j]) *reinterpret_cast<u32x4_t*>(drow[j]) = o0[j];          // (non-temporal stores: -0.4 % per step, profiles/r06_pp_power.txt)
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32x4_t o = unit(h, j, b0, b1);
-                    if (okh && okj[j]) *reinterpret_cast<u32x4_t*>(drow[j] + 32 * h) = o;
+                    if (BD_PP_ABLATE & 4) asm volatile("" :: "v"(o));
+                    else if (okh && okj[j]) *reinterpret_cast<u32x4_t*>(drow[j] + 32 * h) = o;
                 }
             }
         }

@@ -103,14 +103,31 @@ class RetinaNet(FPNDetector):
     # ---- forward -----------------------------------------------------------------------------------------
     def head_forward(self, pl):
         # head (retina_head.py:103-112), all five levels per launch
+        # MODEL.HEAD_TOWERS_CONCURRENT (round 6, default on): the box tower on a second stream beside the class tower -- the two are independent
+        # until the losses.  Each launch is a full persistent grid, so the second tower's workgroups start on a CU the moment the first tower's
+        # finish there: what is recovered is the launch-level loss of a one-workgroup-per-CU kernel (dispatch, the XCDs' finish spread:
+        # the 0.907 factor of profiles/r06_pp_power.txt), +0.4-0.5 % per step on three boxes (profiles/r06_head_towers_ab.txt).  The same on the
+        # BACKWARD pass, where the weight-gradient stream already runs beside the chain, costs 1.2 %: not done.  Steps that keep the weight
+        # gradients on the main stream (bench.py's instrumented steps, --serial-wgrad) stay serial here too: clean per-kernel durations.
+        side = None
+        # (bf16 only: in fp8 mode the tower convolutions may share the main stream's cast scratch)
+        if (bool(self.cfg.MODEL.get("HEAD_TOWERS_CONCURRENT", True)) and self.device.type == "cuda" and self.async_wgrad
+                and self.weight_dtype != "fp8_e4m3"):
+            if getattr(self, "_hstream", None) is None:
+                self._hstream = torch.cuda.Stream()
+            side = self._hstream
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side) if side is not None else _nullcontext():
+            t, t8 = pl.P, getattr(pl, "P8", None)
+            for c, a, a8 in zip(self.box_tower, pl.box_act, pl.box_act8):
+                c.forward(t, pl.pyr, pl.pyr, a, relu=True, x8=t8, y8=a8); t, t8 = a, a8
+            self.bbox_pred.forward(t, pl.pyr, pl.pyr, pl.offsets, x8=t8)
         t, t8 = pl.P, getattr(pl, "P8", None)
         for c, a, a8 in zip(self.cls_tower, pl.cls_act, pl.cls_act8):
             c.forward(t, pl.pyr, pl.pyr, a, relu=True, x8=t8, y8=a8); t, t8 = a, a8
         self.cls_score.forward(t, pl.pyr, pl.pyr, pl.logits, x8=t8)
-        t, t8 = pl.P, getattr(pl, "P8", None)
-        for c, a, a8 in zip(self.box_tower, pl.box_act, pl.box_act8):
-            c.forward(t, pl.pyr, pl.pyr, a, relu=True, x8=t8, y8=a8); t, t8 = a, a8
-        self.bbox_pred.forward(t, pl.pyr, pl.pyr, pl.offsets, x8=t8)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     def get_losses(self, inputs):
         """RetinaNet.get_losses (retinanet.py:120-170)."""
