@@ -113,8 +113,8 @@ class RetinaNet(FPNDetector):
         # (bf16 only: in fp8 mode the tower convolutions may share the main stream's cast scratch)
         # The second stream is the model's EXISTING side stream (_tstream: the target assignment at the start of the forward pass, long done
         # here; the top block's data gradients in the backward pass).  A stream of its own made five per process under torch.distributed (main,
-        # weight gradients, side, communicator, this one) -- more than the hardware queues a process gets -- and the step lost 2.8 ms
-        # (577 against 643 img/s with one rank and a forced all-reduce: profiles/r06_head_towers_ab.txt).
+        # weight gradients, side, communicator, this one) and the step lost 2.8 ms (577 against 643 img/s with one rank and a forced
+        # all-reduce: profiles/r06_head_towers_ab.txt; cause not established -- GPU_MAX_HW_QUEUES=8 did not remove it).
         if (bool(self.cfg.MODEL.get("HEAD_TOWERS_CONCURRENT", True)) and self.device.type == "cuda" and self.async_wgrad
                 and self._tstream is not None and self.weight_dtype != "fp8_e4m3"):
             side = self._tstream
