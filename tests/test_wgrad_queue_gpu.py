@@ -98,3 +98,31 @@ def test_queued_weight_gradients_equal_the_per_layer_ones_bit_for_bit(kind):
     assert set(seen) == set(solver.buckets.ranges), (sorted(seen), sorted(solver.buckets.ranges))
     for name, (lo, hi) in solver.buckets.ranges.items():
         assert torch.equal(seen[name], final[lo:hi]), name
+
+
+def test_retinanet_head_towers_on_two_streams_equal_the_serial_head_bit_for_bit():
+    """MODEL.HEAD_TOWERS_CONCURRENT (round 6, default on): the box tower's forward launches on the model's side stream beside the class tower's.
+    Two steps each (the second one runs behind a backward pass that used the same side stream): logits, box offsets and every gradient of
+    the parameter arena must be the same bits as with the towers one after the other."""
+    from basedet_amd.configs import RetinaNetConfig
+    from basedet_amd.models import RetinaNet, params as P
+    batch = _batch(2)
+    out = {}
+    for conc in (False, True):
+        cfg = RetinaNetConfig()
+        cfg.MODEL.BATCHSIZE = 2
+        cfg.MODEL.HEAD_TOWERS_CONCURRENT = conc
+        m = RetinaNet(cfg, params=P.init_retinanet_params(cfg, seed=0, residual_gamma=0.2))
+        assert m.async_wgrad and m._tstream is not None
+        res = []
+        for _ in range(2):
+            losses = m(batch)
+            m.backward()
+            torch.cuda.synchronize()
+            res.append((float(losses["total_loss"]), m._cur.logits.clone(), m._cur.offsets.clone(), m.arena.g.clone()))
+        out[conc] = res
+    for a, b in zip(out[False], out[True]):
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0])          # (the reported loss scalars are atomic sums: equal to rounding, run to run)
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y)
+    assert float(out[True][0][3].abs().max()) > 0
